@@ -1,0 +1,172 @@
+/*
+ * node_hip.h -- C ABI of libnode_hip.so, the MI355X (gfx950) Neural-ODE
+ * forward/adjoint integrator.
+ *
+ * This is the drop-in boundary for ONE path of fabiocarrara/neural-ode-features:
+ *
+ *     out = self.odeint(self.odefunc, x, self.integration_time,
+ *                       method=self.method, rtol=self.tol, atol=self.tol)
+ *                                                  -- reference model.py:367
+ *
+ * i.e. `torchdiffeq.odeint` / `odeint_adjoint` (imported at model.py:3, an
+ * un-vendored third-party package) driving the Conv-GroupNorm-ReLU dynamics
+ * `ODEfunc.forward` (model.py:339-348) built from `ConcatConv2d`
+ * (model.py:313-323) and `nn.GroupNorm(min(32, C), C)` (model.py:268-271).
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  The reference is
+ * Python, so its FFI for this path is `ctypes`; the binding a maintainer adds
+ * is shown in INTEGRATION.md and shipped as neural-ode-features_amd/_lib.py.
+ *
+ * Contract
+ *  - every device buffer (inputs, outputs, workspace) is allocated and owned by
+ *    the caller; the library never allocates or frees device memory and keeps
+ *    no pointer after the call's work on `stream` has completed;
+ *  - tensors are fp32, contiguous, NCHW exactly as PyTorch hands them over
+ *    (the library converts to its internal NHWC layout inside the workspace);
+ *  - `params` points INTO the live nn.Parameter storages (no copies), in the
+ *    reference's layouts: conv weights are [C, C+1, 3, 3] with input channel 0
+ *    being the time channel (model.py:321-322);
+ *  - all work is enqueued on the caller's HIP stream (`hipStream_t` passed as
+ *    void*); solve calls synchronise that stream once per adaptive step to read
+ *    the accept flag, and once at the end, so `stats` is valid on return;
+ *  - return 0 on success, a negative NODE_ERR_* otherwise; the message is
+ *    available from node_last_error() (thread-local).  No exceptions, no abort.
+ */
+#ifndef NODE_HIP_H
+#define NODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NODE_ABI_VERSION 1
+
+/* method -- the two solver names that reach model.py:367 on the graded configs
+ * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
+enum { NODE_METHOD_DOPRI5 = 0, NODE_METHOD_RK4 = 1 };
+
+enum {
+  NODE_OK = 0,
+  NODE_ERR_NULL = -1,         /* a required pointer is NULL                      */
+  NODE_ERR_SHAPE = -2,        /* n/c/h/w/groups inconsistent                      */
+  NODE_ERR_UNSUPPORTED = -3,  /* shape outside what the gfx950 kernels tile       */
+  NODE_ERR_WORKSPACE = -4,    /* ws_bytes < node_workspace_bytes(...)             */
+  NODE_ERR_MAX_STEPS = -5,    /* max_num_steps exceeded                           */
+  NODE_ERR_NONFINITE = -6,    /* non-finite state / error norm                    */
+  NODE_ERR_DT_UNDERFLOW = -7, /* t + dt == t  (upstream: 'underflow in dt')       */
+  NODE_ERR_HIP = -8,          /* a HIP runtime call failed                        */
+  NODE_ERR_ARG = -9           /* bad scalar argument (method, n_t, time order...) */
+};
+
+/* State shape [n, c, h, w]; groups = min(32, c) (model.py:271); eps = 1e-5. */
+typedef struct node_shape {
+  int32_t n, c, h, w;
+  int32_t groups;
+  float eps;
+} node_shape;
+
+/* The ten parameters of ODEfunc in `ODEfunc.parameters()` order
+ * (model.py:331-336).  Device pointers. */
+typedef struct node_params {
+  const float* norm1_w; /* [C] */
+  const float* norm1_b; /* [C] */
+  const float* conv1_w; /* [C, C+1, 3, 3], input channel 0 = time */
+  const float* conv1_b; /* [C] */
+  const float* norm2_w;
+  const float* norm2_b;
+  const float* conv2_w;
+  const float* conv2_b;
+  const float* norm3_w;
+  const float* norm3_b;
+} node_params;
+
+/* Solver telemetry.  `nfe` follows the reference's counter (model.py:340): one
+ * per ODEfunc.forward, including the recompute inside every adjoint eval. */
+typedef struct node_stats {
+  int32_t nfe;
+  int32_t accepted;
+  int32_t rejected;
+  int32_t status;   /* NODE_OK or the NODE_ERR_* that stopped the solve */
+  double last_dt;   /* step size proposed for the step after the last one */
+  double t_final;   /* solver time reached */
+  double first_dt;  /* initial step chosen (dopri5) */
+} node_stats;
+
+/* Optional knobs (pass NULL for upstream behaviour). */
+typedef struct node_solve_opts {
+  int32_t max_num_steps;    /* <=0: 2^31-1 like upstream                          */
+  int32_t n_forced_dt;      /* >0: replay mode -- take exactly these step sizes,  */
+  const double* forced_dt;  /*     every step accepted (host pointer)             */
+  int32_t record_dt;        /* >0: capacity of dt_log                             */
+  double* dt_log;           /* host: dt tried at each step (<0 => rejected)       */
+  int32_t* n_dt_log;        /* host: number of entries written                    */
+} node_solve_opts;
+
+/* Per-kernel-class timing collected with HIP events on the caller's stream
+ * (bench.py's roofline block).  Classes: 0 conv3x3 fwd/dgrad implicit GEMM,
+ * 1 wgrad GEMM, 2 everything else. */
+#define NODE_PROFILE_CLASSES 3
+typedef struct node_profile {
+  int64_t launches[NODE_PROFILE_CLASSES];
+  double total_ms[NODE_PROFILE_CLASSES];
+  double flops[NODE_PROFILE_CLASSES]; /* algorithmic FLOPs issued in those launches */
+} node_profile;
+
+int node_abi_version(void);
+const char* node_last_error(void);
+
+/* Number of fp32 elements of the flat parameter vector (18*C*C + 26*C). */
+size_t node_param_count(const node_shape* shape);
+
+/* Bytes of caller-provided device workspace needed by the calls below.
+ * adjoint != 0 sizes for node_solve_adjoint / node_odefunc_vjp. */
+size_t node_workspace_bytes(const node_shape* shape, int method, int adjoint, int n_t);
+
+/* f = ODEfunc(t, y)                                     -- model.py:339-348 */
+int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t,
+                     const float* y, float* f,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* What the upstream adjoint asks autograd for at every stage:
+ *   f = ODEfunc(t, y);  (vjp_t, vjp_y, vjp_params) = grad(f, (t, y, *params), cot)
+ * vjp_t: 1 float (device); vjp_params: node_param_count floats (device), flat in
+ * parameters() order, each parameter in its PyTorch layout. */
+int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t,
+                     const float* y, const float* cot,
+                     float* f, float* vjp_y, float* vjp_t, float* vjp_params,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* torchdiffeq.odeint(ODEfunc, y0, t, rtol, atol, method)  -- model.py:367
+ * t_pts: host array of n_t strictly monotonic times; y_out: [n_t, n, c, h, w]
+ * with y_out[0] = y0. */
+int node_solve_fwd(const node_shape* shape, const node_params* params,
+                   const float* y0, const float* t_pts, int n_t,
+                   float rtol, float atol, int method, const node_solve_opts* opts,
+                   float* y_out, node_stats* stats,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of torchdiffeq.odeint_adjoint (triggered by train.py:51):
+ * y_traj = the forward's y_out, grad_out = dL/dy_out, both [n_t, n, c, h, w].
+ * Outputs: grad_y0 [n, c, h, w]; grad_params [node_param_count] flat in
+ * parameters() order; grad_t [n_t] or NULL (the reference discards it). */
+int node_solve_adjoint(const node_shape* shape, const node_params* params,
+                       const float* y_traj, const float* grad_out,
+                       const float* t_pts, int n_t,
+                       float rtol, float atol, int method, const node_solve_opts* opts,
+                       float* grad_y0, float* grad_params, float* grad_t,
+                       node_stats* stats,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Event-based per-kernel-class timing (off by default; adds two event records
+ * per profiled launch).  begin() resets the counters; end() synchronises the
+ * recorded events and fills `out`. */
+int node_profile_begin(void);
+int node_profile_end(node_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NODE_HIP_H */

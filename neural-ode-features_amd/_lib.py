@@ -1,0 +1,113 @@
+"""ctypes binding of libnode_hip.so (the C ABI declared in include/node_hip.h).
+
+This is the stub a maintainer of the reference would add next to ``model.py`` to
+replace ``from torchdiffeq import odeint_adjoint, odeint`` (model.py:3) -- see
+INTEGRATION.md.  There is no CPU or pure-PyTorch fallback: if the library is
+missing or no HIP device is present, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
+
+NODE_ABI_VERSION = 1
+METHOD_DOPRI5, METHOD_RK4 = 0, 1
+METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
+
+ERRORS = {
+    0: 'NODE_OK', -1: 'NODE_ERR_NULL', -2: 'NODE_ERR_SHAPE', -3: 'NODE_ERR_UNSUPPORTED',
+    -4: 'NODE_ERR_WORKSPACE', -5: 'NODE_ERR_MAX_STEPS', -6: 'NODE_ERR_NONFINITE',
+    -7: 'NODE_ERR_DT_UNDERFLOW', -8: 'NODE_ERR_HIP', -9: 'NODE_ERR_ARG',
+}
+
+EXPORTS = [
+    'node_abi_version', 'node_last_error', 'node_param_count', 'node_workspace_bytes',
+    'node_odefunc_fwd', 'node_odefunc_vjp', 'node_solve_fwd', 'node_solve_adjoint',
+    'node_profile_begin', 'node_profile_end',
+]
+
+
+class NodeShape(C.Structure):
+    _fields_ = [('n', C.c_int32), ('c', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+                ('groups', C.c_int32), ('eps', C.c_float)]
+
+
+class NodeParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        'norm1_w', 'norm1_b', 'conv1_w', 'conv1_b', 'norm2_w', 'norm2_b',
+        'conv2_w', 'conv2_b', 'norm3_w', 'norm3_b')]
+
+
+class NodeStats(C.Structure):
+    _fields_ = [('nfe', C.c_int32), ('accepted', C.c_int32), ('rejected', C.c_int32), ('status', C.c_int32),
+                ('last_dt', C.c_double), ('t_final', C.c_double), ('first_dt', C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class NodeSolveOpts(C.Structure):
+    _fields_ = [('max_num_steps', C.c_int32), ('n_forced_dt', C.c_int32), ('forced_dt', C.POINTER(C.c_double)),
+                ('record_dt', C.c_int32), ('dt_log', C.POINTER(C.c_double)), ('n_dt_log', C.POINTER(C.c_int32))]
+
+
+class NodeProfile(C.Structure):
+    _fields_ = [('launches', C.c_int64 * 3), ('total_ms', C.c_double * 3), ('flops', C.c_double * 3)]
+
+
+class NodeHipError(RuntimeError):
+    def __init__(self, code, message):
+        self.code = code
+        super().__init__('libnode_hip: %s (%d): %s' % (ERRORS.get(code, '?'), code, message))
+
+
+_lib = None
+
+
+def load():
+    """Load libnode_hip.so and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libnode_hip.so is not built (%s). Run `python neural-ode-features_amd/build.py` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    P = C.POINTER
+    lib.node_abi_version.restype = i32
+    lib.node_abi_version.argtypes = []
+    lib.node_last_error.restype = C.c_char_p
+    lib.node_last_error.argtypes = []
+    lib.node_param_count.restype = sz
+    lib.node_param_count.argtypes = [P(NodeShape)]
+    lib.node_workspace_bytes.restype = sz
+    lib.node_workspace_bytes.argtypes = [P(NodeShape), i32, i32, i32]
+    lib.node_odefunc_fwd.restype = i32
+    lib.node_odefunc_fwd.argtypes = [P(NodeShape), P(NodeParams), f32, vp, vp, vp, sz, vp]
+    lib.node_odefunc_vjp.restype = i32
+    lib.node_odefunc_vjp.argtypes = [P(NodeShape), P(NodeParams), f32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.node_solve_fwd.restype = i32
+    lib.node_solve_fwd.argtypes = [P(NodeShape), P(NodeParams), vp, P(C.c_float), i32, f32, f32, i32,
+                                   P(NodeSolveOpts), vp, P(NodeStats), vp, sz, vp]
+    lib.node_solve_adjoint.restype = i32
+    lib.node_solve_adjoint.argtypes = [P(NodeShape), P(NodeParams), vp, vp, P(C.c_float), i32, f32, f32, i32,
+                                       P(NodeSolveOpts), vp, vp, vp, P(NodeStats), vp, sz, vp]
+    lib.node_profile_begin.restype = i32
+    lib.node_profile_begin.argtypes = []
+    lib.node_profile_end.restype = i32
+    lib.node_profile_end.argtypes = [P(NodeProfile)]
+    ver = lib.node_abi_version()
+    if ver != NODE_ABI_VERSION:
+        raise RuntimeError('libnode_hip ABI %d != binding ABI %d' % (ver, NODE_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NodeHipError(rc, load().node_last_error().decode('utf-8', 'replace'))

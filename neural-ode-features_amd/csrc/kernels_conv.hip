@@ -1,0 +1,485 @@
+// fp32-MFMA implicit-GEMM kernels of the ODE dynamics (gfx950).
+//
+//   k_conv3x3<MT>  out[m, co] = sum_{tap, ci} A[pix(m) + tap, ci] * Wp[tap, ci, co]
+//                  M = N*H*W pixels, K = 9*C, fp32 in / fp32 accumulate on
+//                  v_mfma_f32_32x32x2_f32 (exact fp32: the embedded-error estimator
+//                  of dopri5 cannot tolerate bf16 noise).
+//                  Forward conv and data-gradient share the kernel (dgrad = conv
+//                  with flipped/transposed packed weights).
+//   k_wgrad        dW[tap, ci, co] = sum_pix A[pix + tap, ci] * dZ[pix, co]   (split-K over samples)
+//
+// MI355X-first design points
+//  * M tiles are aligned to WHOLE SAMPLES (S samples of H*W pixels per tile), and N
+//    tiles to whole GroupNorm groups, so the GroupNorm that follows every conv in
+//    ODEfunc (model.py:343-347) -- and, in the backward, the ReLU mask + GroupNorm
+//    backward that follows every dgrad -- is computed entirely in the epilogue from
+//    the accumulator tile staged once through LDS.  One ODEfunc eval is three
+//    kernels (combine+GN1, conv1+GN2+ReLU, conv2+GN3) instead of ~12 ATen ops.
+//  * The activation chunk (S samples x 32 channels) is staged ONCE per K chunk into
+//    a zero-haloed LDS image; the nine 3x3 taps are nine constant LDS offsets into
+//    that image -- no im2col, no per-tap reload, no border predication.
+//  * The constant-time channel of ConcatConv2d (model.py:321-322) is not carried
+//    through K: its contribution is t * tmap[p, co] (border-aware tap sums), added
+//    with the bias in the epilogue.
+//  * 8 waves (4 M x 2 N) per workgroup, two waves per SIMD so one wave's LDS
+//    operand reads hide behind its partner's 64-cycle MFMAs; global->LDS staging
+//    is register-prefetched one piece ahead (issue early / write late).
+#include "node_internal.h"
+
+namespace node {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline float wave_sum_c(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ inline int slot_of(int p, int W, int Wp) {
+  const int h = p / W;
+  return (h + 1) * Wp + (p - h * W) + 1;
+}
+
+// ============================================================================
+// conv3x3 implicit GEMM + fused epilogue
+// ============================================================================
+template <int MT>
+__global__ __launch_bounds__(CONV_THREADS) void k_conv3x3(ConvArgs a, Dims d) {
+  constexpr int BM = 128 * MT;
+  constexpr int NA = 2 * MT;          // float4 staging units per thread for one A chunk
+  constexpr int CT = BN + 1;          // epilogue tile stride
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mtile = blockIdx.x, nt = blockIdx.y;
+  const int n0 = mtile * d.S;
+  const int c0 = nt * d.BNE;
+  const int nsamp = min(d.S, d.N - n0);
+  const int rows_valid = nsamp * d.HW;
+
+  const int AROWS = d.S * d.SLOTS + 2 * d.MARGIN;
+  const int ABUF = (AROWS * AST + 3) & ~3;
+  float* Abuf0 = smem;
+  float* Abuf1 = smem + ABUF;
+  float* Bbuf0 = smem + 2 * ABUF;
+  float* Bbuf1 = Bbuf0 + KCH * BN;
+
+  // ---- zero both A images (halo, margins, channel padding) ----
+  for (int i = tid; i < 2 * ABUF; i += CONV_THREADS) smem[i] = 0.f;
+
+  // ---- per-thread staging descriptors for the A chunk ----
+  size_t gofs[NA];
+  int lofs[NA];
+  bool aval[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = tid + i * CONV_THREADS;
+    const int row = u >> 3, q = u & 7;
+    aval[i] = row < rows_valid;
+    const int rr = aval[i] ? row : 0;
+    const int s = rr / d.HW, p = rr - s * d.HW;
+    gofs[i] = ((size_t)(n0 + s) * d.HW + p) * d.C + q * 4;
+    lofs[i] = (d.MARGIN + s * d.SLOTS + slot_of(p, d.W, d.Wp)) * AST + q * 4;
+  }
+  // ---- per-lane MFMA A-row offsets ----
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = wm * (32 * MT) + mt * 32 + l31;
+    int slot = 0;
+    if (row < d.S * d.HW) {
+      const int s = row / d.HW, p = row - s * d.HW;
+      slot = s * d.SLOTS + slot_of(p, d.W, d.Wp);
+    }
+    arow[mt] = (d.MARGIN + slot) * AST + hi;
+  }
+  const int boff = hi * BN + wn * 32 + l31;
+
+  const float* wbase = a.wpacked + (size_t)nt * d.nchunk * 9 * (KCH * BN);
+  const int Q = d.nchunk * 9;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  float4 areg[NA];
+  float4 breg;
+  __syncthreads();  // zero fill visible
+
+  // prologue: chunk 0 + piece 0
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int qq = (tid + i * CONV_THREADS) & 7;
+    areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aval[i] && qq * 4 < d.C) areg[i] = *reinterpret_cast<const float4*>(a.in + gofs[i]);
+  }
+  breg = *reinterpret_cast<const float4*>(wbase + tid * 4);
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int qq = (tid + i * CONV_THREADS) & 7;
+    if (aval[i] && qq * 4 < d.C) {
+      float* dst = Abuf0 + lofs[i];
+      dst[0] = areg[i].x; dst[1] = areg[i].y; dst[2] = areg[i].z; dst[3] = areg[i].w;
+    }
+  }
+  *reinterpret_cast<float4*>(Bbuf0 + tid * 4) = breg;
+  __syncthreads();
+
+  for (int q = 0; q < Q; ++q) {
+    const int chunk = q / 9, tap = q - chunk * 9;
+    const bool has_next = (q + 1) < Q;
+    const bool next_new_chunk = has_next && (tap == 8);
+    // ---- issue global loads for piece q+1 (consumed after the MFMA block) ----
+    if (has_next) breg = *reinterpret_cast<const float4*>(wbase + (size_t)(q + 1) * (KCH * BN) + tid * 4);
+    if (next_new_chunk) {
+      const int cbase = (chunk + 1) * KCH;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int qq = (tid + i * CONV_THREADS) & 7;
+        areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (aval[i] && cbase + qq * 4 < d.C)
+          areg[i] = *reinterpret_cast<const float4*>(a.in + gofs[i] + cbase);
+      }
+    }
+    // ---- MFMA block on the current piece ----
+    const float* Ab = (chunk & 1) ? Abuf1 : Abuf0;
+    const float* Bb = (q & 1) ? Bbuf1 : Bbuf0;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int toff = ((kh - 1) * d.Wp + (kw - 1)) * AST;
+#pragma unroll
+    for (int kk = 0; kk < KCH; kk += 2) {
+      const float b = Bb[boff + kk * BN];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av = Ab[arow[mt] + toff + kk];
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[mt], 0, 0, 0);
+      }
+    }
+    // ---- write the prefetched piece into the other buffers ----
+    if (has_next) *reinterpret_cast<float4*>(((q & 1) ? Bbuf0 : Bbuf1) + tid * 4) = breg;
+    if (next_new_chunk) {
+      float* An = (chunk & 1) ? Abuf0 : Abuf1;
+      const int cbase = (chunk + 1) * KCH;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int qq = (tid + i * CONV_THREADS) & 7;
+        if (aval[i] && cbase + qq * 4 < d.C) {
+          float* dst = An + lofs[i];
+          dst[0] = areg[i].x; dst[1] = areg[i].y; dst[2] = areg[i].z; dst[3] = areg[i].w;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ==========================================================================
+  // epilogue: accumulators -> LDS tile -> GroupNorm (fwd or bwd) -> HBM
+  // ==========================================================================
+  float* Ct = smem;                 // [BM][CT]
+  float* Xt = smem + BM * CT;       // [BM][CT]   (bwd only)
+  float* st0 = smem + 2 * BM * CT;  // [S*BN] mean / m1
+  float* st1 = st0 + d.S * BN;      // [S*BN] rstd / m2
+  float* cred = st1 + d.S * BN;     // [512][2]
+
+  const bool fwd = a.mode != CM_BWD_RELU_GN;
+  const int ncols = min(d.BNE, d.C - c0);
+  const float tval = fwd ? eval_time(a.et) : 0.f;
+  {
+    const int col = wn * 32 + l31;
+    const int c = c0 + col;
+    const bool cok = col < ncols;
+    const float bias = (fwd && cok) ? a.bias[c] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * (32 * MT) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float v = acc[mt][r];
+        if (fwd && cok && row < rows_valid) {
+          const int p = row % d.HW;
+          v += bias + tval * a.tmap[(size_t)p * d.C + c];
+        }
+        Ct[row * CT + col] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int col = tid & 63, rg = tid >> 6;  // 64 columns x 8 row groups
+  const int c = c0 + col;
+  const bool cok = col < ncols;
+  const int GT = ncols / d.cpg;             // whole groups in this tile
+  const int npairs = nsamp * GT;
+  const int m = d.HW * d.cpg;
+  const float inv_m = 1.0f / (float)m;
+
+  if (fwd) {
+    for (int pair = wave; pair < npairs; pair += 8) {
+      const int s = pair / GT, gl = pair - s * GT;
+      float sum = 0.f;
+      for (int e = lane; e < m; e += 64) {
+        const int p = e / d.cpg, cc = e - p * d.cpg;
+        sum += Ct[(s * d.HW + p) * CT + gl * d.cpg + cc];
+      }
+      const float mean = wave_sum_c(sum) * inv_m;
+      float s2 = 0.f;
+      for (int e = lane; e < m; e += 64) {
+        const int p = e / d.cpg, cc = e - p * d.cpg;
+        const float dv = Ct[(s * d.HW + p) * CT + gl * d.cpg + cc] - mean;
+        s2 += dv * dv;
+      }
+      const float var = wave_sum_c(s2) * inv_m;
+      const float rstd = 1.0f / sqrtf(var + d.eps);
+      if (lane == 0) {
+        st0[pair] = mean;
+        st1[pair] = rstd;
+        if (a.rstd_out) a.rstd_out[(size_t)(n0 + s) * d.G + c0 / d.cpg + gl] = rstd;
+      }
+    }
+    __syncthreads();
+    if (cok) {
+      const float gm = a.gamma[c], bt = a.beta[c];
+      const int gl = col / d.cpg;
+      const bool relu = a.mode == CM_FWD_GN_RELU;
+      for (int row = rg; row < rows_valid; row += 8) {
+        const int s = row / d.HW, p = row - s * d.HW;
+        const float xh = (Ct[row * CT + col] - st0[s * GT + gl]) * st1[s * GT + gl];
+        float o = xh * gm + bt;
+        if (relu) o = fmaxf(o, 0.f);
+        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c;
+        a.out[off] = a.osign * o;
+        if (a.xhat_out) a.xhat_out[off] = xh;
+      }
+    }
+  } else {
+    // ReLU mask, dxhat = du * gamma, channel partials of (dgamma, dbeta)
+    float dg = 0.f, db = 0.f;
+    if (cok) {
+      const float gm = a.gamma[c];
+      for (int row = rg; row < rows_valid; row += 8) {
+        const int s = row / d.HW, p = row - s * d.HW;
+        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c;
+        const float x = a.xhat[off];
+        const float du = a.act[off] > 0.f ? Ct[row * CT + col] : 0.f;
+        dg += du * x;
+        db += du;
+        Ct[row * CT + col] = du * gm;
+        Xt[row * CT + col] = x;
+      }
+    }
+    cred[tid * 2] = dg;
+    cred[tid * 2 + 1] = db;
+    __syncthreads();
+    if (rg == 0 && cok) {
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { dg += cred[(r * 64 + col) * 2]; db += cred[(r * 64 + col) * 2 + 1]; }
+      a.gpart[((size_t)mtile * 2 + 0) * d.C + c] = dg;
+      a.gpart[((size_t)mtile * 2 + 1) * d.C + c] = db;
+    }
+    for (int pair = wave; pair < npairs; pair += 8) {
+      const int s = pair / GT, gl = pair - s * GT;
+      float s1 = 0.f, s2 = 0.f;
+      for (int e = lane; e < m; e += 64) {
+        const int p = e / d.cpg, cc = e - p * d.cpg;
+        const int idx = (s * d.HW + p) * CT + gl * d.cpg + cc;
+        const float dxh = Ct[idx];
+        s1 += dxh;
+        s2 += dxh * Xt[idx];
+      }
+      s1 = wave_sum_c(s1) * inv_m;
+      s2 = wave_sum_c(s2) * inv_m;
+      if (lane == 0) { st0[pair] = s1; st1[pair] = s2; }
+    }
+    __syncthreads();
+    if (cok) {
+      const int gl = col / d.cpg;
+      for (int row = rg; row < rows_valid; row += 8) {
+        const int s = row / d.HW, p = row - s * d.HW;
+        const float r = a.rstd[(size_t)(n0 + s) * d.G + c0 / d.cpg + gl];
+        const float dx = r * (Ct[row * CT + col] - st0[s * GT + gl] - Xt[row * CT + col] * st1[s * GT + gl]);
+        a.out[((size_t)(n0 + s) * d.HW + p) * d.C + c] = a.osign * dx;
+      }
+    }
+  }
+}
+
+size_t conv_lds_bytes(const Dims& d, int /*mode*/) {
+  const int AROWS = d.S * d.SLOTS + 2 * d.MARGIN;
+  const size_t abuf = ((size_t)AROWS * AST + 3) & ~(size_t)3;
+  const size_t main_loop = 2 * abuf + 2 * KCH * BN;
+  const size_t epi = 2 * (size_t)d.BM * (BN + 1) + 2 * (size_t)d.S * BN + 2 * CONV_THREADS;
+  return (main_loop > epi ? main_loop : epi) * sizeof(float);
+}
+
+void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  const size_t lds = conv_lds_bytes(d, a.mode);
+  dim3 grid(d.mtiles, d.ntile);
+  if (d.BM == 128) {
+    static bool attr1 = false;
+    if (!attr1) { (void)hipFuncSetAttribute((const void*)k_conv3x3<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    hipLaunchKernelGGL(k_conv3x3<1>, grid, dim3(CONV_THREADS), lds, s, a, d);
+  } else {
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)k_conv3x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+    hipLaunchKernelGGL(k_conv3x3<2>, grid, dim3(CONV_THREADS), lds, s, a, d);
+  }
+}
+
+// ============================================================================
+// wgrad: dW[tap][ci][co] = sum_{n,p} act[n, p + tap, ci] * dz[n, p, co]
+// Workgroup tile: 64 ci x 64 co x 9 taps (4 waves, each 32x32x9 = 144 accumulator
+// registers), K = pixels, split over `nsplit` ranges of (sample, row-band) units;
+// deterministic per-split partial slabs reduced by k_theta_finalize.
+// The workgroups of ci-tile 0 also form the masked column sums of dz that give the
+// conv-bias, time-channel-weight and d/dt terms.
+// ============================================================================
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradArgs a, Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int ntc = (d.C + 63) / 64;
+  const int ci_t = blockIdx.x / ntc, co_t = blockIdx.x - ci_t * ntc;
+  const int ci0 = ci_t * 64, co0 = co_t * 64;
+  const int sp = blockIdx.y;
+
+  const int band_slots = (d.RB + 2) * d.Wp;
+  const int AROWS = band_slots + 2 * d.MARGIN;
+  const int band_px = d.RB * d.W;
+  float* As = smem;                          // [AROWS][64]
+  float* Zs = As + (size_t)AROWS * 64;       // [band_px + 1][64]
+  int* slot_tab = reinterpret_cast<int*>(Zs + (size_t)(band_px + 1) * 64);  // [band_px]
+  float* sred = reinterpret_cast<float*>(slot_tab + ((band_px + 3) & ~3));  // [256][9]
+
+  for (int i = tid; i < AROWS * 64 + (band_px + 1) * 64; i += WG_THREADS) smem[i] = 0.f;
+  for (int p = tid; p < band_px; p += WG_THREADS) slot_tab[p] = (p / d.W + 1) * d.Wp + (p % d.W) + 1;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float ssum[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) ssum[t] = 0.f;
+
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * d.Wp + (t % 3 - 1)) * 64;
+
+  const int U = d.N * d.nbands;
+  const int u_begin = (int)(((long long)sp * U) / d.nsplit);
+  const int u_end = (int)(((long long)(sp + 1) * U) / d.nsplit);
+  const bool do_sums = (ci_t == 0);
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const int n = u / d.nbands, band = u - n * d.nbands;
+    const int row0 = band * d.RB;
+    const int rbe = min(d.RB, d.H - row0);   // image rows in this band
+    const int npx = rbe * d.W;
+    __syncthreads();  // previous unit's MFMA reads done
+    // ---- stage activations (with one halo row above/below) ----
+    {
+      const int nunits = (d.RB + 2) * d.W * 16;
+      for (int v = tid; v < nunits; v += WG_THREADS) {
+        const int q = v & 15;
+        const int px = v >> 4;
+        const int hr = px / d.W, x = px - hr * d.W;
+        const int ih = row0 + hr - 1;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ih >= 0 && ih < d.H && hr <= rbe + 1 && ci0 + q * 4 < d.C)
+          val = *reinterpret_cast<const float4*>(a.act + ((size_t)n * d.HW + ih * d.W + x) * d.C + ci0 + q * 4);
+        *reinterpret_cast<float4*>(As + (size_t)(d.MARGIN + hr * d.Wp + x + 1) * 64 + q * 4) = val;
+      }
+      const int zunits = band_px * 16;
+      for (int v = tid; v < zunits; v += WG_THREADS) {
+        const int q = v & 15;
+        const int r = v >> 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < npx && co0 + q * 4 < d.C)
+          val = *reinterpret_cast<const float4*>(a.dz + ((size_t)n * d.HW + row0 * d.W + r) * d.C + co0 + q * 4);
+        *reinterpret_cast<float4*>(Zs + (size_t)r * 64 + q * 4) = val;
+      }
+    }
+    __syncthreads();
+    // ---- masked column sums (bias / time-channel / d-dt terms) ----
+    if (do_sums) {
+      const int cj = tid & 63, part = tid >> 6;
+      for (int r = part; r < npx; r += 4) {
+        const float z = Zs[r * 64 + cj];
+        const int lr = r / d.W, x = r - lr * d.W;
+        const int h = row0 + lr;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = h + t / 3 - 1, xx = x + t % 3 - 1;
+          if (hh >= 0 && hh < d.H && xx >= 0 && xx < d.W) ssum[t] += z;
+        }
+      }
+    }
+    // ---- MFMA: K = pixel pairs of the band ----
+    const int npairs = (npx + 1) >> 1;
+    for (int kp = 0; kp < npairs; ++kp) {
+      const int p0 = 2 * kp + hi;
+      const bool ok = p0 < npx;
+      const int aoff = (d.MARGIN + (ok ? slot_tab[p0] : 0)) * 64 + wi * 32 + l31;
+      const float b = Zs[(ok ? p0 : band_px) * 64 + wj * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float av = As[aoff + toff[t]];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- store the partial slab ----
+  const size_t CC = (size_t)d.C * d.C;
+  float* wp = a.wpart + (size_t)sp * 9 * CC;
+  const int co = co0 + wj * 32 + l31;
+  if (co < d.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (ci < d.C) wp[(size_t)t * CC + (size_t)ci * d.C + co] = acc[t][r];
+      }
+    }
+  }
+  if (do_sums) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sred[tid * 9 + t] = ssum[t];
+    __syncthreads();
+    const int cj = tid & 63, part = tid >> 6;
+    if (part == 0 && co0 + cj < d.C) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float v = (sred[cj * 9 + t] + sred[(64 + cj) * 9 + t]) + (sred[(128 + cj) * 9 + t] + sred[(192 + cj) * 9 + t]);
+        a.spart[((size_t)sp * 9 + t) * d.C + co0 + cj] = v;
+      }
+    }
+  }
+}
+
+size_t wgrad_lds_bytes(const Dims& d) {
+  const int band_slots = (d.RB + 2) * d.Wp;
+  const int AROWS = band_slots + 2 * d.MARGIN;
+  const int band_px = d.RB * d.W;
+  size_t fl = (size_t)AROWS * 64 + (size_t)(band_px + 1) * 64 + ((band_px + 3) & ~3) + 256 * 9;
+  return fl * sizeof(float);
+}
+
+void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  const int ntc = (d.C + 63) / 64;
+  hipLaunchKernelGGL(k_wgrad, dim3(ntc * ntc, d.nsplit), dim3(WG_THREADS), wgrad_lds_bytes(d), s, a, d);
+}
+
+}  // namespace node

@@ -1,0 +1,140 @@
+// Layout kernels: NCHW <-> NHWC at the solve boundary, weight packing for the
+// implicit-GEMM B operand, the time-channel border map, and the theta-segment
+// -> PyTorch flat parameter layout conversion.  All HBM-bound and tiny next to
+// the convolutions (run once per solve, not per stage).
+#include "node_internal.h"
+
+namespace node {
+
+// ---------------------------------------------------------------- transposes
+// per sample: [C][HW] <-> [HW][C] through a 32x33 LDS tile
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst,
+                                                   int rows, int cols) {
+  // src: [n][rows][cols] -> dst: [n][cols][rows]
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* s = src + (size_t)n * rows * cols;
+  float* d = dst + (size_t)n * rows * cols;
+  for (int i = ty; i < 32; i += 8) {
+    int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = s[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) d[(size_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+void launch_nchw_to_nhwc(const Dims& d, const float* src, float* dst, hipStream_t s) {
+  dim3 grid((d.HW + 31) / 32, (d.C + 31) / 32, d.N);
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, src, dst, d.C, d.HW);
+}
+void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_t s) {
+  dim3 grid((d.C + 31) / 32, (d.HW + 31) / 32, d.N);
+  hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, s, src, dst, d.HW, d.C);
+}
+
+// ------------------------------------------------------------- weight packing
+// packed[nt][ch][tap][kk][j]  (32 x 64 floats per (nt, ch, tap) piece, contiguous)
+//   forward : value = W[co = nt*BNE + j][1 + ci = ch*32 + kk][kh][kw],           tap = kh*3 + kw
+//   dgrad   : value = W[co = ch*32 + kk][1 + ci = nt*BNE + j][2 - kh][2 - kw]    (flipped, transposed)
+// zero outside C / beyond BNE so padded K rows and N columns contribute nothing.
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, float* __restrict__ packed,
+                                                      int C, int BNE, int ntile, int nchunk, int dgrad) {
+  size_t total = (size_t)ntile * nchunk * 9 * KCH * BN;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    int j = idx % BN;
+    size_t r = idx / BN;
+    int kk = r % KCH; r /= KCH;
+    int tap = r % 9; r /= 9;
+    int ch = r % nchunk;
+    int nt = r / nchunk;
+    int kh = tap / 3, kw = tap % 3;
+    int kidx = ch * KCH + kk;        // K index (input channel of this GEMM)
+    int nidx = nt * BNE + j;         // N index (output channel of this GEMM)
+    float v = 0.f;
+    if (j < BNE && kidx < C && nidx < C) {
+      if (!dgrad) {
+        v = w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+      } else {
+        v = w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)];
+      }
+    }
+    packed[idx] = v;
+  }
+}
+
+void launch_pack_weights(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
+  size_t total = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, d.nchunk, dgrad);
+}
+
+// -------------------------------------------------------------- time-channel map
+// The constant-t channel (model.py:321-322) is zero-padded like every other input
+// channel, so its contribution is t * sum of the taps that fall inside the image:
+//   tmap[p][co] = sum_{kh,kw : (h+kh-1, w+kw-1) in bounds} W[co][0][kh][kw]
+__global__ __launch_bounds__(256) void k_tmap(const float* __restrict__ w, float* __restrict__ tmap, int C, int H, int W) {
+  int HW = H * W;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW * C; idx += gridDim.x * blockDim.x) {
+    int co = idx % C, p = idx / C;
+    int h = p / W, x = p % W;
+    float sum = 0.f;
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) {
+        int hh = h + kh - 1, ww = x + kw - 1;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) sum += w[(((size_t)co * (C + 1)) * 3 + kh) * 3 + kw];
+      }
+    tmap[idx] = sum;
+  }
+}
+void launch_tmap(const Dims& d, const float* w, float* tmap, hipStream_t s) {
+  int total = d.HW * d.C;
+  hipLaunchKernelGGL(k_tmap, dim3((total + 255) / 256), dim3(256), 0, s, w, tmap, d.C, d.H, d.W);
+}
+
+// ---------------------------------------------- theta internal -> PyTorch flat
+// flat (parameters() order): norm1.w, norm1.b, conv1.w [C][C+1][3][3], conv1.b, norm2.w, ...
+__global__ __launch_bounds__(256) void k_theta_to_torch(const float* __restrict__ th, float* __restrict__ flat, int C) {
+  const ThetaLayout L = theta_layout(C);
+  const size_t cw = (size_t)C * (C + 1) * 9;
+  const size_t P = 6 * (size_t)C + 2 * (cw + C);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < P; idx += (size_t)gridDim.x * blockDim.x) {
+    size_t r = idx;
+    float v;
+    int layer = 0;
+    for (;;) {
+      if (r < (size_t)C) { v = th[L.g[layer] + r]; break; }
+      r -= C;
+      if (r < (size_t)C) { v = th[L.b[layer] + r]; break; }
+      r -= C;
+      if (layer == 2) { v = 0.f; break; }  // unreachable
+      if (r < cw) {
+        int kw = r % 3; size_t q = r / 3;
+        int kh = q % 3; q /= 3;
+        int cin = q % (C + 1);
+        int co = q / (C + 1);
+        int tap = kh * 3 + kw;
+        if (cin == 0) v = th[L.wt[layer] + (size_t)tap * C + co];
+        else v = th[L.wc[layer] + ((size_t)tap * C + (cin - 1)) * C + co];
+        break;
+      }
+      r -= cw;
+      if (r < (size_t)C) { v = th[L.cb[layer] + r]; break; }
+      r -= C;
+      ++layer;
+    }
+    flat[idx] = v;
+  }
+}
+void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s) {
+  int blocks = (int)((d.P + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_theta_to_torch, dim3(blocks), dim3(256), 0, s, theta_int, flat, d.C);
+}
+
+}  // namespace node

@@ -1,0 +1,717 @@
+// HBM-bound kernels of the integrator: Butcher-tableau stage combine fused with
+// GroupNorm+ReLU (and its backward), the wavefront-reduced error norm, the
+// device-resident step controller (accept / dt / t never leave the GPU except
+// for one 64-byte read-back per step), Hairer's initial step, and the quartic
+// dense-output interpolant.
+//
+// Algorithm follows the restated torchdiffeq spec; the CPU
+// statement of the same arithmetic is oracle/torchdiffeq_restated.py.
+#include "node_internal.h"
+#include "../../include/node_hip.h"
+
+namespace node {
+
+// Dormand-Prince / Shampine coefficients (rounded to fp32 exactly as
+// `fp32_tensor * python_float` does on the reference path).
+__device__ __constant__ float c_CSOL[7] = {
+    (float)(35.0 / 384.0), 0.f, (float)(500.0 / 1113.0), (float)(125.0 / 192.0),
+    (float)(-2187.0 / 6784.0), (float)(11.0 / 84.0), 0.f};
+__device__ __constant__ float c_CERR[7] = {
+    (float)(35.0 / 384.0 - 1951.0 / 21600.0), 0.f, (float)(500.0 / 1113.0 - 22642.0 / 50085.0),
+    (float)(125.0 / 192.0 - 451.0 / 720.0), (float)(-2187.0 / 6784.0 - -12231.0 / 42400.0),
+    (float)(11.0 / 84.0 - 649.0 / 6300.0), (float)(-1.0 / 60.0)};
+__device__ __constant__ float c_CMID[7] = {
+    (float)(6025192743.0 / 30085553152.0 / 2.0), 0.f, (float)(51252292925.0 / 65400821598.0 / 2.0),
+    (float)(-2691868925.0 / 45128329728.0 / 2.0), (float)(187940372067.0 / 1594534317056.0 / 2.0),
+    (float)(-1776094331.0 / 19743644256.0 / 2.0), (float)(11237099.0 / 235043384.0 / 2.0)};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// deterministic block sum (256 threads), result valid in every thread
+__device__ inline float block_sum_256(float v, float* red /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ inline float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ============================================================================
+// Stage combine + GroupNorm + ReLU
+//   y_i  = y + scale * sum_j coef_j k_j                  (Butcher row)
+//   act  = relu(GN(y_i) * gamma + beta)                   (model.py:341-342)
+// One workgroup owns (sample n, a slab of whole groups): the combined values stay
+// in LDS between the statistics pass and the normalise pass, so y_i is never
+// written to HBM unless the caller asks for it (last stage -> y1).
+// ============================================================================
+__global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x, c0 = blockIdx.y * d.cs;
+  const int csl = min(d.cs, d.C - c0);
+  const int cs4 = csl >> 2;
+  const int nvec = d.HW * cs4;
+  float* tile = smem;                      // [HW][csl]
+  float* smean = smem + d.HW * d.cs;       // [cs/cpg]
+  float* srstd = smean + d.cs;             // generous
+
+  const float scale = comb_scale(a.comb, a.ctrl);
+  float cf[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
+
+  for (int v = tid; v < nvec; v += 256) {
+    const int p = v / cs4, q = v - p * cs4;
+    const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
+    float4 yv = ld4(a.comb.y + off);
+    if (a.comb.nk > 0) {
+      float4 s;
+      {
+        float4 kv = ld4(a.comb.k[0] + off);
+        s.x = cf[0] * kv.x; s.y = cf[0] * kv.y; s.z = cf[0] * kv.z; s.w = cf[0] * kv.w;
+      }
+      for (int j = 1; j < a.comb.nk; ++j) {
+        float4 kv = ld4(a.comb.k[j] + off);
+        s.x += cf[j] * kv.x; s.y += cf[j] * kv.y; s.z += cf[j] * kv.z; s.w += cf[j] * kv.w;
+      }
+      yv.x += s.x; yv.y += s.y; yv.z += s.z; yv.w += s.w;
+    }
+    st4(tile + p * csl + 4 * q, yv);
+    if (a.y_out) st4(a.y_out + off, yv);
+  }
+  __syncthreads();
+
+  const int ngs = csl / d.cpg;
+  const int m = d.HW * d.cpg;
+  const float inv_m = 1.0f / (float)m;
+  for (int gi = wave; gi < ngs; gi += 4) {
+    float s = 0.f;
+    for (int e = lane; e < m; e += 64) {
+      const int p = e / d.cpg, cc = e - p * d.cpg;
+      s += tile[p * csl + gi * d.cpg + cc];
+    }
+    const float mean = wave_sum(s) * inv_m;
+    float s2 = 0.f;
+    for (int e = lane; e < m; e += 64) {
+      const int p = e / d.cpg, cc = e - p * d.cpg;
+      const float dv = tile[p * csl + gi * d.cpg + cc] - mean;
+      s2 += dv * dv;
+    }
+    const float var = wave_sum(s2) * inv_m;
+    const float rstd = 1.0f / sqrtf(var + d.eps);
+    if (lane == 0) {
+      smean[gi] = mean;
+      srstd[gi] = rstd;
+      if (a.rstd_out) a.rstd_out[(size_t)n * d.G + c0 / d.cpg + gi] = rstd;
+    }
+  }
+  __syncthreads();
+
+  for (int v = tid; v < nvec; v += 256) {
+    const int p = v / cs4, q = v - p * cs4;
+    const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
+    const float4 xv = ld4(tile + p * csl + 4 * q);
+    const float4 gm = ld4(a.gamma + c0 + 4 * q);
+    const float4 bt = ld4(a.beta + c0 + 4 * q);
+    float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    float g[4] = {gm.x, gm.y, gm.z, gm.w};
+    float b[4] = {bt.x, bt.y, bt.z, bt.w};
+    float xh[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gl = (4 * q + i) / d.cpg;
+      xh[i] = (x[i] - smean[gl]) * srstd[gl];
+      o[i] = fmaxf(xh[i] * g[i] + b[i], 0.f);
+    }
+    st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
+    if (a.xhat_out) st4(a.xhat_out + off, make_float4(xh[0], xh[1], xh[2], xh[3]));
+  }
+}
+
+void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s) {
+  size_t lds = ((size_t)d.HW * d.cs + 2 * (size_t)d.cs) * sizeof(float);
+  hipLaunchKernelGGL(k_combine_gn, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
+}
+
+// ============================================================================
+// Top of the backward chain: combine the adjoint state, negate it into the
+// cotangent and push it through GroupNorm-3's backward.
+//   g   = csign * (a + scale * sum coef_j k^a_j)
+//   dz  = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+//   per-sample partials of dgamma = sum g*xhat, dbeta = sum g
+// ============================================================================
+__global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x, c0 = blockIdx.y * d.cs;
+  const int csl = min(d.cs, d.C - c0);
+  const int cs4 = csl >> 2;
+  const int nvec = d.HW * cs4;
+  float* gt = smem;                           // [HW][csl]   g
+  float* xt = gt + d.HW * d.cs;               // [HW][csl]   xhat
+  float* sm1 = xt + d.HW * d.cs;              // [cs]
+  float* sm2 = sm1 + d.cs;                    // [cs]
+  float* cred = sm2 + d.cs;                   // [256][2] channel partials
+
+  const float scale = comb_scale(a.comb, a.ctrl);
+  float cf[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
+
+  for (int v = tid; v < nvec; v += 256) {
+    const int p = v / cs4, q = v - p * cs4;
+    const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
+    float4 av = ld4(a.comb.y + off);
+    if (a.comb.nk > 0) {
+      float4 s;
+      {
+        float4 kv = ld4(a.comb.k[0] + off);
+        s.x = cf[0] * kv.x; s.y = cf[0] * kv.y; s.z = cf[0] * kv.z; s.w = cf[0] * kv.w;
+      }
+      for (int j = 1; j < a.comb.nk; ++j) {
+        float4 kv = ld4(a.comb.k[j] + off);
+        s.x += cf[j] * kv.x; s.y += cf[j] * kv.y; s.z += cf[j] * kv.z; s.w += cf[j] * kv.w;
+      }
+      av.x += s.x; av.y += s.y; av.z += s.z; av.w += s.w;
+    }
+    if (a.a_out) st4(a.a_out + off, av);
+    st4(gt + p * csl + 4 * q, make_float4(a.csign * av.x, a.csign * av.y, a.csign * av.z, a.csign * av.w));
+    st4(xt + p * csl + 4 * q, ld4(a.xhat + off));
+  }
+  __syncthreads();
+
+  // per-channel partial sums over the sample's pixels (dgamma, dbeta)
+  {
+    const int npg = csl <= 256 ? 256 / csl : 1;
+    for (int cbase = 0; cbase < csl; cbase += 256) {
+      const int cl = cbase + (tid % min(csl, 256));
+      const int pg = tid / min(csl, 256);
+      float dg = 0.f, db = 0.f;
+      if (pg < npg && cl < csl) {
+        for (int p = pg; p < d.HW; p += npg) {
+          const float g = gt[p * csl + cl];
+          dg += g * xt[p * csl + cl];
+          db += g;
+        }
+      }
+      cred[tid * 2] = dg;
+      cred[tid * 2 + 1] = db;
+      __syncthreads();
+      if (pg == 0 && cl < csl) {
+        const int stride = min(csl, 256);
+        for (int r = 1; r < npg; ++r) {
+          dg += cred[(r * stride + (tid % stride)) * 2];
+          db += cred[(r * stride + (tid % stride)) * 2 + 1];
+        }
+        a.gpart[((size_t)n * 2 + 0) * d.C + c0 + cl] = dg;
+        a.gpart[((size_t)n * 2 + 1) * d.C + c0 + cl] = db;
+      }
+      __syncthreads();
+    }
+  }
+
+  const int ngs = csl / d.cpg;
+  const int m = d.HW * d.cpg;
+  const float inv_m = 1.0f / (float)m;
+  for (int gi = wave; gi < ngs; gi += 4) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = lane; e < m; e += 64) {
+      const int p = e / d.cpg, cc = e - p * d.cpg;
+      const int col = gi * d.cpg + cc;
+      const float dxh = gt[p * csl + col] * a.gamma[c0 + col];
+      s1 += dxh;
+      s2 += dxh * xt[p * csl + col];
+    }
+    s1 = wave_sum(s1) * inv_m;
+    s2 = wave_sum(s2) * inv_m;
+    if (lane == 0) { sm1[gi] = s1; sm2[gi] = s2; }
+  }
+  __syncthreads();
+
+  for (int v = tid; v < nvec; v += 256) {
+    const int p = v / cs4, q = v - p * cs4;
+    const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
+    const float4 gv = ld4(gt + p * csl + 4 * q);
+    const float4 xv = ld4(xt + p * csl + 4 * q);
+    const float4 gm = ld4(a.gamma + c0 + 4 * q);
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    float w[4] = {gm.x, gm.y, gm.z, gm.w};
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gl = (4 * q + i) / d.cpg;
+      const float r = a.rstd[(size_t)n * d.G + c0 / d.cpg + gl];
+      o[i] = r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]);
+    }
+    st4(a.dz_out + off, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
+  size_t lds = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs + 512) * sizeof(float);
+  hipLaunchKernelGGL(k_gn_bwd, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
+}
+
+// ============================================================================
+// Error norm:  sum_i (err_i / (atol + rtol*max(|y0_i|,|y1_i|)))^2,
+//   err = dt * sum_j c_err_j k_j    -- wave-reduced, one partial per workgroup
+// For segments whose intermediate stages are never consumed (adj_params) the same
+// pass also forms y1 = y0 + dt * sum_j b_j k_j.
+// ============================================================================
+__global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl, float rtol, float atol, float* partial) {
+  __shared__ float red[4];
+  const float dtf = (float)ctrl->dt;
+  float ce[7], cb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { ce[j] = dtf * c_CERR[j]; cb[j] = dtf * c_CSOL[j]; }
+  float acc = 0.f;
+  const size_t n4 = seg.n >> 2;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n4; v += stride) {
+    const size_t off = v * 4;
+    float4 kv[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) kv[j] = (j == 1) ? make_float4(0, 0, 0, 0) : ld4(seg.k[j] + off);
+    const float4 y0 = ld4(seg.y0 + off);
+    float4 y1;
+    if (seg.compute_y1) {
+      float4 s;
+      s.x = cb[0] * kv[0].x; s.y = cb[0] * kv[0].y; s.z = cb[0] * kv[0].z; s.w = cb[0] * kv[0].w;
+#pragma unroll
+      for (int j = 2; j < 6; ++j) { s.x += cb[j] * kv[j].x; s.y += cb[j] * kv[j].y; s.z += cb[j] * kv[j].z; s.w += cb[j] * kv[j].w; }
+      y1 = make_float4(y0.x + s.x, y0.y + s.y, y0.z + s.z, y0.w + s.w);
+      st4(seg.y1 + off, y1);
+    } else {
+      y1 = ld4(seg.y1 + off);
+    }
+    float4 e;
+    e.x = ce[0] * kv[0].x; e.y = ce[0] * kv[0].y; e.z = ce[0] * kv[0].z; e.w = ce[0] * kv[0].w;
+#pragma unroll
+    for (int j = 2; j < 7; ++j) { e.x += ce[j] * kv[j].x; e.y += ce[j] * kv[j].y; e.z += ce[j] * kv[j].z; e.w += ce[j] * kv[j].w; }
+    float r;
+    r = e.x / (atol + rtol * fmaxf(fabsf(y0.x), fabsf(y1.x))); acc += r * r;
+    r = e.y / (atol + rtol * fmaxf(fabsf(y0.y), fabsf(y1.y))); acc += r * r;
+    r = e.z / (atol + rtol * fmaxf(fabsf(y0.z), fabsf(y1.z))); acc += r * r;
+    r = e.w / (atol + rtol * fmaxf(fabsf(y0.w), fabsf(y1.w))); acc += r * r;
+  }
+  // scalar tail (n % 4), handled by block 0
+  if (blockIdx.x == 0) {
+    for (size_t i = (n4 << 2) + threadIdx.x; i < seg.n; i += 256) {
+      float kk[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) kk[j] = (j == 1) ? 0.f : seg.k[j][i];
+      const float y0 = seg.y0[i];
+      float y1;
+      if (seg.compute_y1) {
+        float s = cb[0] * kk[0];
+#pragma unroll
+        for (int j = 2; j < 6; ++j) s += cb[j] * kk[j];
+        y1 = y0 + s;
+        seg.y1[i] = y1;
+      } else {
+        y1 = seg.y1[i];
+      }
+      float e = ce[0] * kk[0];
+#pragma unroll
+      for (int j = 2; j < 7; ++j) e += ce[j] * kk[j];
+      const float r = e / (atol + rtol * fmaxf(fabsf(y0), fabsf(y1)));
+      acc += r * r;
+    }
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+void launch_error_norm(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(k_error_norm, dim3(ERR_BLOCKS), dim3(256), 0, s, seg, ctrl, rtol, atol, partial);
+}
+
+// ============================================================================
+// Step controller (one workgroup).  Mirrors `_adaptive_dopri5_step` /
+// `_optimal_step_size` of the restated solver: accept iff every segment's mean
+// squared error ratio <= 1; dt <- dt / clamp(sqrt(max ratio)^(1/5)/0.9, 0.1, 1/dfactor).
+// t / dt are float64 like upstream's adaptive solvers.
+// ============================================================================
+__device__ inline float reduce_partials_512(const float* p, float* red) {
+  float v = p[threadIdx.x] + p[threadIdx.x + 256];
+  return block_sum_256(v, red);
+}
+
+__global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
+  __shared__ float red[4];
+  __shared__ float ratios[4];
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const float tot = reduce_partials_512(a.partial[sgi], red);
+    if (threadIdx.x == 0) ratios[sgi] = (float)((double)tot / a.numel[sgi]);
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  Ctrl* c = a.ctrl;
+  const double t = c->t, dt = c->dt;
+  const float dtf = (float)dt;
+  int nr = a.nseg;
+  if (a.has_scalar) {
+    float e = (dtf * c_CERR[0]) * c->ts_k[0];
+    float s = (dtf * c_CSOL[0]) * c->ts_k[0];
+#pragma unroll
+    for (int j = 2; j < 7; ++j) { e += (dtf * c_CERR[j]) * c->ts_k[j]; if (j < 6) s += (dtf * c_CSOL[j]) * c->ts_k[j]; }
+    const float y1 = c->ts_cur + s;
+    const float r = e / (a.atol + a.rtol * fmaxf(fabsf(c->ts_cur), fabsf(y1)));
+    ratios[nr++] = r * r;
+    c->ts_new = y1;
+  }
+  bool accept = true, nan = false;
+  float maxr = 0.f;
+  for (int i = 0; i < nr; ++i) {
+    const float r = ratios[i];
+    if (!(r <= 1.0f)) accept = false;
+    if (r != r) nan = true;
+    maxr = fmaxf(maxr, r);
+    c->ratio[i] = r;
+  }
+  for (int i = nr; i < 4; ++i) c->ratio[i] = 0.f;
+  double dt_next;
+  if (a.forced) {
+    accept = true;
+    dt_next = a.forced_next;
+  } else if (nan) {
+    c->status = NODE_ERR_NONFINITE;
+    dt_next = dt;
+  } else if (maxr == 0.f) {
+    dt_next = dt * 10.0;
+  } else {
+    const double dfactor = maxr < 1.0f ? 1.0 : 0.2;
+    const double er = (double)sqrtf(maxr);
+    double factor = pow(er, 0.2) / 0.9;
+    factor = fmin(factor, 1.0 / dfactor);
+    factor = fmax(0.1, factor);
+    dt_next = dt / factor;
+  }
+  c->t_prev = t;
+  c->dt_used = dt;
+  c->accept = accept ? 1 : 0;
+  if (accept) {
+    c->t = t + dt;
+    c->n_acc += 1;
+    if (a.has_scalar) {  // keep the step's (y0, f0) for dense output, then FSAL
+      c->ts_y0_prev = c->ts_cur;
+      c->ts_f0_prev = c->ts_k[0];
+      c->ts_cur = c->ts_new;
+      c->ts_k[0] = c->ts_k[6];
+    }
+  } else {
+    c->n_rej += 1;
+  }
+  c->dt = dt_next;
+}
+
+void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);
+}
+
+// ============================================================================
+// Hairer initial step (`_select_initial_step`, order argument 4)
+//   phase 0: sum (y0/scale)^2, sum (f0/scale)^2      scale = atol + |y0| rtol
+//   phase 1: sum ((f1-f0)/scale)^2
+// ============================================================================
+__global__ __launch_bounds__(256) void k_init_norms(InitSeg seg, float rtol, float atol, int phase, float* partial) {
+  __shared__ float red[4];
+  float a0 = 0.f, a1 = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < seg.n; i += stride) {
+    const float y = seg.y0[i];
+    const float sc = atol + fabsf(y) * rtol;
+    if (phase == 0) {
+      const float u = y / sc, v = seg.f0[i] / sc;
+      a0 += u * u;
+      a1 += v * v;
+    } else {
+      const float u = (seg.f1[i] - seg.f0[i]) / sc;
+      a0 += u * u;
+    }
+  }
+  const float t0 = block_sum_256(a0, red);
+  const float t1 = block_sum_256(a1, red);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = t0; partial[blockIdx.x * 2 + 1] = t1; }
+}
+void launch_init_norms(const InitSeg& seg, float rtol, float atol, int phase, float* partial, const Ctrl*, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_norms, dim3(ERR_BLOCKS), dim3(256), 0, s, seg, rtol, atol, phase, partial);
+}
+
+__global__ __launch_bounds__(256) void k_init_controller(InitCtlArgs a) {
+  __shared__ float red[4];
+  __shared__ float sums[3][2];
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const float* p = a.partial[sgi];
+    float v0 = p[threadIdx.x * 2] + p[(threadIdx.x + 256) * 2];
+    float v1 = p[threadIdx.x * 2 + 1] + p[(threadIdx.x + 256) * 2 + 1];
+    v0 = block_sum_256(v0, red);
+    v1 = block_sum_256(v1, red);
+    if (threadIdx.x == 0) { sums[sgi][0] = v0; sums[sgi][1] = v1; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  Ctrl* c = a.ctrl;
+  if (a.phase == 0) {
+    float d0max = 0.f, d1max = 0.f, qmax = -INFINITY;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) {
+      const float d0 = sqrtf((float)((double)sums[sgi][0] / a.numel[sgi]));
+      const float d1 = sqrtf((float)((double)sums[sgi][1] / a.numel[sgi]));
+      d0max = fmaxf(d0max, d0);
+      d1max = fmaxf(d1max, d1);
+      qmax = fmaxf(qmax, d0 / d1);
+    }
+    if (a.has_scalar) {
+      const float sc = a.atol + fabsf(c->ts_cur) * a.rtol;
+      const float d0 = fabsf(c->ts_cur / sc), d1 = fabsf(c->ts_k[0] / sc);
+      d0max = fmaxf(d0max, d0);
+      d1max = fmaxf(d1max, d1);
+      qmax = fmaxf(qmax, d0 / d1);
+    }
+    float h0;
+    if (d0max < 1e-5f || d1max < 1e-5f) h0 = 1e-6f;
+    else h0 = 0.01f * qmax;
+    c->h0 = h0;
+    c->d0 = d0max;
+    c->d1 = d1max;
+  } else {
+    const float h0 = c->h0;
+    float d2max = 0.f;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) {
+      const float d2 = sqrtf((float)((double)sums[sgi][0] / a.numel[sgi])) / h0;
+      d2max = fmaxf(d2max, d2);
+    }
+    if (a.has_scalar) {
+      const float sc = a.atol + fabsf(c->ts_cur) * a.rtol;
+      d2max = fmaxf(d2max, fabsf((c->ts_k[1] - c->ts_k[0]) / sc) / h0);
+    }
+    float h1;
+    if (c->d1 <= 1e-15f && d2max <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+    else h1 = powf(0.01f / fmaxf(c->d1, d2max), 1.0f / 5.0f);
+    c->dt = (double)fminf(100.f * h0, h1);
+  }
+}
+void launch_init_controller(const InitCtlArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_controller, dim3(1), dim3(256), 0, s, a);
+}
+
+__global__ void k_set_ctrl(Ctrl* c, double t, double dt, int reset) {
+  c->t = t;
+  c->dt = dt;
+  c->t_prev = t;
+  c->dt_used = 0.0;
+  if (reset) {
+    c->accept = 0; c->status = 0; c->n_acc = 0; c->n_rej = 0; c->h0 = 0.f; c->d0 = 0.f; c->d1 = 0.f;
+    for (int i = 0; i < 4; ++i) c->ratio[i] = 0.f;
+    c->ts_cur = 0.f; c->ts_new = 0.f; c->ts_y0_prev = 0.f; c->ts_f0_prev = 0.f;
+    for (int i = 0; i < 7; ++i) c->ts_k[i] = 0.f;
+  }
+}
+void launch_set_ctrl(Ctrl* ctrl, double t, double dt, int reset, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_ctrl, dim3(1), dim3(1), 0, s, ctrl, t, dt, reset);
+}
+// which: 0 ts_cur = v ; 1 rk4 end-of-step: ts_cur += dt*(k0+3k1+3k2+k3)/8 ; 2 ts_k[0] = ts_k[6]
+__global__ void k_set_scalar_state(Ctrl* c, float v, int which) {
+  if (which == 0) c->ts_cur = v;
+  else if (which == 1) {
+    const float dtf = (float)c->dt;
+    c->ts_cur = c->ts_cur + (c->ts_k[0] + 3.f * c->ts_k[1] + 3.f * c->ts_k[2] + c->ts_k[3]) * (dtf * 0.125f);
+  } else if (which == 2) c->ts_k[0] = c->ts_k[6];
+}
+void launch_set_scalar_state(Ctrl* ctrl, float v, int which, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_scalar_state, dim3(1), dim3(1), 0, s, ctrl, v, which);
+}
+
+// ============================================================================
+// Dense output: quartic through (y0, y1, y_mid, f0, f1) of the last accepted step
+//   (`_interp_fit_dopri5` + `_interp_evaluate`, power form like upstream)
+// ============================================================================
+__device__ inline float interp_one(float y0, float y1, const float* k, float dt, float x) {
+  float s = (dt * c_CMID[0]) * k[0];
+#pragma unroll
+  for (int j = 2; j < 7; ++j) s += (dt * c_CMID[j]) * k[j];
+  const float ymid = y0 + s;
+  const float f0 = k[0], f1 = k[6];
+  const float ca = (-2.f * dt) * f0 + (2.f * dt) * f1 + -8.f * y0 + -8.f * y1 + 16.f * ymid;
+  const float cb = (5.f * dt) * f0 + (-3.f * dt) * f1 + 18.f * y0 + 14.f * y1 + -32.f * ymid;
+  const float cc = (-4.f * dt) * f0 + dt * f1 + -11.f * y0 + -5.f * y1 + 16.f * ymid;
+  const float cd = dt * f0;
+  const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+  return ca * x4 + cb * x3 + cc * x2 + cd * x + y0;
+}
+__global__ __launch_bounds__(256) void k_interp(InterpArgs a) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+    float kk[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) kk[j] = (j == 1) ? 0.f : a.k[j][i];
+    a.out[i] = interp_one(a.y0[i], a.y1[i], kk, a.dt, a.x);
+  }
+}
+void launch_interp(const InterpArgs& a, hipStream_t s) {
+  size_t blocks = (a.n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_interp, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+// scalar segment: called right after an ACCEPTED step: ts_cur already holds y1, ts_k[0] holds f1 (FSAL
+// copy), so the controller's pre-accept values are reconstructed from ts_new/ts_k[6].
+__global__ void k_interp_scalar(Ctrl* c, float dt, float x) {
+  // y1 = ts_new, f1 = ts_k[6]; (y0, f0) of the step were saved by the controller before FSAL
+  float kk[7];
+  for (int j = 0; j < 7; ++j) kk[j] = c->ts_k[j];
+  kk[0] = c->ts_f0_prev;
+  c->ts_cur = interp_one(c->ts_y0_prev, c->ts_new, kk, dt, x);
+}
+void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s) {
+  hipLaunchKernelGGL(k_interp_scalar, dim3(1), dim3(1), 0, s, ctrl, dt, x);
+}
+
+__global__ __launch_bounds__(256) void k_axpy(float* y, const float* x, float alpha, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += alpha * x[i];
+}
+void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_axpy, dim3((unsigned)blocks), dim3(256), 0, s, y, x, alpha, n);
+}
+__global__ __launch_bounds__(256) void k_fill(float* p, float v, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+void launch_fill(float* p, float v, size_t n, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, s, p, v, n);
+}
+
+// adj_t <- adj_t - <f_i, g_i>     (adjoint: "effect of moving the current time measurement point")
+__global__ __launch_bounds__(256) void k_dot_partial(const float* a, const float* b, size_t n, float* partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) acc += a[i] * b[i];
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void k_dot_final(Ctrl* c, const float* partial, float* out_dot) {
+  __shared__ float red[4];
+  const float tot = reduce_partials_512(partial, red);
+  if (threadIdx.x == 0) {
+    c->ts_cur = c->ts_cur - tot;
+    if (out_dot) *out_dot = tot;
+  }
+}
+void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float* partial, float* out_dot, hipStream_t s) {
+  hipLaunchKernelGGL(k_dot_partial, dim3(ERR_BLOCKS), dim3(256), 0, s, a, b, n, partial);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, ctrl, partial, out_dot);
+}
+__global__ void k_copy_scalar_out(const Ctrl* c, float* dst) { *dst = c->ts_cur; }
+void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_scalar_out, dim3(1), dim3(1), 0, s, ctrl, dst);
+}
+
+// ============================================================================
+// theta-segment stage derivative: reduce the split-K / per-tile partials written
+// by the wgrad GEMM and the GroupNorm-backward epilogues into one vector in the
+// internal theta layout, times osign (= tsign, the reverse-time negation).
+// ============================================================================
+__global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dims d) {
+  const ThetaLayout L = theta_layout(d.C);
+  const size_t C = d.C, CC = (size_t)d.C * d.C;
+  const float tval = eval_time(a.et);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < d.P; idx += stride) {
+    float v = 0.f;
+    // which piece?
+    int layer = idx >= L.g[2] ? 2 : (idx >= L.g[1] ? 1 : 0);
+    size_t r = idx - L.g[layer];
+    if (r < 2 * C) {  // gamma / beta
+      const int which = r >= C ? 1 : 0;
+      const size_t c = r - which * C;
+      const float* gp = a.gpart[layer];
+      for (int row = 0; row < a.gpart_rows[layer]; ++row) v += gp[((size_t)row * 2 + which) * C + c];
+    } else {
+      r -= 2 * C;
+      if (r < 9 * CC) {  // conv weights [tap][ci][co]
+        const float* wp = a.wpart[layer];
+        for (int sp = 0; sp < d.nsplit; ++sp) v += wp[(size_t)sp * 9 * CC + r];
+      } else {
+        r -= 9 * CC;
+        const float* spp = a.spart[layer];
+        if (r < 9 * C) {  // time-channel taps [tap][co]: t * masked column sums
+          for (int sp = 0; sp < d.nsplit; ++sp) v += spp[(size_t)sp * 9 * C + r];
+          v *= tval;
+        } else {          // conv bias: centre tap sees every pixel
+          r -= 9 * C;
+          for (int sp = 0; sp < d.nsplit; ++sp) v += spp[(size_t)sp * 9 * C + 4 * C + r];
+        }
+      }
+    }
+    a.theta_out[idx] = a.osign * v;
+  }
+}
+
+// vjp_t = sum_layers sum_{tap,co} W[co][0][tap] * S[tap][co]   (d conv / d t = time-channel border map)
+__global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int C = d.C;
+  for (int layer = 0; layer < 2; ++layer) {
+    const float* spp = a.spart[layer];
+    const float* w = a.wraw[layer];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) {
+      const int tap = i / C, co = i - tap * C;
+      float sacc = 0.f;
+      for (int sp = 0; sp < d.nsplit; ++sp) sacc += spp[(size_t)sp * 9 * C + i];
+      acc += sacc * w[((size_t)co * (C + 1)) * 9 + tap];
+    }
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) {
+    if (a.write_scalar) a.ctrl->ts_k[a.kidx] = a.osign * tot;
+    if (a.vjp_t_out) *a.vjp_t_out = a.osign * tot;
+  }
+}
+
+void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s) {
+  size_t blocks = (d.P + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)blocks), dim3(256), 0, s, a, d);
+  hipLaunchKernelGGL(k_vjp_t, dim3(1), dim3(256), 0, s, a, d);
+}
+
+// out = y + scale * sum_j coef_j k_j   (flat; fixed-grid solver's end-of-step update)
+__global__ __launch_bounds__(256) void k_lincomb(Comb c, const Ctrl* ctrl, float* out, size_t n) {
+  const float scale = comb_scale(c, ctrl);
+  float cf[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cf[j] = scale * c.coef[j];
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float s = 0.f;
+    for (int j = 0; j < c.nk; ++j) s += cf[j] * c.k[j][i];
+    out[i] = c.y[i] + s;
+  }
+}
+void launch_lincomb(const Comb& c, const Ctrl* ctrl, float* out, size_t n, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_lincomb, dim3((unsigned)blocks), dim3(256), 0, s, c, ctrl, out, n);
+}
+
+}  // namespace node

@@ -1,0 +1,834 @@
+// C ABI + host-side solver of libnode_hip.so.
+//
+// The host code below is the *driver* of the integrator: it owns no numerics.
+// Every number (stage values, error norms, accept decisions, step sizes) is
+// produced by device kernels and stays in device memory; the host only
+//   * enqueues the kernels of one step on the caller's stream,
+//   * reads back one small `Ctrl` record per adaptive step (accept, t, dt) to
+//     know whether the requested output time has been passed, and
+//   * swaps buffer pointers on accept (FSAL, y <- y1).
+//
+// Algorithm: restated torchdiffeq dopri5 / rk4(3/8) / continuous adjoint, see
+// SURVEY.md 8c and oracle/torchdiffeq_restated.py (the CPU checker).
+#include "node_internal.h"
+#include "../../include/node_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+using namespace node;
+
+// ----------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) return fail(NODE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define TRY(expr)              \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc != NODE_OK) return _rc; \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// profiling (HIP events around the GEMM-class launches, on the caller's stream)
+// ----------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int cls; double flops; };
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  std::mutex mu;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+} g_prof;
+
+struct ProfScope {
+  bool active;
+  ProfRec r;
+  hipStream_t s;
+  ProfScope(int cls, double flops, hipStream_t st) : active(g_prof.on), s(st) {
+    if (!active) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    r.a = g_prof.get();
+    r.b = g_prof.get();
+    r.cls = cls;
+    r.flops = flops;
+    (void)hipEventRecord(r.a, s);
+  }
+  ~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(r.b, s);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.recs.push_back(r);
+  }
+};
+}  // namespace
+
+// ----------------------------------------------------------------------------
+// geometry
+// ----------------------------------------------------------------------------
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+static int make_dims(const node_shape* sh, Dims* out) {
+  if (!sh) return fail(NODE_ERR_NULL, "shape is NULL");
+  Dims d;
+  memset(&d, 0, sizeof(d));
+  d.N = sh->n; d.C = sh->c; d.H = sh->h; d.W = sh->w; d.G = sh->groups; d.eps = sh->eps;
+  if (d.N <= 0 || d.C <= 0 || d.H <= 0 || d.W <= 0 || d.G <= 0) return fail(NODE_ERR_SHAPE, "non-positive dimension");
+  if (d.C % d.G != 0) return fail(NODE_ERR_SHAPE, "groups (%d) must divide channels (%d)", d.G, d.C);
+  if (!(d.eps > 0.f)) return fail(NODE_ERR_SHAPE, "eps must be > 0");
+  if (d.C % 4 != 0) return fail(NODE_ERR_UNSUPPORTED, "channels (%d) must be a multiple of 4", d.C);
+  d.HW = d.H * d.W;
+  d.cpg = d.C / d.G;
+  d.Wp = d.W + 2; d.Hp = d.H + 2; d.SLOTS = d.Hp * d.Wp; d.MARGIN = d.Wp + 1;
+  if (d.cpg > 64) return fail(NODE_ERR_UNSUPPORTED, "channels per group (%d) > 64", d.cpg);
+  d.BNE = (64 / d.cpg) * d.cpg;
+  d.ntile = (d.C + d.BNE - 1) / d.BNE;
+  d.nchunk = (d.C + KCH - 1) / KCH;
+  if (d.HW <= 128) d.BM = 128;
+  else if (d.HW <= 256) d.BM = 256;
+  else return fail(NODE_ERR_UNSUPPORTED, "H*W = %d > 256 is not tiled yet", d.HW);
+  if (d.W > 64) return fail(NODE_ERR_UNSUPPORTED, "W = %d > 64", d.W);
+  d.S = d.BM / d.HW;
+  if (d.S > d.N) d.S = d.N;
+  while (d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
+  if (conv_lds_bytes(d, 0) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "conv tile does not fit LDS");
+  d.mtiles = (d.N + d.S - 1) / d.S;
+  const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
+  int mult = (8192 / d.HW) / unit;
+  if (mult < 1) mult = 1;
+  d.cs = unit * mult;
+  if (d.cs > d.C) d.cs = d.C;
+  if ((size_t)d.HW * d.cs > 16384) return fail(NODE_ERR_UNSUPPORTED, "GroupNorm slab does not fit LDS");
+  d.nslab = (d.C + d.cs - 1) / d.cs;
+  d.RB = 64 / d.W;
+  if (d.RB < 1) d.RB = 1;
+  if (d.RB > d.H) d.RB = d.H;
+  d.nbands = (d.H + d.RB - 1) / d.RB;
+  {
+    const int U = d.N * d.nbands;
+    const int ntc = (d.C + 63) / 64;
+    int ns = 512 / (ntc * ntc);
+    if (ns < 1) ns = 1;
+    if (ns > 32) ns = 32;
+    if (ns > U) ns = U;
+    d.nsplit = ns;
+  }
+  d.P = 18 * (size_t)d.C * d.C + 26 * (size_t)d.C;
+  d.numel = (size_t)d.N * d.C * d.HW;
+  *out = d;
+  return NODE_OK;
+}
+
+// ----------------------------------------------------------------------------
+// workspace plan
+// ----------------------------------------------------------------------------
+namespace {
+struct Plan {
+  // common
+  Ctrl* ctrl;
+  float* partial[3];        // [ERR_BLOCKS][2] each
+  float* wf[2];             // packed forward weights
+  float* wd[2];             // packed dgrad weights (adjoint)
+  float* tmap[2];
+  float *Y, *Y1, *KY[7];
+  float *act1, *act2, *TMP;
+  // adjoint
+  float *A, *A1, *KA[7];
+  float *TH, *TH1, *THTMP, *KT[7];
+  float *xh1, *xh2, *xh3, *r1, *r2, *r3;
+  float *dz1, *dz2, *G;
+  float *wpart[2], *spart[2], *gpart[3];
+  float* dots;              // [n_t] time vjps scratch
+  size_t bytes;
+};
+
+struct Bump {
+  char* base;
+  size_t off;
+  explicit Bump(void* b) : base((char*)b), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = (T*)(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
+  Plan p;
+  memset(&p, 0, sizeof(p));
+  Bump b(base);
+  p.ctrl = b.take<Ctrl>(1);
+  for (int i = 0; i < 3; ++i) p.partial[i] = b.take<float>(ERR_BLOCKS * 2);
+  const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
+  for (int i = 0; i < 2; ++i) p.wf[i] = b.take<float>(wsz);
+  for (int i = 0; i < 2; ++i) p.tmap[i] = b.take<float>((size_t)d.HW * d.C);
+  p.Y = b.take<float>(d.numel);
+  p.Y1 = b.take<float>(d.numel);
+  for (int i = 0; i < 7; ++i) p.KY[i] = b.take<float>(d.numel);
+  p.act1 = b.take<float>(d.numel);
+  p.act2 = b.take<float>(d.numel);
+  p.TMP = b.take<float>(d.numel);
+  if (adjoint) {
+    for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
+    p.A = b.take<float>(d.numel);
+    p.A1 = b.take<float>(d.numel);
+    for (int i = 0; i < 7; ++i) p.KA[i] = b.take<float>(d.numel);
+    p.TH = b.take<float>(d.P);
+    p.TH1 = b.take<float>(d.P);
+    p.THTMP = b.take<float>(d.P);
+    for (int i = 0; i < 7; ++i) p.KT[i] = b.take<float>(d.P);
+    p.xh1 = b.take<float>(d.numel);
+    p.xh2 = b.take<float>(d.numel);
+    p.xh3 = b.take<float>(d.numel);
+    p.r1 = b.take<float>((size_t)d.N * d.G);
+    p.r2 = b.take<float>((size_t)d.N * d.G);
+    p.r3 = b.take<float>((size_t)d.N * d.G);
+    p.dz1 = b.take<float>(d.numel);
+    p.dz2 = b.take<float>(d.numel);
+    p.G = b.take<float>(d.numel);
+    for (int i = 0; i < 2; ++i) {
+      p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
+      p.spart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C);
+    }
+    p.gpart[0] = b.take<float>((size_t)d.mtiles * 2 * d.C);
+    p.gpart[1] = b.take<float>((size_t)d.mtiles * 2 * d.C);
+    p.gpart[2] = b.take<float>((size_t)d.N * 2 * d.C);
+    p.dots = b.take<float>((size_t)(n_t > 0 ? n_t : 1));
+  }
+  p.bytes = ((b.off + 255) & ~(size_t)255);
+  return p;
+}
+
+// pinned host mirror of Ctrl for the per-step read-back
+struct HostMirror {
+  Ctrl* h = nullptr;
+  ~HostMirror() { /* process-lifetime */ }
+};
+thread_local HostMirror g_mirror;
+
+int get_mirror(Ctrl** out) {
+  if (!g_mirror.h) {
+    HIP_TRY(hipHostMalloc((void**)&g_mirror.h, sizeof(Ctrl), hipHostMallocDefault));
+  }
+  *out = g_mirror.h;
+  return NODE_OK;
+}
+
+const double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+const double DP_BETA[6][6] = {
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
+};
+
+// ----------------------------------------------------------------------------
+// The solver context: one solve (forward or augmented/adjoint) on one stream
+// ----------------------------------------------------------------------------
+struct Solver {
+  Dims d;
+  Plan p;
+  node_params prm;
+  hipStream_t st;
+  bool aug = false;
+  float tsign = 1.f;
+  float rtol = 0.f, atol = 0.f;
+  int nfe = 0;
+  Ctrl* hctrl = nullptr;
+
+  double conv_flops() const { return 2.0 * 9.0 * d.C * d.C * (double)d.N * d.HW; }
+
+  int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return NODE_OK;
+  }
+
+  int prepare() {
+    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, st);
+    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, st);
+    launch_tmap(d, prm.conv1_w, p.tmap[0], st);
+    launch_tmap(d, prm.conv2_w, p.tmap[1], st);
+    if (aug) {
+      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, st);
+      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, st);
+    }
+    return check_launch("prepare");
+  }
+
+  static Comb make_comb(const float* y, float* const* k, const double* coef, int ncoef, int scale_mode) {
+    Comb c;
+    memset(&c, 0, sizeof(c));
+    c.y = y;
+    c.scale_mode = scale_mode;
+    int nk = 0;
+    for (int j = 0; j < ncoef; ++j) {
+      if (coef[j] == 0.0) continue;
+      c.k[nk] = k[j];
+      c.coef[nk] = (float)coef[j];
+      ++nk;
+    }
+    c.nk = nk;
+    return c;
+  }
+
+  // f(t, y_i) with y_i = comb; writes k_out = tsign * f  (and y_i to y_out if asked)
+  int eval_fwd(const Comb& cy, float* y_out, const EvalTime& et, float* k_out, bool train) {
+    CombineGnArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
+    ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
+    ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b;
+    launch_combine_gn(d, ca, st);
+
+    ConvArgs c1;
+    memset(&c1, 0, sizeof(c1));
+    c1.in = p.act1; c1.wpacked = p.wf[0]; c1.mode = CM_FWD_GN_RELU;
+    c1.bias = prm.conv1_b; c1.tmap = p.tmap[0]; c1.et = et;
+    c1.gamma = prm.norm2_w; c1.beta = prm.norm2_b; c1.osign = 1.f;
+    c1.out = p.act2; c1.xhat_out = train ? p.xh2 : nullptr; c1.rstd_out = train ? p.r2 : nullptr;
+    { ProfScope ps(0, conv_flops(), st); launch_conv(d, c1, st); }
+
+    ConvArgs c2 = c1;
+    c2.in = p.act2; c2.wpacked = p.wf[1]; c2.mode = CM_FWD_GN;
+    c2.bias = prm.conv2_b; c2.tmap = p.tmap[1];
+    c2.gamma = prm.norm3_w; c2.beta = prm.norm3_b; c2.osign = et.tsign;
+    c2.out = k_out; c2.xhat_out = train ? p.xh3 : nullptr; c2.rstd_out = train ? p.r3 : nullptr;
+    { ProfScope ps(0, conv_flops(), st); launch_conv(d, c2, st); }
+    nfe += 1;
+    return check_launch("odefunc forward");
+  }
+
+  // augmented dynamics: (f, csign*a^T df/dy, csign*a^T df/dt, csign*a^T df/dtheta) * tsign
+  //   upstream adjoint: csign = -1.   kT_out / scalar ts_k[kidx] optional.
+  int eval_aug(const Comb& cy, const Comb& ca, float* y_out, float* a_out, const EvalTime& et,
+               float* kY_out, float* kA_out, float* kT_out, int kidx, float csign, float* vjp_t_out) {
+    TRY(eval_fwd(cy, y_out, et, kY_out, true));
+
+    GnBwdArgs g;
+    memset(&g, 0, sizeof(g));
+    g.comb = ca; g.ctrl = p.ctrl; g.csign = csign; g.a_out = a_out;
+    g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2];
+    launch_gn_bwd(d, g, st);
+
+    WgradArgs w2;
+    w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1]; w2.spart = p.spart[1];
+    { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
+
+    ConvArgs b2;
+    memset(&b2, 0, sizeof(b2));
+    b2.in = p.dz2; b2.wpacked = p.wd[1]; b2.mode = CM_BWD_RELU_GN; b2.et = et;
+    b2.gamma = prm.norm2_w; b2.osign = 1.f; b2.out = p.dz1;
+    b2.act = p.act2; b2.xhat = p.xh2; b2.rstd = p.r2; b2.gpart = p.gpart[1];
+    { ProfScope ps(0, conv_flops(), st); launch_conv(d, b2, st); }
+
+    WgradArgs w1;
+    w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.spart = p.spart[0];
+    { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
+
+    ConvArgs b1 = b2;
+    b1.in = p.dz1; b1.wpacked = p.wd[0];
+    b1.gamma = prm.norm1_w; b1.osign = et.tsign; b1.out = kA_out;
+    b1.act = p.act1; b1.xhat = p.xh1; b1.rstd = p.r1; b1.gpart = p.gpart[0];
+    { ProfScope ps(0, conv_flops(), st); launch_conv(d, b1, st); }
+
+    ThetaFinalizeArgs tf;
+    memset(&tf, 0, sizeof(tf));
+    tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
+    tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
+    tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
+    tf.gpart_rows[0] = d.mtiles; tf.gpart_rows[1] = d.mtiles; tf.gpart_rows[2] = d.N;
+    tf.wraw[0] = prm.conv1_w; tf.wraw[1] = prm.conv2_w;
+    tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
+    tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
+    launch_theta_finalize(d, tf, st);
+    return check_launch("augmented dynamics");
+  }
+
+  EvalTime et_stage(double alpha) const { EvalTime e; e.ctrl = p.ctrl; e.alpha = (float)alpha; e.tsign = tsign; e.mode = TM_STAGE; return e; }
+  EvalTime et_probe() const { EvalTime e; e.ctrl = p.ctrl; e.alpha = 0.f; e.tsign = tsign; e.mode = TM_PROBE; return e; }
+
+  // evaluate the system at (state + scale * sum coef_j k_j) into k[kout]
+  int eval_sys(int kout, const double* coef, int ncoef, int scale_mode, const EvalTime& et, bool write_new) {
+    Comb cy = make_comb(p.Y, p.KY, coef, ncoef, scale_mode);
+    if (!aug) return eval_fwd(cy, write_new ? p.Y1 : nullptr, et, p.KY[kout], false);
+    Comb ca = make_comb(p.A, p.KA, coef, ncoef, scale_mode);
+    return eval_aug(cy, ca, write_new ? p.Y1 : nullptr, write_new ? p.A1 : nullptr, et,
+                    p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr);
+  }
+
+  int readback() {
+    HIP_TRY(hipMemcpyAsync(hctrl, p.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return NODE_OK;
+  }
+
+  // Hairer initial step; leaves dt in ctrl.  Costs one probe eval (upstream: +1 NFE).
+  int initial_step() {
+    const int nseg = aug ? 3 : 1;
+    InitSeg segs[3] = {{p.Y, p.KY[0], p.KY[1], d.numel}, {p.A, p.KA[0], p.KA[1], d.numel}, {p.TH, p.KT[0], p.KT[1], d.P}};
+    for (int i = 0; i < nseg; ++i) launch_init_norms(segs[i], rtol, atol, 0, p.partial[i], p.ctrl, st);
+    InitCtlArgs ic;
+    memset(&ic, 0, sizeof(ic));
+    ic.ctrl = p.ctrl;
+    for (int i = 0; i < nseg; ++i) { ic.partial[i] = p.partial[i]; ic.numel[i] = (double)segs[i].n; }
+    ic.nseg = nseg; ic.has_scalar = aug ? 1 : 0; ic.phase = 0; ic.rtol = rtol; ic.atol = atol;
+    launch_init_controller(ic, st);
+    const double one[1] = {1.0};
+    TRY(eval_sys(1, one, 1, SC_H0, et_probe(), false));
+    for (int i = 0; i < nseg; ++i) launch_init_norms(segs[i], rtol, atol, 1, p.partial[i], p.ctrl, st);
+    ic.phase = 1;
+    launch_init_controller(ic, st);
+    return check_launch("initial step");
+  }
+
+  // one dopri5 step on the device; host learns the outcome from hctrl afterwards
+  int dopri5_step(bool forced, double forced_next) {
+    for (int s = 0; s < 6; ++s) TRY(eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5));
+    const int nseg = aug ? 3 : 1;
+    ErrSeg e0;
+    e0.y0 = p.Y; e0.y1 = p.Y1; e0.n = d.numel; e0.compute_y1 = 0;
+    for (int j = 0; j < 7; ++j) e0.k[j] = p.KY[j];
+    launch_error_norm(e0, p.ctrl, rtol, atol, p.partial[0], st);
+    if (aug) {
+      ErrSeg e1 = e0;
+      e1.y0 = p.A; e1.y1 = p.A1;
+      for (int j = 0; j < 7; ++j) e1.k[j] = p.KA[j];
+      launch_error_norm(e1, p.ctrl, rtol, atol, p.partial[1], st);
+      ErrSeg e2;
+      e2.y0 = p.TH; e2.y1 = p.TH1; e2.n = d.P; e2.compute_y1 = 1;
+      for (int j = 0; j < 7; ++j) e2.k[j] = p.KT[j];
+      launch_error_norm(e2, p.ctrl, rtol, atol, p.partial[2], st);
+    }
+    StepCtlArgs sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.ctrl = p.ctrl;
+    sc.partial[0] = p.partial[0]; sc.partial[1] = p.partial[1]; sc.partial[2] = p.partial[2];
+    sc.numel[0] = (double)d.numel; sc.numel[1] = (double)d.numel; sc.numel[2] = (double)d.P;
+    sc.nseg = nseg; sc.has_scalar = aug ? 1 : 0; sc.rtol = rtol; sc.atol = atol;
+    sc.forced = forced ? 1 : 0; sc.forced_next = forced_next;
+    launch_step_controller(sc, st);
+    TRY(check_launch("dopri5 step"));
+    return readback();
+  }
+
+  void swap_on_accept() {
+    std::swap(p.Y, p.Y1);
+    std::swap(p.KY[0], p.KY[6]);
+    if (aug) {
+      std::swap(p.A, p.A1);
+      std::swap(p.KA[0], p.KA[6]);
+      std::swap(p.TH, p.TH1);
+      std::swap(p.KT[0], p.KT[6]);
+    }
+  }
+
+  // one interval of the fixed-grid RK4 (3/8 rule): state advanced in place
+  int rk4_interval(double t0, double t1) {
+    // upstream keeps the fixed grid in the state dtype (fp32)
+    const float t0f = (float)t0, t1f = (float)t1;
+    launch_set_ctrl(p.ctrl, (double)t0f, (double)(t1f - t0f), 0, st);
+    const double c2[1] = {1.0 / 3}, c3[2] = {-1.0 / 3, 1.0}, c4[3] = {1.0, -1.0, 1.0};
+    const double cf[4] = {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8};
+    TRY(eval_sys(0, nullptr, 0, SC_ABS, et_stage(0.0), false));
+    TRY(eval_sys(1, c2, 1, SC_DT, et_stage(1.0 / 3), false));
+    TRY(eval_sys(2, c3, 2, SC_DT, et_stage(2.0 / 3), false));
+    TRY(eval_sys(3, c4, 3, SC_DT, et_stage(1.0), false));
+    launch_lincomb(make_comb(p.Y, p.KY, cf, 4, SC_DT), p.ctrl, p.Y1, d.numel, st);
+    std::swap(p.Y, p.Y1);
+    if (aug) {
+      launch_lincomb(make_comb(p.A, p.KA, cf, 4, SC_DT), p.ctrl, p.A1, d.numel, st);
+      std::swap(p.A, p.A1);
+      launch_lincomb(make_comb(p.TH, p.KT, cf, 4, SC_DT), p.ctrl, p.TH1, d.P, st);
+      std::swap(p.TH, p.TH1);
+      launch_set_scalar_state(p.ctrl, 0.f, 1, st);
+    }
+    return check_launch("rk4 interval");
+  }
+};
+
+struct DtLog {
+  const node_solve_opts* o;
+  int n = 0;
+  explicit DtLog(const node_solve_opts* opts) : o(opts) { if (o && o->n_dt_log) *o->n_dt_log = 0; }
+  void add(double dt, bool accepted) {
+    if (!o || o->record_dt <= 0 || !o->dt_log) return;
+    if (n < o->record_dt) o->dt_log[n] = accepted ? dt : -dt;
+    ++n;
+    if (o->n_dt_log) *o->n_dt_log = n < o->record_dt ? n : o->record_dt;
+  }
+};
+
+int check_common(const node_shape* shape, const node_params* params, void* ws, size_t ws_bytes, int adjoint, int n_t,
+                 Dims* d, Plan* plan) {
+  if (!params) return fail(NODE_ERR_NULL, "params is NULL");
+  if (!ws) return fail(NODE_ERR_NULL, "workspace is NULL");
+  TRY(make_dims(shape, d));
+  const float* ptrs[10] = {params->norm1_w, params->norm1_b, params->conv1_w, params->conv1_b, params->norm2_w,
+                           params->norm2_b, params->conv2_w, params->conv2_b, params->norm3_w, params->norm3_b};
+  for (int i = 0; i < 10; ++i) {
+    if (!ptrs[i]) return fail(NODE_ERR_NULL, "parameter pointer %d is NULL", i);
+    if (((uintptr_t)ptrs[i]) & 15) return fail(NODE_ERR_ARG, "parameter pointer %d is not 16-byte aligned", i);
+  }
+  if (((uintptr_t)ws) & 255) return fail(NODE_ERR_ARG, "workspace must be 256-byte aligned");
+  *plan = make_plan(*d, adjoint, n_t, ws);
+  if (ws_bytes < plan->bytes) return fail(NODE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, plan->bytes);
+  return NODE_OK;
+}
+
+int check_times(const float* t_pts, int n_t) {
+  if (!t_pts) return fail(NODE_ERR_NULL, "t_pts is NULL");
+  if (n_t < 2) return fail(NODE_ERR_ARG, "need at least two time points (got %d)", n_t);
+  bool inc = true, dec = true;
+  for (int i = 1; i < n_t; ++i) {
+    if (!(t_pts[i] > t_pts[i - 1])) inc = false;
+    if (!(t_pts[i] < t_pts[i - 1])) dec = false;
+  }
+  if (!inc && !dec) return fail(NODE_ERR_ARG, "t must be strictly increasing or strictly decreasing");
+  return NODE_OK;
+}
+
+int status_to_rc(int status) {
+  if (status == 0) return NODE_OK;
+  if (status == NODE_ERR_NONFINITE) return fail(NODE_ERR_NONFINITE, "non-finite error norm / state");
+  return fail(status, "solver stopped with status %d", status);
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+extern "C" {
+
+int node_abi_version(void) { return NODE_ABI_VERSION; }
+const char* node_last_error(void) { return g_err; }
+
+size_t node_param_count(const node_shape* shape) {
+  if (!shape) return 0;
+  return 18 * (size_t)shape->c * shape->c + 26 * (size_t)shape->c;
+}
+
+size_t node_workspace_bytes(const node_shape* shape, int /*method*/, int adjoint, int n_t) {
+  Dims d;
+  if (make_dims(shape, &d) != NODE_OK) return 0;
+  Plan p = make_plan(d, adjoint, n_t, nullptr);
+  return p.bytes;
+}
+
+int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t, const float* y, float* f,
+                     void* ws, size_t ws_bytes, void* stream) {
+  if (!y || !f) return fail(NODE_ERR_NULL, "y / f is NULL");
+  Solver S;
+  TRY(check_common(shape, params, ws, ws_bytes, 0, 2, &S.d, &S.p));
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = false; S.tsign = 1.f;
+  TRY(S.prepare());
+  launch_set_ctrl(S.p.ctrl, (double)t, 0.0, 1, S.st);
+  launch_nchw_to_nhwc(S.d, y, S.p.Y, S.st);
+  TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
+  launch_nhwc_to_nchw(S.d, S.p.KY[0], f, S.st);
+  return S.check_launch("node_odefunc_fwd");
+}
+
+int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t, const float* y, const float* cot,
+                     float* f, float* vjp_y, float* vjp_t, float* vjp_params, void* ws, size_t ws_bytes, void* stream) {
+  if (!y || !cot || !f || !vjp_y || !vjp_t || !vjp_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  Solver S;
+  TRY(check_common(shape, params, ws, ws_bytes, 1, 2, &S.d, &S.p));
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.tsign = 1.f;
+  TRY(S.prepare());
+  launch_set_ctrl(S.p.ctrl, (double)t, 0.0, 1, S.st);
+  launch_nchw_to_nhwc(S.d, y, S.p.Y, S.st);
+  launch_nchw_to_nhwc(S.d, cot, S.p.A, S.st);
+  Comb cy = Solver::make_comb(S.p.Y, S.p.KY, nullptr, 0, SC_ABS);
+  Comb ca = Solver::make_comb(S.p.A, S.p.KA, nullptr, 0, SC_ABS);
+  TRY(S.eval_aug(cy, ca, nullptr, nullptr, S.et_stage(0.0), S.p.KY[0], S.p.KA[0], S.p.KT[0], -1, +1.f, vjp_t));
+  launch_nhwc_to_nchw(S.d, S.p.KY[0], f, S.st);
+  launch_nhwc_to_nchw(S.d, S.p.KA[0], vjp_y, S.st);
+  launch_theta_to_torch(S.d, S.p.KT[0], vjp_params, S.st);
+  return S.check_launch("node_odefunc_vjp");
+}
+
+int node_solve_fwd(const node_shape* shape, const node_params* params, const float* y0, const float* t_pts, int n_t,
+                   float rtol, float atol, int method, const node_solve_opts* opts, float* y_out, node_stats* stats,
+                   void* ws, size_t ws_bytes, void* stream) {
+  if (!y0 || !y_out) return fail(NODE_ERR_NULL, "y0 / y_out is NULL");
+  if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
+  TRY(check_times(t_pts, n_t));
+  Solver S;
+  TRY(check_common(shape, params, ws, ws_bytes, 0, n_t, &S.d, &S.p));
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = false; S.rtol = rtol; S.atol = atol;
+  TRY(get_mirror(&S.hctrl));
+  const bool decreasing = t_pts[1] < t_pts[0];
+  S.tsign = decreasing ? -1.f : 1.f;
+  std::vector<double> ts(n_t);
+  for (int i = 0; i < n_t; ++i) ts[i] = (double)(decreasing ? -t_pts[i] : t_pts[i]);
+  node_stats stt;
+  memset(&stt, 0, sizeof(stt));
+  DtLog dlog(opts);
+  const size_t numel = S.d.numel;
+
+  TRY(S.prepare());
+  launch_nchw_to_nhwc(S.d, y0, S.p.Y, S.st);
+  HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+
+  if (method == NODE_METHOD_RK4) {
+    launch_set_ctrl(S.p.ctrl, ts[0], 0.0, 1, S.st);
+    for (int j = 1; j < n_t; ++j) {
+      TRY(S.rk4_interval(ts[j - 1], ts[j]));
+      launch_nhwc_to_nchw(S.d, S.p.Y, y_out + (size_t)j * numel, S.st);
+      stt.accepted += 1;
+      dlog.add(ts[j] - ts[j - 1], true);
+    }
+    HIP_TRY(hipStreamSynchronize(S.st));
+    stt.nfe = S.nfe; stt.t_final = ts[n_t - 1]; stt.last_dt = ts[n_t - 1] - ts[n_t - 2];
+    if (stats) *stats = stt;
+    return S.check_launch("node_solve_fwd(rk4)");
+  }
+
+  // ---- dopri5 ----
+  const bool forced = opts && opts->n_forced_dt > 0 && opts->forced_dt;
+  int forced_idx = 0;
+  const long long max_steps = (opts && opts->max_num_steps > 0) ? opts->max_num_steps : 2147483647LL;
+  launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
+  TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
+  if (forced) forced_idx = 1;
+  else TRY(S.initial_step());
+  bool first = true;
+  int j = 1;
+  long long steps = 0;
+  double cur_t = ts[0], cur_dt = forced ? opts->forced_dt[0] : 0.0;
+  while (j < n_t) {
+    if (steps >= max_steps) { stt.status = NODE_ERR_MAX_STEPS; break; }
+    double fnext = 0.0;
+    if (forced) { fnext = forced_idx < opts->n_forced_dt ? opts->forced_dt[forced_idx] : -1.0; }
+    // (replay: when the list is exhausted keep the last dt, like the oracle)
+    TRY(S.dopri5_step(forced, 0.0));
+    ++steps;
+    const Ctrl& h = *S.hctrl;
+    if (first) { stt.first_dt = h.dt_used; first = false; }
+    if (h.status != 0) { stt.status = h.status; break; }
+    dlog.add(h.dt_used, h.accept != 0);
+    if (forced) {  // overwrite the controller's proposal with the forced sequence
+      const double nd = fnext > 0.0 ? fnext : h.dt_used;
+      launch_set_ctrl(S.p.ctrl, h.t, nd, 0, S.st);
+      if (fnext > 0.0) ++forced_idx;
+      cur_dt = nd;
+    } else {
+      cur_dt = h.dt;
+    }
+    cur_t = h.t;
+    if (h.accept) {
+      stt.accepted += 1;
+      const double t0 = h.t_prev, t1 = h.t;
+      while (j < n_t && !(ts[j] > t1)) {
+        InterpArgs ia;
+        ia.y0 = S.p.Y; ia.y1 = S.p.Y1;
+        for (int q = 0; q < 7; ++q) ia.k[q] = S.p.KY[q];
+        ia.out = S.p.TMP; ia.n = numel; ia.dt = (float)h.dt_used;
+        {  // upstream rounds t0, t1, t to the state dtype before forming x
+          const float t0f = (float)t0, t1f = (float)t1, tjf = (float)ts[j];
+          ia.x = (tjf - t0f) / (t1f - t0f);
+        }
+        launch_interp(ia, S.st);
+        launch_nhwc_to_nchw(S.d, S.p.TMP, y_out + (size_t)j * numel, S.st);
+        ++j;
+      }
+      S.swap_on_accept();
+    } else {
+      stt.rejected += 1;
+    }
+    if (j < n_t && !(cur_t + cur_dt > cur_t)) { stt.status = NODE_ERR_DT_UNDERFLOW; break; }
+  }
+  HIP_TRY(hipStreamSynchronize(S.st));
+  stt.nfe = S.nfe; stt.t_final = cur_t; stt.last_dt = cur_dt;
+  if (stats) *stats = stt;
+  TRY(S.check_launch("node_solve_fwd(dopri5)"));
+  if (stt.status == NODE_ERR_MAX_STEPS) return fail(NODE_ERR_MAX_STEPS, "max_num_steps exceeded");
+  if (stt.status == NODE_ERR_DT_UNDERFLOW) return fail(NODE_ERR_DT_UNDERFLOW, "underflow in dt %g", cur_dt);
+  return status_to_rc(stt.status);
+}
+
+int node_solve_adjoint(const node_shape* shape, const node_params* params, const float* y_traj, const float* grad_out,
+                       const float* t_pts, int n_t, float rtol, float atol, int method, const node_solve_opts* opts,
+                       float* grad_y0, float* grad_params, float* grad_t, node_stats* stats, void* ws, size_t ws_bytes,
+                       void* stream) {
+  if (!y_traj || !grad_out || !grad_y0 || !grad_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
+  TRY(check_times(t_pts, n_t));
+  Solver S;
+  TRY(check_common(shape, params, ws, ws_bytes, 1, n_t, &S.d, &S.p));
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.rtol = rtol; S.atol = atol;
+  TRY(get_mirror(&S.hctrl));
+  node_stats stt;
+  memset(&stt, 0, sizeof(stt));
+  DtLog dlog(opts);
+  const size_t numel = S.d.numel;
+  const bool forced = opts && opts->n_forced_dt > 0 && opts->forced_dt && method == NODE_METHOD_DOPRI5;
+  int forced_idx = 0;
+  const long long max_steps = (opts && opts->max_num_steps > 0) ? opts->max_num_steps : 2147483647LL;
+
+  TRY(S.prepare());
+  launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
+  launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
+  launch_nchw_to_nhwc(S.d, grad_out + (size_t)(n_t - 1) * numel, S.p.A, S.st);  // adj_y = grad_output[-1]
+  double cur_t = 0.0, cur_dt = 0.0;
+  bool first = true;
+
+  for (int i = n_t - 1; i >= 1 && stt.status == 0; --i) {
+    // the interval is integrated from t_i to t_{i-1}; upstream negates time when that is decreasing
+    const bool decreasing = t_pts[i - 1] < t_pts[i];
+    S.tsign = decreasing ? -1.f : 1.f;
+    const double s0 = (double)(decreasing ? -t_pts[i] : t_pts[i]);
+    const double s1 = (double)(decreasing ? -t_pts[i - 1] : t_pts[i - 1]);
+
+    launch_nchw_to_nhwc(S.d, y_traj + (size_t)i * numel, S.p.Y, S.st);
+    launch_nchw_to_nhwc(S.d, grad_out + (size_t)i * numel, S.p.G, S.st);
+    // func_i = f(t_i, y_i)  (plain, un-negated) ; adj_time -= <func_i, grad_output_i>
+    {
+      const float keep = S.tsign;
+      S.tsign = 1.f;
+      launch_set_ctrl(S.p.ctrl, (double)t_pts[i], 0.0, 0, S.st);
+      Comb cy = Solver::make_comb(S.p.Y, S.p.KY, nullptr, 0, SC_ABS);
+      TRY(S.eval_fwd(cy, nullptr, S.et_stage(0.0), S.p.KY[1], false));
+      S.tsign = keep;
+      launch_dot_sub_scalar(S.p.ctrl, S.p.KY[1], S.p.G, numel, S.p.partial[0], grad_t ? S.p.dots + i : nullptr, S.st);
+    }
+
+    if (method == NODE_METHOD_RK4) {
+      TRY(S.rk4_interval(s0, s1));
+      stt.accepted += 1;
+      dlog.add(s1 - s0, true);
+      cur_t = s1; cur_dt = s1 - s0;
+    } else {
+      forced_idx = 0;  // replay list restarts per interval (one odeint call each upstream)
+      launch_set_ctrl(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, 0, S.st);
+      if (forced) forced_idx = 1;
+      TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
+      if (!forced) TRY(S.initial_step());
+      long long steps = 0;
+      bool done = false;
+      while (!done) {
+        if (steps >= max_steps) { stt.status = NODE_ERR_MAX_STEPS; break; }
+        double fnext = -1.0;
+        if (forced) fnext = forced_idx < opts->n_forced_dt ? opts->forced_dt[forced_idx] : -1.0;
+        TRY(S.dopri5_step(forced, 0.0));
+        ++steps;
+        const Ctrl& h = *S.hctrl;
+        if (first) { stt.first_dt = h.dt_used; first = false; }
+        if (h.status != 0) { stt.status = h.status; break; }
+        dlog.add(h.dt_used, h.accept != 0);
+        if (forced) {
+          const double nd = fnext > 0.0 ? fnext : h.dt_used;
+          launch_set_ctrl(S.p.ctrl, h.t, nd, 0, S.st);
+          if (fnext > 0.0) ++forced_idx;
+          cur_dt = nd;
+        } else {
+          cur_dt = h.dt;
+        }
+        cur_t = h.t;
+        if (h.accept) {
+          stt.accepted += 1;
+          if (!(s1 > h.t)) {
+            // dense output at s1 for the adjoint, parameter and time segments (y is reloaded per interval)
+            const double t0 = h.t_prev, t1 = h.t;
+            const float t0f = (float)t0, t1f = (float)t1, s1f = (float)s1;
+            const float x = (s1f - t0f) / (t1f - t0f);
+            InterpArgs ia;
+            ia.y0 = S.p.A; ia.y1 = S.p.A1;
+            for (int q = 0; q < 7; ++q) ia.k[q] = S.p.KA[q];
+            ia.out = S.p.TMP; ia.n = numel; ia.dt = (float)h.dt_used; ia.x = x;
+            launch_interp(ia, S.st);
+            InterpArgs it = ia;
+            it.y0 = S.p.TH; it.y1 = S.p.TH1;
+            for (int q = 0; q < 7; ++q) it.k[q] = S.p.KT[q];
+            it.out = S.p.THTMP; it.n = S.d.P;
+            launch_interp(it, S.st);
+            launch_interp_scalar(S.p.ctrl, (float)h.dt_used, x, S.st);
+            std::swap(S.p.A, S.p.TMP);
+            std::swap(S.p.TH, S.p.THTMP);
+            done = true;
+          } else {
+            S.swap_on_accept();
+          }
+        } else {
+          stt.rejected += 1;
+        }
+        if (!done && !(cur_t + cur_dt > cur_t)) { stt.status = NODE_ERR_DT_UNDERFLOW; break; }
+      }
+    }
+    // adj_y += grad_output[i-1]
+    launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+    launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+  }
+
+  launch_nhwc_to_nchw(S.d, S.p.A, grad_y0, S.st);
+  launch_theta_to_torch(S.d, S.p.TH, grad_params, S.st);
+  if (grad_t) {
+    // time_vjps = [adj_time, dLd_t1, ..., dLd_t_{T-1}]
+    launch_copy_scalar_out(S.p.ctrl, S.p.dots, S.st);
+    HIP_TRY(hipMemcpyAsync(grad_t, S.p.dots, (size_t)n_t * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  }
+  HIP_TRY(hipStreamSynchronize(S.st));
+  stt.nfe = S.nfe; stt.t_final = cur_t; stt.last_dt = cur_dt;
+  if (stats) *stats = stt;
+  TRY(S.check_launch("node_solve_adjoint"));
+  if (stt.status == NODE_ERR_MAX_STEPS) return fail(NODE_ERR_MAX_STEPS, "max_num_steps exceeded");
+  if (stt.status == NODE_ERR_DT_UNDERFLOW) return fail(NODE_ERR_DT_UNDERFLOW, "underflow in dt %g", cur_dt);
+  return status_to_rc(stt.status);
+}
+
+int node_profile_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+  g_prof.recs.clear();
+  g_prof.on = true;
+  return NODE_OK;
+}
+
+int node_profile_end(node_profile* out) {
+  if (!out) return fail(NODE_ERR_NULL, "out is NULL");
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = false;
+  memset(out, 0, sizeof(*out));
+  for (auto& r : g_prof.recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return fail(NODE_ERR_HIP, "hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return fail(NODE_ERR_HIP, "hipEventElapsedTime failed");
+    out->launches[r.cls] += 1;
+    out->total_ms[r.cls] += ms;
+    out->flops[r.cls] += r.flops;
+    g_prof.pool.push_back(r.a);
+    g_prof.pool.push_back(r.b);
+  }
+  g_prof.recs.clear();
+  return NODE_OK;
+}
+
+}  // extern "C"

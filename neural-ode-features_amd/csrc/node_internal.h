@@ -1,0 +1,243 @@
+// Internal declarations shared by the HIP translation units of libnode_hip.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace node {
+
+// ----------------------------------------------------------------------------
+// Geometry
+// ----------------------------------------------------------------------------
+constexpr int KCH = 32;          // input channels per K chunk of the implicit GEMM
+constexpr int BN = 64;           // output-channel tile (two 32-wide MFMA column tiles)
+constexpr int AST = KCH + 1;     // LDS stride (floats) of one halo slot of the A chunk
+constexpr int CONV_THREADS = 512;  // 8 waves: 4 (M) x 2 (N)
+constexpr int WG_THREADS = 256;    // wgrad / pointwise kernels
+
+struct Dims {
+  int N, C, H, W, HW, G, cpg;
+  float eps;
+  int Wp, Hp, SLOTS;   // halo-padded image: (H+2) x (W+2) slots
+  int MARGIN;          // Wp + 1 zero slots before/after so every tap offset stays in bounds
+  int BNE;             // effective N tile: largest multiple of cpg <= 64 (groups never straddle tiles)
+  int ntile;           // ceil(C / BNE)
+  int nchunk;          // ceil(C / 32)
+  int BM;              // rows per M tile: 128 or 256
+  int S;               // whole samples per M tile
+  int mtiles;          // ceil(N / S)
+  // pointwise slab (combine+GN kernels)
+  int cs;              // channels per slab (multiple of lcm(cpg,4))
+  int nslab;
+  // wgrad
+  int RB;              // image rows per staging band
+  int nbands;          // bands per sample
+  int nsplit;          // K-split factor
+  size_t P;            // flat parameter count
+  size_t numel;        // N*C*H*W
+};
+
+// theta-segment internal layout (a permutation of the PyTorch flat layout):
+//   [g1 C][b1 C][Wc1 9*C*C as [tap][ci][co]][Wt1 9*C as [tap][co]][cb1 C]
+//   [g2 C][b2 C][Wc2 ...][Wt2 ...][cb2 C][g3 C][b3 C]
+struct ThetaLayout {
+  size_t g[3], b[3], wc[2], wt[2], cb[2];
+};
+__host__ __device__ inline ThetaLayout theta_layout(int C) {
+  ThetaLayout L;
+  size_t o = 0, cc = (size_t)C;
+  L.g[0] = o; o += cc; L.b[0] = o; o += cc;
+  L.wc[0] = o; o += 9 * cc * cc; L.wt[0] = o; o += 9 * cc; L.cb[0] = o; o += cc;
+  L.g[1] = o; o += cc; L.b[1] = o; o += cc;
+  L.wc[1] = o; o += 9 * cc * cc; L.wt[1] = o; o += 9 * cc; L.cb[1] = o; o += cc;
+  L.g[2] = o; o += cc; L.b[2] = o; o += cc;
+  return L;
+}
+
+// ----------------------------------------------------------------------------
+// Device-resident step controller state (one per solve, lives in the workspace)
+// ----------------------------------------------------------------------------
+struct Ctrl {
+  double t;        // solver time at the start of the current step
+  double dt;       // step size of the current step
+  double t_prev;   // start of the step just finished (== t unless accepted)
+  double dt_used;  // dt of the step just finished
+  float ratio[4];  // mean squared error ratio per state segment (y, a, adj_t, adj_params)
+  float h0;        // initial-step probe size
+  float d0, d1;    // initial-step norms (max over segments)
+  int accept;      // last step accepted?
+  int status;      // 0 or NODE_ERR_*
+  int n_acc, n_rej;
+  // scalar (adj_t) segment of the augmented state
+  float ts_cur;    // current value
+  float ts_new;    // end-of-step value
+  float ts_k[7];   // stage derivatives
+  float ts_y0_prev; // value at the start of the last accepted step (dense output)
+  float ts_f0_prev; // derivative at the start of the last accepted step
+  float pad;
+};
+
+enum TimeMode { TM_STAGE = 0, TM_PROBE = 1 };
+
+// how an eval derives its time:  t_real = tsign * ((float)t + (mode==TM_STAGE ? alpha*(float)dt : h0))
+struct EvalTime {
+  const Ctrl* ctrl;
+  float alpha;
+  float tsign;
+  int mode;
+};
+__device__ inline float eval_time(const EvalTime& et) {
+  float tf = (float)et.ctrl->t;
+  float inc = et.mode == TM_STAGE ? et.alpha * (float)et.ctrl->dt : et.ctrl->h0;
+  return et.tsign * (tf + inc);
+}
+
+// linear combination  y + scale * sum_j coef[j] * k[j]
+enum ScaleMode { SC_ABS = 0, SC_DT = 1, SC_H0 = 2 };
+struct Comb {
+  const float* y;
+  const float* k[7];
+  float coef[7];
+  int nk;
+  int scale_mode;
+};
+__device__ inline float comb_scale(const Comb& c, const Ctrl* ctrl) {
+  return c.scale_mode == SC_ABS ? 1.0f : (c.scale_mode == SC_DT ? (float)ctrl->dt : ctrl->h0);
+}
+
+// ----------------------------------------------------------------------------
+// kernel launchers (defined in the kernels_*.hip units)
+// ----------------------------------------------------------------------------
+// layout
+void launch_nchw_to_nhwc(const Dims& d, const float* src, float* dst, hipStream_t s);
+void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_t s);
+void launch_pack_weights(const Dims& d, const float* w /*[C][C+1][3][3]*/, float* packed, int dgrad, hipStream_t s);
+void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStream_t s);
+void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
+
+// pointwise / reductions
+struct CombineGnArgs {
+  Comb comb;
+  const Ctrl* ctrl;
+  float* y_out;        // nullable
+  float* act_out;      // relu(GN(y_i))
+  float* xhat_out;     // nullable
+  float* rstd_out;     // nullable [N][G]
+  const float* gamma;
+  const float* beta;
+};
+void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s);
+
+struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN_bwd(g)
+  Comb comb;
+  const Ctrl* ctrl;
+  float csign;
+  float* a_out;        // nullable: combined adjoint state
+  const float* xhat;   // [N,HW,C]
+  const float* rstd;   // [N][G]
+  const float* gamma;
+  float* dz_out;
+  float* gpart;        // [N][2][C] per-sample (dgamma, dbeta) partials
+};
+void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s);
+
+struct ErrSeg {
+  const float* y0;
+  float* y1;           // read, or written when compute_y1
+  const float* k[7];
+  size_t n;
+  int compute_y1;
+};
+constexpr int ERR_BLOCKS = 512;
+void launch_error_norm(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial /*[ERR_BLOCKS]*/, hipStream_t s);
+
+struct StepCtlArgs {
+  Ctrl* ctrl;
+  const float* partial[3];
+  double numel[3];
+  int nseg;            // tensor segments (1 fwd, 3 aug: y, a, theta)
+  int has_scalar;      // adj_t segment present
+  float rtol, atol;
+  int forced;          // replay mode
+  double forced_next;
+};
+void launch_step_controller(const StepCtlArgs& a, hipStream_t s);
+
+// initial step (Hairer)
+struct InitSeg { const float* y0; const float* f0; const float* f1; size_t n; };
+void launch_init_norms(const InitSeg& seg, float rtol, float atol, int phase, float* partial /*[ERR_BLOCKS][2]*/, const Ctrl* ctrl, hipStream_t s);
+struct InitCtlArgs {
+  Ctrl* ctrl;
+  const float* partial[3];
+  double numel[3];
+  int nseg, has_scalar, phase;
+  float rtol, atol;
+};
+void launch_init_controller(const InitCtlArgs& a, hipStream_t s);
+void launch_set_ctrl(Ctrl* ctrl, double t, double dt, int reset_counters, hipStream_t s);
+void launch_set_scalar_state(Ctrl* ctrl, float v, int which, hipStream_t s);
+
+struct InterpArgs {
+  const float* y0; const float* y1; const float* k[7];
+  float* out; size_t n; float dt; float x;
+};
+void launch_interp(const InterpArgs& a, hipStream_t s);
+void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s);   // ts_cur <- interp
+void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s);  // y += alpha*x
+void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float* partial, float* out_dot, hipStream_t s);
+void launch_fill(float* p, float v, size_t n, hipStream_t s);
+void launch_lincomb(const Comb& c, const Ctrl* ctrl, float* out, size_t n, hipStream_t s);
+void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s);
+
+// conv implicit GEMM
+enum ConvMode { CM_FWD_GN_RELU = 0, CM_FWD_GN = 1, CM_BWD_RELU_GN = 2 };
+struct ConvArgs {
+  const float* in;        // [N,HW,C] NHWC: activation (fwd) or dz (dgrad)
+  const float* wpacked;   // [ntile][nchunk][9][32][64]
+  int mode;
+  // fwd epilogue
+  const float* bias;      // [C]
+  const float* tmap;      // [HW][C]
+  EvalTime et;
+  const float* gamma;     // [C]
+  const float* beta;      // [C]   (fwd)
+  float osign;            // output multiplier
+  float* out;             // fwd: post-affine (ReLU'd for CM_FWD_GN_RELU) ; bwd: dx
+  float* xhat_out;        // fwd nullable
+  float* rstd_out;        // fwd nullable [N][G]
+  // bwd epilogue
+  const float* act;       // [N,HW,C] post-ReLU activation of the layer below (mask)
+  const float* xhat;      // [N,HW,C]
+  const float* rstd;      // [N][G]
+  float* gpart;           // [mtiles][2][C]
+};
+void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s);
+size_t conv_lds_bytes(const Dims& d, int mode);
+
+struct WgradArgs {
+  const float* act;       // [N,HW,C] conv input activation
+  const float* dz;        // [N,HW,C] cotangent of conv output
+  float* wpart;           // [nsplit][9][C][C]
+  float* spart;           // [nsplit][9][C]   masked column sums of dz (bias / time-channel grads)
+};
+void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s);
+size_t wgrad_lds_bytes(const Dims& d);
+
+struct ThetaFinalizeArgs {
+  const float* wpart[2];   // conv1, conv2
+  const float* spart[2];
+  const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)
+  int gpart_rows[3];
+  const float* wraw[2];    // raw PyTorch conv weights (time-channel taps for vjp_t)
+  EvalTime et;
+  float osign;             // tsign
+  float* theta_out;        // [P] internal layout
+  Ctrl* ctrl;              // ts_k[kidx] <- osign * vjp_t   (when write_scalar)
+  int kidx;
+  int write_scalar;
+  float* vjp_t_out;        // nullable device float
+};
+void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s);
+
+}  // namespace node

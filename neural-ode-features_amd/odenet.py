@@ -1,0 +1,113 @@
+"""The caller of the hot path: `ODENet` = stem -> ODEBlock -> classifier head.
+
+Mirrors the observable semantics and state_dict keys of the reference's
+`ODENet.forward` (`/root/reference/model.py:6-62`), its stems (`model.py:119-178`)
+and head (`model.py:231-250`) so checkpoints load unchanged (`utils.py:248-270`).
+The stem and head are a handful of plain convolutions run once per batch
+(~1 ODEfunc-eval of FLOPs): they stay on
+PyTorch-ROCm/MIOpen.  Only the ODE block is the accelerated path.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .modules import ODEBlock, normalization
+
+
+class ResBlock(nn.Module):
+    """Pre-activation residual block (model.py:284-310)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm='group'):
+        super().__init__()
+        make_norm = normalization(norm)
+        self.norm1 = make_norm(inplanes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.norm2 = make_norm(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+
+    def forward(self, x):
+        pre = self.relu(self.norm1(x))
+        skip = x if self.downsample is None else self.downsample(pre)
+        h = self.conv2(self.relu(self.norm2(self.conv1(pre))))
+        return h + skip
+
+
+def _stem(kind, in_ch, out_ch, norm):
+    """Stem bodies keyed like the reference's `--downsample` choices."""
+    if kind == 'residual':       # model.py:167-178
+        return nn.Sequential(
+            nn.Conv2d(in_ch, 64, 3, 1),
+            ResBlock(64, 64, stride=2, downsample=nn.Conv2d(64, 64, 1, 2, bias=False), norm=norm),
+            ResBlock(64, out_ch, stride=2, downsample=nn.Conv2d(64, out_ch, 1, 2, bias=False), norm=norm))
+    if kind == 'one-shot':       # model.py:119-126
+        return nn.Conv2d(in_ch, out_ch, 4, 2, 1)
+    if kind in ('convolution', 'minimal'):   # model.py:129-164
+        mid = 64 if kind == 'convolution' else 24
+        make_norm = normalization(norm)
+        return nn.Sequential(
+            nn.Conv2d(in_ch, mid, 3, 1), make_norm(mid), nn.ReLU(inplace=True),
+            nn.Conv2d(mid, mid, 4, 2, 1), make_norm(mid), nn.ReLU(inplace=True),
+            nn.Conv2d(mid, out_ch, 4, 2, 1))
+    raise NotImplementedError("downsample=%r (the ODE stems 'ode'/'ode2' are a later row, SURVEY.md 8f)" % (kind,))
+
+
+class _Wrapped(nn.Module):
+    """Holds a body under the attribute name `module` (state_dict key parity)."""
+
+    def __init__(self, body):
+        super().__init__()
+        self.module = body
+
+    def forward(self, x):
+        return self.module(x)
+
+
+class Flatten(nn.Module):
+    def forward(self, x):
+        return x.flatten(1)
+
+
+class FCClassifier(_Wrapped):
+    """GN -> ReLU -> global average pool -> [Dropout] -> Linear (model.py:231-250)."""
+
+    def __init__(self, in_ch=64, out=10, dropout=0, norm='group'):
+        layers = [normalization(norm)(in_ch), nn.ReLU(inplace=True), nn.AdaptiveAvgPool2d((1, 1))]
+        if dropout:
+            layers.append(nn.Dropout(dropout))
+        layers += [Flatten(), nn.Linear(in_ch, out)]
+        super().__init__(nn.Sequential(*layers))
+
+
+class ODENet(nn.Module):
+    def __init__(self, in_ch, out=10, n_filters=64, downsample='residual', method='dopri5', tol=1e-3,
+                 adjoint=False, t1=1, dropout=0, norm='group'):
+        super().__init__()
+        self.downsample = _Wrapped(_stem(downsample, in_ch, n_filters, norm))
+        self.odeblock = ODEBlock(n_filters=n_filters, tol=tol, adjoint=adjoint, t1=t1, method=method, norm=norm)
+        self.classifier = FCClassifier(in_ch=n_filters, out=out, dropout=dropout, norm=norm)
+
+    def forward(self, x):
+        x = self.odeblock(self.downsample(x))
+        if x.dim() > 4:   # [T, N, C, H, W]: head applied per time slice (model.py:39-40)
+            x = torch.stack([self.classifier(xi) for xi in x])
+        else:
+            x = self.classifier(x)
+        return x
+
+    def to_features_extractor(self, keep_pool=True):
+        """model.py:48-56: expose the trajectory and drop the classification layer."""
+        self.odeblock.return_last_only = False
+        if keep_pool:
+            self.classifier.module[-1] = nn.Sequential()
+        else:
+            self.classifier = nn.Sequential(*list(self.classifier.module.children())[:2])
+
+    def nfe(self, reset=False):
+        count = self.odeblock.nfe
+        if reset:
+            self.odeblock.nfe = 0
+        return count

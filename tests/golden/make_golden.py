@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py
+
+The reference's ``model.py`` is imported unchanged.  Its single third-party
+import (``from torchdiffeq import odeint_adjoint, odeint``, model.py:3) cannot
+resolve -- torchdiffeq is an empty submodule -- so a stub module carrying the
+oracle restatement (oracle/torchdiffeq_restated.py) is registered under that
+name first.  What the fixtures pin:
+
+  odefunc_c{8,16,64}.pt   reference ``ODEfunc`` (model.py:326-348): inputs, parameters,
+                          f(t, y) and autograd VJPs (d/dy, d/dt, d/dtheta) for a fixed cotangent
+  odenet_t0.pt            reference ``ODENet(..., t1=0)`` logits (stem + head, no solver; model.py:27-46,363-364)
+  odeblock_t1_cases.json  reference ``ODEBlock.t1`` setter semantics (model.py:380-403)
+  odenet_rk4.pt /         reference ``ODENet`` driven end-to-end (forward, CE loss, backward) with the
+  odenet_dopri5.pt        oracle standing in for torchdiffeq: logits, loss, NFE-F/NFE-B, selected grads
+
+Fixtures are data (tensors / json).  No reference source text is stored.
+"""
+import json
+import os
+import sys
+import types
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import torchdiffeq_restated as tdq  # noqa: E402
+
+REF = '/root/reference'
+
+
+def import_reference_model():
+    stub = types.ModuleType('torchdiffeq')
+    stub.odeint = tdq.odeint
+    stub.odeint_adjoint = tdq.odeint_adjoint
+    sys.modules['torchdiffeq'] = stub
+    sys.path.insert(0, REF)
+    import model as ref_model  # noqa
+    sys.path.remove(REF)
+    return ref_model
+
+
+def randomize_(module, gen):
+    """Make every parameter non-trivial (GroupNorm defaults to w=1, b=0)."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if 'norm' in name and name.endswith('weight'):
+                p.copy_(1.0 + 0.25 * torch.randn(p.shape, generator=gen))
+            elif 'norm' in name and name.endswith('bias'):
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+def make_odefunc(ref, C, N, H, W, seed):
+    torch.manual_seed(seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    func = ref.ODEfunc(C)
+    randomize_(func, gen)
+    y = torch.randn(N, C, H, W, generator=gen)
+    cot = torch.randn(N, C, H, W, generator=gen)
+    t = torch.tensor(0.37)
+    tt = t.clone().requires_grad_(True)
+    yy = y.clone().requires_grad_(True)
+    params = tuple(func.parameters())
+    f = func(tt, yy)
+    grads = torch.autograd.grad(f, (tt, yy) + params, cot)
+    out = {
+        'C': C, 'N': N, 'H': H, 'W': W, 't': t, 'y': y, 'cotangent': cot,
+        'state_dict': {k: v.clone() for k, v in func.state_dict().items()},
+        'param_names': [n for n, _ in func.named_parameters()],
+        'f': f.detach(), 'vjp_t': grads[0], 'vjp_y': grads[1],
+        'vjp_params': torch.cat([g.reshape(-1) for g in grads[2:]]),
+    }
+    torch.save(out, os.path.join(HERE, 'odefunc_c%d.pt' % C))
+    print('odefunc C=%d: |f|=%.4f |vjp_y|=%.4f vjp_t=%.5f P=%d' % (
+        C, f.norm(), grads[1].norm(), grads[0], out['vjp_params'].numel()))
+
+
+def make_odenet_t0(ref):
+    torch.manual_seed(23)  # train.py:224,227
+    net = ref.ODENet(1, out=10, n_filters=8, downsample='residual', t1=0)
+    net.eval()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, 28, 28, generator=gen)
+    with torch.no_grad():
+        logits = net(x)
+    torch.save({'x': x, 'logits': logits, 'state_dict': net.state_dict(),
+                'keys': list(net.state_dict().keys())}, os.path.join(HERE, 'odenet_t0.pt'))
+    print('odenet_t0 logits', logits.shape, float(logits.abs().mean()))
+
+
+def make_t1_cases(ref):
+    cases = []
+    for value in [1, 0, 0.5, [0.1, 0.2, 1], (0, 0.25, 0.5), [0, 1], torch.tensor([0.3, 0.6]), 2.0]:
+        blk = ref.ODEBlock(n_filters=8, t1=1)
+        import io
+        import contextlib
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):  # the setter prints value[0] when it prepends 0 (model.py:398)
+            blk.t1 = value
+        it = blk.integration_time
+        cases.append({
+            'value': value.tolist() if torch.is_tensor(value) else (list(value) if isinstance(value, tuple) else value),
+            'kind': type(value).__name__,
+            'integration_time': None if it is None else it.tolist(),
+            'dtype': None if it is None else str(it.dtype),
+        })
+    with open(os.path.join(HERE, 'odeblock_t1_cases.json'), 'w') as fh:
+        json.dump(cases, fh, indent=1)
+    print('t1 cases', len(cases))
+
+
+def make_odenet_e2e(ref, name, method, tol, in_ch, filters, hw, bs, t1, seed):
+    torch.manual_seed(seed)
+    net = ref.ODENet(in_ch, out=10, n_filters=filters, downsample='residual', method=method, tol=tol,
+                     adjoint=True, t1=t1, dropout=0)
+    gen = torch.Generator().manual_seed(seed + 7)
+    randomize_(net.odeblock.odefunc, gen)
+    net.train()
+    x = torch.rand(bs, in_ch, hw, hw, generator=gen)
+    y = torch.randint(0, 10, (bs,), generator=gen)
+    p = net(x)
+    loss = F.cross_entropy(p, y)
+    nfe_f = net.nfe(reset=True)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    grads = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+    torch.save({
+        'method': method, 'tol': tol, 'in_ch': in_ch, 'filters': filters, 't1': t1,
+        'x': x, 'y': y, 'logits': p.detach(), 'loss': loss.detach(), 'nfe_f': nfe_f, 'nfe_b': nfe_b,
+        'state_dict': net.state_dict(),
+        'grads': grads,
+    }, os.path.join(HERE, name))
+    print(name, 'loss %.5f nfe_f %d nfe_b %d' % (loss, nfe_f, nfe_b))
+
+
+def main():
+    ref = import_reference_model()
+    make_odefunc(ref, 8, 2, 7, 7, seed=23)
+    make_odefunc(ref, 16, 3, 5, 6, seed=24)
+    make_odefunc(ref, 64, 2, 8, 8, seed=25)
+    make_odenet_t0(ref)
+    make_t1_cases(ref)
+    # config-1-like plumbing case (MNIST-shaped, rk4, one 3/8 step) and a small dopri5 case
+    make_odenet_e2e(ref, 'odenet_rk4.pt', 'rk4', 1e-3, 1, 8, 28, 4, 1, seed=23)
+    make_odenet_e2e(ref, 'odenet_dopri5.pt', 'dopri5', 1e-3, 3, 8, 32, 2, 1, seed=29)
+
+
+if __name__ == '__main__':
+    main()

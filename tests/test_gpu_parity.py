@@ -1,0 +1,52 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import pytest
+import torch
+
+from tests.helpers import make_func, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (N, C, H, W)
+    (2, 8, 7, 7),       # 1 channel / group, odd image, C < one K chunk
+    (3, 16, 5, 6),      # non-square
+    (2, 64, 8, 8),      # MNIST-like width, 2 ch / group
+    (5, 64, 7, 7),      # MNIST config state (49 px: 2 samples per 128-row tile, ragged last tile)
+    (4, 96, 4, 4),      # 3 ch / group: N tile of 63 columns
+    (3, 256, 8, 8),     # CIFAR width
+    (2, 32, 16, 16),    # 256-row tiles (one sample per tile)
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_odefunc_forward_matches_oracle(shape):
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=C + H, device='cuda')
+    gen = torch.Generator().manual_seed(1)
+    y = torch.randn(N, C, H, W, generator=gen)
+    t = 0.37
+    got = nof.odefunc_forward(f, t, y.cuda())
+    with torch.no_grad():
+        want = twin(torch.tensor(t), y)
+    err = rel_err(got, want)
+    print('fwd', shape, err)
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_odefunc_vjp_matches_oracle(shape):
+    import neural_ode_features_amd as nof
+    from oracle.dynamics import odefunc_vjp as oracle_vjp
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=C + H, device='cuda')
+    gen = torch.Generator().manual_seed(2)
+    y = torch.randn(N, C, H, W, generator=gen)
+    cot = torch.randn(N, C, H, W, generator=gen)
+    t = -0.61
+    fo, vy, vt, vp = nof.odefunc_vjp(f, t, y.cuda(), cot.cuda())
+    p = dict(twin.named_parameters())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(t, y, p, cot)
+    errs = dict(f=rel_err(fo, f_ref), vy=rel_err(vy, vy_ref), vp=rel_err(vp, vp_ref),
+                vt=abs(float(vt) - float(vt_ref)) / (abs(float(vt_ref)) + 1e-6))
+    print('vjp', shape, errs)
+    assert errs['f'] < 2e-5 and errs['vy'] < 5e-5 and errs['vp'] < 5e-5 and errs['vt'] < 1e-4, errs
