@@ -1,0 +1,165 @@
+"""GPU parity of the integrator: free-running and replay-mode dopri5, rk4 (3/8 rule),
+dense output at interior points, and the continuous-adjoint backward -- HIP path via
+the C ABI vs oracle/torchdiffeq_restated.py on identical inputs.
+
+Tolerances (BASELINE.json north_star): free-running <= 10 x atol; replay (forced dt
+sequence, so no accept/reject discontinuity) <= 1e-5 relative.
+"""
+import pytest
+import torch
+
+from oracle import torchdiffeq_restated as tdq
+from tests.helpers import make_func, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_solve(twin, y, t, tol, method, options=None):
+    st = tdq.SolverStats()
+    with torch.no_grad():
+        out = tdq.odeint(twin, y, t, rtol=tol, atol=tol, method=method, options=options, stats=st)
+    return out, st
+
+
+@pytest.mark.parametrize('shape,tol', [((4, 64, 7, 7), 1e-3), ((3, 16, 5, 6), 1e-5), ((2, 256, 8, 8), 1e-3),
+                                       ((2, 32, 16, 16), 1e-4)])
+def test_dopri5_free_running(shape, tol):
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=11, device='cuda')
+    y = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([0.0, 1.0])
+    want, st = _oracle_solve(twin, y, t, tol, 'dopri5')
+    f.nfe = 0
+    with torch.no_grad():
+        got = nof.odeint(f, y.cuda(), t.cuda(), rtol=tol, atol=tol, method='dopri5', options={'record_dt': 256})
+    fs = f.last_forward_stats
+    print(shape, tol, 'oracle', st.nfe, st.accepted, st.rejected, 'hip', fs['nfe'], fs['accepted'], fs['rejected'],
+          'first_dt', st.first_step, fs['first_dt'])
+    assert got.shape == (2, N, C, H, W)
+    assert torch.equal(got[0].cpu(), y)
+    err = float((got[-1].cpu() - want[-1]).abs().max())
+    print('max abs err', err)
+    assert err <= 10 * tol
+    # same accept/reject history => NFE law 2 + 6*steps (show.py:199) and tight agreement
+    assert f.nfe == fs['nfe'] == 2 + 6 * (fs['accepted'] + fs['rejected'])
+    if (fs['accepted'], fs['rejected']) == (st.accepted, st.rejected):
+        assert rel_err(got[-1], want[-1]) < 2e-4
+        for a, b in zip(fs['dts'], st.dts):
+            assert abs(a - b) <= 1e-3 * abs(b)
+
+
+def test_dopri5_replay_mode_tight():
+    import neural_ode_features_amd as nof
+    f, twin = make_func(64, seed=5, device='cuda')
+    y = torch.randn(3, 64, 8, 8, generator=torch.Generator().manual_seed(4))
+    t = torch.tensor([0.0, 1.0])
+    dts = [0.05, 0.1, 0.2, 0.3, 0.3, 0.2]
+    want, st = _oracle_solve(twin, y, t, 1e-3, 'dopri5', options={'forced_dts': dts})
+    with torch.no_grad():
+        got = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5', options={'forced_dts': dts})
+    fs = f.last_forward_stats
+    assert fs['accepted'] == st.accepted and fs['rejected'] == 0
+    assert fs['nfe'] == 1 + 6 * st.accepted
+    err = rel_err(got[-1], want[-1])
+    print('replay rel err', err)
+    assert err < 1e-5
+
+
+def test_dense_output_interior_points():
+    """evaluate.py:62,424: 21 time points 0, .05, ..., 1 -> quartic interpolant inside accepted steps."""
+    import neural_ode_features_amd as nof
+    f, twin = make_func(16, seed=7, device='cuda')
+    y = torch.randn(2, 16, 6, 6, generator=torch.Generator().manual_seed(5))
+    t = torch.linspace(0, 1, 21)
+    want, st = _oracle_solve(twin, y, t, 1e-3, 'dopri5')
+    with torch.no_grad():
+        got = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5')
+    assert got.shape == want.shape
+    err = float((got.cpu() - want).abs().max())
+    print('dense output max abs err', err, 'steps', st.accepted, st.rejected)
+    assert err <= 10 * 1e-3
+    if f.last_forward_stats['accepted'] == st.accepted:
+        assert rel_err(got, want) < 2e-4
+
+
+@pytest.mark.parametrize('tpts', [[0.0, 1.0], [0.0, 0.25, 0.7, 1.0]])
+def test_rk4_three_eighths(tpts):
+    import neural_ode_features_amd as nof
+    f, twin = make_func(64, seed=9, device='cuda')
+    y = torch.rand(4, 64, 7, 7, generator=torch.Generator().manual_seed(6))
+    t = torch.tensor(tpts)
+    want, st = _oracle_solve(twin, y, t, 1e-3, 'rk4')
+    f.nfe = 0
+    with torch.no_grad():
+        got = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='rk4')
+    assert f.nfe == st.nfe == 4 * (len(tpts) - 1)
+    err = rel_err(got, want)
+    print('rk4 rel err', err)
+    assert err < 1e-5
+
+
+def _adjoint_pair(shape, tol, method, tpts, seed, options=None, boptions=None):
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=seed, device='cuda')
+    gen = torch.Generator().manual_seed(seed + 1)
+    y = torch.randn(N, C, H, W, generator=gen)
+    wgt = torch.randn(len(tpts), N, C, H, W, generator=gen) / (N * C * H * W) ** 0.5
+    t = torch.tensor(tpts)
+    # oracle
+    yo = y.clone().requires_grad_(True)
+    fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
+    out_o = tdq.odeint_adjoint(twin, yo, t, rtol=tol, atol=tol, method=method, options=options,
+                               fwd_stats=fs_o, bwd_stats=bs_o)
+    (out_o * wgt).sum().backward()
+    g_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
+    # hip
+    yh = y.cuda().requires_grad_(True)
+    f.nfe = 0
+    out_h = nof.odeint_adjoint(f, yh, t.cuda(), rtol=tol, atol=tol, method=method, options=options)
+    nfe_f = f.nfe
+    (out_h * wgt.cuda()).sum().backward()
+    nfe_b = f.nfe - nfe_f
+    g_h = torch.cat([p.grad.reshape(-1) for p in f.parameters()])
+    return dict(out_o=out_o, out_h=out_h, gy_o=yo.grad, gy_h=yh.grad, gp_o=g_o, gp_h=g_h, fs_o=fs_o, bs_o=bs_o,
+                fs_h=f.last_forward_stats, bs_h=f.last_backward_stats, nfe_f=nfe_f, nfe_b=nfe_b)
+
+
+@pytest.mark.parametrize('shape,tol,tpts', [((4, 64, 7, 7), 1e-3, [0.0, 1.0]),
+                                           ((2, 16, 6, 6), 1e-5, [0.0, 1.0]),
+                                           ((2, 256, 8, 8), 1e-3, [0.0, 1.0]),
+                                           ((2, 32, 8, 8), 1e-3, [0.0, 0.3, 1.0])])
+def test_adjoint_dopri5_free_running(shape, tol, tpts):
+    r = _adjoint_pair(shape, tol, 'dopri5', tpts, seed=21)
+    print(shape, tol, 'oracle bwd', r['bs_o'].nfe, r['bs_o'].accepted, r['bs_o'].rejected,
+          'hip bwd', r['bs_h']['nfe'], r['bs_h']['accepted'], r['bs_h']['rejected'])
+    same = (r['bs_h']['accepted'], r['bs_h']['rejected']) == (r['bs_o'].accepted, r['bs_o'].rejected) and \
+           (r['fs_h']['accepted'], r['fs_h']['rejected']) == (r['fs_o'].accepted, r['fs_o'].rejected)
+    e_y, e_p = rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print('grad rel err', e_y, e_p, 'same history', same)
+    # NFE-B = (T-1) * (1 + 2) + 6 * steps   
+    T = len(tpts)
+    assert r['nfe_b'] == r['bs_h']['nfe'] == 3 * (T - 1) + 6 * (r['bs_h']['accepted'] + r['bs_h']['rejected'])
+    if same:
+        assert e_y < 1e-3 and e_p < 1e-3
+    else:  # a flipped accept/reject moves the trajectory by O(tol)
+        assert e_y < 0.05 and e_p < 0.05
+
+
+def test_adjoint_rk4():
+    r = _adjoint_pair((4, 64, 7, 7), 1e-3, 'rk4', [0.0, 1.0], seed=31)
+    assert r['nfe_f'] == 4 and r['nfe_b'] == 5   # golden odenet_rk4.pt: nfe_f 4, nfe_b 5
+    e_o, e_y, e_p = rel_err(r['out_h'], r['out_o']), rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print('rk4 adjoint rel errs', e_o, e_y, e_p)
+    assert e_o < 1e-5 and e_y < 2e-5 and e_p < 2e-5
+
+
+def test_adjoint_replay_mode_tight():
+    fd = [0.1, 0.2, 0.3, 0.4]
+    bd = [0.05, 0.15, 0.3, 0.3, 0.2]
+    r = _adjoint_pair((3, 64, 8, 8), 1e-3, 'dopri5', [0.0, 1.0], seed=41,
+                      options={'forced_dts': fd, 'forced_dts_bwd': bd})
+    e_o, e_y, e_p = rel_err(r['out_h'], r['out_o']), rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print('replay adjoint rel errs', e_o, e_y, e_p)
+    assert e_o < 1e-5 and e_y < 2e-5 and e_p < 2e-5
