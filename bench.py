@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec (forward + adjoint backward + SGD step) of the
+CIFAR-10 ODE-ResNet, dopri5 tol=1e-3, bs=128 per GPU (BASELINE.json configs[1];
+with --gpus N the batch shards data-parallel, N x 128 = configs[3] at N=8).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is the loop body of the reference's train.py:40-58 on device-resident
+synthetic tensors: p = model(x); loss = CE(p, y); loss.backward(); optimizer.step();
+optimizer.zero_grad().  Stem/head run on PyTorch-ROCm (MIOpen); the ODE block --
+the hot path -- runs in libnode_hip.so through the C ABI.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
+(k_conv3x3, fp32-MFMA implicit GEMM): algorithmic FLOPs per launch / average launch
+duration from HIP events recorded by the library on the launch stream, over a
+repeat of the timed steps.  `cpu_baseline` is the oracle (CPU restatement of the
+torchdiffeq path driving PyTorch-CPU conv/group_norm) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def build_model(device, filters, tol, method):
+    import neural_ode_features_amd as nof
+    torch.manual_seed(23)       # train.py:224,227
+    model = nof.ODENet(3, out=10, n_filters=filters, downsample='residual', method=method, tol=tol,
+                       adjoint=True, t1=1, dropout=0.5)
+    return model.to(device)
+
+
+def train_step(model, opt, x, y, reducer=None):
+    p = model(x)
+    loss = F.cross_entropy(p, y)
+    nfe_f = model.nfe(reset=True)
+    loss.backward()
+    nfe_b = model.nfe(reset=True)
+    if reducer is not None:
+        reducer.finish()
+    opt.step()
+    opt.zero_grad()
+    return loss, nfe_f, nfe_b
+
+
+def cpu_baseline(state_dict, filters, tol, method, bs, iters):
+    """The reference-equivalent CPU path: same ODENet, the oracle standing in for
+    torchdiffeq (which cannot be installed here), all host cores."""
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(23)
+    model = nof.ODENet(3, out=10, n_filters=filters, downsample='residual', method=method, tol=tol,
+                       adjoint=True, t1=1, dropout=0.5)
+    model.load_state_dict(state_dict)
+    model.odeblock.odeint = tdq.odeint_adjoint       # CPU solver = the checker, timed as the baseline
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(1234)
+    xw = torch.randn(8, 3, 32, 32, generator=gen)
+    yw = torch.randint(0, 10, (8,), generator=gen)
+    train_step(model, opt, xw, yw)                    # warm-up (thread pool, oneDNN primitives)
+    x = torch.randn(bs, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, (bs,), generator=gen)
+    t0 = time.perf_counter()
+    nf = nb = 0
+    for _ in range(iters):
+        _, a, b = train_step(model, opt, x, y)
+        nf, nb = a, b
+    dt = time.perf_counter() - t0
+    return {'value': iters * bs / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d training iterations at bs=%d (fwd + adjoint + SGD), last NFE-F %d NFE-B %d, %.1f s'
+                      % (iters, bs, nf, nb, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (bs=128: BASELINE.json)')
+    ap.add_argument('--filters', type=int, default=256)
+    ap.add_argument('--tol', type=float, default=1e-3)
+    ap.add_argument('--method', default='dopri5')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (there is no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    model = build_model(device, args.filters, args.tol, args.method)
+    init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    reducer = None
+    if world > 1:
+        nof.dp.broadcast_parameters(model, 0)
+        reducer = nof.dp.GradientReducer(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)  # reproduce.sh:3-6, train.py:136
+    model.train()
+
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, 32, 32, generator=gen).to(device)      # normalised CIFAR-shaped
+    y = torch.randint(0, 10, (args.batch,), generator=gen).to(device)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        train_step(model, opt, x, y, reducer)
+    sync()
+    t0 = time.perf_counter()
+    nfe_f = nfe_b = 0
+    for _ in range(args.steps):
+        _, a, b = train_step(model, opt, x, y, reducer)
+        nfe_f += a
+        nfe_b += b
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fstats = model.odeblock.odefunc.last_forward_stats
+    bstats = model.odeblock.odefunc.last_backward_stats
+
+    roofline = None
+    if not args.no_roofline:
+        # repeat of the timed steps with per-launch HIP events on the launch stream
+        integrate.profile_begin()
+        for _ in range(min(args.steps, 5)):
+            train_step(model, opt, x, y, reducer)
+        torch.cuda.synchronize(device)
+        prof = integrate.profile_end()
+        k = prof['conv3x3_implicit_gemm']
+        if k['launches'] > 0:
+            avg_ms = k['total_ms'] / k['launches']
+            flops_per_launch = k['flops'] / k['launches']
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'k_conv3x3 (fp32 MFMA implicit GEMM, fwd+dgrad)',
+                        'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                        'avg_launch_us': avg_ms * 1e3, 'launches': k['launches'],
+                        'flops_per_launch': flops_per_launch}
+            w = prof['wgrad_gemm']
+            if w['launches'] > 0:
+                wavg = w['total_ms'] / w['launches']
+                roofline['wgrad'] = {'achieved': w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12,
+                                     'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
+
+    if rank == 0:
+        global_batch = args.batch * world
+        result = {
+            'metric': 'images/sec (fwd+adjoint) CIFAR-10 ODE-ResNet bs=128 at 1/2/4/8 GPU',
+            'value': args.steps * global_batch / elapsed,
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'CIFAR-10 ODE-ResNet (odenet, residual stem, %d filters), %s tol=%g, adjoint backward, '
+                            'bs=%d per GPU, SGD step' % (args.filters, args.method, args.tol, args.batch),
+                'global_batch': global_batch, 'state': [args.batch, args.filters, 8, 8],
+                'parallelism': 'dp%d' % world,
+                'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
+                'last_forward_steps': [fstats['accepted'], fstats['rejected']],
+                'last_backward_steps': [bstats['accepted'], bstats['rejected']],
+            },
+        }
+        if roofline is not None:
+            result['roofline'] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(init_state, args.filters, args.tol, args.method,
+                                                  args.batch, args.cpu_iters)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -655,6 +655,7 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
         const float* spp = a.spart[layer];
         if (r < 9 * C) {  // time-channel taps [tap][co]: t * masked column sums
           for (int sp = 0; sp < d.nsplit; ++sp) v += spp[(size_t)sp * 9 * C + r];
+          a.sred[(size_t)layer * 9 * C + r] = v;   // reduced once here, reused by k_vjp_t
           v *= tval;
         } else {          // conv bias: centre tap sees every pixel
           r -= 9 * C;
@@ -672,13 +673,11 @@ __global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
   float acc = 0.f;
   const int C = d.C;
   for (int layer = 0; layer < 2; ++layer) {
-    const float* spp = a.spart[layer];
+    const float* sr = a.sred + (size_t)layer * 9 * C;
     const float* w = a.wraw[layer];
     for (int i = threadIdx.x; i < 9 * C; i += 256) {
       const int tap = i / C, co = i - tap * C;
-      float sacc = 0.f;
-      for (int sp = 0; sp < d.nsplit; ++sp) sacc += spp[(size_t)sp * 9 * C + i];
-      acc += sacc * w[((size_t)co * (C + 1)) * 9 + tap];
+      acc += sr[i] * w[((size_t)co * (C + 1)) * 9 + tap];
     }
   }
   const float tot = block_sum_256(acc, red);

@@ -129,7 +129,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
   {
     const int U = d.N * d.nbands;
     const int ntc = (d.C + 63) / 64;
-    int ns = 512 / (ntc * ntc);
+    int ns = 256 / (ntc * ntc);   // one workgroup per CU (307 VGPR+AGPR: one wave per SIMD)
     if (ns < 1) ns = 1;
     if (ns > 32) ns = 32;
     if (ns > U) ns = U;
@@ -159,7 +159,7 @@ struct Plan {
   float *TH, *TH1, *THTMP, *KT[7];
   float *xh1, *xh2, *xh3, *r1, *r2, *r3;
   float *dz1, *dz2, *G;
-  float *wpart[2], *spart[2], *gpart[3];
+  float *wpart[2], *spart[2], *gpart[3], *sred;
   float* dots;              // [n_t] time vjps scratch
   size_t bytes;
 };
@@ -214,6 +214,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
       p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
       p.spart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C);
     }
+    p.sred = b.take<float>((size_t)2 * 9 * d.C);
     p.gpart[0] = b.take<float>((size_t)d.mtiles * 2 * d.C);
     p.gpart[1] = b.take<float>((size_t)d.mtiles * 2 * d.C);
     p.gpart[2] = b.take<float>((size_t)d.N * 2 * d.C);
@@ -364,7 +365,7 @@ struct Solver {
     tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
     tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
     tf.gpart_rows[0] = d.mtiles; tf.gpart_rows[1] = d.mtiles; tf.gpart_rows[2] = d.N;
-    tf.wraw[0] = prm.conv1_w; tf.wraw[1] = prm.conv2_w;
+    tf.wraw[0] = prm.conv1_w; tf.wraw[1] = prm.conv2_w; tf.sred = p.sred;
     tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
     tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
     launch_theta_finalize(d, tf, st);

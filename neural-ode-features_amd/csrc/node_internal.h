@@ -230,6 +230,7 @@ struct ThetaFinalizeArgs {
   const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)
   int gpart_rows[3];
   const float* wraw[2];    // raw PyTorch conv weights (time-channel taps for vjp_t)
+  float* sred;             // [2][9][C] split-reduced masked column sums (scratch)
   EvalTime et;
   float osign;             // tsign
   float* theta_out;        // [P] internal layout

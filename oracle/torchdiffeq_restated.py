@@ -253,7 +253,7 @@ class _Dopri5:
             first_step = _select_initial_step(self.func, t[0], self.y0, 4, self.rtol, self.atol, f0=f0).to(t)
         else:
             first_step = torch.tensor(self.forced_dts.pop(0)).to(t)
-        self.stats.first_step = float(first_step)
+        self.stats.first_step = float(first_step.detach())
         # (y, f, t0, t1, dt, interp)
         self.state = (self.y0, f0, t[0], t[0], first_step, [self.y0] * 5)
 

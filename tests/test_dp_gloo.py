@@ -1,0 +1,103 @@
+"""Data-parallel path on CPU: world_size-2 `gloo` processes.  The DP wiring (sharding,
+bucketed overlapped all-reduce, averaging) is host logic; the ODE solve inside each rank
+is stood in for by the oracle (tests may), exactly as bench.py's cpu_baseline does."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build(method='rk4'):
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    torch.manual_seed(23)
+    net = nof.ODENet(1, out=10, n_filters=8, downsample='residual', method=method, tol=1e-3, adjoint=True, dropout=0)
+    net.odeblock.odeint = tdq.odeint_adjoint
+    return net
+
+
+def _data(n):
+    gen = torch.Generator().manual_seed(7)
+    return torch.rand(n, 1, 28, 28, generator=gen), torch.randint(0, 10, (n,), generator=gen)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import neural_ode_features_amd as nof
+    net = _build()
+    if rank != 0:                       # ranks start from different weights; broadcast must fix that
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.1)
+    nof.dp.broadcast_parameters(net, 0)
+    reducer = nof.dp.GradientReducer(net, bucket_bytes=1 << 16)
+    x, y = _data(4 * world)
+    xs, ys = nof.dp.shard_batch(x, rank, world), nof.dp.shard_batch(y, rank, world)
+    loss = F.cross_entropy(net(xs), ys)
+    loss.backward()
+    order = list(reducer.launch_order)
+    owners = [('classifier' if any(p is q for q in net.classifier.parameters()) else
+               'odeblock' if any(p is q for q in net.odeblock.parameters()) else 'downsample')
+              for p in [b.params[0] for b in reducer.buckets]]
+    reducer.finish()
+    grads = {k: v.grad.clone() for k, v in net.named_parameters()}
+    torch.save({'grads': grads, 'order': order, 'owners': owners, 'nfe': net.nfe()},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'), weights_only=False)
+    for k in r0['grads']:
+        assert torch.equal(r0['grads'][k], r1['grads'][k]), k        # every rank holds the same averaged gradient
+    # single-process full batch (rk4: fixed steps, so sharding does not change the arithmetic)
+    net = _build()
+    x, y = _data(4 * world)
+    F.cross_entropy(net(x), y).backward()
+    for k, v in net.named_parameters():
+        assert torch.allclose(r0['grads'][k], v.grad, rtol=2e-4, atol=2e-6), k
+    # overlap order: buckets are launched head first, then the ODE block, then the stem
+    assert r0['order'] == sorted(r0['order'])
+    launched = [r0['owners'][i] for i in r0['order']]
+    assert launched[0] == 'classifier' and launched[-1] == 'downsample' and 'odeblock' in launched
+    assert launched.index('odeblock') < launched.index('downsample')
+
+
+def test_shard_batch_and_single_process_reducer():
+    import neural_ode_features_amd as nof
+    x = torch.arange(12).view(12, 1)
+    assert nof.dp.shard_batch(x, 1, 4).flatten().tolist() == [3, 4, 5]
+    with pytest.raises(ValueError):
+        nof.dp.shard_batch(x, 0, 5)
+    lin = torch.nn.Linear(3, 2)
+    red = nof.dp.GradientReducer(lin)          # world size 1: hooks fire, nothing is communicated
+    lin(torch.ones(1, 3)).sum().backward()
+    g = lin.weight.grad.clone()
+    red.finish()
+    assert torch.equal(lin.weight.grad, g)
+    red.remove()

@@ -1,0 +1,135 @@
+"""GPU: the HIP path against the fixtures generated from the REFERENCE's own modules
+(tests/golden/), and size-independent properties at BASELINE.json's full sizes."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import make_func, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
+
+
+@pytest.mark.parametrize('name', ['odefunc_c8.pt', 'odefunc_c16.pt', 'odefunc_c64.pt'])
+def test_hip_dynamics_match_reference_odefunc_fixture(golden_dir, name):
+    import neural_ode_features_amd as nof
+    g = _load(golden_dir, name)
+    f = nof.ODEfunc(g['C'])
+    f.load_state_dict(g['state_dict'])            # reference state_dict loads unchanged
+    f = f.cuda()
+    fo, vy, vt, vp = nof.odefunc_vjp(f, float(g['t']), g['y'].cuda(), g['cotangent'].cuda())
+    assert rel_err(fo, g['f']) < 1e-5              # <= 1e-6-class agreement with the reference ODEfunc
+    assert rel_err(vy, g['vjp_y']) < 2e-5
+    assert rel_err(vp, g['vjp_params']) < 2e-5
+    assert abs(float(vt) - float(g['vjp_t'])) < 2e-5 * max(1.0, abs(float(g['vjp_t'])))
+    assert rel_err(nof.odefunc_forward(f, float(g['t']), g['y'].cuda()), g['f']) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['odenet_rk4.pt', 'odenet_dopri5.pt'])
+def test_hip_end_to_end_matches_reference_run(golden_dir, name):
+    """Reference ODENet + oracle solver (fixture)  vs  package ODENet + HIP solver."""
+    import neural_ode_features_amd as nof
+    g = _load(golden_dir, name)
+    net = nof.ODENet(g['in_ch'], out=10, n_filters=g['filters'], downsample='residual', method=g['method'],
+                     tol=g['tol'], adjoint=True, t1=g['t1'], dropout=0)
+    net.load_state_dict(g['state_dict'])
+    net = net.cuda().train()
+    p = net(g['x'].cuda())
+    loss = F.cross_entropy(p, g['y'].cuda())
+    nfe_f = net.nfe(reset=True)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    assert (nfe_f, nfe_b) == (g['nfe_f'], g['nfe_b'])            # same steps taken, same NFE accounting
+    assert float((p.detach().cpu() - g['logits']).abs().max()) <= 10 * g['tol']
+    assert rel_err(p, g['logits']) < 1e-3
+    assert abs(float(loss) - float(g['loss'])) < 1e-4
+    for k, v in net.named_parameters():
+        assert rel_err(v.grad, g['grads'][k]) < 5e-3, k
+
+
+def test_full_size_cifar_state_forward_and_vjp_vs_oracle():
+    """BASELINE configs[1] state [128, 256, 8, 8]: one dynamics eval + VJP against the oracle."""
+    import neural_ode_features_amd as nof
+    from oracle.dynamics import odefunc_vjp as oracle_vjp
+    f, twin = make_func(256, seed=2, device='cuda')
+    gen = torch.Generator().manual_seed(8)
+    y = torch.randn(128, 256, 8, 8, generator=gen)
+    cot = torch.randn(128, 256, 8, 8, generator=gen)
+    fo, vy, vt, vp = nof.odefunc_vjp(f, 0.5, y.cuda(), cot.cuda())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.5, y, dict(twin.named_parameters()), cot)
+    assert rel_err(fo, f_ref) < 2e-5 and rel_err(vy, vy_ref) < 5e-5 and rel_err(vp, vp_ref) < 5e-5
+    assert abs(float(vt) - float(vt_ref)) < 1e-4 * abs(float(vt_ref)) + 1e-3
+    # linearity of the VJP in the cotangent (size-independent property)
+    _, vy2, vt2, vp2 = nof.odefunc_vjp(f, 0.5, y.cuda(), (-2.0 * cot).cuda())
+    assert rel_err(vy2, -2.0 * vy) < 1e-5 and rel_err(vp2, -2.0 * vp) < 1e-5
+
+
+def test_full_size_solve_properties():
+    """configs[1]/[2] at full size: NFE law, y_out[0] == y0, sample independence under a
+    forced step sequence (the only cross-sample coupling is the error norm), and agreement
+    with the oracle within 10 x atol."""
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    f, twin = make_func(256, seed=4, device='cuda')
+    y = torch.randn(128, 256, 8, 8, generator=torch.Generator().manual_seed(9))
+    t = torch.tensor([0.0, 1.0])
+    for tol in (1e-3, 1e-5):
+        f.nfe = 0
+        with torch.no_grad():
+            out = nof.odeint(f, y.cuda(), t.cuda(), rtol=tol, atol=tol, method='dopri5')
+        st = f.last_forward_stats
+        assert f.nfe == 2 + 6 * (st['accepted'] + st['rejected'])
+        assert torch.equal(out[0].cpu(), y)
+        with torch.no_grad():
+            want = tdq.odeint(twin, y, t, rtol=tol, atol=tol, method='dopri5')
+        assert float((out[-1].cpu() - want[-1]).abs().max()) <= 10 * tol
+    dts = [0.1, 0.25, 0.35, 0.4]
+    with torch.no_grad():
+        full = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
+        part = nof.odeint(f, y[5:37].cuda(), t.cuda(), rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
+    assert torch.equal(full[5:37], part)          # bit-identical: batch rows never mix
+
+
+def test_ragged_and_edge_shapes():
+    """N not a multiple of the samples-per-tile, single sample, single time interval reversed."""
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    for shape in [(1, 64, 7, 7), (7, 64, 7, 7), (3, 8, 1, 1)]:
+        N, C, H, W = shape
+        f, twin = make_func(C, seed=13, device='cuda')
+        y = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(10))
+        t = torch.tensor([0.0, 1.0])
+        with torch.no_grad():
+            got = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5')
+            want = tdq.odeint(twin, y, t, rtol=1e-3, atol=1e-3, method='dopri5')
+        assert float((got[-1].cpu() - want[-1]).abs().max()) <= 1e-2, shape
+    f, twin = make_func(16, seed=14, device='cuda')
+    y = torch.randn(2, 16, 4, 4, generator=torch.Generator().manual_seed(11))
+    t = torch.tensor([1.0, 0.25])                 # decreasing times: upstream negates t and f
+    with torch.no_grad():
+        got = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-4, atol=1e-4, method='dopri5')
+        want = tdq.odeint(twin, y, t, rtol=1e-4, atol=1e-4, method='dopri5')
+    assert float((got[-1].cpu() - want[-1]).abs().max()) <= 1e-3
+
+
+def test_errors_surface_as_python_exceptions():
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd._lib import NodeHipError
+    f, _ = make_func(8, seed=1, device='cuda')
+    y = torch.randn(2, 8, 4, 4).cuda()
+    with pytest.raises(NodeHipError, match='MAX_STEPS'):
+        nof.odeint(f, y, torch.tensor([0.0, 1.0]).cuda(), rtol=1e-9, atol=1e-9, options={'max_num_steps': 2})
+    with pytest.raises(ValueError):
+        nof.odeint(f, y, torch.tensor([0.0, 1.0, 0.5]).cuda())
+    with pytest.raises(TypeError):
+        nof.odeint(f, y.double(), torch.tensor([0.0, 1.0]).cuda())
+    g, _ = make_func(16, seed=1, device='cuda')
+    with pytest.raises(ValueError):
+        nof.odeint(g, y, torch.tensor([0.0, 1.0]).cuda())          # channel mismatch
+    with pytest.raises(NodeHipError, match='UNSUPPORTED'):
+        nof.odeint(f, torch.randn(1, 8, 20, 20).cuda(), torch.tensor([0.0, 1.0]).cuda())

@@ -1,0 +1,174 @@
+"""CPU-side checks: the host logic of the boundary, fail-loudly behaviour without a
+GPU, and that libnode_hip.so loads and exports every symbol include/node_hip.h declares
+(no compute calls here -- there is no GPU in this container)."""
+import ctypes as C
+import os
+import re
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from neural_ode_features_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'node_hip.h')).read()
+    declared = set(re.findall(r'\b(node_[a-z_0-9]+)\s*\(', header))
+    declared -= {'node_shape', 'node_params', 'node_stats', 'node_solve_opts', 'node_profile'}
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.node_abi_version() == 1
+    m = re.search(r'#define NODE_ABI_VERSION (\d+)', header)
+    assert int(m.group(1)) == _lib.NODE_ABI_VERSION
+
+
+def test_host_only_entry_points():
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    shape = _lib.NodeShape(128, 256, 8, 8, 32, 1e-5)
+    assert lib.node_param_count(C.byref(shape)) == 1186304          # SURVEY.md section 8 (C=256)
+    fwd = lib.node_workspace_bytes(C.byref(shape), 0, 0, 2)
+    adj = lib.node_workspace_bytes(C.byref(shape), 0, 1, 2)
+    assert 0 < fwd < adj < (2 << 30)
+    assert lib.node_param_count(C.byref(_lib.NodeShape(1, 64, 7, 7, 32, 1e-5))) == 75392
+    # unsupported / inconsistent shapes are refused with a message, never a crash
+    for bad in [_lib.NodeShape(4, 30, 8, 8, 30, 1e-5), _lib.NodeShape(4, 64, 8, 8, 7, 1e-5),
+                _lib.NodeShape(4, 64, 40, 40, 32, 1e-5), _lib.NodeShape(0, 64, 8, 8, 32, 1e-5)]:
+        assert lib.node_workspace_bytes(C.byref(bad), 0, 0, 2) == 0
+        assert len(lib.node_last_error()) > 0
+
+
+def test_error_paths_of_the_c_abi_without_a_gpu():
+    """NULL / misaligned / undersized arguments are rejected before any HIP call."""
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    shape = _lib.NodeShape(2, 8, 4, 4, 8, 1e-5)
+    params = _lib.NodeParams(*([0] * 10))
+    stats = _lib.NodeStats()
+    tarr = (C.c_float * 2)(0.0, 1.0)
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(params), None, tarr, 2, 1e-3, 1e-3, 0, None, None,
+                            C.byref(stats), None, 0, None)
+    assert rc == -1 and b'NULL' in lib.node_last_error()
+    bad_t = (C.c_float * 3)(0.0, 1.0, 0.5)
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(params), 256, bad_t, 3, 1e-3, 1e-3, 0, None, 256,
+                            C.byref(stats), 256, 1 << 20, None)
+    assert rc == -9                                                    # non-monotonic time grid
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(params), 256, tarr, 2, 1e-3, 1e-3, 7, None, 256,
+                            C.byref(stats), 256, 1 << 20, None)
+    assert rc == -9                                                    # unknown method
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(params), 256, tarr, 2, 1e-3, 1e-3, 0, None, 256,
+                            C.byref(stats), 256, 1 << 20, None)
+    assert rc == -1                                                    # NULL parameter pointers
+    good = _lib.NodeParams(*([4096] * 10))
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(good), 256, tarr, 2, 1e-3, 1e-3, 0, None, 256,
+                            C.byref(stats), 256, 16, None)
+    assert rc == -4 and b'workspace too small' in lib.node_last_error()
+    mis = _lib.NodeParams(*([4100] * 10))
+    rc = lib.node_solve_fwd(C.byref(shape), C.byref(mis), 256, tarr, 2, 1e-3, 1e-3, 0, None, 256,
+                            C.byref(stats), 256, 1 << 20, None)
+    assert rc == -9
+
+
+def test_product_path_has_no_cpu_fallback():
+    import neural_ode_features_amd as nof
+    blk = nof.ODEBlock(n_filters=8, adjoint=True)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        blk(torch.randn(2, 8, 4, 4))
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        nof.odeint(blk.odefunc, torch.randn(2, 8, 4, 4), torch.tensor([0.0, 1.0]))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from neural_ode_features_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='not built'):
+        _lib.load()
+
+
+def test_argument_validation_mirrors_torchdiffeq():
+    from neural_ode_features_amd import integrate
+    import neural_ode_features_amd as nof
+    f = nof.ODEfunc(8)
+    rec = integrate.Recognised(f)
+    assert rec.dim == 8 and rec.groups == 8 and len(rec.params) == 10
+    assert [n for n, _ in f.named_parameters()] == [
+        'norm1.weight', 'norm1.bias', 'conv1._layer.weight', 'conv1._layer.bias',
+        'norm2.weight', 'norm2.bias', 'conv2._layer.weight', 'conv2._layer.bias', 'norm3.weight', 'norm3.bias']
+    assert integrate._method_id(None) == 0 and integrate._method_id('dopri5') == 0 and integrate._method_id('rk4') == 1
+    with pytest.raises(NotImplementedError):
+        integrate._method_id('adams')                 # train.py:219 offers it; not implemented
+    with pytest.raises(TypeError):
+        integrate._host_times(torch.tensor([0, 1]))
+    with pytest.raises(ValueError):
+        integrate._host_times(torch.tensor([0.0]))
+    assert integrate._host_times(torch.tensor([0.0, 0.5, 1.0])) == [0.0, 0.5, 1.0]
+    with pytest.raises(NotImplementedError):
+        integrate.Recognised(torch.nn.Linear(3, 3))   # unrecognised dynamics are refused, not emulated
+    with pytest.raises(NotImplementedError):
+        nof.ODEfunc(8, norm='batch')
+    with pytest.raises(ValueError):
+        integrate._odeint_impl(lambda t, y: y, _FakeCuda(), torch.tensor([0.0, 1.0]), 1e-3, 1e-3, None, None)
+
+
+class _FakeCuda(torch.Tensor):
+    """A CPU tensor that claims to be a float32 CUDA tensor: lets the host-side checks past
+    `_check_state` be exercised without a GPU."""
+    @staticmethod
+    def __new__(cls):
+        return torch.Tensor._make_subclass(cls, torch.zeros(1, 8, 2, 2))
+
+    @property
+    def is_cuda(self):
+        return True
+
+
+def test_odeblock_attribute_surface():
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    blk = nof.ODEBlock(n_filters=16, tol=1e-2, method='rk4', adjoint=True, t1=[0.1, 0.2, 1])
+    assert blk.odeint is integrate.odeint_adjoint and blk.return_last_only is True
+    assert blk.tol == 1e-2 and blk.method == 'rk4'
+    assert nof.ODEBlock(n_filters=16).odeint is integrate.odeint
+    blk.nfe = 5
+    assert blk.odefunc.nfe == 5 and blk.nfe == 5
+    net = nof.ODENet(3, n_filters=16, adjoint=True)
+    net.odeblock.nfe = 7
+    assert net.nfe(reset=True) == 7 and net.nfe() == 0
+    net.to_features_extractor()
+    assert net.odeblock.return_last_only is False
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/model.py'), reason='reference checkout not present')
+def test_reference_model_py_runs_on_top_of_the_package_unchanged():
+    """Drop-in: alias the package as `torchdiffeq`, import the reference's model.py as is;
+    its ODEBlock then calls OUR odeint with ITS OWN ODEfunc, which is recognised."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    saved = sys.modules.get('torchdiffeq')
+    sys.modules['torchdiffeq'] = nof
+    sys.path.insert(0, '/root/reference')
+    try:
+        sys.modules.pop('model', None)
+        import model as ref_model
+        net = ref_model.ODENet(3, n_filters=16, adjoint=True, tol=1e-3)
+        assert net.odeblock.odeint is integrate.odeint_adjoint
+        rec = integrate.Recognised(net.odeblock.odefunc)       # the reference's own class
+        assert rec.dim == 16 and rec.groups == 16
+        mine = nof.ODENet(3, n_filters=16, adjoint=True, tol=1e-3)
+        assert list(mine.state_dict().keys()) == list(net.state_dict().keys())
+        mine.load_state_dict(net.state_dict())
+        with pytest.raises(RuntimeError, match='no CPU path'):  # reaches our boundary; no GPU here
+            net(torch.randn(2, 3, 32, 32))
+    finally:
+        sys.path.remove('/root/reference')
+        sys.modules.pop('model', None)
+        if saved is not None:
+            sys.modules['torchdiffeq'] = saved
+        else:
+            sys.modules.pop('torchdiffeq', None)

@@ -1,0 +1,106 @@
+"""Pins the oracle's dynamics half against fixtures generated FROM THE REFERENCE
+(tests/golden/make_golden.py imports /root/reference/model.py): f(t, y) and the
+autograd VJPs of the reference's own ODEfunc, the stem+head plumbing of ODENet(t1=0),
+and the end-to-end ODENet runs (reference modules + oracle solver)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torchdiffeq_restated as tdq
+from oracle.dynamics import OracleODEfunc, PARAM_ORDER, odefunc_forward, odefunc_vjp
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
+
+
+@pytest.mark.parametrize('name', ['odefunc_c8.pt', 'odefunc_c16.pt', 'odefunc_c64.pt'])
+def test_oracle_dynamics_match_reference_odefunc(golden_dir, name):
+    g = _load(golden_dir, name)
+    assert g['param_names'] == PARAM_ORDER                       # flat-gradient layout
+    p = g['state_dict']
+    f = odefunc_forward(g['t'], g['y'], p)
+    assert torch.allclose(f, g['f'], rtol=1e-5, atol=1e-6)
+    f2, vy, vt, vp = odefunc_vjp(g['t'], g['y'], p, g['cotangent'])
+    assert torch.allclose(vy, g['vjp_y'], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(vt, g['vjp_t'], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(vp, g['vjp_params'], rtol=1e-5, atol=1e-5)
+    twin = OracleODEfunc(g['C'])
+    twin.load_state_dict(p)                                      # reference-identical keys / shapes
+    assert torch.allclose(twin(g['t'], g['y']), g['f'], rtol=1e-5, atol=1e-6)
+    assert p['conv1._layer.weight'].shape == (g['C'], g['C'] + 1, 3, 3)
+
+
+def _package_net_on_oracle(g, n_filters, **kw):
+    """The package's ODENet (host mirror of the reference interface) with the oracle
+    standing in for the HIP solve -- CPU plumbing check of configs[0]."""
+    import neural_ode_features_amd as nof
+    net = nof.ODENet(g['in_ch'], out=10, n_filters=n_filters, downsample='residual', method=g['method'],
+                     tol=g['tol'], adjoint=True, t1=g['t1'], dropout=0)
+    net.load_state_dict(g['state_dict'])
+    net.odeblock.odeint = tdq.odeint_adjoint
+    return net
+
+
+@pytest.mark.parametrize('name', ['odenet_rk4.pt', 'odenet_dopri5.pt'])
+def test_end_to_end_fixture_reproduced(golden_dir, name):
+    g = _load(golden_dir, name)
+    net = _package_net_on_oracle(g, g['filters'])
+    net.train()
+    p = net(g['x'])
+    loss = F.cross_entropy(p, g['y'])
+    nfe_f = net.nfe(reset=True)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    assert (nfe_f, nfe_b) == (g['nfe_f'], g['nfe_b'])
+    assert torch.allclose(p, g['logits'], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(loss, g['loss'], rtol=1e-5, atol=1e-6)
+    for k, v in net.named_parameters():
+        assert torch.allclose(v.grad, g['grads'][k], rtol=2e-3, atol=2e-5), k
+
+
+def test_config1_rk4_nfe(golden_dir):
+    g = _load(golden_dir, 'odenet_rk4.pt')
+    assert g['method'] == 'rk4' and g['nfe_f'] == 4 and g['nfe_b'] == 5   # one 3/8 step; 1 + 4 backward
+
+
+def test_odenet_t0_stem_and_head(golden_dir):
+    import neural_ode_features_amd as nof
+    g = _load(golden_dir, 'odenet_t0.pt')
+    net = nof.ODENet(1, out=10, n_filters=8, downsample='residual', t1=0)
+    assert list(net.state_dict().keys()) == g['keys']            # checkpoint compatibility (utils.py:267-268)
+    net.load_state_dict(g['state_dict'])
+    net.eval()
+    with torch.no_grad():
+        logits = net(g['x'])                                     # t1 == 0: identity block, no solver (model.py:363-364)
+    assert torch.allclose(logits, g['logits'], rtol=1e-5, atol=1e-6)
+
+
+def test_t1_setter_cases(golden_dir):
+    import io
+    import contextlib
+    import neural_ode_features_amd as nof
+    with open(os.path.join(golden_dir, 'odeblock_t1_cases.json')) as fh:
+        cases = json.load(fh)
+    for c in cases:
+        value = c['value']
+        if c['kind'] == 'tuple':
+            value = tuple(value)
+        elif c['kind'] == 'Tensor':
+            value = torch.tensor(value)
+        blk = nof.ODEBlock(n_filters=8, t1=1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            blk.t1 = value
+        it = blk.integration_time
+        if c['integration_time'] is None:
+            assert it is None
+            x = torch.randn(1, 8, 4, 4)
+            assert blk(x) is x
+        else:
+            assert it.tolist() == c['integration_time'] and str(it.dtype) == c['dtype']
+            assert float(blk.t1) == c['integration_time'][1]
+    with pytest.raises(ValueError):
+        nof.ODEBlock(n_filters=8).t1 = 'one'
