@@ -26,13 +26,13 @@
 //    is register-prefetched one piece ahead (issue early / write late).
 #include "node_internal.h"
 #include <cstdlib>
+#include <cstdio>
 
 namespace node {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int g_conv_variant = -1;
-int g_wgrad_variant = -1;
 
 // Diagnostic builds only (tools/kbench.hip, -DNODE_STAMPS): per-wave s_memtime / s_memrealtime stamps
 // written to a buffer nothing else reads.  Production builds compile this to nothing.
@@ -57,9 +57,11 @@ int g_wgrad_variant = -1;
       (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
     }                                                                                            \
   } while (0)
+#define WABL(bit) (a.ablate & (bit))
 #else
 #define STAMP(buf, slot) do { } while (0)
 #define STAMP_REAL(buf, slot) do { } while (0)
+#define WABL(bit) 0
 #endif
 
 __device__ inline float wave_sum_c(float v) {
@@ -373,8 +375,81 @@ static size_t tune_min_lds() {
   return (size_t)v;
 }
 
+// ---- debugging aid (NODE_DEBUG_CONV_XCHECK=1): every launch runs BOTH kernels and reports the largest
+// difference of the primary output; development only (allocates, synchronises, prints) ----
+static const float* g_xc_v1[8];
+static float* g_xc_v0[8];
+static int g_xc_n = 0;
+static bool xcheck_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NODE_DEBUG_CONV_XCHECK"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
+void xcheck_register(const Dims& d, const float* wraw, const float* packed_v1, int dgrad, hipStream_t s) {
+  if (!xcheck_on()) return;
+  const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
+  int slot = -1;
+  for (int i = 0; i < g_xc_n; ++i) if (g_xc_v1[i] == packed_v1) slot = i;
+  if (slot < 0) { slot = g_xc_n++ % 8; g_xc_v1[slot] = packed_v1; (void)hipMalloc((void**)&g_xc_v0[slot], wsz * sizeof(float)); }
+  launch_pack_weights(d, wraw, g_xc_v0[slot], dgrad, 0, s);
+}
+__global__ void k_xc_diff(const float* a, const float* b, size_t n, float* out) {
+  float m = 0.f, r = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) { m = fmaxf(m, fabsf(a[i] - b[i])); r = fmaxf(r, fabsf(b[i])); }
+  for (int off = 32; off > 0; off >>= 1) { m = fmaxf(m, __shfl_xor(m, off, 64)); r = fmaxf(r, __shfl_xor(r, off, 64)); }
+  __shared__ float sm[32];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = m; sm[16 + (threadIdx.x >> 6)] = r; }
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int i = 1; i < (int)(blockDim.x >> 6); ++i) { m = fmaxf(m, sm[i]); r = fmaxf(r, sm[16 + i]); } out[0] = m; out[1] = r; }
+}
+static void launch_conv_v0(const Dims& d, const ConvArgs& a, hipStream_t s);
+
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  if (conv_variant() >= 1 && xcheck_on()) {
+    static float *tmp = nullptr, *dres = nullptr;
+    static size_t tmpn = 0;
+    if (tmpn < d.numel) { if (tmp) (void)hipFree(tmp); (void)hipMalloc((void**)&tmp, d.numel * sizeof(float)); tmpn = d.numel; }
+    if (!dres) (void)hipMalloc((void**)&dres, 2 * sizeof(float));
+    launch_conv_p(d, a, s);
+    ConvArgs b = a;
+    for (int i = 0; i < 8; ++i) if (g_xc_v1[i] == a.wpacked) b.wpacked = g_xc_v0[i];
+    static float *tmpx = nullptr, *tmpr = nullptr;
+    if (!tmpx) { (void)hipMalloc((void**)&tmpx, (size_t)64 << 20); (void)hipMalloc((void**)&tmpr, (size_t)1 << 20); }
+    b.out = tmp; b.xhat_out = a.xhat_out ? tmpx : nullptr; b.rstd_out = a.rstd_out ? tmpr : nullptr;
+    float* gp2 = nullptr;
+    if (a.mode == CM_BWD_RELU_GN) { (void)hipMalloc((void**)&gp2, (size_t)d.mtiles * 2 * d.C * sizeof(float)); b.gpart = gp2; }
+    launch_conv_v0(d, b, s);
+    hipLaunchKernelGGL(k_xc_diff, dim3(1), dim3(1024), 0, s, a.out, tmp, d.numel, dres);
+    float h[2];
+    (void)hipMemcpyAsync(h, dres, sizeof(h), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    static int call = 0;
+    fprintf(stderr, "[xcheck] conv call %3d mode %d osign %+.0f  max|v1 - v0| = %.3e (ref max %.3e)%s\n", call++, a.mode, a.osign, h[0], h[1],
+            h[0] > 1e-4f * h[1] + 1e-12f ? "   <<<<<" : "");
+    if (a.xhat_out) {
+      hipLaunchKernelGGL(k_xc_diff, dim3(1), dim3(1024), 0, s, a.xhat_out, tmpx, d.numel, dres);
+      (void)hipMemcpyAsync(h, dres, sizeof(h), hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "[xcheck]      xhat_out max diff %.3e (ref %.3e)%s\n", h[0], h[1], h[0] > 1e-4f * h[1] ? "   <<<<<" : "");
+      hipLaunchKernelGGL(k_xc_diff, dim3(1), dim3(1024), 0, s, a.rstd_out, tmpr, (size_t)d.N * d.G, dres);
+      (void)hipMemcpyAsync(h, dres, sizeof(h), hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "[xcheck]      rstd_out max diff %.3e (ref %.3e)%s\n", h[0], h[1], h[0] > 1e-4f * h[1] ? "   <<<<<" : "");
+    }
+    if (gp2) {
+      hipLaunchKernelGGL(k_xc_diff, dim3(1), dim3(1024), 0, s, a.gpart, gp2, (size_t)d.mtiles * 2 * d.C, dres);
+      (void)hipMemcpyAsync(h, dres, sizeof(h), hipMemcpyDeviceToHost, s);
+      (void)hipStreamSynchronize(s);
+      fprintf(stderr, "[xcheck]      gpart max diff %.3e (ref %.3e)%s\n", h[0], h[1], h[0] > 1e-3f * h[1] ? "   <<<<<" : "");
+      (void)hipFree(gp2);
+    }
+    return;
+  }
   if (conv_variant() >= 1) { launch_conv_p(d, a, s); return; }
+  launch_conv_v0(d, a, s);
+}
+
+static void launch_conv_v0(const Dims& d, const ConvArgs& a, hipStream_t s) {
   size_t lds = conv_v0_lds_bytes(d);
   if (lds < tune_min_lds()) lds = tune_min_lds();
   dim3 grid(d.mtiles, d.ntile);
@@ -387,157 +462,6 @@ void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
     if (!attr2) { (void)hipFuncSetAttribute((const void*)k_conv3x3<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
     hipLaunchKernelGGL(k_conv3x3<2>, grid, dim3(CONV_THREADS), lds, s, a, d);
   }
-}
-
-// ============================================================================
-// wgrad: dW[tap][ci][co] = sum_{n,p} act[n, p + tap, ci] * dz[n, p, co]
-// Workgroup tile: 64 ci x 64 co x 9 taps (4 waves, each 32x32x9 = 144 accumulator
-// registers), K = pixels, split over `nsplit` ranges of (sample, row-band) units;
-// deterministic per-split partial slabs reduced by k_theta_finalize.
-// The workgroups of ci-tile 0 also form the masked column sums of dz that give the
-// conv-bias, time-channel-weight and d/dt terms.
-// ============================================================================
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradArgs a, Dims d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int wi = wave >> 1, wj = wave & 1;
-  const int ntc = (d.C + 63) / 64;
-  const int ci_t = blockIdx.x / ntc, co_t = blockIdx.x - ci_t * ntc;
-  const int ci0 = ci_t * 64, co0 = co_t * 64;
-  const int sp = blockIdx.y;
-
-  const int band_slots = (d.RB + 2) * d.Wp;
-  const int AROWS = band_slots + 2 * d.MARGIN;
-  const int band_px = d.RB * d.W;
-  float* As = smem;                          // [AROWS][64]
-  float* Zs = As + (size_t)AROWS * 64;       // [band_px + 1][64]
-  int* slot_tab = reinterpret_cast<int*>(Zs + (size_t)(band_px + 1) * 64);  // [band_px]
-  float* sred = reinterpret_cast<float*>(slot_tab + ((band_px + 3) & ~3));  // [256][9]
-
-  for (int i = tid; i < AROWS * 64 + (band_px + 1) * 64; i += WG_THREADS) smem[i] = 0.f;
-  for (int p = tid; p < band_px; p += WG_THREADS) slot_tab[p] = (p / d.W + 1) * d.Wp + (p % d.W) + 1;
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float ssum[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) ssum[t] = 0.f;
-
-  int toff[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * d.Wp + (t % 3 - 1)) * 64;
-
-  const int U = d.N * d.nbands;
-  const int u_begin = (int)(((long long)sp * U) / d.nsplit);
-  const int u_end = (int)(((long long)(sp + 1) * U) / d.nsplit);
-  const bool do_sums = (ci_t == 0);
-
-  for (int u = u_begin; u < u_end; ++u) {
-    const int n = u / d.nbands, band = u - n * d.nbands;
-    const int row0 = band * d.RB;
-    const int rbe = min(d.RB, d.H - row0);   // image rows in this band
-    const int npx = rbe * d.W;
-    __syncthreads();  // previous unit's MFMA reads done
-    // ---- stage activations (with one halo row above/below) ----
-    {
-      const int nunits = (d.RB + 2) * d.W * 16;
-      for (int v = tid; v < nunits; v += WG_THREADS) {
-        const int q = v & 15;
-        const int px = v >> 4;
-        const int hr = px / d.W, x = px - hr * d.W;
-        const int ih = row0 + hr - 1;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ih >= 0 && ih < d.H && hr <= rbe + 1 && ci0 + q * 4 < d.C)
-          val = *reinterpret_cast<const float4*>(a.act + ((size_t)n * d.HW + ih * d.W + x) * d.C + ci0 + q * 4);
-        *reinterpret_cast<float4*>(As + (size_t)(d.MARGIN + hr * d.Wp + x + 1) * 64 + q * 4) = val;
-      }
-      const int zunits = band_px * 16;
-      for (int v = tid; v < zunits; v += WG_THREADS) {
-        const int q = v & 15;
-        const int r = v >> 4;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < npx && co0 + q * 4 < d.C)
-          val = *reinterpret_cast<const float4*>(a.dz + ((size_t)n * d.HW + row0 * d.W + r) * d.C + co0 + q * 4);
-        *reinterpret_cast<float4*>(Zs + (size_t)r * 64 + q * 4) = val;
-      }
-    }
-    __syncthreads();
-    // ---- masked column sums (bias / time-channel / d-dt terms) ----
-    if (do_sums) {
-      const int cj = tid & 63, part = tid >> 6;
-      for (int r = part; r < npx; r += 4) {
-        const float z = Zs[r * 64 + cj];
-        const int lr = r / d.W, x = r - lr * d.W;
-        const int h = row0 + lr;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int hh = h + t / 3 - 1, xx = x + t % 3 - 1;
-          if (hh >= 0 && hh < d.H && xx >= 0 && xx < d.W) ssum[t] += z;
-        }
-      }
-    }
-    // ---- MFMA: K = pixel pairs of the band ----
-    const int npairs = (npx + 1) >> 1;
-    for (int kp = 0; kp < npairs; ++kp) {
-      const int p0 = 2 * kp + hi;
-      const bool ok = p0 < npx;
-      const int aoff = (d.MARGIN + (ok ? slot_tab[p0] : 0)) * 64 + wi * 32 + l31;
-      const float b = Zs[(ok ? p0 : band_px) * 64 + wj * 32 + l31];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float av = As[aoff + toff[t]];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[t], 0, 0, 0);
-      }
-    }
-  }
-
-  // ---- store the partial slab ----
-  const size_t CC = (size_t)d.C * d.C;
-  float* wp = a.wpart + (size_t)sp * 9 * CC;
-  const int co = co0 + wj * 32 + l31;
-  if (co < d.C) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (ci < d.C) wp[(size_t)t * CC + (size_t)ci * d.C + co] = acc[t][r];
-      }
-    }
-  }
-  if (do_sums) {
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 9; ++t) sred[tid * 9 + t] = ssum[t];
-    __syncthreads();
-    const int cj = tid & 63, part = tid >> 6;
-    if (part == 0 && co0 + cj < d.C) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float v = (sred[cj * 9 + t] + sred[(64 + cj) * 9 + t]) + (sred[(128 + cj) * 9 + t] + sred[(192 + cj) * 9 + t]);
-        a.spart[((size_t)sp * 9 + t) * d.C + co0 + cj] = v;
-      }
-    }
-  }
-}
-
-size_t wgrad_lds_bytes(const Dims& d) {
-  const int band_slots = (d.RB + 2) * d.Wp;
-  const int AROWS = band_slots + 2 * d.MARGIN;
-  const int band_px = d.RB * d.W;
-  size_t fl = (size_t)AROWS * 64 + (size_t)(band_px + 1) * 64 + ((band_px + 3) & ~3) + 256 * 9;
-  return fl * sizeof(float);
-}
-
-void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  const int ntc = (d.C + 63) / 64;
-  hipLaunchKernelGGL(k_wgrad, dim3(ntc * ntc, d.nsplit), dim3(WG_THREADS), wgrad_lds_bytes(d), s, a, d);
 }
 
 }  // namespace node

@@ -75,7 +75,7 @@ __device__ inline int slot_of_p(int p, int W, int Wp) {
 #define ABL(bit) 0
 #endif
 
-template <int MT>
+template <int MT, bool SAFE>
 __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3_p(ConvArgs a, Dims d) {
   PSTAMP(a.stamps, 0, "s_memrealtime");
   PSTAMP(a.stamps, 1, "s_memtime");
@@ -280,9 +280,12 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv3x3_p(ConvArgs a, Dims d) 
     SB;                                                                                            \
     TAPTAIL(((T) == 8 ? Anxt : Acur) + toff[TN], Bbuf + BSLOT(TN) * BBUF2);                        \
     if (!ABL(2)) {                                                                                 \
-      if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                    \
-      else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                      \
-      __builtin_amdgcn_s_barrier();                                                                \
+      if constexpr (SAFE) __syncthreads();                                                         \
+      else {                                                                                       \
+        if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                  \
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                    \
+        __builtin_amdgcn_s_barrier();                                                              \
+      }                                                                                            \
       SB;                                                                                          \
     }                                                                                              \
   }
@@ -519,16 +522,17 @@ size_t conv_p_lds_bytes(const Dims& d) {
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
 }
 
-template <int MT>
+template <int MT, bool SAFE>
 static void launch_conv_p_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_p<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL((k_conv3x3_p<MT>), dim3(d.mtiles, d.ntile), dim3(CONV_THREADS), conv_p_lds_bytes(d), s, a, d);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_p<MT, SAFE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_conv3x3_p<MT, SAFE>), dim3(d.mtiles, d.ntile), dim3(CONV_THREADS), conv_p_lds_bytes(d), s, a, d);
 }
 
 void launch_conv_p(const Dims& d, const ConvArgs& a, hipStream_t s) {
-  if (d.BM == 128) launch_conv_p_t<1>(d, a, s);
-  else launch_conv_p_t<2>(d, a, s);
+  const bool safe = conv_variant() == 2;   // debugging aid: full __syncthreads() per tap
+  if (d.BM == 128) { if (safe) launch_conv_p_t<1, true>(d, a, s); else launch_conv_p_t<1, false>(d, a, s); }
+  else { if (safe) launch_conv_p_t<2, true>(d, a, s); else launch_conv_p_t<2, false>(d, a, s); }
 }
 
 }  // namespace node

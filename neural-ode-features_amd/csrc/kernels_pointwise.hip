@@ -654,12 +654,12 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
         r -= 9 * CC;
         const float* spp = a.spart[layer];
         if (r < 9 * C) {  // time-channel taps [tap][co]: t * masked column sums
-          for (int sp = 0; sp < d.nsplit; ++sp) v += spp[(size_t)sp * 9 * C + r];
+          for (int sp = 0; sp < d.N; ++sp) v += spp[(size_t)sp * 9 * C + r];
           a.sred[(size_t)layer * 9 * C + r] = v;   // reduced once here, reused by k_vjp_t
           v *= tval;
         } else {          // conv bias: centre tap sees every pixel
           r -= 9 * C;
-          for (int sp = 0; sp < d.nsplit; ++sp) v += spp[(size_t)sp * 9 * C + 4 * C + r];
+          for (int sp = 0; sp < d.N; ++sp) v += spp[(size_t)sp * 9 * C + 4 * C + r];
         }
       }
     }

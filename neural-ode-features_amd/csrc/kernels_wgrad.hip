@@ -1,0 +1,495 @@
+// Weight-gradient kernels of the adjoint dynamics (gfx950).
+//
+//   dW[tap][ci][co] = sum_{n,p} act[n, p + tap, ci] * dz[n, p, co]        K = N*H*W pixels
+//
+// 64 ci x 64 co x 9 taps per workgroup; 4 waves (one per SIMD), each holding the
+// 32x32 tile of all nine taps = 144 accumulator registers; K split over `nsplit`
+// ranges of (sample, row band) units; deterministic partial slabs, reduced by
+// k_theta_finalize.  fp32 v_mfma_f32_32x32x2_f32 at 64 cycles per MFMA is the bound,
+// and one wave per SIMD has nobody to hide behind, so the inner loop is built to have
+// NOTHING but MFMAs and LDS reads in it:
+//  * nine independent accumulator chains: consecutive MFMAs never depend on each other;
+//  * operands of pixel pair k+1 are read while the nine MFMAs of pair k execute, in
+//    the order the next step consumes them (LDS returns in order: counted lgkmcnt);
+//  * k_wgrad_t<W, RB>: the image geometry is a template parameter, so every LDS
+//    address in the loop is `per-lane base + immediate` -- zero VALU / SALU
+//    instructions between the MFMAs.  Measured (tools/mfma_rate2): address
+//    arithmetic interleaved with 32x32x2 MFMAs costs 10+ cycles of matrix-pipe time
+//    per VALU instruction (85.9 vs 64.2 cycles per MFMA for the table-driven step).
+//    Pixel pairs never straddle image rows (odd W gets one zero pad pixel per row);
+//  * units are double-buffered in LDS: the global loads of unit u+1 are issued before
+//    the MFMAs of unit u and written to the other buffer after them.
+// k_wgrad_p is the geometry-generic fallback (slot table + five VALU per step).
+//
+// The masked column sums of dz (conv-bias, time-channel-weight and d/dt terms) are a
+// separate HBM-bound kernel (k_colsum): inside the GEMM they unbalanced a quarter of
+// the workgroups by 50 %.
+#include "node_internal.h"
+#include <cstdlib>
+
+namespace node {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int g_wgrad_variant = -1;
+
+#ifdef NODE_STAMPS
+#define WSTAMP(buf, slot, INS)                                                                   \
+  do {                                                                                           \
+    if ((buf) != nullptr && (threadIdx.x & 63) == 0) {                                           \
+      unsigned long long _t;                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      asm volatile(INS " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                       \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+    }                                                                                            \
+  } while (0)
+#else
+#define WSTAMP(buf, slot, INS) do { } while (0)
+#endif
+
+constexpr int WG_MAXA = 6;   // float4 staging units per thread: activations ((RB + 2) * W * 16 <= 6 * 256)
+constexpr int WG_MAXZ = 4;   // dz (RB * W * 16 <= 4 * 256)
+
+// ----------------------------------------------------------------------------
+// shared pieces: staging of one unit, slab store
+// ----------------------------------------------------------------------------
+struct WgGeom {
+  int ci0, co0, sp, wi, wj, l31, hi, tid, q16;
+  bool ci_ok, co_ok;
+};
+
+__device__ inline void wg_store_slab(const WgradArgs& a, const Dims& d, const WgGeom& g, const f32x16 (&acc)[9]) {
+  const size_t CC = (size_t)d.C * d.C;
+  float* wp = a.wpart + (size_t)g.sp * 9 * CC;
+  const int co = g.co0 + g.wj * 32 + g.l31;
+  if (co < d.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = g.ci0 + g.wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g.hi;
+        if (ci < d.C) wp[(size_t)t * CC + (size_t)ci * d.C + co] = acc[t][r];
+      }
+    }
+  }
+}
+
+// ============================================================================
+// k_wgrad_t<W, RB>: geometry-templated, immediate-offset inner loop
+//   requires H % RB == 0, (RB + 2) * W * 16 <= 6 * 256, RB * WZ * 16 <= 4 * 256
+// ============================================================================
+template <int W, int RB>
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_t(WgradArgs a, Dims d) {
+  WSTAMP(a.stamps, 0, "s_memrealtime");
+  WSTAMP(a.stamps, 1, "s_memtime");
+  constexpr int WP = W + 2;
+  constexpr int MARGIN = WP + 1;
+  constexpr int NJ = (W + 1) / 2;          // pixel pairs per image row
+  constexpr int WZ = 2 * NJ;               // dz row length in LDS (odd W: one zero pad pixel)
+  constexpr int AROWS = (RB + 2) * WP + 2 * MARGIN;
+  constexpr int ASZ = AROWS * 64, ZSZ = RB * WZ * 64;
+  constexpr int NUA = (RB + 2) * W * 16, NUZ = RB * W * 16;
+  static_assert(NUA <= WG_MAXA * WG_THREADS && NUZ <= WG_MAXZ * WG_THREADS, "staging registers");
+  static_assert(((RB + 2) * WP + WZ + 2) * 256 < 65536, "LDS immediates");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WgGeom g;
+  g.tid = tid; g.l31 = lane & 31; g.hi = lane >> 5; g.wi = wave >> 1; g.wj = wave & 1;
+  const int ntc = (d.C + 63) / 64;
+  const int ci_t = blockIdx.x / ntc, co_t = blockIdx.x - ci_t * ntc;
+  g.ci0 = ci_t * 64; g.co0 = co_t * 64; g.sp = blockIdx.y; g.q16 = tid & 15;
+  g.ci_ok = g.ci0 + g.q16 * 4 < d.C; g.co_ok = g.co0 + g.q16 * 4 < d.C;
+
+  float* As0 = smem;            // 2 x [AROWS][64]
+  float* Zs0 = smem + 2 * ASZ;  // 2 x [RB * WZ][64]
+  for (int i = tid * 4; i < 2 * ASZ + 2 * ZSZ; i += WG_THREADS * 4)
+    *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nbands = d.H / RB;
+  const int U = d.N * nbands;
+  const int u_begin = (int)(((long long)g.sp * U) / d.nsplit);
+  const int u_end = (int)(((long long)(g.sp + 1) * U) / d.nsplit);
+
+  // staging descriptors: unit v -> (pixel, float4 column); all geometry compile-time
+  float4 ra[WG_MAXA], rz[WG_MAXZ];
+  auto stage_load = [&](int u) {
+    const int n = u / nbands, band = u - n * nbands;
+    const int row0 = band * RB;
+#pragma unroll
+    for (int i = 0; i < WG_MAXA; ++i) {
+      const int v = tid + i * WG_THREADS;
+      const int px = v >> 4, hr = px / W, x = px - hr * W;
+      const int ih = row0 + hr - 1;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < NUA && ih >= 0 && ih < d.H && g.ci_ok)
+        ra[i] = *reinterpret_cast<const float4*>(a.act + ((size_t)n * d.HW + ih * W + x) * d.C + g.ci0 + g.q16 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < WG_MAXZ; ++i) {
+      const int v = tid + i * WG_THREADS;
+      rz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < NUZ && g.co_ok)
+        rz[i] = *reinterpret_cast<const float4*>(a.dz + ((size_t)n * d.HW + row0 * W + (v >> 4)) * d.C + g.co0 + g.q16 * 4);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* As = As0 + buf * ASZ;
+    float* Zs = Zs0 + buf * ZSZ;
+#pragma unroll
+    for (int i = 0; i < WG_MAXA; ++i) {
+      const int v = tid + i * WG_THREADS;
+      const int px = v >> 4, hr = px / W, x = px - hr * W;
+      if (v < NUA) *reinterpret_cast<float4*>(As + (MARGIN + hr * WP + x + 1) * 64 + g.q16 * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WG_MAXZ; ++i) {
+      const int v = tid + i * WG_THREADS;
+      const int px = v >> 4, r = px / W, x = px - r * W;
+      if (v < NUZ) *reinterpret_cast<float4*>(Zs + (r * WZ + x) * 64 + g.q16 * 4) = rz[i];
+    }
+  };
+
+  __syncthreads();  // zero fill visible
+  if (u_begin < u_end) {
+    stage_load(u_begin);
+    stage_write(0);
+  }
+  __syncthreads();
+  WSTAMP(a.stamps, 2, "s_memtime");
+
+  // per-lane bases; slot of tap (kh, kw) of pixel (r, x) = MARGIN + (r + kh) * WP + x + kw
+  const int abase = (MARGIN + g.hi) * 64 + g.wi * 32 + g.l31;
+  const int zbase = g.hi * 64 + g.wj * 32 + g.l31;
+  int buf = 0;
+  for (int u = u_begin; u < u_end; ++u) {
+    const float* As = As0 + buf * ASZ + abase;
+    const float* Zs = Zs0 + buf * ZSZ + zbase;
+    const bool more = (u + 1) < u_end;
+    if (more) stage_load(u + 1);  // in flight during this unit's MFMAs
+
+    float av[2][9], bv[2];
+    bv[0] = Zs[0];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) av[0][t] = As[((t / 3) * WP + (t % 3)) * 64];
+#pragma unroll
+    for (int s = 0; s < RB * NJ; ++s) {
+      constexpr int NS = RB * NJ;
+      const int cur = s & 1, nxt = cur ^ 1;
+      const int sn = s + 1 < NS ? s + 1 : s;            // (last step re-reads itself: no branch)
+      const int rn = sn / NJ, jn = sn - rn * NJ;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][t], bv[cur], acc[t], 0, 0, 0);
+        if (t == 0) bv[nxt] = Zs[(rn * WZ + 2 * jn) * 64];
+        av[nxt][t] = As[((rn + t / 3) * WP + 2 * jn + (t % 3)) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) stage_write(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  WSTAMP(a.stamps, 3, "s_memtime");
+  wg_store_slab(a, d, g, acc);
+  WSTAMP(a.stamps, 4, "s_memtime");
+  WSTAMP(a.stamps, 5, "s_memrealtime");
+}
+
+// ============================================================================
+// k_wgrad_p: geometry-generic fallback (slot table; five VALU instructions per step)
+// ============================================================================
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_p(WgradArgs a, Dims d) {
+  WSTAMP(a.stamps, 0, "s_memrealtime");
+  WSTAMP(a.stamps, 1, "s_memtime");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  WgGeom g;
+  g.tid = tid; g.l31 = lane & 31; g.hi = lane >> 5; g.wi = wave >> 1; g.wj = wave & 1;
+  const int l31 = g.l31, hi = g.hi, wi = g.wi, wj = g.wj;
+  const int ntc = (d.C + 63) / 64;
+  const int ci_t = blockIdx.x / ntc, co_t = blockIdx.x - ci_t * ntc;
+  const int ci0 = ci_t * 64, co0 = co_t * 64;
+  g.ci0 = ci0; g.co0 = co0; g.sp = blockIdx.y; g.q16 = tid & 15;
+  const int sp = g.sp;
+
+  const int band_slots = (d.RB + 2) * d.Wp;
+  const int AROWS = band_slots + 2 * d.MARGIN;
+  const int band_px = d.RB * d.W;
+  const int ASZ = AROWS * 64, ZSZ = (band_px + 1) * 64;
+  float* As0 = smem;                 // 2 x [AROWS][64]
+  float* Zs0 = smem + 2 * ASZ;       // 2 x [band_px + 1][64]   (last row = zeros: odd pixel counts)
+  int* atab = reinterpret_cast<int*>(Zs0 + 2 * ZSZ);   // [band_px + 4]: float offset of pixel p's slot in the A image
+
+  for (int i = tid * 4; i < 2 * ASZ + 2 * ZSZ; i += WG_THREADS * 4)
+    *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * d.Wp + (t % 3 - 1)) * 64;
+
+  const int U = d.N * d.nbands;
+  const int u_begin = (int)(((long long)sp * U) / d.nsplit);
+  const int u_end = (int)(((long long)(sp + 1) * U) / d.nsplit);
+
+  // ---- staging descriptors (unit-independent part) ----
+  const int q16 = tid & 15;          // float4 column of the 64-channel tile
+  const int nunitsA = (d.RB + 2) * d.W * 16, nunitsZ = band_px * 16;
+  int a_hr[WG_MAXA], a_x[WG_MAXA], a_lds[WG_MAXA];
+#pragma unroll
+  for (int i = 0; i < WG_MAXA; ++i) {
+    const int v = tid + i * WG_THREADS;
+    const int px = v >> 4;
+    a_hr[i] = px / d.W;
+    a_x[i] = px - a_hr[i] * d.W;
+    a_lds[i] = (d.MARGIN + a_hr[i] * d.Wp + a_x[i] + 1) * 64 + q16 * 4;
+  }
+  const bool ci_ok = ci0 + q16 * 4 < d.C, co_ok = co0 + q16 * 4 < d.C;
+  float4 ra[WG_MAXA], rz[WG_MAXZ];
+
+  auto stage_load = [&](int u) {
+    const int n = u / d.nbands, band = u - n * d.nbands;
+    const int row0 = band * d.RB;
+    const int rbe = min(d.RB, d.H - row0);
+    const int npx = rbe * d.W;
+#pragma unroll
+    for (int i = 0; i < WG_MAXA; ++i) {
+      const int v = tid + i * WG_THREADS;
+      const int ih = row0 + a_hr[i] - 1;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < nunitsA && ih >= 0 && ih < d.H && a_hr[i] <= rbe + 1 && ci_ok)
+        ra[i] = *reinterpret_cast<const float4*>(a.act + ((size_t)n * d.HW + ih * d.W + a_x[i]) * d.C + ci0 + q16 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < WG_MAXZ; ++i) {
+      const int v = tid + i * WG_THREADS;
+      const int r = v >> 4;
+      rz[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v < nunitsZ && r < npx && co_ok)
+        rz[i] = *reinterpret_cast<const float4*>(a.dz + ((size_t)n * d.HW + row0 * d.W + r) * d.C + co0 + q16 * 4);
+    }
+  };
+  auto stage_write = [&](int buf) {
+    float* As = As0 + buf * ASZ;
+    float* Zs = Zs0 + buf * ZSZ;
+#pragma unroll
+    for (int i = 0; i < WG_MAXA; ++i)
+      if (tid + i * WG_THREADS < nunitsA) *reinterpret_cast<float4*>(As + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WG_MAXZ; ++i) {
+      const int v = tid + i * WG_THREADS;
+      if (v < nunitsZ) *reinterpret_cast<float4*>(Zs + (v >> 4) * 64 + q16 * 4) = rz[i];
+    }
+  };
+
+  for (int p = tid; p < band_px + 4; p += WG_THREADS) {
+    const int pp = min(p, band_px - 1);
+    const int pr = pp / d.W;
+    atab[p] = (d.MARGIN + (pr + 1) * d.Wp + (pp - pr * d.W) + 1) * 64;
+  }
+  __syncthreads();   // zero fill + table visible
+  if (u_begin < u_end) {
+    stage_load(u_begin);
+    stage_write(0);
+  }
+  __syncthreads();
+  WSTAMP(a.stamps, 2, "s_memtime");
+
+  int buf = 0;
+  for (int u = u_begin; u < u_end; ++u) {
+    const int band = u % d.nbands;
+    const int row0 = band * d.RB;
+    const int rbe = min(d.RB, d.H - row0);
+    const int npx = rbe * d.W;
+    const float* As = As0 + buf * ASZ;
+    const float* Zs = Zs0 + buf * ZSZ;
+    const bool more = (u + 1) < u_end;
+    if (more) stage_load(u + 1);   // in flight during this unit's MFMAs
+
+    // ---- MFMA: K = pixel pairs of the band, operands one pair ahead ----
+    const int npairs = (npx + 1) >> 1;
+    const int abase = wi * 32 + l31;
+    const int bbase = wj * 32 + l31;
+    const int azero = d.MARGIN * 64;   // a slot with finite data for the masked half of an odd last pair (its dz is 0)
+    float av0[9], bv0, av1[9], bv1;
+    int slot_nxt;
+    {
+      const bool ok = hi < npx;
+      const int aoff = abase + (ok ? atab[hi] : azero);
+      bv0 = Zs[(ok ? hi : band_px) * 64 + bbase];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) av0[t] = As[aoff + toff[t]];
+      slot_nxt = atab[2 + hi];
+    }
+#define WSTEP(CUR, BCUR, NXT, BNXT, KP)                                                             \
+  {                                                                                                 \
+    const int p1 = 2 * ((KP) + 1) + hi;                                                             \
+    const bool ok = p1 < npx;                                                                       \
+    const int aoff = abase + (ok ? slot_nxt : azero);                                               \
+    const int zoff = (ok ? p1 : band_px) * 64 + bbase;                                              \
+    /* reads in the order the next step consumes them; the slot of pair k+2 goes first */           \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                 \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(CUR[t], BCUR, acc[t], 0, 0, 0);                 \
+      if (t == 0) { slot_nxt = atab[min(p1 + 2, band_px + 3)]; BNXT = Zs[zoff]; }                   \
+      NXT[t] = As[aoff + toff[t]];                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
+  }
+    int kp = 0;
+    for (; kp + 1 < npairs; kp += 2) {
+      WSTEP(av0, bv0, av1, bv1, kp)
+      WSTEP(av1, bv1, av0, bv0, kp + 1)
+    }
+    if (kp < npairs) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[t], bv0, acc[t], 0, 0, 0);
+    }
+#undef WSTEP
+    if (more) stage_write(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  WSTAMP(a.stamps, 3, "s_memtime");
+  wg_store_slab(a, d, g, acc);
+  WSTAMP(a.stamps, 4, "s_memtime");
+  WSTAMP(a.stamps, 5, "s_memrealtime");
+}
+
+// ============================================================================
+// k_colsum: masked column sums of dz per sample,
+//   spart[n][tap][c] = sum_{pixels p of sample n whose tap neighbour p + tap is inside the image} dz[n, p, c]
+// (the conv-bias gradient is tap 4; t * these are the time-channel weight gradients; their
+// contraction with the time-channel weights is d f / d t).  One workgroup per sample; nine
+// inclusion-exclusion terms from: total, first/last row, first/last column, four corners.
+// ============================================================================
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dz, float* __restrict__ spart, Dims d) {
+  __shared__ float4 red[9 * 256];      // [pixel group][tap][quad]
+  __shared__ unsigned char flg[256];   // per pixel: bit0 first row, bit1 last row, bit2 first column, bit3 last column
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int c4n = d.C >> 2;                         // float4 columns
+  const int QB = min(c4n, 256);                     // quads per pass
+  const int ngrp = max(1, min(8, 256 / QB));        // pixel groups working in parallel on one quad
+  for (int p = tid; p < d.HW; p += 256) {
+    const int h = p / d.W, x = p - h * d.W;
+    flg[p] = (unsigned char)((h == 0 ? 1 : 0) | (h == d.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == d.W - 1 ? 8 : 0));
+  }
+  __syncthreads();
+  const int ql = tid % QB, pg = tid / QB;
+  const bool active = pg < ngrp;
+  auto add = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+  auto sub = [](float4& s, const float4& v) { s.x -= v.x; s.y -= v.y; s.z -= v.z; s.w -= v.w; };
+  for (int q0 = 0; q0 < c4n; q0 += QB) {
+    const int q = q0 + ql;
+    const bool on = active && q < c4n;
+    float4 T = make_float4(0.f, 0.f, 0.f, 0.f), rf = T, rl = T, cf = T, cl = T, k00 = T, k01 = T, k10 = T, k11 = T;
+    if (on) {
+      const float* base = dz + (size_t)n * d.HW * d.C + q * 4;
+      for (int p0 = pg; p0 < d.HW; p0 += 4 * ngrp) {
+        float4 v[4];
+        int f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // four independent loads in flight
+          const int p = p0 + i * ngrp;
+          const bool ok = p < d.HW;
+          v[i] = ok ? *reinterpret_cast<const float4*>(base + (size_t)p * d.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+          f[i] = ok ? flg[p] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          add(T, v[i]);
+          if (f[i] & 1) add(rf, v[i]);
+          if (f[i] & 2) add(rl, v[i]);
+          if (f[i] & 4) add(cf, v[i]);
+          if (f[i] & 8) add(cl, v[i]);
+          if ((f[i] & 5) == 5) add(k00, v[i]);
+          if ((f[i] & 9) == 9) add(k01, v[i]);
+          if ((f[i] & 6) == 6) add(k10, v[i]);
+          if ((f[i] & 10) == 10) add(k11, v[i]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {   // tap (kh, kw) excludes the first (k == 0) / last (k == 2) row and column
+        const int kh = t / 3, kw = t % 3;
+        float4 o = T;
+        if (kh == 0) sub(o, rf);
+        if (kh == 2) sub(o, rl);
+        if (kw == 0) sub(o, cf);
+        if (kw == 2) sub(o, cl);
+        if (kh == 0 && kw == 0) add(o, k00);
+        if (kh == 0 && kw == 2) add(o, k01);
+        if (kh == 2 && kw == 0) add(o, k10);
+        if (kh == 2 && kw == 2) add(o, k11);
+        red[(pg * 9 + t) * QB + ql] = o;
+      }
+    }
+    __syncthreads();
+    if (on && pg == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float4 o = red[t * QB + ql];
+        for (int r = 1; r < ngrp; ++r) add(o, red[(r * 9 + t) * QB + ql]);
+        *reinterpret_cast<float4*>(spart + ((size_t)n * 9 + t) * d.C + q * 4) = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_colsum(const Dims& d, const float* dz, float* spart, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum, dim3(d.N), dim3(256), 0, s, dz, spart, d);
+}
+
+// ----------------------------------------------------------------------------
+// launch
+// ----------------------------------------------------------------------------
+size_t wgrad_lds_bytes(const Dims& d) {
+  const int band_slots = (d.RB + 2) * d.Wp;
+  const int AROWS = band_slots + 2 * d.MARGIN;
+  const int band_px = d.RB * (d.W + 1);   // covers the padded dz rows of the templated kernel
+  return (2 * (size_t)AROWS * 64 + 2 * (size_t)(band_px + 1) * 64 + (size_t)band_px + 4) * sizeof(float);
+}
+
+int wgrad_variant() {
+  if (g_wgrad_variant >= 0) return g_wgrad_variant;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("NODE_TUNE_WGRAD_VARIANT"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
+template <int W, int RB>
+static void launch_wgrad_t(const Dims& d, const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_t<W, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_wgrad_t<W, RB>), grid, dim3(WG_THREADS), lds, s, a, d);
+}
+
+// variant 1 (production): templated kernel where the geometry has an instance, generic otherwise;
+// variant 0: always the generic kernel.
+void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
+  const int ntc = (d.C + 63) / 64;
+  const dim3 grid(ntc * ntc, d.nsplit);
+  const size_t lds = wgrad_lds_bytes(d);
+  if (wgrad_variant() >= 1 && d.H % d.RB == 0) {
+    if (d.W == 8 && d.RB == 8) { launch_wgrad_t<8, 8>(d, a, grid, lds, s); return; }
+    if (d.W == 16 && d.RB == 4) { launch_wgrad_t<16, 4>(d, a, grid, lds, s); return; }
+    if (d.W == 7 && d.RB == 7) { launch_wgrad_t<7, 7>(d, a, grid, lds, s); return; }
+    if (d.W == 4 && d.RB == 4) { launch_wgrad_t<4, 4>(d, a, grid, lds, s); return; }
+  }
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(k_wgrad_p, grid, dim3(WG_THREADS), lds, s, a, d);
+}
+
+}  // namespace node

@@ -126,6 +126,9 @@ static int make_dims(const node_shape* sh, Dims* out) {
   if (d.RB < 1) d.RB = 1;
   if (d.RB > d.H) d.RB = d.H;
   d.nbands = (d.H + d.RB - 1) / d.RB;
+  if ((d.RB + 2) * d.W * 16 > 6 * WG_THREADS || d.RB * d.W * 16 > 4 * WG_THREADS)
+    return fail(NODE_ERR_UNSUPPORTED, "W = %d: wgrad staging does not fit its registers", d.W);
+  if (wgrad_lds_bytes(d) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "wgrad tile does not fit LDS");
   {
     const int U = d.N * d.nbands;
     const int ntc = (d.C + 63) / 64;
@@ -217,7 +220,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.G = b.take<float>(d.numel);
     for (int i = 0; i < 2; ++i) {
       p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
-      p.spart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C);
+      p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
     }
     p.sred = b.take<float>((size_t)2 * 9 * d.C);
     p.gpart[0] = b.take<float>((size_t)d.mtiles * 2 * d.C);
@@ -280,11 +283,15 @@ struct Solver {
     const int cm = conv_variant() >= 1 ? 1 : 0;
     launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, cm, st);
     launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, cm, st);
+    xcheck_register(d, prm.conv1_w, p.wf[0], 0, st);
+    xcheck_register(d, prm.conv2_w, p.wf[1], 0, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);
     launch_tmap(d, prm.conv2_w, p.tmap[1], st);
     if (aug) {
       launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, cm, st);
       launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, cm, st);
+      xcheck_register(d, prm.conv1_w, p.wd[0], 1, st);
+      xcheck_register(d, prm.conv2_w, p.wd[1], 1, st);
     }
     return check_launch("prepare");
   }
@@ -344,8 +351,10 @@ struct Solver {
     g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2];
     launch_gn_bwd(d, g, st);
 
+    launch_colsum(d, p.dz2, p.spart[1], st);
     WgradArgs w2;
-    w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1]; w2.spart = p.spart[1];
+    memset(&w2, 0, sizeof(w2));
+    w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
     { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
 
     ConvArgs b2;
@@ -355,8 +364,10 @@ struct Solver {
     b2.act = p.act2; b2.xhat = p.xh2; b2.rstd = p.r2; b2.gpart = p.gpart[1];
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b2, st); }
 
+    launch_colsum(d, p.dz1, p.spart[0], st);
     WgradArgs w1;
-    w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.spart = p.spart[0];
+    memset(&w1, 0, sizeof(w1));
+    w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0];
     { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
 
     ConvArgs b1 = b2;

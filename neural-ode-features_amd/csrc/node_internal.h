@@ -218,6 +218,7 @@ struct ConvArgs {
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s);
 void launch_conv_p(const Dims& d, const ConvArgs& a, hipStream_t s);
 size_t conv_p_lds_bytes(const Dims& d);
+void xcheck_register(const Dims& d, const float* wraw, const float* packed_v1, int dgrad, hipStream_t s);  // debugging aid
 int conv_variant();   // 0: k_conv3x3, 1: k_conv3x3_p (production default; NODE_TUNE_CONV_VARIANT / g_conv_variant override)
 // tuning (tools/kbench.hip): kernel variant override (<0: production choice)
 extern int g_conv_variant;
@@ -228,14 +229,16 @@ struct WgradArgs {
   const float* act;       // [N,HW,C] conv input activation
   const float* dz;        // [N,HW,C] cotangent of conv output
   float* wpart;           // [nsplit][9][C][C]
-  float* spart;           // [nsplit][9][C]   masked column sums of dz (bias / time-channel grads)
+  unsigned long long* stamps;  // diagnostics only (NODE_STAMPS builds)
 };
 void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s);
+// masked column sums of dz per sample: spart[N][9][C] (conv-bias / time-channel-weight / d-dt terms)
+void launch_colsum(const Dims& d, const float* dz, float* spart, hipStream_t s);
 size_t wgrad_lds_bytes(const Dims& d);
 
 struct ThetaFinalizeArgs {
   const float* wpart[2];   // conv1, conv2
-  const float* spart[2];
+  const float* spart[2];   // [N][9][C] each
   const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)
   int gpart_rows[3];
   const float* wraw[2];    // raw PyTorch conv weights (time-channel taps for vjp_t)

@@ -6,8 +6,16 @@ import torch
 from oracle.dynamics import OracleODEfunc, PARAM_ORDER, odefunc_vjp as oracle_vjp
 
 
-def make_func(C, seed=0, device='cpu'):
-    """An ODEfunc (package class) with non-trivial parameters + an oracle twin on CPU."""
+def make_func(C, seed=0, device='cpu', kink_free=False):
+    """An ODEfunc (package class) with non-trivial parameters + an oracle twin on CPU.
+
+    kink_free=True shifts the GroupNorm biases in front of the two ReLUs to +8, so every
+    pre-activation is positive and the ReLU derivative has no discontinuity anywhere near the data.
+    Gradient parity through a whole solve can then be asserted tightly: with ordinary parameters one
+    or two of the ~10^6 pre-activations of a solve land within fp32 rounding (~1e-6) of zero, two
+    correct fp32 implementations then disagree on that element's ReLU mask, and the gradient changes
+    by O(1) around that pixel (measured: the oracle against either GPU kernel generation, 4 of 6 seeds
+    at [2, 256, 8, 8]).  The mask logic itself is covered by the single-evaluation VJP tests."""
     import neural_ode_features_amd as nof
     torch.manual_seed(seed)
     f = nof.ODEfunc(C)
@@ -18,6 +26,8 @@ def make_func(C, seed=0, device='cpu'):
                 p.copy_(1.0 + 0.25 * torch.randn(p.shape, generator=gen))
             elif 'norm' in name and name.endswith('bias'):
                 p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+                if kink_free and not name.startswith('norm3'):
+                    p.add_(8.0)
     twin = OracleODEfunc(C)
     twin.load_state_dict(f.state_dict())
     return f.to(device), twin
@@ -27,3 +37,13 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def robust_grad_err(a, b):
+    """(relative L2 error, fraction of elements off by more than 1e-3 x max|b|) -- for gradients that
+    went through ReLU kinks, where a max-norm comparison is ill-posed (see make_func)."""
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    l2 = float((a - b).norm() / (b.norm() + 1e-30))
+    frac = float(((a - b).abs() > 1e-3 * b.abs().max()).double().mean())
+    return l2, frac

@@ -22,7 +22,7 @@
 #include <vector>
 
 using namespace node;
-namespace node { int dims_for(const node_shape* sh, Dims* out); extern int g_wgrad_variant; }
+namespace node { int dims_for(const node_shape* sh, Dims* out); }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -165,16 +165,18 @@ int main(int argc, char** argv) {
 #endif
     }
   } else if (what == "wgrad") {
-    std::vector<float*> wp, sp;
+    // variant 0: generic kernel (k_wgrad_p); 1: geometry-templated kernel where an instance exists
+    std::vector<float*> wp;
     std::vector<std::vector<double>> times(variants.size());
     float* dz = dev_rand(numel, gen);
-    const size_t wpn = (size_t)d.nsplit * 9 * C * C, spn = (size_t)d.nsplit * 9 * C;
-    for (size_t v = 0; v < variants.size(); ++v) { wp.push_back(dev_zero(wpn)); sp.push_back(dev_zero(spn)); }
-    auto run = [&](size_t v) {
+    const size_t wpn = (size_t)d.nsplit * 9 * C * C;
+    for (size_t v = 0; v < variants.size(); ++v) wp.push_back(dev_zero(wpn));
+    auto run = [&](size_t v, unsigned long long* stp = nullptr) {
       WgradArgs a;
       memset(&a, 0, sizeof(a));
-      a.act = act; a.dz = dz; a.wpart = wp[v]; a.spart = sp[v];
+      a.act = act; a.dz = dz; a.wpart = wp[v];
       g_wgrad_variant = variants[v];
+      a.stamps = stp;
       launch_wgrad(d, a, st);
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v);
@@ -190,24 +192,81 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         times[v].push_back(ms * 1e3);
       }
-    // compare the split-reduced sums (variants may split K differently)
-    auto reduce = [&](float* p, size_t per) {
-      auto h = to_host(p, (size_t)d.nsplit * per);
+    auto reduce = [&](float* p, size_t per, int nsl) {
+      auto h = to_host(p, (size_t)nsl * per);
       std::vector<float> r(per, 0.f);
-      for (int s = 0; s < d.nsplit; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
+      for (int s = 0; s < nsl; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
       return r;
     };
-    auto refw = reduce(wp[0], 9 * C * C);
-    auto refs = reduce(sp[0], 9 * C);
+    // host reference of dW on a sample of entries (double precision)
+    auto hact = to_host(act, numel), hdz = to_host(dz, numel);
+    auto refw_v0 = reduce(wp[0], 9 * C * C, d.nsplit);
+    double ref_err = 0, ref_max = 0;
+    for (int k = 0; k < 64; ++k) {
+      const int t = k % 9, ci = (k * 37) % d.C, co = (k * 101 + 3) % d.C;
+      double acc = 0;
+      for (int n = 0; n < d.N; ++n)
+        for (int h = 0; h < d.H; ++h)
+          for (int x = 0; x < d.W; ++x) {
+            const int hh = h + t / 3 - 1, xx = x + t % 3 - 1;
+            if (hh < 0 || hh >= d.H || xx < 0 || xx >= d.W) continue;
+            acc += (double)hact[((size_t)n * d.HW + hh * d.W + xx) * C + ci] * (double)hdz[((size_t)n * d.HW + h * d.W + x) * C + co];
+          }
+      ref_err = std::max(ref_err, std::fabs(acc - (double)refw_v0[((size_t)t * C + ci) * C + co]));
+      ref_max = std::max(ref_max, std::fabs(acc));
+    }
+    printf("first variant vs fp64 host reference on 64 entries: max err %.3e (ref max %.3e)\n", ref_err, ref_max);
     for (size_t v = 0; v < variants.size(); ++v) {
       std::sort(times[v].begin(), times[v].end());
       const double med = times[v][times[v].size() / 2], mn = times[v][0];
-      double rmax, smax;
-      const double diff = max_abs_diff(reduce(wp[v], 9 * C * C), refw, &rmax);
-      const double sdiff = max_abs_diff(reduce(sp[v], 9 * C), refs, &smax);
-      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-v0| %.3e (ref max %.3e)  colsum diff %.3e (ref %.3e)\n",
-             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, sdiff, smax);
+      double rmax;
+      const double diff = max_abs_diff(reduce(wp[v], 9 * C * C, d.nsplit), refw_v0, &rmax);
+      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-first| %.3e (ref max %.3e)\n",
+             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax);
+#ifdef NODE_STAMPS
+      CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
+      run(v, stamps);
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hs(nstamp);
+      CK(hipMemcpy(hs.data(), stamps, nstamp * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      double pro = 0, mainl = 0, epi = 0, clk = 0;
+      int cnt = 0;
+      for (size_t w = 0; w < nstamp / 8; ++w) {
+        const unsigned long long* s = &hs[w * 8];
+        if (s[1] == 0 || s[4] == 0) continue;
+        pro += (double)(s[2] - s[1]); mainl += (double)(s[3] - s[2]); epi += (double)(s[4] - s[3]);
+        if (s[5] > s[0]) clk += (double)(s[4] - s[1]) / (double)(s[5] - s[0]) * 100.0;
+        ++cnt;
+      }
+      if (cnt) printf("            stamps over %d waves: prologue %.0f  main %.0f  store %.0f cycles; in-kernel clock %.0f MHz\n",
+                      cnt, pro / cnt, mainl / cnt, epi / cnt, clk / cnt);
+#endif
     }
+    // masked column sums
+    float* sp = dev_zero((size_t)d.N * 9 * C);
+    for (int i = 0; i < 3; ++i) launch_colsum(d, dz, sp, st);
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 10; ++i) launch_colsum(d, dz, sp, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    auto hs_ = reduce(sp, 9 * C, d.N);
+    double serr = 0, smax = 0;
+    for (int t = 0; t < 9; ++t)
+      for (int c = 0; c < d.C; ++c) {
+        double acc = 0;
+        for (int n = 0; n < d.N; ++n)
+          for (int h = 0; h < d.H; ++h)
+            for (int x = 0; x < d.W; ++x) {
+              const int hh = h + t / 3 - 1, xx = x + t % 3 - 1;
+              if (hh < 0 || hh >= d.H || xx < 0 || xx >= d.W) continue;
+              acc += (double)hdz[((size_t)n * d.HW + h * d.W + x) * C + c];
+            }
+        serr = std::max(serr, std::fabs(acc - (double)hs_[(size_t)t * C + c]));
+        smax = std::max(smax, std::fabs(acc));
+      }
+    printf("k_colsum %.2f us per launch; vs fp64 host reference: max err %.3e (ref max %.3e)\n", ms * 1e3 / 10, serr, smax);
   } else {
     fprintf(stderr, "unknown bench %s\n", what.c_str());
     return 2;
