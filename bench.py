@@ -33,6 +33,22 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None for other shapes."""
+    path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_eval_cfg2.json')
+    if not (args.batch == 128 and args.filters == 256 and os.path.exists(path)):
+        return None
+    try:
+        with open(path) as fh:
+            pmc = json.load(fh)
+        k = next(v for n, v in pmc.items() if 'k_conv3x3_p' in n)
+        return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+    except Exception:
+        return None
+
+
 def build_model(device, filters, tol, method):
     import neural_ode_features_amd as nof
     torch.manual_seed(23)       # train.py:224,227
@@ -173,9 +189,9 @@ def main():
             avg_ms = k['total_ms'] / k['launches']
             flops_per_launch = k['flops'] / k['launches']
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'k_conv3x3 (fp32 MFMA implicit GEMM, fwd+dgrad)',
+            roofline = {'bound': 'mfma', 'kernel': 'k_conv3x3_p (fp32 MFMA implicit GEMM, fwd+dgrad)',
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': None,
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args),
                         'avg_launch_us': avg_ms * 1e3, 'launches': k['launches'],
                         'flops_per_launch': flops_per_launch}
             w = prof['wgrad_gemm']
