@@ -98,6 +98,17 @@ void launch_tmap(const Dims& d, const float* w, float* tmap, hipStream_t s) {
   hipLaunchKernelGGL(k_tmap, dim3((total + 255) / 256), dim3(256), 0, s, w, tmap, d.C, d.H, d.W);
 }
 
+// time-channel weights W[co][0][kh][kw] gathered as [tap][co] (d f / d t contracts them with the masked dz sums)
+__global__ __launch_bounds__(256) void k_wtime(const float* __restrict__ w, float* __restrict__ wt, int C) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 9 * C; i += gridDim.x * blockDim.x) {
+    const int tap = i / C, co = i - tap * C;
+    wt[i] = w[((size_t)co * (C + 1)) * 9 + tap];
+  }
+}
+void launch_wtime(const Dims& d, const float* w, float* wtime, hipStream_t s) {
+  hipLaunchKernelGGL(k_wtime, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, w, wtime, d.C);
+}
+
 // ---------------------------------------------- theta internal -> PyTorch flat
 // flat (parameters() order): norm1.w, norm1.b, conv1.w [C][C+1][3][3], conv1.b, norm2.w, ...
 __global__ __launch_bounds__(256) void k_theta_to_torch(const float* __restrict__ th, float* __restrict__ flat, int C) {

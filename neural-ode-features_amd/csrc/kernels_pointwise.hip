@@ -630,40 +630,71 @@ void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {
 // by the wgrad GEMM and the GroupNorm-backward epilogues into one vector in the
 // internal theta layout, times osign (= tsign, the reverse-time negation).
 // ============================================================================
-__global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dims d) {
+// Bulk of the vector: the two conv-weight blocks, out[r] = osign * sum_sp wpart[sp][r], as float4 with
+// four slabs in flight per thread (the split-K slabs are 16 x 2.36 MB at C = 256: this pass is HBM-bound).
+__global__ __launch_bounds__(256) void k_theta_wsum(ThetaFinalizeArgs a, Dims d) {
   const ThetaLayout L = theta_layout(d.C);
-  const size_t C = d.C, CC = (size_t)d.C * d.C;
-  const float tval = eval_time(a.et);
+  const size_t CC = (size_t)d.C * d.C;
+  const size_t n4 = 9 * CC / 4;   // C % 4 == 0
+  const int layer = blockIdx.y;
+  const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
+  float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < d.P; idx += stride) {
-    float v = 0.f;
-    // which piece?
-    int layer = idx >= L.g[2] ? 2 : (idx >= L.g[1] ? 1 : 0);
-    size_t r = idx - L.g[layer];
-    if (r < 2 * C) {  // gamma / beta
-      const int which = r >= C ? 1 : 0;
-      const size_t c = r - which * C;
-      const float* gp = a.gpart[layer];
-      for (int row = 0; row < a.gpart_rows[layer]; ++row) v += gp[((size_t)row * 2 + which) * C + c];
-    } else {
-      r -= 2 * C;
-      if (r < 9 * CC) {  // conv weights [tap][ci][co]
-        const float* wp = a.wpart[layer];
-        for (int sp = 0; sp < d.nsplit; ++sp) v += wp[(size_t)sp * 9 * CC + r];
-      } else {
-        r -= 9 * CC;
-        const float* spp = a.spart[layer];
-        if (r < 9 * C) {  // time-channel taps [tap][co]: t * masked column sums
-          for (int sp = 0; sp < d.N; ++sp) v += spp[(size_t)sp * 9 * C + r];
-          a.sred[(size_t)layer * 9 * C + r] = v;   // reduced once here, reused by k_vjp_t
-          v *= tval;
-        } else {          // conv bias: centre tap sees every pixel
-          r -= 9 * C;
-          for (int sp = 0; sp < d.N; ++sp) v += spp[(size_t)sp * 9 * C + 4 * C + r];
-        }
-      }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sp = 0;
+    for (; sp + 4 <= d.nsplit; sp += 4) {
+      const float4 v0 = wp[(size_t)sp * n4 + i], v1 = wp[(size_t)(sp + 1) * n4 + i];
+      const float4 v2 = wp[(size_t)(sp + 2) * n4 + i], v3 = wp[(size_t)(sp + 3) * n4 + i];
+      acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+      acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    a.theta_out[idx] = a.osign * v;
+    for (; sp < d.nsplit; ++sp) {
+      const float4 v = wp[(size_t)sp * n4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    out[i] = make_float4(a.osign * acc.x, a.osign * acc.y, a.osign * acc.z, a.osign * acc.w);
+  }
+}
+
+// The small pieces (26 C values): GroupNorm affine gradients, time-channel taps, conv biases -- column
+// sums of short matrices ([rows][2C] per-tile GroupNorm partials, [N][9C] per-sample masked dz sums).
+// blockIdx.y = job (0..2: GroupNorm layer; 3, 4: conv layer), blockIdx.x = 64-column chunk; the 256
+// threads are 64 columns x 4 row groups, four loads in flight each.
+__global__ __launch_bounds__(256) void k_theta_small(ThetaFinalizeArgs a, Dims d) {
+  __shared__ float red[256];
+  const ThetaLayout L = theta_layout(d.C);
+  const int job = blockIdx.y;
+  const int C = d.C;
+  const bool gn = job < 3;
+  const int layer = gn ? job : job - 3;
+  const int ncol = gn ? 2 * C : 9 * C;
+  const int rows = gn ? a.gpart_rows[layer] : d.N;
+  const float* src = gn ? a.gpart[layer] : a.spart[layer];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  if (blockIdx.x * 64 >= ncol) return;
+  float v = 0.f;
+  if (col < ncol) {
+    int r = rg;
+    for (; r + 12 < rows; r += 16) {
+      const float v0 = src[(size_t)r * ncol + col], v1 = src[(size_t)(r + 4) * ncol + col];
+      const float v2 = src[(size_t)(r + 8) * ncol + col], v3 = src[(size_t)(r + 12) * ncol + col];
+      v += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < rows; r += 4) v += src[(size_t)r * ncol + col];
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (rg != 0 || col >= ncol) return;
+  v = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
+  if (gn) {   // columns [0, C) = dgamma, [C, 2C) = dbeta
+    const int which = col >= C ? 1 : 0;
+    a.theta_out[(which ? L.b[layer] : L.g[layer]) + (col - which * C)] = a.osign * v;
+  } else {    // column = tap * C + co
+    a.sred[(size_t)layer * 9 * C + col] = v;                         // reused by k_vjp_t
+    a.theta_out[L.wt[layer] + col] = a.osign * (v * eval_time(a.et));  // time-channel taps: t * masked sums
+    if (col >= 4 * C && col < 5 * C) a.theta_out[L.cb[layer] + (col - 4 * C)] = a.osign * v;  // conv bias = centre tap
   }
 }
 
@@ -674,11 +705,8 @@ __global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
   const int C = d.C;
   for (int layer = 0; layer < 2; ++layer) {
     const float* sr = a.sred + (size_t)layer * 9 * C;
-    const float* w = a.wraw[layer];
-    for (int i = threadIdx.x; i < 9 * C; i += 256) {
-      const int tap = i / C, co = i - tap * C;
-      acc += sr[i] * w[((size_t)co * (C + 1)) * 9 + tap];
-    }
+    const float* wt = a.wtime[layer];   // [tap][co], gathered once per solve (k_wtime)
+    for (int i = threadIdx.x; i < 9 * C; i += 256) acc += sr[i] * wt[i];
   }
   const float tot = block_sum_256(acc, red);
   if (threadIdx.x == 0) {
@@ -688,9 +716,10 @@ __global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
 }
 
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s) {
-  size_t blocks = (d.P + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)blocks), dim3(256), 0, s, a, d);
+  size_t wblocks = (9 * (size_t)d.C * d.C / 4 + 255) / 256;
+  if (wblocks > 1024) wblocks = 1024;
+  hipLaunchKernelGGL(k_theta_wsum, dim3((unsigned)wblocks, 2), dim3(256), 0, s, a, d);
+  hipLaunchKernelGGL(k_theta_small, dim3((unsigned)((9 * d.C + 63) / 64), 5), dim3(256), 0, s, a, d);
   hipLaunchKernelGGL(k_vjp_t, dim3(1), dim3(256), 0, s, a, d);
 }
 

@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -116,7 +117,9 @@ static int make_dims(const node_shape* sh, Dims* out) {
   if (conv_lds_bytes(d, 0) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "conv tile does not fit LDS");
   d.mtiles = (d.N + d.S - 1) / d.S;
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
-  int mult = (8192 / d.HW) / unit;
+  static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels
+  if (slab_elems < 0) { const char* e = getenv("NODE_TUNE_SLAB"); slab_elems = e ? atoi(e) : 2048; }
+  int mult = (slab_elems / d.HW) / unit;
   if (mult < 1) mult = 1;
   d.cs = unit * mult;
   if (d.cs > d.C) d.cs = d.C;
@@ -167,7 +170,7 @@ struct Plan {
   float *TH, *TH1, *THTMP, *KT[7];
   float *xh1, *xh2, *xh3, *r1, *r2, *r3;
   float *dz1, *dz2, *G;
-  float *wpart[2], *spart[2], *gpart[3], *sred;
+  float *wpart[2], *spart[2], *gpart[3], *sred, *wtime[2];
   float* dots;              // [n_t] time vjps scratch
   size_t bytes;
 };
@@ -223,6 +226,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
       p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
     }
     p.sred = b.take<float>((size_t)2 * 9 * d.C);
+    for (int i = 0; i < 2; ++i) p.wtime[i] = b.take<float>((size_t)9 * d.C);
     p.gpart[0] = b.take<float>((size_t)d.mtiles * 2 * d.C);
     p.gpart[1] = b.take<float>((size_t)d.mtiles * 2 * d.C);
     p.gpart[2] = b.take<float>((size_t)d.N * 2 * d.C);
@@ -290,6 +294,8 @@ struct Solver {
     if (aug) {
       launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, cm, st);
       launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, cm, st);
+      launch_wtime(d, prm.conv1_w, p.wtime[0], st);
+      launch_wtime(d, prm.conv2_w, p.wtime[1], st);
       xcheck_register(d, prm.conv1_w, p.wd[0], 1, st);
       xcheck_register(d, prm.conv2_w, p.wd[1], 1, st);
     }
@@ -382,7 +388,7 @@ struct Solver {
     tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
     tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
     tf.gpart_rows[0] = d.mtiles; tf.gpart_rows[1] = d.mtiles; tf.gpart_rows[2] = d.N;
-    tf.wraw[0] = prm.conv1_w; tf.wraw[1] = prm.conv2_w; tf.sred = p.sred;
+    tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
     tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
     tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
     launch_theta_finalize(d, tf, st);

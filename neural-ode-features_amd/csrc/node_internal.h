@@ -115,6 +115,7 @@ void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_
 // colmajor = 0: piece laid out [kk][j] (k_conv3x3); 1: [j][kk] (k_conv3x3_p, b128 operand reads)
 void launch_pack_weights(const Dims& d, const float* w /*[C][C+1][3][3]*/, float* packed, int dgrad, int colmajor, hipStream_t s);
 void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStream_t s);
+void launch_wtime(const Dims& d, const float* w, float* wtime /*[9][C]*/, hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
 
 // pointwise / reductions
@@ -241,7 +242,7 @@ struct ThetaFinalizeArgs {
   const float* spart[2];   // [N][9][C] each
   const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)
   int gpart_rows[3];
-  const float* wraw[2];    // raw PyTorch conv weights (time-channel taps for vjp_t)
+  const float* wtime[2];   // time-channel weights [tap][co] gathered from the raw conv weights (launch_wtime)
   float* sred;             // [2][9][C] split-reduced masked column sums (scratch)
   EvalTime et;
   float osign;             // tsign
