@@ -38,18 +38,18 @@ void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_
 }
 
 // ------------------------------------------------------------- weight packing
-// packed[nt][ch][tap][kk][j]  (32 x 64 floats per (nt, ch, tap) piece, contiguous); colmajor: [...][j][kk]
+// packed[nt][ch][tap][j][kk]  (64 output columns x 32 K values per (nt, ch, tap) tile, contiguous:
+// one ds_read_b128 of a column feeds four MFMA steps)
 //   forward : value = W[co = nt*BNE + j][1 + ci = ch*32 + kk][kh][kw],           tap = kh*3 + kw
 //   dgrad   : value = W[co = ch*32 + kk][1 + ci = nt*BNE + j][2 - kh][2 - kw]    (flipped, transposed)
 // zero outside C / beyond BNE so padded K rows and N columns contribute nothing.
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ w, float* __restrict__ packed,
-                                                      int C, int BNE, int ntile, int nchunk, int dgrad, int colmajor) {
+                                                      int C, int BNE, int ntile, int nchunk, int dgrad) {
   size_t total = (size_t)ntile * nchunk * 9 * KCH * BN;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    int j, kk;
-    size_t r;
-    if (colmajor) { kk = idx % KCH; r = idx / KCH; j = r % BN; r /= BN; }
-    else { j = idx % BN; r = idx / BN; kk = r % KCH; r /= KCH; }
+    const int kk = idx % KCH;
+    size_t r = idx / KCH;
+    const int j = r % BN; r /= BN;
     int tap = r % 9; r /= 9;
     int ch = r % nchunk;
     int nt = r / nchunk;
@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
   }
 }
 
-void launch_pack_weights(const Dims& d, const float* w, float* packed, int dgrad, int colmajor, hipStream_t s) {
+void launch_pack_weights(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
   size_t total = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, d.nchunk, dgrad, colmajor);
+  hipLaunchKernelGGL(k_pack_weights, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, d.nchunk, dgrad);
 }
 
 // -------------------------------------------------------------- time-channel map

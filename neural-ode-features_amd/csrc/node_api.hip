@@ -110,6 +110,16 @@ static int make_dims(const node_shape* sh, Dims* out) {
   if (d.HW <= 128) d.BM = 128;
   else if (d.HW <= 256) d.BM = 256;
   else return fail(NODE_ERR_UNSUPPORTED, "H*W = %d > 256 is not tiled yet", d.HW);
+  if (d.HW <= 64) {
+    // grids that cannot fill the chip with 128-row tiles (MNIST-sized states, bs=1 census) use 64-row
+    // tiles in four-wave workgroups: twice the workgroups (measured [32,64,7,7]: 31 -> 22.6 us).  Once
+    // the 128-row grid reaches one workgroup per CU it is the faster one (cfg 2: 91.5 vs 95 us): two
+    // co-resident 64-row workgroups run in lockstep and hide nothing of each other.
+    const int s128 = 128 / d.HW < d.N ? 128 / d.HW : d.N;
+    const long wg128 = (long)((d.N + s128 - 1) / s128) * d.ntile;
+    const bool want64 = g_conv_bm > 0 ? g_conv_bm == 64 : wg128 < 256;
+    if (want64) d.BM = 64;
+  }
   if (d.W > 64) return fail(NODE_ERR_UNSUPPORTED, "W = %d > 64", d.W);
   d.S = d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
@@ -284,20 +294,15 @@ struct Solver {
   }
 
   int prepare() {
-    const int cm = conv_variant() >= 1 ? 1 : 0;
-    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, cm, st);
-    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, cm, st);
-    xcheck_register(d, prm.conv1_w, p.wf[0], 0, st);
-    xcheck_register(d, prm.conv2_w, p.wf[1], 0, st);
+    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, st);
+    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);
     launch_tmap(d, prm.conv2_w, p.tmap[1], st);
     if (aug) {
-      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, cm, st);
-      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, cm, st);
+      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, st);
+      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, st);
       launch_wtime(d, prm.conv1_w, p.wtime[0], st);
       launch_wtime(d, prm.conv2_w, p.wtime[1], st);
-      xcheck_register(d, prm.conv1_w, p.wd[0], 1, st);
-      xcheck_register(d, prm.conv2_w, p.wd[1], 1, st);
     }
     return check_launch("prepare");
   }

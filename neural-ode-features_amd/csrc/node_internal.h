@@ -12,8 +12,6 @@ namespace node {
 // ----------------------------------------------------------------------------
 constexpr int KCH = 32;          // input channels per K chunk of the implicit GEMM
 constexpr int BN = 64;           // output-channel tile (two 32-wide MFMA column tiles)
-constexpr int AST = KCH + 1;     // LDS stride (floats) of one halo slot of the A chunk
-constexpr int CONV_THREADS = 512;  // 8 waves: 4 (M) x 2 (N)
 constexpr int WG_THREADS = 256;    // wgrad / pointwise kernels
 
 struct Dims {
@@ -112,8 +110,7 @@ __device__ inline float comb_scale(const Comb& c, const Ctrl* ctrl) {
 // layout
 void launch_nchw_to_nhwc(const Dims& d, const float* src, float* dst, hipStream_t s);
 void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_t s);
-// colmajor = 0: piece laid out [kk][j] (k_conv3x3); 1: [j][kk] (k_conv3x3_p, b128 operand reads)
-void launch_pack_weights(const Dims& d, const float* w /*[C][C+1][3][3]*/, float* packed, int dgrad, int colmajor, hipStream_t s);
+void launch_pack_weights(const Dims& d, const float* w /*[C][C+1][3][3]*/, float* packed, int dgrad, hipStream_t s);
 void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStream_t s);
 void launch_wtime(const Dims& d, const float* w, float* wtime /*[9][C]*/, hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
@@ -217,13 +214,9 @@ struct ConvArgs {
   int ablate;                  // diagnostics only (NODE_STAMPS builds): timing-only ablation bits
 };
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s);
-void launch_conv_p(const Dims& d, const ConvArgs& a, hipStream_t s);
-size_t conv_p_lds_bytes(const Dims& d);
-void xcheck_register(const Dims& d, const float* wraw, const float* packed_v1, int dgrad, hipStream_t s);  // debugging aid
-int conv_variant();   // 0: k_conv3x3, 1: k_conv3x3_p (production default; NODE_TUNE_CONV_VARIANT / g_conv_variant override)
 // tuning (tools/kbench.hip): kernel variant override (<0: production choice)
-extern int g_conv_variant;
 extern int g_wgrad_variant;
+extern int g_conv_bm;      // force the conv M tile (64 / 128) where the geometry allows; <= 0: heuristic
 size_t conv_lds_bytes(const Dims& d, int mode);
 
 struct WgradArgs {

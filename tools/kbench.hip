@@ -4,11 +4,11 @@
 // also records s_memtime / s_memrealtime stamps, from which this tool prints the
 // share of prologue / main loop / epilogue and the in-kernel clock.
 //
-//   kbench conv  N C H W [reps] [variants...]     forward conv + GN epilogue
-//   kbench dgrad N C H W [reps] [variants...]     data-gradient conv + ReLU/GN-backward epilogue
-//   kbench wgrad N C H W [reps] [variants...]
+//   kbench conv  N C H W [reps] [tiles...]     forward conv + GN epilogue; tiles = M tile 0 (heuristic) / 64 / 128
+//   kbench dgrad N C H W [reps] [tiles...]     data-gradient conv + ReLU/GN-backward epilogue
+//   kbench wgrad N C H W [reps] [variants...]  0 generic kernel, 1 geometry-templated kernel
 //
-// Every variant's output is compared with variant 0's (the pytest-verified kernel).
+// Every variant's output is compared with the first one's; conv and wgrad also against an fp64 host reference.
 #include "../neural-ode-features_amd/csrc/node_internal.h"
 #include "../include/node_hip.h"
 
@@ -81,14 +81,12 @@ int main(int argc, char** argv) {
   float* rstd = dev_rand((size_t)d.N * d.G, gen, 0.1f, 1.f);
   const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
   float* wpk = dev_zero(wsz);
-  float* wpk_cm = dev_zero(wsz);
   float* tmap = dev_zero((size_t)d.HW * C);
   Ctrl* ctrl;
   CK(hipMalloc(&ctrl, sizeof(Ctrl)));
   launch_set_ctrl(ctrl, 0.3, 0.1, 1, st);
   const bool bwd = what == "dgrad";
-  launch_pack_weights(d, wraw, wpk, bwd ? 1 : 0, 0, st);
-  launch_pack_weights(d, wraw, wpk_cm, bwd ? 1 : 0, 1, st);
+  launch_pack_weights(d, wraw, wpk, bwd ? 1 : 0, st);
   launch_tmap(d, wraw, tmap, st);
   CK(hipStreamSynchronize(st));
 
@@ -101,25 +99,31 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&stamps, nstamp * sizeof(unsigned long long)));
 
   if (what == "conv" || what == "dgrad") {
+    // variants = conv M tile (g_conv_bm): 0 heuristic, 64, 128
     std::vector<float*> outs, xh, rs, gp;
+    std::vector<Dims> dv;
     std::vector<std::vector<double>> times(variants.size());
     for (size_t v = 0; v < variants.size(); ++v) {
+      g_conv_bm = variants[v] & 0xfff;
+      Dims dd;
+      if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
+      dv.push_back(dd);
       outs.push_back(dev_zero(numel)); xh.push_back(dev_zero(numel)); rs.push_back(dev_zero((size_t)d.N * d.G));
-      gp.push_back(dev_zero((size_t)d.mtiles * 2 * C + 64));
+      gp.push_back(dev_zero((size_t)dd.mtiles * 2 * C + 64));
     }
+    g_conv_bm = -1;
     auto run = [&](size_t v, unsigned long long* stp) {
       ConvArgs a;
       memset(&a, 0, sizeof(a));
-      a.in = in; a.wpacked = (variants[v] & 15) >= 1 ? wpk_cm : wpk; a.mode = bwd ? CM_BWD_RELU_GN : CM_FWD_GN_RELU;
+      a.in = in; a.wpacked = wpk; a.mode = bwd ? CM_BWD_RELU_GN : CM_FWD_GN_RELU;
       a.bias = bias; a.tmap = tmap;
       a.et.ctrl = ctrl; a.et.alpha = 0.5f; a.et.tsign = 1.f; a.et.mode = TM_STAGE;
       a.gamma = gamma; a.beta = beta; a.osign = 1.f; a.out = outs[v];
       a.xhat_out = bwd ? nullptr : xh[v]; a.rstd_out = bwd ? nullptr : rs[v];
       a.act = act; a.xhat = xhat; a.rstd = rstd; a.gpart = gp[v];
       a.stamps = stp;
-      g_conv_variant = variants[v] & 15;
-      a.ablate = variants[v] >> 4;
-      launch_conv(d, a, st);
+      a.ablate = variants[v] >> 12;
+      launch_conv(dv[v], a, st);
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v, nullptr);
     CK(hipStreamSynchronize(st));
@@ -134,16 +138,66 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         times[v].push_back(ms * 1e3);
       }
+    // fp64 host reference of sample 0 (forward: conv + bias + t*tmap -> GroupNorm -> affine -> ReLU)
+    double host_err = -1, host_max = 0;
+    if (!bwd) {
+      auto hin = to_host(in, (size_t)d.HW * C), hw = to_host(wraw, C * (C + 1) * 9), hb = to_host(bias, C);
+      auto hg = to_host(gamma, C), hbt = to_host(beta, C), ho = to_host(outs[0], (size_t)d.HW * C);
+      const double tval = 0.3 + 0.5 * 0.1;
+      std::vector<double> pre((size_t)d.HW * C);
+      for (int p = 0; p < d.HW; ++p)
+        for (int co = 0; co < d.C; ++co) {
+          const int h = p / d.W, x = p % d.W;
+          double acc = hb[co];
+          for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+              const int hh = h + kh - 1, xx = x + kw - 1;
+              if (hh < 0 || hh >= d.H || xx < 0 || xx >= d.W) continue;
+              const float* wrow = &hw[(((size_t)co * (C + 1)) * 3 + kh) * 3 + kw];
+              acc += tval * (double)wrow[0];
+              const float* irow = &hin[((size_t)hh * d.W + xx) * C];
+              for (int ci = 0; ci < d.C; ++ci) acc += (double)irow[ci] * (double)wrow[(size_t)(1 + ci) * 9];
+            }
+          pre[(size_t)p * C + co] = acc;
+        }
+      host_err = 0;
+      for (int g = 0; g < d.G; ++g) {
+        double m = 0, v = 0;
+        for (int p = 0; p < d.HW; ++p) for (int cc = 0; cc < d.cpg; ++cc) m += pre[(size_t)p * C + g * d.cpg + cc];
+        m /= d.HW * d.cpg;
+        for (int p = 0; p < d.HW; ++p) for (int cc = 0; cc < d.cpg; ++cc) { const double e = pre[(size_t)p * C + g * d.cpg + cc] - m; v += e * e; }
+        v /= d.HW * d.cpg;
+        const double rstdv = 1.0 / std::sqrt(v + 1e-5);
+        for (int p = 0; p < d.HW; ++p)
+          for (int cc = 0; cc < d.cpg; ++cc) {
+            const int c = g * d.cpg + cc;
+            const double o = std::max(0.0, (pre[(size_t)p * C + c] - m) * rstdv * hg[c] + hbt[c]);
+            host_err = std::max(host_err, std::fabs(o - (double)ho[(size_t)p * C + c]));
+            host_max = std::max(host_max, std::fabs(o));
+          }
+      }
+      printf("first variant vs fp64 host reference (sample 0): max err %.3e (ref max %.3e)\n", host_err, host_max);
+    }
     auto ref = to_host(outs[0], numel);
-    auto refg = to_host(gp[0], (size_t)d.mtiles * 2 * C);
     for (size_t v = 0; v < variants.size(); ++v) {
       std::sort(times[v].begin(), times[v].end());
       const double med = times[v][times[v].size() / 2], mn = times[v][0];
-      double rmax, gmax = 0;
+      double rmax;
       const double diff = max_abs_diff(to_host(outs[v], numel), ref, &rmax);
-      const double gdiff = bwd ? max_abs_diff(to_host(gp[v], (size_t)d.mtiles * 2 * C), refg, &gmax) : 0.0;
-      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-v0| %.3e (ref max %.3e)  gpart diff %.3e\n",
-             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
+      // (dgamma, dbeta) partials are per M tile: compare their sums
+      double gdiff = 0;
+      if (bwd) {
+        auto red = [&](size_t w) {
+          auto h = to_host(gp[w], (size_t)dv[w].mtiles * 2 * C);
+          std::vector<float> r(2 * C, 0.f);
+          for (int m = 0; m < dv[w].mtiles; ++m) for (size_t i = 0; i < 2 * C; ++i) r[i] += h[(size_t)m * 2 * C + i];
+          return r;
+        };
+        double gm;
+        gdiff = max_abs_diff(red(v), red(0), &gm);
+      }
+      printf("tile %4d (BM=%d, %d workgroups)  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-first| %.3e (ref max %.3e)  gpart diff %.3e\n",
+             variants[v] & 0xfff, dv[v].BM, dv[v].mtiles * dv[v].ntile, med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
 #ifdef NODE_STAMPS
       CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
       run(v, stamps);
