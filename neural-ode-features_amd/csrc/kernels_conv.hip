@@ -550,7 +550,7 @@ static void launch_conv_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
 // barriers / prologue / epilogue when the grid is small; 128 / 256 = eight waves.
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
   if (d.BM == 64) launch_conv_t<2, 1>(d, a, s);
-  else if (d.BM == 128) launch_conv_t<4, 1>(d, a, s);
+  else if (d.BM == 128) launch_conv_t<4, 1>(d, a, s);   // (four waves x (64 x 32) per wave measured slower: 94 vs 91 us at cfg 2)
   else launch_conv_t<4, 2>(d, a, s);
 }
 

@@ -608,17 +608,17 @@ __global__ __launch_bounds__(256) void k_dot_partial(const float* a, const float
   const float tot = block_sum_256(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(256) void k_dot_final(Ctrl* c, const float* partial, float* out_dot) {
+__global__ __launch_bounds__(256) void k_dot_final(Ctrl* c, const float* partial, float sign, float* out_dot) {
   __shared__ float red[4];
-  const float tot = reduce_partials_512(partial, red);
+  const float tot = sign * reduce_partials_512(partial, red);
   if (threadIdx.x == 0) {
     c->ts_cur = c->ts_cur - tot;
     if (out_dot) *out_dot = tot;
   }
 }
-void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float* partial, float* out_dot, hipStream_t s) {
+void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float sign, float* partial, float* out_dot, hipStream_t s) {
   hipLaunchKernelGGL(k_dot_partial, dim3(ERR_BLOCKS), dim3(256), 0, s, a, b, n, partial);
-  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, ctrl, partial, out_dot);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, s, ctrl, partial, sign, out_dot);
 }
 __global__ void k_copy_scalar_out(const Ctrl* c, float* dst) { *dst = c->ts_cur; }
 void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {

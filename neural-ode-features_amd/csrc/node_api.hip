@@ -479,13 +479,14 @@ struct Solver {
   }
 
   // one interval of the fixed-grid RK4 (3/8 rule): state advanced in place
-  int rk4_interval(double t0, double t1) {
+  int rk4_interval(double t0, double t1, const float* dot_with = nullptr, float* dot_out = nullptr) {
     // upstream keeps the fixed grid in the state dtype (fp32)
     const float t0f = (float)t0, t1f = (float)t1;
     launch_set_ctrl(p.ctrl, (double)t0f, (double)(t1f - t0f), 0, st);
     const double c2[1] = {1.0 / 3}, c3[2] = {-1.0 / 3, 1.0}, c4[3] = {1.0, -1.0, 1.0};
     const double cf[4] = {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8};
     TRY(eval_sys(0, nullptr, 0, SC_ABS, et_stage(0.0), false));
+    if (dot_with) launch_dot_sub_scalar(p.ctrl, p.KY[0], dot_with, d.numel, tsign, p.partial[0], dot_out, st);   // adjoint: adj_t -= <f_i, g_i>
     TRY(eval_sys(1, c2, 1, SC_DT, et_stage(1.0 / 3), false));
     TRY(eval_sys(2, c3, 2, SC_DT, et_stage(2.0 / 3), false));
     TRY(eval_sys(3, c4, 3, SC_DT, et_stage(1.0), false));
@@ -739,19 +740,15 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
 
     launch_nchw_to_nhwc(S.d, y_traj + (size_t)i * numel, S.p.Y, S.st);
     launch_nchw_to_nhwc(S.d, grad_out + (size_t)i * numel, S.p.G, S.st);
-    // func_i = f(t_i, y_i)  (plain, un-negated) ; adj_time -= <func_i, grad_output_i>
-    {
-      const float keep = S.tsign;
-      S.tsign = 1.f;
-      launch_set_ctrl(S.p.ctrl, (double)t_pts[i], 0.0, 0, S.st);
-      Comb cy = Solver::make_comb(S.p.Y, S.p.KY, nullptr, 0, SC_ABS);
-      TRY(S.eval_fwd(cy, nullptr, S.et_stage(0.0), S.p.KY[1], false));
-      S.tsign = keep;
-      launch_dot_sub_scalar(S.p.ctrl, S.p.KY[1], S.p.G, numel, S.p.partial[0], grad_t ? S.p.dots + i : nullptr, S.st);
-    }
+    // func_i = f(t_i, y_i); adj_time -= <func_i, grad_output_i>.  Upstream evaluates f here and again as
+    // the first stage of the augmented solve at the same (t_i, y_i); the stage-0 evaluation below
+    // produces tsign * f bit-identically, so the dot product is taken from it (times tsign) and the
+    // separate evaluation is only COUNTED (the reference's nfe counter, model.py:340, would have seen it).
+    S.nfe += 1;
+    float* dots_i = grad_t ? S.p.dots + i : nullptr;
 
     if (method == NODE_METHOD_RK4) {
-      TRY(S.rk4_interval(s0, s1));
+      TRY(S.rk4_interval(s0, s1, S.p.G, dots_i));
       stt.accepted += 1;
       dlog.add(s1 - s0, true);
       cur_t = s1; cur_dt = s1 - s0;
@@ -760,6 +757,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       launch_set_ctrl(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, 0, S.st);
       if (forced) forced_idx = 1;
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
+      launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], S.p.G, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
       long long steps = 0;
       bool done = false;

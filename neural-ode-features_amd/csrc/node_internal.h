@@ -184,7 +184,8 @@ struct InterpArgs {
 void launch_interp(const InterpArgs& a, hipStream_t s);
 void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s);   // ts_cur <- interp
 void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s);  // y += alpha*x
-void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float* partial, float* out_dot, hipStream_t s);
+// ctrl->ts_cur -= sign * <a, b>;  *out_dot = sign * <a, b>
+void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float sign, float* partial, float* out_dot, hipStream_t s);
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
 void launch_lincomb(const Comb& c, const Ctrl* ctrl, float* out, size_t n, hipStream_t s);
 void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s);

@@ -123,7 +123,9 @@ int main(int argc, char** argv) {
       a.act = act; a.xhat = xhat; a.rstd = rstd; a.gpart = gp[v];
       a.stamps = stp;
       a.ablate = variants[v] >> 12;
+      g_conv_bm = variants[v] & 0xfff;
       launch_conv(dv[v], a, st);
+      g_conv_bm = -1;
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v, nullptr);
     CK(hipStreamSynchronize(st));
