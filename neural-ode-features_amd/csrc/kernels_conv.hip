@@ -78,13 +78,204 @@ __device__ inline int slot_of_p(int p, int W, int Wp) {
 #define ABL(bit) 0
 #endif
 
+// ----------------------------------------------------------------------------
+// Shared epilogue tail.  On entry the pre-normalisation tile Ct[BM][CT2] (conv output + bias + t*tmap,
+// or the raw data gradient) is complete in LDS and the workgroup is synchronised.  Forward: GroupNorm
+// statistics with a lane<->pixel mapping (conflict-free, no integer division in any loop, DPP wave
+// reductions), normalise (+ReLU), 16-B stores of the activation and of xhat / rstd for the backward.
+// Backward: ReLU mask, (dgamma, dbeta) tile partials, GroupNorm backward, 16-B stores.
+// ----------------------------------------------------------------------------
+template <int THREADS, int BM>
+__device__ inline void conv_epilogue_tail(const ConvArgs& a, const Dims& d, float* smem, int n0, int c0, int nsamp,
+                                          int ncols, int mtile) {
+  constexpr int NWAVES = THREADS / 64;
+  constexpr int RL = THREADS / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool fwd = a.mode != CM_BWD_RELU_GN;
+  float* Ct = smem;                   // [BM][CT2]
+  float* Xt = smem + BM * CT2;        // [BM][CT2]   (bwd only)
+  float* st0 = smem + 2 * BM * CT2;   // [S*BN] mean / m1
+  float* st1 = st0 + d.S * BN;        // [S*BN] rstd / m2
+  float* cred = st1 + d.S * BN;       // [RL][64][2]
+  const int GT = ncols / d.cpg;  // whole groups in this tile
+  const int npairs = nsamp * GT;
+  const float inv_m = 1.0f / (float)(d.HW * d.cpg);
+  // thread <-> (column quad, row lane) mapping of the store passes
+  const int colq = (tid & 15) * 4, rr = tid >> 4;
+  const bool vec_ok = ((c0 & 3) == 0) && ((ncols & 3) == 0);
+  int glq[4];
+  bool okq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    okq[i] = (colq + i) < ncols;
+    glq[i] = okq[i] ? (colq + i) / d.cpg : 0;
+  }
+
+  if (fwd) {
+    for (int pair = wave; pair < npairs; pair += NWAVES) {
+      const int s = pair / GT, gl = pair - s * GT;
+      const float* base = Ct + (s * d.HW) * CT2 + gl * d.cpg;
+      float sum = 0.f;
+      for (int p = lane; p < d.HW; p += 64) {
+#pragma unroll 8
+        for (int cc = 0; cc < d.cpg; ++cc) sum += base[p * CT2 + cc];
+      }
+      const float mean = wave_sum_p(sum) * inv_m;
+      float s2 = 0.f;
+      for (int p = lane; p < d.HW; p += 64) {
+#pragma unroll 8
+        for (int cc = 0; cc < d.cpg; ++cc) {
+          const float dv = base[p * CT2 + cc] - mean;
+          s2 += dv * dv;
+        }
+      }
+      const float var = wave_sum_p(s2) * inv_m;
+      const float rstd = 1.0f / sqrtf(var + d.eps);
+      if (lane == 0) {
+        st0[pair] = mean;
+        st1[pair] = rstd;
+        if (a.rstd_out) a.rstd_out[(size_t)(n0 + s) * d.G + c0 / d.cpg + gl] = rstd;
+      }
+    }
+    __syncthreads();
+    PSTAMP(a.stamps, 7, "s_memtime");
+    float gm[4], bt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gm[i] = okq[i] ? a.gamma[c0 + colq + i] : 0.f;
+      bt[i] = okq[i] ? a.beta[c0 + colq + i] : 0.f;
+    }
+    const bool relu = a.mode == CM_FWD_GN_RELU;
+    for (int s = 0; s < nsamp; ++s) {
+      float mean[4], rstd[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { mean[i] = st0[s * GT + glq[i]]; rstd[i] = st1[s * GT + glq[i]]; }
+      for (int p = rr; p < d.HW; p += RL) {
+        const float* src = Ct + (s * d.HW + p) * CT2 + colq;
+        float xh[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xh[i] = (src[i] - mean[i]) * rstd[i];
+          float v = xh[i] * gm[i] + bt[i];
+          if (relu) v = fmaxf(v, 0.f);
+          o[i] = a.osign * v;
+        }
+        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
+        if (vec_ok) {
+          if (okq[0]) {
+            *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.xhat_out) *reinterpret_cast<float4*>(a.xhat_out + off) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (okq[i]) {
+              a.out[off + i] = o[i];
+              if (a.xhat_out) a.xhat_out[off + i] = xh[i];
+            }
+        }
+      }
+    }
+  } else {
+    // ReLU mask, dxhat = du * gamma, column partials of (dgamma, dbeta)
+    float gm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gm[i] = okq[i] ? a.gamma[c0 + colq + i] : 0.f;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsamp; ++s) {
+      for (int p = rr; p < d.HW; p += RL) {
+        const int row = s * d.HW + p;
+        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
+        float x[4], ac[4];
+        if (vec_ok) {
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), av = xv;
+          if (okq[0]) {
+            xv = *reinterpret_cast<const float4*>(a.xhat + off);
+            av = *reinterpret_cast<const float4*>(a.act + off);
+          }
+          x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
+          ac[0] = av.x; ac[1] = av.y; ac[2] = av.z; ac[3] = av.w;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            x[i] = okq[i] ? a.xhat[off + i] : 0.f;
+            ac[i] = okq[i] ? a.act[off + i] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float du = (okq[i] && ac[i] > 0.f) ? Ct[row * CT2 + colq + i] : 0.f;
+          dg[i] += du * x[i];
+          db[i] += du;
+          Ct[row * CT2 + colq + i] = du * gm[i];
+          Xt[row * CT2 + colq + i] = x[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cred[(rr * 64 + colq + i) * 2] = dg[i];
+      cred[(rr * 64 + colq + i) * 2 + 1] = db[i];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int col = tid & 63, which = tid >> 6;
+      if (col < ncols) {
+        float v = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RL; ++r) v += cred[(r * 64 + col) * 2 + which];
+        a.gpart[((size_t)mtile * 2 + which) * d.C + c0 + col] = v;
+      }
+    }
+    for (int pair = wave; pair < npairs; pair += NWAVES) {
+      const int s = pair / GT, gl = pair - s * GT;
+      const int base = (s * d.HW) * CT2 + gl * d.cpg;
+      float s1 = 0.f, s2 = 0.f;
+      for (int p = lane; p < d.HW; p += 64) {
+#pragma unroll 8
+        for (int cc = 0; cc < d.cpg; ++cc) {
+          const float dxh = Ct[base + p * CT2 + cc];
+          s1 += dxh;
+          s2 += dxh * Xt[base + p * CT2 + cc];
+        }
+      }
+      s1 = wave_sum_p(s1) * inv_m;
+      s2 = wave_sum_p(s2) * inv_m;
+      if (lane == 0) { st0[pair] = s1; st1[pair] = s2; }
+    }
+    __syncthreads();
+    for (int s = 0; s < nsamp; ++s) {
+      float m1[4], m2[4], rs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        m1[i] = st0[s * GT + glq[i]];
+        m2[i] = st1[s * GT + glq[i]];
+        rs[i] = okq[i] ? a.rstd[(size_t)(n0 + s) * d.G + c0 / d.cpg + glq[i]] : 0.f;
+      }
+      for (int p = rr; p < d.HW; p += RL) {
+        const int row = s * d.HW + p;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o[i] = a.osign * (rs[i] * (Ct[row * CT2 + colq + i] - m1[i] - Xt[row * CT2 + colq + i] * m2[i]));
+        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
+        if (vec_ok) {
+          if (okq[0]) *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (okq[i]) a.out[off + i] = o[i];
+        }
+      }
+    }
+  }
+}
+
 template <int WM, int MT>
 __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
   PSTAMP(a.stamps, 0, "s_memrealtime");
   PSTAMP(a.stamps, 1, "s_memtime");
   constexpr int THREADS = WM * 128;        // WM waves in M x 2 in N
-  constexpr int NWAVES = WM * 2;
-  constexpr int RL = THREADS / 16;         // row lanes of the epilogue's (column quad, row) mapping
   constexpr int NB = 512 / THREADS;        // float4 of one B tile per thread
   constexpr int BM = WM * 32 * MT;
   constexpr int NA = 2 * MT;  // float4 staging units per thread for one A chunk
@@ -331,11 +522,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
   // ==========================================================================
   // epilogue: accumulators -> LDS tile -> GroupNorm (fwd or bwd) -> HBM
   // ==========================================================================
-  float* Ct = smem;                   // [BM][CT2]
-  float* Xt = smem + BM * CT2;        // [BM][CT2]   (bwd only)
-  float* st0 = smem + 2 * BM * CT2;   // [S*BN] mean / m1
-  float* st1 = st0 + d.S * BN;        // [S*BN] rstd / m2
-  float* cred = st1 + d.S * BN;       // [RL][64][2]
+  float* Ct = smem;                   // [BM][CT2] pre-normalisation tile (the tail lays out the rest of the LDS)
 
   {
     const float tval = fwd ? eval_time(a.et) : 0.f;
@@ -356,178 +543,7 @@ __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
   __syncthreads();
   PSTAMP(a.stamps, 6, "s_memtime");
 
-  const int GT = ncols / d.cpg;  // whole groups in this tile
-  const int npairs = nsamp * GT;
-  const float inv_m = 1.0f / (float)(d.HW * d.cpg);
-  // thread <-> (column quad, row lane) mapping of the store passes
-  const int colq = (tid & 15) * 4, rr = tid >> 4;
-  const bool vec_ok = ((c0 & 3) == 0) && ((ncols & 3) == 0);
-  int glq[4];
-  bool okq[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    okq[i] = (colq + i) < ncols;
-    glq[i] = okq[i] ? (colq + i) / d.cpg : 0;
-  }
-
-  if (fwd) {
-    for (int pair = wave; pair < npairs; pair += NWAVES) {
-      const int s = pair / GT, gl = pair - s * GT;
-      const float* base = Ct + (s * d.HW) * CT2 + gl * d.cpg;
-      float sum = 0.f;
-      for (int p = lane; p < d.HW; p += 64) {
-#pragma unroll 8
-        for (int cc = 0; cc < d.cpg; ++cc) sum += base[p * CT2 + cc];
-      }
-      const float mean = wave_sum_p(sum) * inv_m;
-      float s2 = 0.f;
-      for (int p = lane; p < d.HW; p += 64) {
-#pragma unroll 8
-        for (int cc = 0; cc < d.cpg; ++cc) {
-          const float dv = base[p * CT2 + cc] - mean;
-          s2 += dv * dv;
-        }
-      }
-      const float var = wave_sum_p(s2) * inv_m;
-      const float rstd = 1.0f / sqrtf(var + d.eps);
-      if (lane == 0) {
-        st0[pair] = mean;
-        st1[pair] = rstd;
-        if (a.rstd_out) a.rstd_out[(size_t)(n0 + s) * d.G + c0 / d.cpg + gl] = rstd;
-      }
-    }
-    __syncthreads();
-    PSTAMP(a.stamps, 7, "s_memtime");
-    float gm[4], bt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      gm[i] = okq[i] ? a.gamma[c0 + colq + i] : 0.f;
-      bt[i] = okq[i] ? a.beta[c0 + colq + i] : 0.f;
-    }
-    const bool relu = a.mode == CM_FWD_GN_RELU;
-    for (int s = 0; s < nsamp; ++s) {
-      float mean[4], rstd[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { mean[i] = st0[s * GT + glq[i]]; rstd[i] = st1[s * GT + glq[i]]; }
-      for (int p = rr; p < d.HW; p += RL) {
-        const float* src = Ct + (s * d.HW + p) * CT2 + colq;
-        float xh[4], o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          xh[i] = (src[i] - mean[i]) * rstd[i];
-          float v = xh[i] * gm[i] + bt[i];
-          if (relu) v = fmaxf(v, 0.f);
-          o[i] = a.osign * v;
-        }
-        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
-        if (vec_ok) {
-          if (okq[0]) {
-            *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
-            if (a.xhat_out) *reinterpret_cast<float4*>(a.xhat_out + off) = make_float4(xh[0], xh[1], xh[2], xh[3]);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (okq[i]) {
-              a.out[off + i] = o[i];
-              if (a.xhat_out) a.xhat_out[off + i] = xh[i];
-            }
-        }
-      }
-    }
-  } else {
-    // ReLU mask, dxhat = du * gamma, column partials of (dgamma, dbeta)
-    float gm[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gm[i] = okq[i] ? a.gamma[c0 + colq + i] : 0.f;
-    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsamp; ++s) {
-      for (int p = rr; p < d.HW; p += RL) {
-        const int row = s * d.HW + p;
-        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
-        float x[4], ac[4];
-        if (vec_ok) {
-          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), av = xv;
-          if (okq[0]) {
-            xv = *reinterpret_cast<const float4*>(a.xhat + off);
-            av = *reinterpret_cast<const float4*>(a.act + off);
-          }
-          x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
-          ac[0] = av.x; ac[1] = av.y; ac[2] = av.z; ac[3] = av.w;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            x[i] = okq[i] ? a.xhat[off + i] : 0.f;
-            ac[i] = okq[i] ? a.act[off + i] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float du = (okq[i] && ac[i] > 0.f) ? Ct[row * CT2 + colq + i] : 0.f;
-          dg[i] += du * x[i];
-          db[i] += du;
-          Ct[row * CT2 + colq + i] = du * gm[i];
-          Xt[row * CT2 + colq + i] = x[i];
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      cred[(rr * 64 + colq + i) * 2] = dg[i];
-      cred[(rr * 64 + colq + i) * 2 + 1] = db[i];
-    }
-    __syncthreads();
-    if (tid < 128) {
-      const int col = tid & 63, which = tid >> 6;
-      if (col < ncols) {
-        float v = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < RL; ++r) v += cred[(r * 64 + col) * 2 + which];
-        a.gpart[((size_t)mtile * 2 + which) * d.C + c0 + col] = v;
-      }
-    }
-    for (int pair = wave; pair < npairs; pair += NWAVES) {
-      const int s = pair / GT, gl = pair - s * GT;
-      const int base = (s * d.HW) * CT2 + gl * d.cpg;
-      float s1 = 0.f, s2 = 0.f;
-      for (int p = lane; p < d.HW; p += 64) {
-#pragma unroll 8
-        for (int cc = 0; cc < d.cpg; ++cc) {
-          const float dxh = Ct[base + p * CT2 + cc];
-          s1 += dxh;
-          s2 += dxh * Xt[base + p * CT2 + cc];
-        }
-      }
-      s1 = wave_sum_p(s1) * inv_m;
-      s2 = wave_sum_p(s2) * inv_m;
-      if (lane == 0) { st0[pair] = s1; st1[pair] = s2; }
-    }
-    __syncthreads();
-    for (int s = 0; s < nsamp; ++s) {
-      float m1[4], m2[4], rs[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        m1[i] = st0[s * GT + glq[i]];
-        m2[i] = st1[s * GT + glq[i]];
-        rs[i] = okq[i] ? a.rstd[(size_t)(n0 + s) * d.G + c0 / d.cpg + glq[i]] : 0.f;
-      }
-      for (int p = rr; p < d.HW; p += RL) {
-        const int row = s * d.HW + p;
-        float o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          o[i] = a.osign * (rs[i] * (Ct[row * CT2 + colq + i] - m1[i] - Xt[row * CT2 + colq + i] * m2[i]));
-        const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
-        if (vec_ok) {
-          if (okq[0]) *reinterpret_cast<float4*>(a.out + off) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (okq[i]) a.out[off + i] = o[i];
-        }
-      }
-    }
-  }
+  conv_epilogue_tail<THREADS, BM>(a, d, smem, n0, c0, nsamp, ncols, mtile);
   PSTAMP(a.stamps, 4, "s_memtime");
   PSTAMP(a.stamps, 5, "s_memrealtime");
 }
