@@ -36,6 +36,7 @@ namespace node {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int g_conv_bm = -1;
+int g_conv_wino = -1;
 
 constexpr int AST2 = 36;          // floats per halo slot of the A image
 constexpr int BST2 = 36;          // floats per output column of the B tile
@@ -548,11 +549,370 @@ __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
   PSTAMP(a.stamps, 5, "s_memrealtime");
 }
 
-size_t conv_lds_bytes(const Dims& d, int /*mode*/) {
+// ============================================================================
+// k_conv3x3_w -- the same convolution through a 1-D Winograd F(2,3) transform along the image rows:
+//   out[h, 2t + {0,1}] from in[h + kh - 1, 2t - 1 .. 2t + 2]:   12 instead of 18 multiplies per output pair
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3          (input,  at staging time)
+//     U0 = g0   U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2          (filter, once per solve: k_pack_weights_w)
+//     M_j[h, t, co] = sum_{kh, ci} V_j[h + kh - 1, t, ci] * U_j[kh, ci, co]     (MFMA: 4 components x 3 row taps)
+//     y0 = M0 + M1 + M2          y1 = M1 - M2 - M3                         (output, in the epilogue)
+// 1.5 x fewer MFMAs for fp32-benign coefficients (+-1, 1/2).  The GEMM rows are (sample, row, column
+// pair) "tile-rows"; a workgroup owns 32*MT tile-rows = 64*MT pixels = whole samples x 64 output channels;
+// its eight waves are 4 components x 2 column halves, MT accumulators each.  K chunks are 16 channels
+// (MFMA step s multiplies channels {s, 8 + s}: one ds_read_b128 per operand feeds four steps), a piece is
+// (chunk, kh): 2 operand groups of 4 steps.  Pipeline, staging discipline and barrier are those of
+// k_conv3x3; the epilogue folds the four component tiles into the pixel tile in LDS (four passes of
+// read-modify-write, one per component), adds bias + t*tmap, then runs the shared tail.
+// Requires even W (the direct kernel serves odd widths).
+// ============================================================================
+constexpr int KCW = 16;            // channels per K chunk
+constexpr int ASTW = 20;           // floats per (slot, component) row of the A image: 16 channels + 16-B pad
+constexpr int BSTW = 20;           // floats per (component, column) row of a B tile
+constexpr int BBUFW = 4 * BN * BSTW;
+
+template <int MT>
+__global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
+  PSTAMP(a.stamps, 0, "s_memrealtime");
+  PSTAMP(a.stamps, 1, "s_memtime");
+  constexpr int THREADS = 512;
+  constexpr int TR = 32 * MT;        // tile-rows per workgroup
+  constexpr int BM = 64 * MT;        // pixels per workgroup
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int jc = wave >> 1, wn = wave & 1;   // Winograd component, column half
+  const int mtile = blockIdx.x, nt = blockIdx.y;
+  const int n0 = mtile * d.S;
+  const int c0 = nt * d.BNE;
+  const int nsamp = min(d.S, d.N - n0);
+  const int NT = d.W >> 1;           // column pairs per image row
+  const int TRS = d.H * NT;          // tile-rows per sample
+  const int SLW = (d.H + 2) * NT;    // slots per sample: one zero halo row above and below
+  const int tr_valid = nsamp * TRS;
+  const bool fwd = a.mode != CM_BWD_RELU_GN;
+  const int ncols = min(d.BNE, d.C - c0);
+
+  const int ABUF = d.S * SLW * (4 * ASTW);
+  float* Abuf = smem;             // 2 x ABUF
+  float* Bbuf = smem + 2 * ABUF;  // 3 x BBUFW
+
+  for (int i = tid * 4; i < 2 * ABUF; i += THREADS * 4)
+    *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- staging descriptor: thread u < 4 * TR handles (tile-row u >> 2, channel quad u & 3) ----
+  const int q4s = tid & 3;
+  bool sval = false;
+  size_t sgofs = 0;       // global offset of pixel (h, 2t) of the tile-row, channel quad q4s
+  int slofs = 0;          // LDS offset of its slot, component 0
+  int sx0 = 0;
+  if (tid < 4 * TR) {
+    const int m = tid >> 2;
+    if (m < tr_valid) {
+      const int s = m / TRS, rem = m - s * TRS;
+      const int h = rem / NT, t = rem - h * NT;
+      sval = true;
+      sx0 = 2 * t;
+      sgofs = ((size_t)(n0 + s) * d.HW + h * d.W + 2 * t) * d.C + q4s * 4;
+      slofs = ((s * SLW + (h + 1) * NT + t) * 4) * ASTW + q4s * 4;
+    }
+  }
+  // ---- tile-row tables (one thread per tile-row does the two integer divisions; lanes read LDS) ----
+  int* stab = reinterpret_cast<int*>(Bbuf + 3 * BBUFW);   // [TR] A-image slot of tile-row m (row tap kh adds kh * NT)
+  int* ptab = stab + TR;                                   // [TR] pixel row of output pixel (h, 2t) in the tile, -1 if none
+  if (tid < TR) {
+    int slot = 0, pr = -1;
+    if (tid < d.S * TRS) {
+      const int s = tid / TRS, rem = tid - s * TRS;
+      const int h = rem / NT, t = rem - h * NT;
+      slot = s * SLW + h * NT + t;
+      pr = s * d.HW + h * d.W + 2 * t;
+    }
+    stab[tid] = slot;
+    ptab[tid] = pr;
+  }
+  const int boff = ((jc * BN) + wn * 32 + l31) * BSTW + 8 * hi;
+  int bwr[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int f = tid + b * THREADS;          // float4 index inside the packed tile [j][col][16]
+    bwr[b] = (f >> 2) * BSTW + (f & 3) * 4;   // (j * 64 + col) = f >> 2
+  }
+
+  const int nchunk = (d.C + KCW - 1) / KCW;
+  const int Q = nchunk * 3;
+  const float* wbase = a.wpacked + (size_t)nt * Q * (4 * BN * KCW);
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  float4 areg[4];
+  float4 breg[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) breg[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();  // zero fill + tables visible
+  int arow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = (stab[mt * 32 + l31] * 4 + jc) * ASTW + 8 * hi;
+
+  // load the four pixels 2t-1 .. 2t+2 of a tile-row (zero outside the row) for channels cbase + 4*q4s ..
+#define ALOAD(CBASE)                                                                       \
+  {                                                                                        \
+    const bool cv = sval && (CBASE) + q4s * 4 < d.C;                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                        \
+      const int x = sx0 - 1 + i;                                                           \
+      areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                           \
+      if (cv && x >= 0 && x < d.W)                                                         \
+        areg[i] = *reinterpret_cast<const float4*>(a.in + sgofs + (ptrdiff_t)(i - 1) * d.C + (CBASE)); \
+    }                                                                                      \
+  }
+  // input transform + write of the four components
+#define AWRITE(ABASE)                                                                      \
+  if (sval) {                                                                              \
+    const float4 d0 = areg[0], d1 = areg[1], d2 = areg[2], d3 = areg[3];                   \
+    float* dst = (ABASE) + slofs;                                                          \
+    *reinterpret_cast<float4*>(dst) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);             \
+    *reinterpret_cast<float4*>(dst + ASTW) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);      \
+    *reinterpret_cast<float4*>(dst + 2 * ASTW) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);  \
+    *reinterpret_cast<float4*>(dst + 3 * ASTW) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);  \
+  }
+
+  // ---- prologue: A chunk 0, B tiles of pieces 0 and 1 ----
+  {
+    float4 bpro[2][2];
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bpro[jq][b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jq < Q) bpro[jq][b] = *reinterpret_cast<const float4*>(wbase + (size_t)jq * (4 * BN * KCW) + (tid + b * THREADS) * 4);
+      }
+    ALOAD(0)
+    AWRITE(Abuf)
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) *reinterpret_cast<float4*>(Bbuf + jq * BBUFW + bwr[b]) = bpro[jq][b];
+  }
+  __syncthreads();
+  PSTAMP(a.stamps, 2, "s_memtime");
+
+  // bias + t * tmap of the pixel-tile elements this thread finalises: column tid & 63, rows tid >> 6 (+8k)
+  float tmv[BM / 8];
+  {
+    const int col = tid & 63;
+    const bool cok = fwd && col < ncols;
+    const float tval = fwd ? eval_time(a.et) : 0.f;
+    const float bias = cok ? a.bias[c0 + col] : 0.f;
+    int p = tid >> 6;
+    while (p >= d.HW) p -= d.HW;
+#pragma unroll
+    for (int i = 0; i < BM / 8; ++i) {
+      tmv[i] = cok ? bias + tval * a.tmap[(size_t)p * d.C + c0 + col] : 0.f;
+      p += 8;
+      while (p >= d.HW) p -= d.HW;
+    }
+  }
+
+  float4 pa0[MT], pa1[MT], pb0, pb1;
+#define LOADG(PA, PB, AB, BB, G)                                                          \
+  do {                                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        PA[mt] = *reinterpret_cast<const float4*>((AB) + arow[mt] + 4 * (G));             \
+    PB = *reinterpret_cast<const float4*>((BB) + boff + 4 * (G));                         \
+  } while (0)
+#define MFMA4(PA, PB)                                                                     \
+  do {                                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[mt].x, PB.x, acc[mt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[mt].y, PB.y, acc[mt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[mt].z, PB.z, acc[mt], 0, 0, 0); \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                      \
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[mt].w, PB.w, acc[mt], 0, 0, 0); \
+  } while (0)
+#define SB __builtin_amdgcn_sched_barrier(0)
+
+  const int khoff = NT * (4 * ASTW);   // one image row of slots
+  LOADG(pa0, pb0, Abuf, Bbuf, 0);
+  {  // B tile of piece 2: written at the end of piece 0
+    if (2 < Q) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) breg[b] = *reinterpret_cast<const float4*>(wbase + (size_t)2 * (4 * BN * KCW) + (tid + b * THREADS) * 4);
+    }
+  }
+  // One piece = (chunk, kh): same discipline as k_conv3x3's PIECE (write B tile q+2, request q+3,
+  // prefetch the first group of piece q+1, last MFMA group, counted wait, barrier).
+#define WPIECE(KH)                                                                                 \
+  {                                                                                                \
+    constexpr int KN = ((KH) + 1) % 3;                                                             \
+    if constexpr ((KH) == 0) {                                                                     \
+      if (more_chunks) ALOAD((chunk + 1) * KCW)                                                    \
+    }                                                                                              \
+    LOADG(pa1, pb1, Acur + (KH) * khoff, Bbuf + (KH) * BBUFW, 1); SB;                              \
+    MFMA4(pa0, pb0); SB;                                                                           \
+    if (qbase + (KH) + 2 < Q) {                                                                    \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                \
+        *reinterpret_cast<float4*>(Bbuf + (((KH) + 2) % 3) * BBUFW + bwr[b]) = breg[b];            \
+    }                                                                                              \
+    if constexpr ((KH) == 1) {                                                                     \
+      if (more_chunks) AWRITE(Anxt)                                                                \
+    }                                                                                              \
+    if (qbase + (KH) + 3 < Q) {                                                                    \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                \
+        breg[b] = *reinterpret_cast<const float4*>(wbase + (size_t)(qbase + (KH) + 3) * (4 * BN * KCW) + (tid + b * THREADS) * 4); \
+    }                                                                                              \
+    SB;                                                                                            \
+    LOADG(pa0, pb0, ((KH) == 2 ? Anxt : Acur) + KN * khoff, Bbuf + KN * BBUFW, 0); SB;             \
+    MFMA4(pa1, pb1); SB;                                                                           \
+    if constexpr (MT == 1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                      \
+    else if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                 \
+    else asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                                  \
+    SB;                                                                                            \
+  }
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const bool more_chunks = (chunk + 1) < nchunk;
+    const int qbase = chunk * 3;
+    float* Acur = Abuf + (chunk & 1) * ABUF;
+    float* Anxt = more_chunks ? Abuf + ((chunk + 1) & 1) * ABUF : Acur;
+    WPIECE(0) WPIECE(1) WPIECE(2)
+  }
+#undef WPIECE
+#undef SB
+#undef LOADG
+#undef MFMA4
+#undef ALOAD
+#undef AWRITE
+  PSTAMP(a.stamps, 3, "s_memtime");
+
+  // ---- output transform into the pixel tile: y0 = M0 + M1 + M2, y1 = M1 - M2 - M3 ----
+  // pass A: component 0 sets y0, component 3 sets y1 (disjoint); pass B: component 1 adds to both;
+  // pass C: component 2 adds to y0 and subtracts from y1.  Each lane's reads are batched ahead of
+  // its writes (its 16 x MT addresses are distinct, which the compiler cannot know).
+  int prw[MT][16];   // the table values live in registers across the passes
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) prw[mt][r] = ptab[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+  __syncthreads();   // every wave holds its table values: the tile may now overwrite the LDS
+  float* Ct = smem;  // [BM][CT2]
+  {
+    const int col = wn * 32 + l31;
+    if (jc == 0 || jc == 3) {
+      const int o = jc == 0 ? 0 : CT2;
+      const float sg = jc == 0 ? 1.f : -1.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (prw[mt][r] >= 0) Ct[prw[mt][r] * CT2 + col + o] = sg * acc[mt][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 1; pass <= 2; ++pass) {
+      if (jc == pass) {
+        const float s1 = pass == 1 ? 1.f : -1.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float o0[16], o1[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int pr = prw[mt][r] >= 0 ? prw[mt][r] : 0;
+            o0[r] = Ct[pr * CT2 + col];
+            o1[r] = Ct[pr * CT2 + col + CT2];
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (prw[mt][r] >= 0) {
+              Ct[prw[mt][r] * CT2 + col] = o0[r] + acc[mt][r];
+              Ct[prw[mt][r] * CT2 + col + CT2] = o1[r] + s1 * acc[mt][r];
+            }
+        }
+      }
+      __syncthreads();
+    }
+    if (fwd) {
+      const int colf = tid & 63;
+      float o[BM / 8];
+#pragma unroll
+      for (int i = 0; i < BM / 8; ++i) o[i] = Ct[((tid >> 6) + 8 * i) * CT2 + colf];
+#pragma unroll
+      for (int i = 0; i < BM / 8; ++i) Ct[((tid >> 6) + 8 * i) * CT2 + colf] = o[i] + tmv[i];
+      __syncthreads();
+    }
+  }
+  PSTAMP(a.stamps, 6, "s_memtime");
+  conv_epilogue_tail<THREADS, BM>(a, d, smem, n0, c0, nsamp, ncols, mtile);
+  PSTAMP(a.stamps, 4, "s_memtime");
+  PSTAMP(a.stamps, 5, "s_memrealtime");
+}
+
+static size_t conv_w_lds_bytes(const Dims& d) {
+  const size_t abuf = (size_t)d.S * (d.H + 2) * (d.W / 2) * (4 * ASTW);
+  const size_t main_loop = 2 * abuf + 3 * (size_t)BBUFW + 2 * (size_t)(d.BM / 2);   // + the two tile-row tables
+  const size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
+  return (main_loop > epi ? main_loop : epi) * sizeof(float);
+}
+
+static size_t conv_d_lds_bytes(const Dims& d) {
   const size_t arows = (size_t)d.S * d.SLOTS + 2 * d.MARGIN;
   const size_t main_loop = 2 * arows * AST2 + 3 * (size_t)BBUF2;
   const size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
+}
+size_t conv_lds_bytes(const Dims& d, int /*mode*/) { return d.wino ? conv_w_lds_bytes(d) : conv_d_lds_bytes(d); }
+
+// packed-weight elements of one conv layer (forward or dgrad operand)
+size_t conv_packed_elems(const Dims& d) {
+  return d.wino ? (size_t)d.ntile * ((d.C + KCW - 1) / KCW) * 3 * (4 * BN * KCW) : (size_t)d.ntile * d.nchunk * 9 * (KCH * BN);
+}
+
+// Winograd filter transform + packing: packed[nt][chunk16][kh][j][col 64][k 16]
+//   forward: g_kw = W[co = nt*BNE + col][1 + ci = chunk*16 + k][kh][kw];  dgrad: flipped and transposed
+__global__ __launch_bounds__(256) void k_pack_weights_w(const float* __restrict__ w, float* __restrict__ packed,
+                                                        int C, int BNE, int ntile, int nchunk, int dgrad) {
+  const size_t total = (size_t)ntile * nchunk * 3 * 4 * BN * KCW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int kk = idx % KCW;
+    size_t r = idx / KCW;
+    const int col = r % BN; r /= BN;
+    const int j = r % 4; r /= 4;
+    const int kh = r % 3; r /= 3;
+    const int ch = r % nchunk;
+    const int nt = r / nchunk;
+    const int kidx = ch * KCW + kk, nidx = nt * BNE + col;
+    float v = 0.f;
+    if (col < BNE && kidx < C && nidx < C) {
+      float g[3];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        g[kw] = dgrad ? w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                      : w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+      v = j == 0 ? g[0] : j == 1 ? 0.5f * (g[0] + g[1] + g[2]) : j == 2 ? 0.5f * (g[0] - g[1] + g[2]) : g[2];
+    }
+    packed[idx] = v;
+  }
+}
+void launch_pack_weights_w(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
+  const int nchunk = (d.C + KCW - 1) / KCW;
+  const size_t total = (size_t)d.ntile * nchunk * 3 * 4 * BN * KCW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_weights_w, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, nchunk, dgrad);
+}
+
+template <int MT>
+static void launch_conv_w_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_w<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_conv3x3_w<MT>), dim3(d.mtiles, d.ntile), dim3(512), conv_w_lds_bytes(d), s, a, d);
 }
 
 template <int WM, int MT>
@@ -565,6 +925,12 @@ static void launch_conv_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
 // d.BM (chosen by make_dims): 64 = four-wave workgroups, two of which share a CU and cover each other's
 // barriers / prologue / epilogue when the grid is small; 128 / 256 = eight waves.
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  if (d.wino) {   // 1-D Winograd along the rows (even W); weights packed by launch_pack_weights_w
+    if (d.BM == 64) launch_conv_w_t<1>(d, a, s);
+    else if (d.BM == 128) launch_conv_w_t<2>(d, a, s);
+    else launch_conv_w_t<4>(d, a, s);
+    return;
+  }
   if (d.BM == 64) launch_conv_t<2, 1>(d, a, s);
   else if (d.BM == 128) launch_conv_t<4, 1>(d, a, s);   // (four waves x (64 x 32) per wave measured slower: 94 vs 91 us at cfg 2)
   else launch_conv_t<4, 2>(d, a, s);

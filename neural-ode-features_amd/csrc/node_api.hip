@@ -121,6 +121,12 @@ static int make_dims(const node_shape* sh, Dims* out) {
     if (want64) d.BM = 64;
   }
   if (d.W > 64) return fail(NODE_ERR_UNSUPPORTED, "W = %d > 64", d.W);
+  {
+    static int wino_env = -2;
+    if (wino_env == -2) { const char* e = getenv("NODE_TUNE_CONV_WINO"); wino_env = e ? atoi(e) : -1; }
+    const int want = g_conv_wino >= 0 ? g_conv_wino : wino_env;
+    d.wino = (d.W % 2 == 0) && (want < 0 ? 1 : want);   // even widths: Winograd kernel; odd: direct kernel
+  }
   d.S = d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
   while (d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
@@ -204,7 +210,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   Bump b(base);
   p.ctrl = b.take<Ctrl>(1);
   for (int i = 0; i < 3; ++i) p.partial[i] = b.take<float>(ERR_BLOCKS * 2);
-  const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
+  const size_t wsz = conv_packed_elems(d);
   for (int i = 0; i < 2; ++i) p.wf[i] = b.take<float>(wsz);
   for (int i = 0; i < 2; ++i) p.tmap[i] = b.take<float>((size_t)d.HW * d.C);
   p.Y = b.take<float>(d.numel);
@@ -294,13 +300,14 @@ struct Solver {
   }
 
   int prepare() {
-    launch_pack_weights(d, prm.conv1_w, p.wf[0], 0, st);
-    launch_pack_weights(d, prm.conv2_w, p.wf[1], 0, st);
+    auto pack = d.wino ? launch_pack_weights_w : launch_pack_weights;
+    pack(d, prm.conv1_w, p.wf[0], 0, st);
+    pack(d, prm.conv2_w, p.wf[1], 0, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);
     launch_tmap(d, prm.conv2_w, p.tmap[1], st);
     if (aug) {
-      launch_pack_weights(d, prm.conv1_w, p.wd[0], 1, st);
-      launch_pack_weights(d, prm.conv2_w, p.wd[1], 1, st);
+      pack(d, prm.conv1_w, p.wd[0], 1, st);
+      pack(d, prm.conv2_w, p.wd[1], 1, st);
       launch_wtime(d, prm.conv1_w, p.wtime[0], st);
       launch_wtime(d, prm.conv2_w, p.wtime[1], st);
     }

@@ -104,7 +104,8 @@ int main(int argc, char** argv) {
     std::vector<Dims> dv;
     std::vector<std::vector<double>> times(variants.size());
     for (size_t v = 0; v < variants.size(); ++v) {
-      g_conv_bm = variants[v] & 0xfff;
+      g_conv_bm = (variants[v] & 0xfff) % 1000;
+      g_conv_wino = (variants[v] & 0xfff) >= 1000 ? 1 : 0;
       Dims dd;
       if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
       dv.push_back(dd);
@@ -112,10 +113,18 @@ int main(int argc, char** argv) {
       gp.push_back(dev_zero((size_t)dd.mtiles * 2 * C + 64));
     }
     g_conv_bm = -1;
+    g_conv_wino = -1;
+    std::vector<float*> wpks;
+    for (size_t v = 0; v < variants.size(); ++v) {
+      float* w = dev_zero(conv_packed_elems(dv[v]));
+      if (dv[v].wino) launch_pack_weights_w(dv[v], wraw, w, bwd ? 1 : 0, st);
+      else launch_pack_weights(dv[v], wraw, w, bwd ? 1 : 0, st);
+      wpks.push_back(w);
+    }
     auto run = [&](size_t v, unsigned long long* stp) {
       ConvArgs a;
       memset(&a, 0, sizeof(a));
-      a.in = in; a.wpacked = wpk; a.mode = bwd ? CM_BWD_RELU_GN : CM_FWD_GN_RELU;
+      a.in = in; a.wpacked = wpks[v]; a.mode = bwd ? CM_BWD_RELU_GN : CM_FWD_GN_RELU;
       a.bias = bias; a.tmap = tmap;
       a.et.ctrl = ctrl; a.et.alpha = 0.5f; a.et.tsign = 1.f; a.et.mode = TM_STAGE;
       a.gamma = gamma; a.beta = beta; a.osign = 1.f; a.out = outs[v];
@@ -123,9 +132,7 @@ int main(int argc, char** argv) {
       a.act = act; a.xhat = xhat; a.rstd = rstd; a.gpart = gp[v];
       a.stamps = stp;
       a.ablate = variants[v] >> 12;
-      g_conv_bm = variants[v] & 0xfff;
       launch_conv(dv[v], a, st);
-      g_conv_bm = -1;
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v, nullptr);
     CK(hipStreamSynchronize(st));
@@ -198,8 +205,8 @@ int main(int argc, char** argv) {
         double gm;
         gdiff = max_abs_diff(red(v), red(0), &gm);
       }
-      printf("tile %4d (BM=%d, %d workgroups)  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-first| %.3e (ref max %.3e)  gpart diff %.3e\n",
-             variants[v] & 0xfff, dv[v].BM, dv[v].mtiles * dv[v].ntile, med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
+      printf("tile %4d (BM=%d%s, %d workgroups)  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-first| %.3e (ref max %.3e)  gpart diff %.3e\n",
+             variants[v] & 0xfff, dv[v].BM, dv[v].wino ? " winograd" : "", dv[v].mtiles * dv[v].ntile, med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
 #ifdef NODE_STAMPS
       CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
       run(v, stamps);
