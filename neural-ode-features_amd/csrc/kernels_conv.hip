@@ -70,7 +70,7 @@ __device__ inline int slot_of_p(int p, int W, int Wp) {
       __builtin_amdgcn_sched_barrier(0);                                                         \
       asm volatile(INS " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                       \
       __builtin_amdgcn_sched_barrier(0);                                                         \
-      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = _t; \
     }                                                                                            \
   } while (0)
 #define ABL(bit) (a.ablate & (bit))   /* timing-only ablations: 1 no B stream, 2 no barrier, 4 no operand reads, 8 no A stream */
@@ -621,16 +621,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   // ---- tile-row tables (one thread per tile-row does the two integer divisions; lanes read LDS) ----
   int* stab = reinterpret_cast<int*>(Bbuf + 3 * BBUFW);   // [TR] A-image slot of tile-row m (row tap kh adds kh * NT)
   int* ptab = stab + TR;                                   // [TR] pixel row of output pixel (h, 2t) in the tile, -1 if none
+  int* qtab = ptab + TR;                                   // [TR] the same pixel's index inside its sample
   if (tid < TR) {
-    int slot = 0, pr = -1;
+    int slot = 0, pr = -1, q = 0;
     if (tid < d.S * TRS) {
       const int s = tid / TRS, rem = tid - s * TRS;
       const int h = rem / NT, t = rem - h * NT;
       slot = s * SLW + h * NT + t;
-      pr = s * d.HW + h * d.W + 2 * t;
+      q = h * d.W + 2 * t;
+      pr = s * d.HW + q;
     }
     stab[tid] = slot;
     ptab[tid] = pr;
+    qtab[tid] = q;
   }
   const int boff = ((jc * BN) + wn * 32 + l31) * BSTW + 8 * hi;
   int bwr[2];
@@ -701,20 +704,35 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   __syncthreads();
   PSTAMP(a.stamps, 2, "s_memtime");
 
-  // bias + t * tmap of the pixel-tile elements this thread finalises: column tid & 63, rows tid >> 6 (+8k)
+  // bias + t * tmap of the pixel-tile elements this thread finalises in the output transform, requested
+  // now so their latency hides behind the main loop.  MT <= 2: column tid & 63, tile-rows (tid >> 6) + 8i,
+  // both pixels of the pair; MT == 4: column tid & 63, pixel rows (tid >> 6) + 8i.
   float tmv[BM / 8];
+  int ptr_[MT <= 2 ? TR / 8 : 1];   // pixel rows of this thread's tile-rows (single-pass transform)
   {
     const int col = tid & 63;
     const bool cok = fwd && col < ncols;
     const float tval = fwd ? eval_time(a.et) : 0.f;
     const float bias = cok ? a.bias[c0 + col] : 0.f;
-    int p = tid >> 6;
-    while (p >= d.HW) p -= d.HW;
+    if constexpr (MT <= 2) {
 #pragma unroll
-    for (int i = 0; i < BM / 8; ++i) {
-      tmv[i] = cok ? bias + tval * a.tmap[(size_t)p * d.C + c0 + col] : 0.f;
-      p += 8;
+      for (int i = 0; i < TR / 8; ++i) {
+        const int m = (tid >> 6) + 8 * i;
+        ptr_[i] = ptab[m];
+        const int q = qtab[m];
+        tmv[2 * i] = cok ? bias + tval * a.tmap[(size_t)q * d.C + c0 + col] : 0.f;
+        tmv[2 * i + 1] = cok ? bias + tval * a.tmap[(size_t)(q + 1) * d.C + c0 + col] : 0.f;
+      }
+    } else {
+      ptr_[0] = 0;
+      int p = tid >> 6;
       while (p >= d.HW) p -= d.HW;
+#pragma unroll
+      for (int i = 0; i < BM / 8; ++i) {
+        tmv[i] = cok ? bias + tval * a.tmap[(size_t)p * d.C + c0 + col] : 0.f;
+        p += 8;
+        while (p >= d.HW) p -= d.HW;
+      }
     }
   }
 
@@ -793,17 +811,45 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   PSTAMP(a.stamps, 3, "s_memtime");
 
   // ---- output transform into the pixel tile: y0 = M0 + M1 + M2, y1 = M1 - M2 - M3 ----
-  // pass A: component 0 sets y0, component 3 sets y1 (disjoint); pass B: component 1 adds to both;
-  // pass C: component 2 adds to y0 and subtracts from y1.  Each lane's reads are batched ahead of
-  // its writes (its 16 x MT addresses are distinct, which the compiler cannot know).
-  int prw[MT][16];   // the table values live in registers across the passes
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) prw[mt][r] = ptab[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
-  __syncthreads();   // every wave holds its table values: the tile may now overwrite the LDS
   float* Ct = smem;  // [BM][CT2]
-  {
+  if constexpr (MT <= 2) {
+    // single pass: the four component tiles go to LDS side by side (behind the region the tail uses),
+    // then every thread folds the pairs of its (column, tile-rows) and adds bias + t * tmap
+    float* Mt = smem + 2 * BM * CT2 + 2 * d.S * BN + 32 * 64 * 2;   // [4][TR][CT2]
+    {
+      const int col = wn * 32 + l31;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Mt[(jc * TR + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CT2 + col] = acc[mt][r];
+    }
+    __syncthreads();
+    PSTAMP(a.stamps, 8, "s_memtime");
+    {
+      const int col = tid & 63;
+#pragma unroll
+      for (int i = 0; i < TR / 8; ++i) {
+        const int m = (tid >> 6) + 8 * i;
+        const float m0 = Mt[m * CT2 + col], m1 = Mt[(TR + m) * CT2 + col];
+        const float m2 = Mt[(2 * TR + m) * CT2 + col], m3 = Mt[(3 * TR + m) * CT2 + col];
+        if (ptr_[i] >= 0) {
+          Ct[ptr_[i] * CT2 + col] = ((m0 + m1) + m2) + tmv[2 * i];
+          Ct[(ptr_[i] + 1) * CT2 + col] = ((m1 - m2) - m3) + tmv[2 * i + 1];
+        }
+      }
+    }
+    __syncthreads();
+  } else {
+    // LDS cannot hold four 128-row component tiles next to the 256-row pixel tile: three passes of
+    // read-modify-write (component 0 sets y0 and component 3 sets y1; component 1 adds to both; component 2
+    // adds to y0 and subtracts from y1), each lane's reads batched ahead of its writes
+    int prw[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prw[mt][r] = ptab[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+    __syncthreads();   // every wave holds its table values: the tile may now overwrite the LDS
     const int col = wn * 32 + l31;
     if (jc == 0 || jc == 3) {
       const int o = jc == 0 ? 0 : CT2;
@@ -856,8 +902,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
 
 static size_t conv_w_lds_bytes(const Dims& d) {
   const size_t abuf = (size_t)d.S * (d.H + 2) * (d.W / 2) * (4 * ASTW);
-  const size_t main_loop = 2 * abuf + 3 * (size_t)BBUFW + 2 * (size_t)(d.BM / 2);   // + the two tile-row tables
-  const size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
+  const size_t main_loop = 2 * abuf + 3 * (size_t)BBUFW + 3 * (size_t)(d.BM / 2);   // + the three tile-row tables
+  size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
+  if (d.BM <= 128) epi += 4 * (size_t)(d.BM / 2) * CT2;                               // + the four component tiles
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
 }
 

@@ -41,7 +41,7 @@ int g_wgrad_variant = -1;
       __builtin_amdgcn_sched_barrier(0);                                                         \
       asm volatile(INS " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                       \
       __builtin_amdgcn_sched_barrier(0);                                                         \
-      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+      (buf)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (slot)] = _t; \
     }                                                                                            \
   } while (0)
 #else
