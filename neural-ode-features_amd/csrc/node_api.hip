@@ -144,6 +144,17 @@ static int make_dims(const node_shape* sh, Dims* out) {
   d.RB = 64 / d.W;
   if (d.RB < 1) d.RB = 1;
   if (d.RB > d.H) d.RB = d.H;
+  {
+    // weight gradient in the Winograd domain where an instance of k_wgrad_w exists (W % 4 == 0)
+    static int ww_env = -2;
+    if (ww_env == -2) { const char* e = getenv("NODE_TUNE_WGRAD_WINO"); ww_env = e ? atoi(e) : -1; }
+    const int want = g_wgrad_wino >= 0 ? g_wgrad_wino : (ww_env >= 0 ? ww_env : 1);
+    d.wgrad_wino = 0;
+    if (want && ((d.W == 8 && d.H % 8 == 0) || (d.W == 16 && d.H % 2 == 0) || (d.W == 4 && d.H % 4 == 0))) {
+      d.wgrad_wino = 1;
+      d.RB = d.W == 8 ? 8 : d.W == 16 ? 2 : 4;
+    }
+  }
   d.nbands = (d.H + d.RB - 1) / d.RB;
   if ((d.RB + 2) * d.W * 16 > 6 * WG_THREADS || d.RB * d.W * 16 > 4 * WG_THREADS)
     return fail(NODE_ERR_UNSUPPORTED, "W = %d: wgrad staging does not fit its registers", d.W);
@@ -238,7 +249,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.dz2 = b.take<float>(d.numel);
     p.G = b.take<float>(d.numel);
     for (int i = 0; i < 2; ++i) {
-      p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
+      p.wpart[i] = b.take<float>((size_t)d.nsplit * (d.wgrad_wino ? 12 : 9) * d.C * d.C);
       p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
     }
     p.sred = b.take<float>((size_t)2 * 9 * d.C);

@@ -25,6 +25,7 @@ struct Dims {
   int BM;              // rows per M tile: 128 or 256
   int S;               // whole samples per M tile
   int wino;            // conv through the 1-D Winograd F(2,3) kernel (even W)
+  int wgrad_wino;      // weight gradient in the same Winograd domain: slabs hold 12 taps [kh][j]
   int mtiles;          // ceil(N / S)
   // pointwise slab (combine+GN kernels)
   int cs;              // channels per slab (multiple of lcm(cpg,4))
@@ -219,6 +220,7 @@ void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s);
 // tuning (tools/kbench.hip): kernel variant override (<0: production choice)
 extern int g_wgrad_variant;
 extern int g_conv_bm;      // force the conv M tile (64 / 128) where the geometry allows; <= 0: heuristic
+extern int g_wgrad_wino;   // 0 / 1: force the direct / Winograd wgrad kernel; < 0: heuristic
 extern int g_conv_wino;    // 0 / 1: force the direct / Winograd conv kernel; < 0: heuristic
 size_t conv_lds_bytes(const Dims& d, int mode);
 size_t conv_packed_elems(const Dims& d);

@@ -231,19 +231,26 @@ int main(int argc, char** argv) {
 #endif
     }
   } else if (what == "wgrad") {
-    // variant 0: generic kernel (k_wgrad_p); 1: geometry-templated kernel where an instance exists
+    // variant 0: generic kernel (k_wgrad_p); 1: geometry-templated kernel; 2: Winograd-domain kernel (k_wgrad_w)
     std::vector<float*> wp;
+    std::vector<Dims> dv;
     std::vector<std::vector<double>> times(variants.size());
     float* dz = dev_rand(numel, gen);
-    const size_t wpn = (size_t)d.nsplit * 9 * C * C;
-    for (size_t v = 0; v < variants.size(); ++v) wp.push_back(dev_zero(wpn));
+    for (size_t v = 0; v < variants.size(); ++v) {
+      g_wgrad_wino = variants[v] == 2 ? 1 : 0;
+      Dims dd;
+      if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
+      dv.push_back(dd);
+      wp.push_back(dev_zero((size_t)dd.nsplit * (dd.wgrad_wino ? 12 : 9) * C * C));
+    }
+    g_wgrad_wino = -1;
     auto run = [&](size_t v, unsigned long long* stp = nullptr) {
       WgradArgs a;
       memset(&a, 0, sizeof(a));
       a.act = act; a.dz = dz; a.wpart = wp[v];
-      g_wgrad_variant = variants[v];
+      g_wgrad_variant = variants[v] == 0 ? 0 : 1;
       a.stamps = stp;
-      launch_wgrad(d, a, st);
+      launch_wgrad(dv[v], a, st);
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v);
     CK(hipStreamSynchronize(st));
@@ -258,15 +265,28 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         times[v].push_back(ms * 1e3);
       }
-    auto reduce = [&](float* p, size_t per, int nsl) {
-      auto h = to_host(p, (size_t)nsl * per);
+    // slab-reduced dW[tap][ci][co] of a variant (Winograd slabs are transformed back on the host)
+    auto reduced = [&](size_t v) {
+      const int ntap = dv[v].wgrad_wino ? 12 : 9;
+      const size_t per = (size_t)ntap * C * C;
+      auto h = to_host(wp[v], (size_t)dv[v].nsplit * per);
       std::vector<float> r(per, 0.f);
-      for (int s = 0; s < nsl; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
-      return r;
+      for (int s = 0; s < dv[v].nsplit; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
+      if (!dv[v].wgrad_wino) return r;
+      std::vector<float> w((size_t)9 * C * C);
+      const size_t CC = (size_t)C * C;
+      for (int kh = 0; kh < 3; ++kh)
+        for (size_t i = 0; i < CC; ++i) {
+          const float u0 = r[(kh * 4 + 0) * CC + i], u1 = r[(kh * 4 + 1) * CC + i], u2 = r[(kh * 4 + 2) * CC + i], u3 = r[(kh * 4 + 3) * CC + i];
+          w[(kh * 3 + 0) * CC + i] = u0 + 0.5f * (u1 + u2);
+          w[(kh * 3 + 1) * CC + i] = 0.5f * (u1 - u2);
+          w[(kh * 3 + 2) * CC + i] = u3 + 0.5f * (u1 + u2);
+        }
+      return w;
     };
     // host reference of dW on a sample of entries (double precision)
     auto hact = to_host(act, numel), hdz = to_host(dz, numel);
-    auto refw_v0 = reduce(wp[0], 9 * C * C, d.nsplit);
+    auto refw_v0 = reduced(0);
     double ref_err = 0, ref_max = 0;
     for (int k = 0; k < 64; ++k) {
       const int t = k % 9, ci = (k * 37) % d.C, co = (k * 101 + 3) % d.C;
@@ -286,9 +306,9 @@ int main(int argc, char** argv) {
       std::sort(times[v].begin(), times[v].end());
       const double med = times[v][times[v].size() / 2], mn = times[v][0];
       double rmax;
-      const double diff = max_abs_diff(reduce(wp[v], 9 * C * C, d.nsplit), refw_v0, &rmax);
-      printf("variant %2d  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-first| %.3e (ref max %.3e)\n",
-             variants[v], med, mn, flops / (med * 1e-6) / 1e12, diff, rmax);
+      const double diff = max_abs_diff(reduced(v), refw_v0, &rmax);
+      printf("variant %2d%s  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-first| %.3e (ref max %.3e)\n",
+             variants[v], dv[v].wgrad_wino ? " winograd" : "", med, mn, flops / (med * 1e-6) / 1e12, diff, rmax);
 #ifdef NODE_STAMPS
       CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
       run(v, stamps);
@@ -317,6 +337,12 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
+    auto reduce = [&](float* p, size_t per, int nsl) {
+      auto h = to_host(p, (size_t)nsl * per);
+      std::vector<float> r(per, 0.f);
+      for (int s = 0; s < nsl; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
+      return r;
+    };
     auto hs_ = reduce(sp, 9 * C, d.N);
     double serr = 0, smax = 0;
     for (int t = 0; t < 9; ++t)
