@@ -567,6 +567,8 @@ __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
 // ============================================================================
 constexpr int KCW = 16;            // channels per K chunk
 constexpr int ASTW = 20;           // floats per (slot, component) row of the A image: 16 channels + 16-B pad
+constexpr int SSTW = 4 * ASTW + 4; // floats per slot: 21 16-B units, odd, so the ds_read_b128 of 16 consecutive tile-rows
+                                   // (= 16 consecutive slots) hit 16 different bank quads -- 80 floats gave a 4-way conflict
 constexpr int BSTW = 20;           // floats per (component, column) row of a B tile
 constexpr int BBUFW = 4 * BN * BSTW;
 
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   const bool fwd = a.mode != CM_BWD_RELU_GN;
   const int ncols = min(d.BNE, d.C - c0);
 
-  const int ABUF = d.S * SLW * (4 * ASTW);
+  const int ABUF = d.S * SLW * SSTW;
   float* Abuf = smem;             // 2 x ABUF
   float* Bbuf = smem + 2 * ABUF;  // 3 x BBUFW
 
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
       sval = true;
       sx0 = 2 * t;
       sgofs = ((size_t)(n0 + s) * d.HW + h * d.W + 2 * t) * d.C + q4s * 4;
-      slofs = ((s * SLW + (h + 1) * NT + t) * 4) * ASTW + q4s * 4;
+      slofs = (s * SLW + (h + 1) * NT + t) * SSTW + q4s * 4;
     }
   }
   // ---- tile-row tables (one thread per tile-row does the two integer divisions; lanes read LDS) ----
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   __syncthreads();  // zero fill + tables visible
   int arow[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) arow[mt] = (stab[mt * 32 + l31] * 4 + jc) * ASTW + 8 * hi;
+  for (int mt = 0; mt < MT; ++mt) arow[mt] = stab[mt * 32 + l31] * SSTW + jc * ASTW + 8 * hi;
 
   // load the four pixels 2t-1 .. 2t+2 of a tile-row (zero outside the row) for channels cbase + 4*q4s ..
 #define ALOAD(CBASE)                                                                       \
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
   } while (0)
 #define SB __builtin_amdgcn_sched_barrier(0)
 
-  const int khoff = NT * (4 * ASTW);   // one image row of slots
+  const int khoff = NT * SSTW;   // one image row of slots
   LOADG(pa0, pb0, Abuf, Bbuf, 0);
   {  // B tile of piece 2: written at the end of piece 0
     if (2 < Q) {
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
 }
 
 static size_t conv_w_lds_bytes(const Dims& d) {
-  const size_t abuf = (size_t)d.S * (d.H + 2) * (d.W / 2) * (4 * ASTW);
+  const size_t abuf = (size_t)d.S * (d.H + 2) * (d.W / 2) * SSTW;
   const size_t main_loop = 2 * abuf + 3 * (size_t)BBUFW + 3 * (size_t)(d.BM / 2);   // + the three tile-row tables
   size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
   if (d.BM <= 128) epi += 4 * (size_t)(d.BM / 2) * CT2;                               // + the four component tiles
