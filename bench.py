@@ -37,13 +37,13 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None for other shapes."""
-    path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_eval_cfg2.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_f_pmc_eval_cfg2.json')
     if not (args.batch == 128 and args.filters == 256 and os.path.exists(path)):
         return None
     try:
         with open(path) as fh:
             pmc = json.load(fh)
-        k = next(v for n, v in pmc.items() if 'k_conv3x3_p' in n)
+        k = next(v for n, v in pmc.items() if 'k_conv3x3' in n)
         return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
     except Exception:
         return None
@@ -189,11 +189,14 @@ def main():
             avg_ms = k['total_ms'] / k['launches']
             flops_per_launch = k['flops'] / k['launches']
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'k_conv3x3_p (fp32 MFMA implicit GEMM, fwd+dgrad)',
+            # `achieved` counts ALGORITHMIC FLOPs (direct 3x3 conv: 2*9*C^2*N*H*W); the kernel
+            # reaches them through a 1-D Winograd F(2,3) transform that issues 2/3 of those as MFMA work,
+            # so the fraction is against the fp32-MFMA peak priced in algorithmic FLOPs.
+            roofline = {'bound': 'mfma', 'kernel': 'k_conv3x3_w (fp32 MFMA implicit GEMM, 1-D Winograd F(2,3), fwd+dgrad)',
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args),
                         'avg_launch_us': avg_ms * 1e3, 'launches': k['launches'],
-                        'flops_per_launch': flops_per_launch}
+                        'flops_per_launch': flops_per_launch, 'mfma_flops_per_launch': flops_per_launch * 2.0 / 3.0}
             w = prof['wgrad_gemm']
             if w['launches'] > 0:
                 wavg = w['total_ms'] / w['launches']

@@ -1,4 +1,5 @@
-"""Adjoint solve: HIP (conv variant v) vs the CPU oracle, several seeds (debug aid for ReLU-boundary sensitivity)."""
+"""Adjoint solve: HIP, with the Winograd (1) and the direct (0) conv kernel, vs the CPU oracle over several seeds.
+Debug aid for the ReLU-kink sensitivity of solve-level gradients described in DESIGN.md section 2."""
 import ctypes, sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ from oracle import torchdiffeq_restated as tdq
 from tests.helpers import make_func, rel_err
 
 lib = _lib.load()
-gv = ctypes.c_int.in_dll(lib, '_ZN4node14g_conv_variantE')
+gv = ctypes.c_int.in_dll(lib, '_ZN4node11g_conv_winoE')
 N, C, H, W = 2, 256, 8, 8
 tol = 1e-3
 for seed in (21, 31, 41, 51, 61, 71):
