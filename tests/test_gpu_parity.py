@@ -13,15 +13,24 @@ SHAPES = [  # (N, C, H, W)
     (5, 64, 7, 7),      # MNIST config state (49 px: 2 samples per 128-row tile, ragged last tile)
     (4, 96, 4, 4),      # 3 ch / group: N tile of 63 columns
     (3, 256, 8, 8),     # CIFAR width
-    (2, 32, 16, 16),    # 256-row tiles (one sample per tile)
+    (2, 32, 16, 16),    # 256-row tiles (one sample per tile); Winograd conv MT=4, Winograd wgrad <16, 2>
+    (2, 32, 6, 6),      # even width, odd number of column pairs: Winograd conv, direct wgrad
+    (3, 64, 4, 4),      # Winograd wgrad <4, 4>, four samples per 64-pixel tile (ragged: 3)
+    (2, 32, 12, 12),    # HW = 144: 256-pixel tile with one sample; wgrad falls back to the generic kernel
+    (2, 16, 10, 14),    # non-square, even width 14 (7 column pairs)
+    (130, 64, 8, 8),    # 130 tiles of 64 pixels, Winograd wgrad <8, 8>, split-K over 65 units per slab
 ]
+# Shapes with >= 10^5 elements use the kink-free parameter set (tests/helpers.py:make_func): with ordinary
+# parameters one pre-activation of this very input lands within fp32 rounding of a ReLU kink and the oracle and
+# the GPU disagree on ONE element of vjp_y by 5 % (measured; 0 elements with kink-free parameters).
+KINK_FREE = {(130, 64, 8, 8)}
 
 
 @pytest.mark.parametrize('shape', SHAPES)
 def test_odefunc_forward_matches_oracle(shape):
     import neural_ode_features_amd as nof
     N, C, H, W = shape
-    f, twin = make_func(C, seed=C + H, device='cuda')
+    f, twin = make_func(C, seed=C + H, device='cuda', kink_free=shape in KINK_FREE)
     gen = torch.Generator().manual_seed(1)
     y = torch.randn(N, C, H, W, generator=gen)
     t = 0.37
@@ -38,7 +47,7 @@ def test_odefunc_vjp_matches_oracle(shape):
     import neural_ode_features_amd as nof
     from oracle.dynamics import odefunc_vjp as oracle_vjp
     N, C, H, W = shape
-    f, twin = make_func(C, seed=C + H, device='cuda')
+    f, twin = make_func(C, seed=C + H, device='cuda', kink_free=shape in KINK_FREE)
     gen = torch.Generator().manual_seed(2)
     y = torch.randn(N, C, H, W, generator=gen)
     cot = torch.randn(N, C, H, W, generator=gen)
