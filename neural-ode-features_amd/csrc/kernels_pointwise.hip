@@ -657,46 +657,6 @@ __global__ __launch_bounds__(256) void k_theta_wsum(ThetaFinalizeArgs a, Dims d)
   }
 }
 
-// The same for Winograd-domain slabs [nsplit][kh][j][ci][co] (k_wgrad_w): sum the slabs, then
-//   dW[kh][0] = dU0 + (dU1 + dU2)/2,  dW[kh][1] = (dU1 - dU2)/2,  dW[kh][2] = dU3 + (dU1 + dU2)/2.
-__global__ __launch_bounds__(256) void k_theta_wsum_w(ThetaFinalizeArgs a, Dims d) {
-  const ThetaLayout L = theta_layout(d.C);
-  const size_t CC = (size_t)d.C * d.C;
-  const size_t c4 = CC / 4;          // float4 per [ci][co] plane
-  const size_t n4 = 12 * c4;         // float4 per slab
-  const int layer = blockIdx.y;
-  const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
-  float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < 3 * c4; i += stride) {
-    const size_t kh = i / c4, r = i - kh * c4;
-    float4 u[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4* src = wp + (kh * 4 + j) * c4 + r;
-      int sp = 0;
-      for (; sp + 2 <= d.nsplit; sp += 2) {
-        const float4 v0 = src[(size_t)sp * n4], v1 = src[(size_t)(sp + 1) * n4];
-        acc.x += v0.x + v1.x; acc.y += v0.y + v1.y; acc.z += v0.z + v1.z; acc.w += v0.w + v1.w;
-      }
-      for (; sp < d.nsplit; ++sp) {
-        const float4 v = src[(size_t)sp * n4];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-      }
-      u[j] = acc;
-    }
-    auto comb = [&](float u0, float u1, float u2, float u3, int kw) {
-      const float hs = 0.5f * (u1 + u2);
-      return a.osign * (kw == 0 ? u0 + hs : kw == 1 ? 0.5f * (u1 - u2) : u3 + hs);
-    };
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-      out[(kh * 3 + kw) * c4 + r] = make_float4(comb(u[0].x, u[1].x, u[2].x, u[3].x, kw), comb(u[0].y, u[1].y, u[2].y, u[3].y, kw),
-                                                comb(u[0].z, u[1].z, u[2].z, u[3].z, kw), comb(u[0].w, u[1].w, u[2].w, u[3].w, kw));
-  }
-}
-
 // The small pieces (26 C values): GroupNorm affine gradients, time-channel taps, conv biases -- column
 // sums of short matrices ([rows][2C] per-tile GroupNorm partials, [N][9C] per-sample masked dz sums).
 // blockIdx.y = job (0..2: GroupNorm layer; 3, 4: conv layer), blockIdx.x = 64-column chunk; the 256
@@ -758,8 +718,7 @@ __global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s) {
   size_t wblocks = (9 * (size_t)d.C * d.C / 4 + 255) / 256;
   if (wblocks > 1024) wblocks = 1024;
-  if (d.wgrad_wino) hipLaunchKernelGGL(k_theta_wsum_w, dim3((unsigned)(wblocks > 768 ? 768 : wblocks), 2), dim3(256), 0, s, a, d);
-  else hipLaunchKernelGGL(k_theta_wsum, dim3((unsigned)wblocks, 2), dim3(256), 0, s, a, d);
+  hipLaunchKernelGGL(k_theta_wsum, dim3((unsigned)wblocks, 2), dim3(256), 0, s, a, d);
   hipLaunchKernelGGL(k_theta_small, dim3((unsigned)((9 * d.C + 63) / 64), 5), dim3(256), 0, s, a, d);
   hipLaunchKernelGGL(k_vjp_t, dim3(1), dim3(256), 0, s, a, d);
 }

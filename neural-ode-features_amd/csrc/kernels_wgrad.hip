@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_t(WgradArgs a, Dims d) {
 //   dU_j[kh][ci][co] = sum_{n,h,t} V_j[n, h + kh - 1, t, ci] * Z_j[n, h, t, co]        j = 0..3, kh = 0..2
 //   V = input transform of the activations (as in the forward kernel), Z = transposed output transform
 //   of dz:  Z0 = dy0, Z1 = dy0 + dy1, Z2 = dy0 - dy1, Z3 = -dy1   (dy0, dy1 = the pixel pair of tile t)
-//   and afterwards (k_theta_wsum)  dW[kh][0] = dU0 + (dU1+dU2)/2, dW[kh][1] = (dU1-dU2)/2, dW[kh][2] = dU3 + (dU1+dU2)/2.
+//   and, before the slab is stored,  dW[kh][0] = dU0 + (dU1+dU2)/2, dW[kh][1] = (dU1-dU2)/2, dW[kh][2] = dU3 + (dU1+dU2)/2.
 // K = tile-rows (half the pixels), 12 "taps" instead of 9: 1.5 x fewer MFMAs.  Same structure as
 // k_wgrad_t: 4 waves x 32x32 x 12 accumulators (192 AGPRs), immediate-offset inner loop, operands one
 // step ahead in consumption order, double-buffered units; both transforms happen at staging time.
@@ -358,7 +358,20 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w(WgradArgs a, Dims d) {
     buf ^= 1;
   }
   WSTAMP(a.stamps, 3, "s_memtime");
-  wg_store_slab<12>(a, d, g, acc);
+  // back to the nine filter taps before the slab leaves the registers (G^T applied per row tap kh):
+  //   dW[kh][0] = dU0 + (dU1 + dU2)/2,  dW[kh][1] = (dU1 - dU2)/2,  dW[kh][2] = dU3 + (dU1 + dU2)/2
+  f32x16 wacc[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float u0 = acc[kh * 4 + 0][r], u1 = acc[kh * 4 + 1][r], u2 = acc[kh * 4 + 2][r], u3 = acc[kh * 4 + 3][r];
+      const float hs = 0.5f * (u1 + u2);
+      wacc[kh * 3 + 0][r] = u0 + hs;
+      wacc[kh * 3 + 1][r] = 0.5f * (u1 - u2);
+      wacc[kh * 3 + 2][r] = u3 + hs;
+    }
+  wg_store_slab<9>(a, d, g, wacc);
   WSTAMP(a.stamps, 4, "s_memtime");
   WSTAMP(a.stamps, 5, "s_memrealtime");
 }
@@ -650,7 +663,7 @@ void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
   const int ntc = (d.C + 63) / 64;
   const dim3 grid(ntc * ntc, d.nsplit);
   const size_t lds = wgrad_lds_bytes(d);
-  if (d.wgrad_wino) {   // slabs hold 12 Winograd taps; k_theta_wsum transforms them back (make_dims sets RB)
+  if (d.wgrad_wino) {   // Winograd-domain accumulation, ordinary nine-tap slabs (make_dims sets RB)
     if (d.W == 8 && d.RB == 8) { launch_wgrad_w<8, 8>(d, a, grid, s); return; }
     if (d.W == 16 && d.RB == 2) { launch_wgrad_w<16, 2>(d, a, grid, s); return; }
     if (d.W == 4 && d.RB == 4) { launch_wgrad_w<4, 4>(d, a, grid, s); return; }

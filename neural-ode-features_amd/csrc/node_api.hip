@@ -249,7 +249,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.dz2 = b.take<float>(d.numel);
     p.G = b.take<float>(d.numel);
     for (int i = 0; i < 2; ++i) {
-      p.wpart[i] = b.take<float>((size_t)d.nsplit * (d.wgrad_wino ? 12 : 9) * d.C * d.C);
+      p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
       p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
     }
     p.sred = b.take<float>((size_t)2 * 9 * d.C);

@@ -25,7 +25,7 @@ struct Dims {
   int BM;              // rows per M tile: 128 or 256
   int S;               // whole samples per M tile
   int wino;            // conv through the 1-D Winograd F(2,3) kernel (even W)
-  int wgrad_wino;      // weight gradient in the same Winograd domain: slabs hold 12 taps [kh][j]
+  int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
   int mtiles;          // ceil(N / S)
   // pointwise slab (combine+GN kernels)
   int cs;              // channels per slab (multiple of lcm(cpg,4))

@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
       Dims dd;
       if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
       dv.push_back(dd);
-      wp.push_back(dev_zero((size_t)dd.nsplit * (dd.wgrad_wino ? 12 : 9) * C * C));
+      wp.push_back(dev_zero((size_t)dd.nsplit * 9 * C * C));
     }
     g_wgrad_wino = -1;
     auto run = [&](size_t v, unsigned long long* stp = nullptr) {
@@ -267,22 +267,12 @@ int main(int argc, char** argv) {
       }
     // slab-reduced dW[tap][ci][co] of a variant (Winograd slabs are transformed back on the host)
     auto reduced = [&](size_t v) {
-      const int ntap = dv[v].wgrad_wino ? 12 : 9;
+      const int ntap = 9;
       const size_t per = (size_t)ntap * C * C;
       auto h = to_host(wp[v], (size_t)dv[v].nsplit * per);
       std::vector<float> r(per, 0.f);
       for (int s = 0; s < dv[v].nsplit; ++s) for (size_t i = 0; i < per; ++i) r[i] += h[(size_t)s * per + i];
-      if (!dv[v].wgrad_wino) return r;
-      std::vector<float> w((size_t)9 * C * C);
-      const size_t CC = (size_t)C * C;
-      for (int kh = 0; kh < 3; ++kh)
-        for (size_t i = 0; i < CC; ++i) {
-          const float u0 = r[(kh * 4 + 0) * CC + i], u1 = r[(kh * 4 + 1) * CC + i], u2 = r[(kh * 4 + 2) * CC + i], u3 = r[(kh * 4 + 3) * CC + i];
-          w[(kh * 3 + 0) * CC + i] = u0 + 0.5f * (u1 + u2);
-          w[(kh * 3 + 1) * CC + i] = 0.5f * (u1 - u2);
-          w[(kh * 3 + 2) * CC + i] = u3 + 0.5f * (u1 + u2);
-        }
-      return w;
+      return r;
     };
     // host reference of dW on a sample of entries (double precision)
     auto hact = to_host(act, numel), hdz = to_host(dz, numel);
