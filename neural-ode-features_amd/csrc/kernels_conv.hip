@@ -910,16 +910,367 @@ static size_t conv_w_lds_bytes(const Dims& d) {
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
 }
 
+// ============================================================================
+// k_conv3x3_w2 -- 2-D Winograd F(2x2, 3x3): each 2x2 output tile comes from a 4x4 input patch through
+// sixteen component products instead of 36 multiplies per channel pair (2.25 x fewer MFMAs than the
+// direct kernel, 1.5 x fewer than k_conv3x3_w):
+//     V = B^T d B  (4x4, at staging time)    U = G g G^T  (4x4, once per solve: k_pack_weights_w2)
+//     M_c[tile, co] = sum_ci V_c[tile, ci] * U_c[ci, co],  c = (xi, nu)           (MFMA, K = channels only)
+//     Y = A^T M A  (2x2, in the epilogue)
+// Workgroup = 32 tiles (128 pixels = whole samples) x 64 output channels x 16 components; wave w owns
+// components 2w, 2w+1 for both column halves (four accumulators).  No two waves share a filter
+// operand, so U never touches LDS: two pieces ahead it goes from L2 straight into registers (eight
+// float4 per lane and K chunk).  The A image [tile][component][16 channels] is triple-buffered in LDS,
+// which leaves ONE barrier per K chunk of 32 MFMAs per wave.  The 4x4 input transform is split over
+// the four lanes of a quad: each lane loads one patch row, transforms it along x, and gets the one other
+// row it needs for the transform along y through a DPP quad permute.  The epilogue folds the sixteen
+// component tiles in two rounds (eight at a time through LDS) and then runs the shared tail.
+// Requires even H and W and 128-pixel tiles; other geometries use k_conv3x3_w / k_conv3x3.
+// ============================================================================
+constexpr int SST2 = 16 * ASTW + 4;   // floats per tile of the A image: 16 components x 20, + 4: 81 16-B units (odd)
+
+__global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
+  PSTAMP(a.stamps, 0, "s_memrealtime");
+  PSTAMP(a.stamps, 1, "s_memtime");
+  constexpr int THREADS = 512;
+  constexpr int TT = 32;             // tiles per workgroup
+  constexpr int BM = 128;            // pixels per workgroup
+  constexpr int ABUF = TT * SST2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int mtile = blockIdx.x, nt = blockIdx.y;
+  const int n0 = mtile * d.S;
+  const int c0 = nt * d.BNE;
+  const int nsamp = min(d.S, d.N - n0);
+  const int TW = d.W >> 1, TH = d.H >> 1;
+  const int TPS = TH * TW;           // tiles per sample
+  const int tiles_valid = nsamp * TPS;
+  const bool fwd = a.mode != CM_BWD_RELU_GN;
+  const int ncols = min(d.BNE, d.C - c0);
+
+  float* Abuf = smem;                // 3 x ABUF: chunk c in buffer c % 3
+  // the tables sit behind BOTH the activation buffers and the epilogue's transform region: the first waves out
+  // of the main loop write that region while the last ones still read the tables
+  const int epi_end = 2 * BM * CT2 + 2 * d.S * BN + 32 * 64 * 2 + 8 * TT * CT2;
+  int* ptab = reinterpret_cast<int*>(smem + max(3 * ABUF, epi_end));   // [TT] pixel row (in the tile) of output pixel (2 th, 2 tw), -1 if none
+  int* qtab = ptab + TT;                                  // [TT] the same pixel's index inside its sample
+  if (tid < TT) {
+    int pr = -1, q = 0;
+    if (tid < d.S * TPS) {
+      const int s = tid / TPS, rem = tid - s * TPS;
+      const int th = rem / TW, tw = rem - th * TW;
+      q = (2 * th) * d.W + 2 * tw;
+      pr = s * d.HW + q;
+    }
+    ptab[tid] = pr;
+    qtab[tid] = q;
+  }
+
+  // ---- staging descriptor: thread = (tile, channel quad, patch row r).  The patch pixels are fetched with raw
+  //      buffer loads through a descriptor covering this workgroup's samples: a pixel outside the image (or a
+  //      tile past the batch) gets an out-of-range offset and the range check returns the zero halo, so the
+  //      loads are branch-free and the compiler's vmcnt bookkeeping stays exact (with exec-masked loads it had
+  //      to assume none was issued and waited for the youngest request at every use). ----
+  const int sr = tid & 3, sq4 = (tid >> 2) & 3, stile = tid >> 4;
+  const int slofs = stile * SST2 + (sr * 4) * ASTW + sq4 * 4;   // component (xi = sr, nu = 0)
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned svoff[4] = {OOB, OOB, OOB, OOB};   // byte offsets of the four patch pixels of row sr
+  if (stile < tiles_valid) {
+    const int s = stile / TPS, rem = stile - s * TPS;
+    const int th = rem / TW, tw = rem - th * TW;
+    const int sy = 2 * th - 1 + sr;
+    if (sy >= 0 && sy < d.H) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int x = 2 * tw - 1 + i;
+        if (x >= 0 && x < d.W) svoff[i] = (unsigned)((((s * d.HW) + sy * d.W + x) * d.C + sq4 * 4) * 4);
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in + (size_t)n0 * d.HW * d.C), 0, nsamp * d.HW * d.C * 4, 0x00020000);
+  const bool ragged_k = (d.C & (KCW - 1)) != 0;
+
+  // ---- operand offsets: wave w = components 2w, 2w+1 ----
+  const int arow = l31 * SST2 + (2 * wave) * ASTW + 8 * hi;      // + ASTW for the second component, + 4 g
+  const int nchunk = (d.C + KCW - 1) / KCW;
+  const float* wbase = a.wpacked + (size_t)nt * nchunk * (16 * BN * KCW);
+  const int bofs = ((2 * wave) * BN + l31) * KCW + 8 * hi;       // [comp][col][16]: + BN*KCW second component, + 32*KCW second column half, + 4 g
+
+  f32x16 acc[2][2];   // [component][column half]
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][nn][r] = 0.f;
+
+  for (int i = tid * 4; i < 3 * ABUF; i += THREADS * 4)
+    *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  float4 areg[4];
+  // channels past C in the last chunk: the neighbouring pixel's values would meet zero filter taps, but a
+  // non-finite value there must not leak, so those quads are pushed out of range as well
+#define ALOAD2(DST, CBASE)                                                                     \
+  {                                                                                        \
+    const bool cdead = ragged_k && (CBASE) + sq4 * 4 >= d.C;                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+      DST[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, cdead ? OOB : svoff[i], (CBASE) * 4, 0)); \
+  }
+  // x transform of this lane's patch row, then the y transform with ONE other row of the quad:
+  //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(1) - e(3)    (lane r = xi owns e(r))
+#define QP(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
+#define AWRITE2(SRC, ABASE)                                                                    \
+  {                                                                                        \
+    const float4 p0 = SRC[0], p1 = SRC[1], p2 = SRC[2], p3 = SRC[3];                       \
+    float e[4][4] = {{p0.x - p2.x, p0.y - p2.y, p0.z - p2.z, p0.w - p2.w},                 \
+                     {p1.x + p2.x, p1.y + p2.y, p1.z + p2.z, p1.w + p2.w},                 \
+                     {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, p2.w - p1.w},                 \
+                     {p1.x - p3.x, p1.y - p3.y, p1.z - p3.z, p1.w - p3.w}};                \
+    const float so = sr == 3 ? -1.f : 1.f, sp = (sr == 0 || sr == 2) ? -1.f : 1.f;         \
+    float* dst = (ABASE) + slofs;                                                          \
+    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                     \
+      float o[4];                                                                          \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) o[k] = so * e[nu][k] + sp * QP(e[nu][k]); \
+      *reinterpret_cast<float4*>(dst + nu * ASTW) = make_float4(o[0], o[1], o[2], o[3]);   \
+    }                                                                                      \
+  }
+
+  float4 pb[8];      // filter operands [component 2][column half 2][group 2]; group g is reloaded for the next
+                     // chunk right after this chunk's MFMAs of group g have been issued
+#define BLOAD2(PQ, G)                                                                       \
+  {                                                                                         \
+    const float* src = wbase + (size_t)(PQ) * (16 * BN * KCW) + bofs + 4 * (G);             \
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                           \
+      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn)                                      \
+        pb[(c * 2 + nn) * 2 + (G)] = *reinterpret_cast<const float4*>(src + (c * BN + nn * 32) * KCW); \
+  }
+
+  __syncthreads();  // zero fill + tables visible
+  // Both first activation chunks are requested up front, then the filter operands: entering the loop the
+  // outstanding requests are then exactly the steady state's (filter groups 0 and 1, in that order), so the
+  // merged loop-entry wait state costs the steady state nothing.  Pinned so the compiler keeps that order.
+  {
+    float4 areg0[4];
+    ALOAD2(areg0, 0)
+    ALOAD2(areg, min(1, nchunk - 1) * KCW)
+    __builtin_amdgcn_sched_barrier(0);
+    BLOAD2(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    BLOAD2(0, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    AWRITE2(areg0, Abuf)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  PSTAMP(a.stamps, 2, "s_memtime");
+
+  float4 pa0[2], pa1[2];
+#define LOADA2(PA, AB, G)                                                                  \
+  do {                                                                                     \
+    PA[0] = *reinterpret_cast<const float4*>((AB) + arow + 4 * (G));                       \
+    PA[1] = *reinterpret_cast<const float4*>((AB) + arow + ASTW + 4 * (G));                \
+  } while (0)
+#define MFMA1W(PA, G, E)                                                                                             \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[0].E, pb[0 + (G)].E, acc[0][0], 0, 0, 0);                          \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[0].E, pb[2 + (G)].E, acc[0][1], 0, 0, 0);                          \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[1].E, pb[4 + (G)].E, acc[1][0], 0, 0, 0);                          \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[1].E, pb[6 + (G)].E, acc[1][1], 0, 0, 0);
+#define MFMA16(PA, G) do { MFMA1W(PA, G, x) MFMA1W(PA, G, y) MFMA1W(PA, G, z) MFMA1W(PA, G, w) } while (0)
+#define SB __builtin_amdgcn_sched_barrier(0)
+  // MFMA intrinsics carry no chain, so instruction selection may float them past a sched_barrier and the loads
+  // behind it (the reloaded operand then lands in a temporary and is copied behind a vmcnt(0) at the loop end):
+  // an empty asm that "uses" the accumulators ties the group to its place.
+#define PIN2 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory")
+
+  LOADA2(pa0, Abuf, 0);
+  // One piece = one K chunk (16 channels, two operand groups of 16 MFMAs).  Every request is unconditional (the
+  // last chunks re-request the final chunk) and runs a full chunk ahead of its use: the filter operands of
+  // group g are reloaded for chunk q+1 as soon as chunk q's group g has been issued; the activations of chunk
+  // q+1, requested in the middle of chunk q-1, are transformed and written to buffer (q + 1) % 3 after chunk
+  // q's first group, and the registers are refilled with chunk q+2 straight away.  One barrier per chunk:
+  // buffer (q + 1) % 3 was last read in chunk q-2, which every wave had left before anyone passed the
+  // previous barrier.
+  {
+    int abuf_n = 1;
+    float* Acur = Abuf;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      const bool more_chunks = (chunk + 1) < nchunk;
+      float* Anxt = more_chunks ? Abuf + abuf_n * ABUF : Acur;
+      const int q1 = min(chunk + 1, nchunk - 1), q2 = min(chunk + 2, nchunk - 1);
+      LOADA2(pa1, Acur, 1); SB;
+      MFMA16(pa0, 0); PIN2; SB;
+      if (more_chunks) AWRITE2(areg, Anxt)
+      SB;
+      ALOAD2(areg, q2 * KCW)
+      BLOAD2(q1, 0)
+      SB;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging writes (and, older, pa1)
+      __builtin_amdgcn_s_barrier();
+      SB;
+      LOADA2(pa0, Anxt, 0); SB;   // first group of the next chunk
+      MFMA16(pa1, 1); PIN2; SB;
+      BLOAD2(q1, 1)
+      SB;
+      Acur = Anxt;
+      abuf_n = abuf_n == 2 ? 0 : abuf_n + 1;
+    }
+  }
+#undef SB
+#undef PIN2
+#undef LOADA2
+#undef MFMA16
+#undef MFMA1W
+#undef BLOAD2
+#undef ALOAD2
+#undef AWRITE2
+#undef QP
+  PSTAMP(a.stamps, 3, "s_memtime");
+
+  // bias + t * tmap of the pixel-tile elements this thread finalises (column tid & 63, tiles (tid >> 6) + 8 i, 2x2
+  // pixels each): requested here, consumed after the two transform rounds (the kernel is at its register limit,
+  // so they are not held across the main loop)
+  float tmv[16];
+  int ptl[4];
+  {
+    const int col = tid & 63;
+    const bool cok = fwd && col < ncols;
+    const float tval = fwd ? eval_time(a.et) : 0.f;
+    const float bias = cok ? a.bias[c0 + col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tl = (tid >> 6) + 8 * i;
+      ptl[i] = ptab[tl];
+      const int q = qtab[tl];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qq = q + (e >> 1) * d.W + (e & 1);
+        tmv[4 * i + e] = cok ? bias + tval * a.tmap[(size_t)qq * d.C + c0 + col] : 0.f;
+      }
+    }
+  }
+
+  // ---- output transform Y = A^T M A in two rounds of eight components (xi = 0,1 then xi = 2,3) ----
+  //   T[xi][0] = M[xi][0] + M[xi][1] + M[xi][2]     T[xi][1] = M[xi][1] - M[xi][2] - M[xi][3]
+  //   Y[0][j] = T[0][j] + T[1][j] + T[2][j]         Y[1][j] = T[1][j] - T[2][j] - T[3][j]
+  float* Ct = smem;  // [BM][CT2]
+  float* Mt = smem + 2 * BM * CT2 + 2 * d.S * BN + 32 * 64 * 2;   // [8][TT][CT2], behind the region the tail uses
+  float y[4][4];     // [tile i][pixel e = 2 * row + col]
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    if ((wave >> 2) == round) {
+      const int cb = (wave & 3) * 2;   // component index within the round
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Mt[((cb + c) * TT + (r & 3) + 8 * (r >> 2) + 4 * hi) * CT2 + nn * 32 + l31] = acc[c][nn][r];
+    }
+    __syncthreads();
+    {
+      const int col = tid & 63;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tl = (tid >> 6) + 8 * i;
+        float t[2][2];
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) {
+          const float m0 = Mt[((x2 * 4 + 0) * TT + tl) * CT2 + col], m1 = Mt[((x2 * 4 + 1) * TT + tl) * CT2 + col];
+          const float m2 = Mt[((x2 * 4 + 2) * TT + tl) * CT2 + col], m3 = Mt[((x2 * 4 + 3) * TT + tl) * CT2 + col];
+          t[x2][0] = (m0 + m1) + m2;
+          t[x2][1] = (m1 - m2) - m3;
+        }
+        if (round == 0) {   // xi = 0, 1
+          y[i][0] = t[0][0] + t[1][0]; y[i][1] = t[0][1] + t[1][1];
+          y[i][2] = t[1][0];           y[i][3] = t[1][1];
+        } else {            // xi = 2, 3
+          y[i][0] += t[0][0];             y[i][1] += t[0][1];
+          y[i][2] += -t[0][0] - t[1][0];  y[i][3] += -t[0][1] - t[1][1];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  {
+    const int col = tid & 63;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (ptl[i] >= 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ct[(ptl[i] + (e >> 1) * d.W + (e & 1)) * CT2 + col] = y[i][e] + tmv[4 * i + e];
+      }
+  }
+  __syncthreads();
+  PSTAMP(a.stamps, 6, "s_memtime");
+  conv_epilogue_tail<THREADS, BM>(a, d, smem, n0, c0, nsamp, ncols, mtile);
+  PSTAMP(a.stamps, 4, "s_memtime");
+  PSTAMP(a.stamps, 5, "s_memrealtime");
+}
+
+static size_t conv_w2_lds_bytes(const Dims& d) {
+  const size_t main_loop = 3 * (size_t)32 * SST2;
+  const size_t epi = 2 * (size_t)128 * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2 + 8 * (size_t)32 * CT2;
+  return ((main_loop > epi ? main_loop : epi) + 64) * sizeof(float);   // + the two tile tables
+}
+
+// 2-D filter transform + packing: packed[nt][chunk16][comp = xi*4 + nu][col 64][k 16],  U = G g G^T
+__global__ __launch_bounds__(256) void k_pack_weights_w2(const float* __restrict__ w, float* __restrict__ packed,
+                                                         int C, int BNE, int ntile, int nchunk, int dgrad) {
+  const size_t total = (size_t)ntile * nchunk * 16 * BN * KCW;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int kk = idx % KCW;
+    size_t r = idx / KCW;
+    const int col = r % BN; r /= BN;
+    const int comp = r % 16; r /= 16;
+    const int ch = r % nchunk;
+    const int nt = r / nchunk;
+    const int kidx = ch * KCW + kk, nidx = nt * BNE + col;
+    float v = 0.f;
+    if (col < BNE && kidx < C && nidx < C) {
+      float g[3][3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          g[kh][kw] = dgrad ? w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                            : w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+      const int xi = comp >> 2, nu = comp & 3;
+      auto G = [](int a, int b) -> float {   // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+        return a == 0 ? (b == 0 ? 1.f : 0.f) : a == 1 ? 0.5f : a == 2 ? (b == 1 ? -0.5f : 0.5f) : (b == 2 ? 1.f : 0.f);
+      };
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) v += G(xi, kh) * g[kh][kw] * G(nu, kw);
+    }
+    packed[idx] = v;
+  }
+}
+void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
+  const int nchunk = (d.C + KCW - 1) / KCW;
+  const size_t total = (size_t)d.ntile * nchunk * 16 * BN * KCW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_pack_weights_w2, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, nchunk, dgrad);
+}
+
 static size_t conv_d_lds_bytes(const Dims& d) {
   const size_t arows = (size_t)d.S * d.SLOTS + 2 * d.MARGIN;
   const size_t main_loop = 2 * arows * AST2 + 3 * (size_t)BBUF2;
   const size_t epi = 2 * (size_t)d.BM * CT2 + 2 * (size_t)d.S * BN + 32 * 64 * 2;
   return (main_loop > epi ? main_loop : epi) * sizeof(float);
 }
-size_t conv_lds_bytes(const Dims& d, int /*mode*/) { return d.wino ? conv_w_lds_bytes(d) : conv_d_lds_bytes(d); }
+size_t conv_lds_bytes(const Dims& d, int /*mode*/) { return d.wino == 2 ? conv_w2_lds_bytes(d) : d.wino ? conv_w_lds_bytes(d) : conv_d_lds_bytes(d); }
 
 // packed-weight elements of one conv layer (forward or dgrad operand)
 size_t conv_packed_elems(const Dims& d) {
+  if (d.wino == 2) return (size_t)d.ntile * ((d.C + KCW - 1) / KCW) * (16 * BN * KCW);
   return d.wino ? (size_t)d.ntile * ((d.C + KCW - 1) / KCW) * 3 * (4 * BN * KCW) : (size_t)d.ntile * d.nchunk * 9 * (KCH * BN);
 }
 
@@ -974,6 +1325,12 @@ static void launch_conv_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
 // d.BM (chosen by make_dims): 64 = four-wave workgroups, two of which share a CU and cover each other's
 // barriers / prologue / epilogue when the grid is small; 128 / 256 = eight waves.
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  if (d.wino == 2) {   // 2-D Winograd (128-pixel tiles, even H and W); weights packed by launch_pack_weights_w2
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(k_conv3x3_w2, dim3(d.mtiles, d.ntile), dim3(512), conv_w2_lds_bytes(d), s, a, d);
+    return;
+  }
   if (d.wino) {   // 1-D Winograd along the rows (even W); weights packed by launch_pack_weights_w
     if (d.BM == 64) launch_conv_w_t<1>(d, a, s);
     else if (d.BM == 128) launch_conv_w_t<2>(d, a, s);

@@ -125,7 +125,8 @@ static int make_dims(const node_shape* sh, Dims* out) {
     static int wino_env = -2;
     if (wino_env == -2) { const char* e = getenv("NODE_TUNE_CONV_WINO"); wino_env = e ? atoi(e) : -1; }
     const int want = g_conv_wino >= 0 ? g_conv_wino : wino_env;
-    d.wino = (d.W % 2 == 0) && (want < 0 ? 1 : want);   // even widths: Winograd kernel; odd: direct kernel
+    d.wino = (d.W % 2 == 0) ? (want < 0 ? 1 : want) : 0;   // even widths: Winograd kernel; odd: direct kernel
+    if (d.wino == 2 && !(d.H % 2 == 0 && d.BM == 128 && 128 % d.HW == 0 && d.HW >= 16)) d.wino = 1;   // 2-D variant: whole samples in 32 tiles
   }
   d.S = d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
@@ -311,7 +312,7 @@ struct Solver {
   }
 
   int prepare() {
-    auto pack = d.wino ? launch_pack_weights_w : launch_pack_weights;
+    auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
     pack(d, prm.conv1_w, p.wf[0], 0, st);
     pack(d, prm.conv2_w, p.wf[1], 0, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);

@@ -24,7 +24,7 @@ struct Dims {
   int nchunk;          // ceil(C / 32)
   int BM;              // rows per M tile: 128 or 256
   int S;               // whole samples per M tile
-  int wino;            // conv through the 1-D Winograd F(2,3) kernel (even W)
+  int wino;            // conv kernel: 0 direct, 1 Winograd F(2,3) along the rows (even W), 2 Winograd F(2x2,3x3) (even H, W; 128-pixel tiles)
   int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
   int mtiles;          // ceil(N / S)
   // pointwise slab (combine+GN kernels)
@@ -221,10 +221,11 @@ void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s);
 extern int g_wgrad_variant;
 extern int g_conv_bm;      // force the conv M tile (64 / 128) where the geometry allows; <= 0: heuristic
 extern int g_wgrad_wino;   // 0 / 1: force the direct / Winograd wgrad kernel; < 0: heuristic
-extern int g_conv_wino;    // 0 / 1: force the direct / Winograd conv kernel; < 0: heuristic
+extern int g_conv_wino;    // 0 / 1 / 2: force the direct / 1-D Winograd / 2-D Winograd conv kernel; < 0: heuristic
 size_t conv_lds_bytes(const Dims& d, int mode);
 size_t conv_packed_elems(const Dims& d);
 void launch_pack_weights_w(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
+void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
 
 struct WgradArgs {
   const float* act;       // [N,HW,C] conv input activation

@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
     std::vector<std::vector<double>> times(variants.size());
     for (size_t v = 0; v < variants.size(); ++v) {
       g_conv_bm = (variants[v] & 0xfff) % 1000;
-      g_conv_wino = (variants[v] & 0xfff) >= 1000 ? 1 : 0;
+      g_conv_wino = (variants[v] & 0xfff) >= 2000 ? 2 : (variants[v] & 0xfff) >= 1000 ? 1 : 0;
       Dims dd;
       if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
       dv.push_back(dd);
@@ -117,7 +117,8 @@ int main(int argc, char** argv) {
     std::vector<float*> wpks;
     for (size_t v = 0; v < variants.size(); ++v) {
       float* w = dev_zero(conv_packed_elems(dv[v]));
-      if (dv[v].wino) launch_pack_weights_w(dv[v], wraw, w, bwd ? 1 : 0, st);
+      if (dv[v].wino == 2) launch_pack_weights_w2(dv[v], wraw, w, bwd ? 1 : 0, st);
+      else if (dv[v].wino) launch_pack_weights_w(dv[v], wraw, w, bwd ? 1 : 0, st);
       else launch_pack_weights(dv[v], wraw, w, bwd ? 1 : 0, st);
       wpks.push_back(w);
     }
@@ -206,7 +207,7 @@ int main(int argc, char** argv) {
         gdiff = max_abs_diff(red(v), red(0), &gm);
       }
       printf("tile %4d (BM=%d%s, %d workgroups)  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|out-first| %.3e (ref max %.3e)  gpart diff %.3e\n",
-             variants[v] & 0xfff, dv[v].BM, dv[v].wino ? " winograd" : "", dv[v].mtiles * dv[v].ntile, med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
+             variants[v] & 0xfff, dv[v].BM, dv[v].wino == 2 ? " winograd-2d" : dv[v].wino ? " winograd" : "", dv[v].mtiles * dv[v].ntile, med, mn, flops / (med * 1e-6) / 1e12, diff, rmax, gdiff);
 #ifdef NODE_STAMPS
       CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
       run(v, stamps);
