@@ -992,7 +992,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   }
   const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in + (size_t)n0 * d.HW * d.C), 0, nsamp * d.HW * d.C * 4, 0x00020000);
-  const bool ragged_k = (d.C & (KCW - 1)) != 0;
 
   // ---- operand offsets: wave w = components 2w, 2w+1 ----
   const int arow = l31 * SST2 + (2 * wave) * ASTW + 8 * hi;      // + ASTW for the second component, + 4 g
@@ -1011,60 +1010,50 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   for (int i = tid * 4; i < 3 * ABUF; i += THREADS * 4)
     *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   float4 areg[4];
-  // channels past C in the last chunk: the neighbouring pixel's values would meet zero filter taps, but a
-  // non-finite value there must not leak, so those quads are pushed out of range as well
-#define ALOAD2(DST, CBASE)                                                                     \
-  {                                                                                        \
-    const bool cdead = ragged_k && (CBASE) + sq4 * 4 >= d.C;                               \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
-      DST[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, cdead ? OOB : svoff[i], (CBASE) * 4, 0)); \
-  }
+  // channels past C (the last chunk of a ragged C, and the phantom chunk that evens out the piece count): the
+  // neighbouring pixel's values would meet zero filter taps, but a non-finite value there must not leak, so
+  // those quads are pushed out of range as well
+#define ALOAD1(DST, CBASE, I)                                                              \
+  DST[I] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (CBASE) + sq4 * 4 >= d.C ? OOB : svoff[I], (CBASE) * 4, 0));
   // x transform of this lane's patch row, then the y transform with ONE other row of the quad:
   //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(1) - e(3)    (lane r = xi owns e(r))
 #define QP(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
-#define AWRITE2(SRC, ABASE)                                                                    \
+  const float so = sr == 3 ? -1.f : 1.f, sp = (sr == 0 || sr == 2) ? -1.f : 1.f;
+  // one transformed column nu of the patch row: 4 channels, one 16-B LDS write
+#define AWRITE1(SRC, ABASE, NU)                                                            \
   {                                                                                        \
-    const float4 p0 = SRC[0], p1 = SRC[1], p2 = SRC[2], p3 = SRC[3];                       \
-    float e[4][4] = {{p0.x - p2.x, p0.y - p2.y, p0.z - p2.z, p0.w - p2.w},                 \
-                     {p1.x + p2.x, p1.y + p2.y, p1.z + p2.z, p1.w + p2.w},                 \
-                     {p2.x - p1.x, p2.y - p1.y, p2.z - p1.z, p2.w - p1.w},                 \
-                     {p1.x - p3.x, p1.y - p3.y, p1.z - p3.z, p1.w - p3.w}};                \
-    const float so = sr == 3 ? -1.f : 1.f, sp = (sr == 0 || sr == 2) ? -1.f : 1.f;         \
-    float* dst = (ABASE) + slofs;                                                          \
-    _Pragma("unroll") for (int nu = 0; nu < 4; ++nu) {                                     \
-      float o[4];                                                                          \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) o[k] = so * e[nu][k] + sp * QP(e[nu][k]); \
-      *reinterpret_cast<float4*>(dst + nu * ASTW) = make_float4(o[0], o[1], o[2], o[3]);   \
-    }                                                                                      \
+    const float4 pl = (NU) == 0 ? SRC[0] : (NU) == 2 ? SRC[2] : SRC[1];                    \
+    const float4 pr = (NU) == 0 ? SRC[2] : (NU) == 2 ? SRC[1] : (NU) == 1 ? SRC[2] : SRC[3]; \
+    const float sg = (NU) == 1 ? 1.f : -1.f;                                               \
+    const float e0 = pl.x + sg * pr.x, e1 = pl.y + sg * pr.y, e2 = pl.z + sg * pr.z, e3 = pl.w + sg * pr.w; \
+    *reinterpret_cast<float4*>((ABASE) + slofs + (NU) * ASTW) =                            \
+        make_float4(so * e0 + sp * QP(e0), so * e1 + sp * QP(e1), so * e2 + sp * QP(e2), so * e3 + sp * QP(e3)); \
   }
 
-  float4 pb[8];      // filter operands [component 2][column half 2][group 2]; group g is reloaded for the next
-                     // chunk right after this chunk's MFMAs of group g have been issued
-#define BLOAD2(PQ, G)                                                                       \
-  {                                                                                         \
-    const float* src = wbase + (size_t)(PQ) * (16 * BN * KCW) + bofs + 4 * (G);             \
-    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                           \
-      _Pragma("unroll") for (int nn = 0; nn < 2; ++nn)                                      \
-        pb[(c * 2 + nn) * 2 + (G)] = *reinterpret_cast<const float4*>(src + (c * BN + nn * 32) * KCW); \
-  }
+  // filter operands [register set][(component 2 x column half 2) x group 2]: the set of chunk q+1 fills while
+  // chunk q computes
+  float4 pb[2][8];
+#define BLOAD1(SET, PQ, G, J)                                                               \
+  pb[SET][(J) * 2 + (G)] = *reinterpret_cast<const float4*>(wbase + (size_t)(PQ) * (16 * BN * KCW) + bofs + 4 * (G) + (((J) >> 1) * BN + ((J) & 1) * 32) * KCW);
 
+#define SB __builtin_amdgcn_sched_barrier(0)
   __syncthreads();  // zero fill + tables visible
-  // Both first activation chunks are requested up front, then the filter operands: entering the loop the
-  // outstanding requests are then exactly the steady state's (filter groups 0 and 1, in that order), so the
-  // merged loop-entry wait state costs the steady state nothing.  Pinned so the compiler keeps that order.
+  // Prologue requests in the steady state's order (filter group 0, activations, filter group 1), pinned: the
+  // compiler merges the wait state of the loop entry into every iteration, so a different order here would
+  // cost a wait for the youngest request in every chunk.
   {
     float4 areg0[4];
-    ALOAD2(areg0, 0)
-    ALOAD2(areg, min(1, nchunk - 1) * KCW)
-    __builtin_amdgcn_sched_barrier(0);
-    BLOAD2(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    BLOAD2(0, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    AWRITE2(areg0, Abuf)
-    __builtin_amdgcn_sched_barrier(0);
+    ALOAD1(areg0, 0, 0) ALOAD1(areg0, 0, 1) ALOAD1(areg0, 0, 2) ALOAD1(areg0, 0, 3)
+    SB;
+    BLOAD1(0, 0, 0, 0) BLOAD1(0, 0, 0, 1) BLOAD1(0, 0, 0, 2) BLOAD1(0, 0, 0, 3)
+    SB;
+    ALOAD1(areg, KCW, 0) ALOAD1(areg, KCW, 1) ALOAD1(areg, KCW, 2) ALOAD1(areg, KCW, 3)
+    SB;
+    BLOAD1(0, 0, 1, 0) BLOAD1(0, 0, 1, 1) BLOAD1(0, 0, 1, 2) BLOAD1(0, 0, 1, 3)
+    SB;
+    AWRITE1(areg0, Abuf, 0) AWRITE1(areg0, Abuf, 1) AWRITE1(areg0, Abuf, 2) AWRITE1(areg0, Abuf, 3)
+    SB;
   }
   __syncthreads();
   PSTAMP(a.stamps, 2, "s_memtime");
@@ -1075,59 +1064,92 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
     PA[0] = *reinterpret_cast<const float4*>((AB) + arow + 4 * (G));                       \
     PA[1] = *reinterpret_cast<const float4*>((AB) + arow + ASTW + 4 * (G));                \
   } while (0)
-#define MFMA1W(PA, G, E)                                                                                             \
-  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[0].E, pb[0 + (G)].E, acc[0][0], 0, 0, 0);                          \
-  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[0].E, pb[2 + (G)].E, acc[0][1], 0, 0, 0);                          \
-  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[1].E, pb[4 + (G)].E, acc[1][0], 0, 0, 0);                          \
-  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[1].E, pb[6 + (G)].E, acc[1][1], 0, 0, 0);
-#define MFMA16(PA, G) do { MFMA1W(PA, G, x) MFMA1W(PA, G, y) MFMA1W(PA, G, z) MFMA1W(PA, G, w) } while (0)
-#define SB __builtin_amdgcn_sched_barrier(0)
-  // MFMA intrinsics carry no chain, so instruction selection may float them past a sched_barrier and the loads
-  // behind it (the reloaded operand then lands in a temporary and is copied behind a vmcnt(0) at the loop end):
-  // an empty asm that "uses" the accumulators ties the group to its place.
-#define PIN2 asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory")
+  // Half a k step: the two MFMAs of component CC (both column halves).  MFMA intrinsics carry no chain, so
+  // instruction selection may float them past a sched_barrier and the memory operations behind it; the empty
+  // asm that "uses" the accumulators ties the pair to its place.
+#define HSTEP(CC, PA, SET, G, E)                                                                                             \
+  acc[CC][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[CC].E, pb[SET][((CC) * 2 + 0) * 2 + (G)].E, acc[CC][0], 0, 0, 0);      \
+  acc[CC][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[CC].E, pb[SET][((CC) * 2 + 1) * 2 + (G)].E, acc[CC][1], 0, 0, 0);      \
+  asm volatile("" : "+v"(acc[CC][0]), "+v"(acc[CC][1]) :: "memory");
 
   LOADA2(pa0, Abuf, 0);
-  // One piece = one K chunk (16 channels, two operand groups of 16 MFMAs).  Every request is unconditional (the
-  // last chunks re-request the final chunk) and runs a full chunk ahead of its use: the filter operands of
-  // group g are reloaded for chunk q+1 as soon as chunk q's group g has been issued; the activations of chunk
-  // q+1, requested in the middle of chunk q-1, are transformed and written to buffer (q + 1) % 3 after chunk
-  // q's first group, and the registers are refilled with chunk q+2 straight away.  One barrier per chunk:
-  // buffer (q + 1) % 3 was last read in chunk q-2, which every wave had left before anyone passed the
-  // previous barrier.
+#ifdef NODE_STAMPS
+  unsigned long long tk_prev, tk_acc[4] = {0, 0, 0, 0};
+#define TICK0 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk_prev)::"memory")
+#define TICK(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); tk_acc[k] += t_ - tk_prev; tk_prev = t_; } while (0)
+#else
+#define TICK0 do { } while (0)
+#define TICK(k) do { } while (0)
+#endif
+  // One piece = one K chunk (16 channels): 16 half steps of two MFMAs, each followed by ONE staging item, so
+  // that neither the vector-memory issue (16 cycles of address path per 16-B request), the LDS writes nor the
+  // transform VALU come as a burst in which the matrix pipe idles:
+  //   half steps  0- 3 (group 0, k = 0,1): the four group-0 filter requests of chunk q+1 (other register set)
+  //   half steps  4- 7 (group 0, k = 2,3): transform + LDS write of the four columns of chunk q+1's patch row
+  //   half steps  8-11 (group 1, k = 0,1): the four activation requests of chunk q+2
+  //   -- lgkmcnt(0) + barrier (the LDS writes have had four half steps to drain), group-0 operands of q+1 --
+  //   half steps 12-15 (group 1, k = 2,3): the four group-1 filter requests of chunk q+1
+  // Every request is unconditional and at least half a chunk ahead of its use; the in-order vmcnt waits the
+  // compiler derives are exact (8 / 8 / 4 younger requests).  Buffer (q + 1) % 3 was last read in chunk q-2,
+  // which every wave had left before anyone passed the previous barrier.  The pieces alternate between the two
+  // filter register sets; an odd chunk count gets a phantom piece (activations out of range = zero).
+#define PIECE2(SET, NSET)                                                                  \
+  {                                                                                        \
+    float* Anxt = Abuf + abuf_n * ABUF;                                                    \
+    const int q1 = min(chunk + 1, nchunk - 1);                                             \
+    const int cb2 = (chunk + 2) * KCW;                                                     \
+    LOADA2(pa1, Acur, 1); SB;                                                              \
+    HSTEP(0, pa0, SET, 0, x) BLOAD1(NSET, q1, 0, 0) SB;                                    \
+    HSTEP(1, pa0, SET, 0, x) BLOAD1(NSET, q1, 0, 1) SB;                                    \
+    HSTEP(0, pa0, SET, 0, y) BLOAD1(NSET, q1, 0, 2) SB;                                    \
+    HSTEP(1, pa0, SET, 0, y) BLOAD1(NSET, q1, 0, 3) SB;                                    \
+    TICK(0);                                                                               \
+    HSTEP(0, pa0, SET, 0, z) AWRITE1(areg, Anxt, 0) SB;                                    \
+    HSTEP(1, pa0, SET, 0, z) AWRITE1(areg, Anxt, 1) SB;                                    \
+    HSTEP(0, pa0, SET, 0, w) AWRITE1(areg, Anxt, 2) SB;                                    \
+    HSTEP(1, pa0, SET, 0, w) AWRITE1(areg, Anxt, 3) SB;                                    \
+    TICK(1);                                                                               \
+    HSTEP(0, pa1, SET, 1, x) ALOAD1(areg, cb2, 0) SB;                                      \
+    HSTEP(1, pa1, SET, 1, x) ALOAD1(areg, cb2, 1) SB;                                      \
+    HSTEP(0, pa1, SET, 1, y) ALOAD1(areg, cb2, 2) SB;                                      \
+    HSTEP(1, pa1, SET, 1, y) ALOAD1(areg, cb2, 3) SB;                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+    __builtin_amdgcn_s_barrier();                                                          \
+    SB;                                                                                    \
+    TICK(2);                                                                               \
+    LOADA2(pa0, Anxt, 0); SB;                                                              \
+    HSTEP(0, pa1, SET, 1, z) BLOAD1(NSET, q1, 1, 0) SB;                                    \
+    HSTEP(1, pa1, SET, 1, z) BLOAD1(NSET, q1, 1, 1) SB;                                    \
+    HSTEP(0, pa1, SET, 1, w) BLOAD1(NSET, q1, 1, 2) SB;                                    \
+    HSTEP(1, pa1, SET, 1, w) BLOAD1(NSET, q1, 1, 3) SB;                                    \
+    TICK(3);                                                                               \
+    Acur = Anxt;                                                                           \
+    abuf_n = abuf_n == 2 ? 0 : abuf_n + 1;                                                 \
+    ++chunk;                                                                               \
+  }
   {
     int abuf_n = 1;
     float* Acur = Abuf;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-      const bool more_chunks = (chunk + 1) < nchunk;
-      float* Anxt = more_chunks ? Abuf + abuf_n * ABUF : Acur;
-      const int q1 = min(chunk + 1, nchunk - 1), q2 = min(chunk + 2, nchunk - 1);
-      LOADA2(pa1, Acur, 1); SB;
-      MFMA16(pa0, 0); PIN2; SB;
-      if (more_chunks) AWRITE2(areg, Anxt)
-      SB;
-      ALOAD2(areg, q2 * KCW)
-      BLOAD2(q1, 0)
-      SB;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging writes (and, older, pa1)
-      __builtin_amdgcn_s_barrier();
-      SB;
-      LOADA2(pa0, Anxt, 0); SB;   // first group of the next chunk
-      MFMA16(pa1, 1); PIN2; SB;
-      BLOAD2(q1, 1)
-      SB;
-      Acur = Anxt;
-      abuf_n = abuf_n == 2 ? 0 : abuf_n + 1;
+    TICK0;
+    for (int chunk = 0; chunk < nchunk;) {
+      PIECE2(0, 1)
+      PIECE2(1, 0)
     }
   }
+#undef PIECE2
+#ifdef NODE_STAMPS
+  if (a.stamps != nullptr && (threadIdx.x & 63) == 0)
+    for (int k = 0; k < 4; ++k)
+      a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + 12 + k] = tk_acc[k];
+#endif
+#undef TICK0
+#undef TICK
 #undef SB
-#undef PIN2
+#undef HSTEP
 #undef LOADA2
-#undef MFMA16
-#undef MFMA1W
-#undef BLOAD2
-#undef ALOAD2
-#undef AWRITE2
+#undef ALOAD1
+#undef AWRITE1
+#undef BLOAD1
 #undef QP
   PSTAMP(a.stamps, 3, "s_memtime");
 

@@ -125,12 +125,12 @@ static int make_dims(const node_shape* sh, Dims* out) {
     static int wino_env = -2;
     if (wino_env == -2) { const char* e = getenv("NODE_TUNE_CONV_WINO"); wino_env = e ? atoi(e) : -1; }
     const int want = g_conv_wino >= 0 ? g_conv_wino : wino_env;
-    d.wino = (d.W % 2 == 0) ? (want < 0 ? 1 : want) : 0;   // even widths: Winograd kernel; odd: direct kernel
+    d.wino = (d.W % 2 == 0) ? (want < 0 ? 2 : want) : 0;   // even widths: Winograd kernels (2-D where the tile fits, else 1-D); odd: direct kernel
     if (d.wino == 2 && !(d.H % 2 == 0 && d.BM == 128 && 128 % d.HW == 0 && d.HW >= 16)) d.wino = 1;   // 2-D variant: whole samples in 32 tiles
   }
   d.S = d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
-  while (d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
+  while (d.wino != 2 && d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
   if (conv_lds_bytes(d, 0) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "conv tile does not fit LDS");
   d.mtiles = (d.N + d.S - 1) / d.S;
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)

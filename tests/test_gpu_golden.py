@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.helpers import make_func, rel_err
+from tests.helpers import make_func, rel_err, robust_grad_err
 
 pytestmark = pytest.mark.gpu
 
@@ -60,13 +60,21 @@ def test_hip_end_to_end_matches_reference_run(golden_dir, name):
 
 
 def test_full_size_cifar_state_forward_and_vjp_vs_oracle():
-    """BASELINE configs[1] state [128, 256, 8, 8]: one dynamics eval + VJP against the oracle."""
+    """BASELINE configs[1] state [128, 256, 8, 8]: one dynamics eval + VJP against the oracle.
+
+    4.2 M pre-activations pass a ReLU here, so with generic parameters about one of them lies within fp32
+    rounding of zero and its mask may flip between two correct implementations; GroupNorm's backward
+    then spreads the difference over that one sample (measured: exactly one sample differs, the other
+    127 agree to 1e-6).  The tight element-wise comparison therefore runs on the kink-free parameter
+    set (helpers.make_func); the generic set is held to: forward tight, at most two samples affected,
+    all others tight."""
     import neural_ode_features_amd as nof
     from oracle.dynamics import odefunc_vjp as oracle_vjp
-    f, twin = make_func(256, seed=2, device='cuda')
     gen = torch.Generator().manual_seed(8)
     y = torch.randn(128, 256, 8, 8, generator=gen)
     cot = torch.randn(128, 256, 8, 8, generator=gen)
+
+    f, twin = make_func(256, seed=2, device='cuda', kink_free=True)
     fo, vy, vt, vp = nof.odefunc_vjp(f, 0.5, y.cuda(), cot.cuda())
     f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.5, y, dict(twin.named_parameters()), cot)
     assert rel_err(fo, f_ref) < 2e-5 and rel_err(vy, vy_ref) < 5e-5 and rel_err(vp, vp_ref) < 5e-5
@@ -74,6 +82,14 @@ def test_full_size_cifar_state_forward_and_vjp_vs_oracle():
     # linearity of the VJP in the cotangent (size-independent property)
     _, vy2, vt2, vp2 = nof.odefunc_vjp(f, 0.5, y.cuda(), (-2.0 * cot).cuda())
     assert rel_err(vy2, -2.0 * vy) < 1e-5 and rel_err(vp2, -2.0 * vp) < 1e-5
+
+    f, twin = make_func(256, seed=2, device='cuda')
+    fo, vy, vt, vp = nof.odefunc_vjp(f, 0.5, y.cuda(), cot.cuda())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.5, y, dict(twin.named_parameters()), cot)
+    assert rel_err(fo, f_ref) < 2e-5
+    per_sample = (vy.cpu() - vy_ref).abs().amax(dim=(1, 2, 3)) / float(vy_ref.abs().max())
+    assert int((per_sample > 5e-5).sum()) <= 2, per_sample.topk(4)
+    assert robust_grad_err(vp, vp_ref)[0] < 5e-2
 
 
 def test_full_size_solve_properties():
@@ -99,7 +115,13 @@ def test_full_size_solve_properties():
     with torch.no_grad():
         full = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
         part = nof.odeint(f, y[5:37].cuda(), t.cuda(), rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
-    assert torch.equal(full[5:37], part)          # bit-identical: batch rows never mix
+        y2 = torch.randn(128, 256, 8, 8, generator=torch.Generator().manual_seed(19))
+        big = nof.odeint(f, torch.cat([y, y2]).cuda(), t.cuda(), rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
+    # batch rows never mix: bit-identical where the same conv kernel serves both batches (128 and 256 samples:
+    # the 2-D Winograd tile), to rounding where the small batch is served by another tiling (32 samples fill
+    # too few workgroups for the 128-pixel tile, so the 64-pixel 1-D Winograd kernel runs instead)
+    assert torch.equal(big[:128], full)
+    assert float((full[5:37] - part).abs().max()) <= 2e-5 * float(full.abs().max())
 
 
 def test_ragged_and_edge_shapes():

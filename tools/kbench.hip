@@ -214,11 +214,12 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(st));
       std::vector<unsigned long long> hs(nstamp);
       CK(hipMemcpy(hs.data(), stamps, nstamp * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      double pro = 0, mainl = 0, epi = 0, clk = 0, e1 = 0, e2 = 0, e3 = 0, sub[5] = {0, 0, 0, 0, 0};
+      double pro = 0, mainl = 0, epi = 0, clk = 0, e1 = 0, e2 = 0, e3 = 0, sub[5] = {0, 0, 0, 0, 0}, ph[4] = {0, 0, 0, 0};
       int cnt = 0;
       for (size_t w = 0; w < nstamp / 16; ++w) {
         const unsigned long long* s = &hs[w * 16];
         if (s[1] == 0 || s[4] == 0) continue;
+        for (int q = 0; q < 4; ++q) ph[q] += (double)s[12 + q];
         pro += (double)(s[2] - s[1]); mainl += (double)(s[3] - s[2]); epi += (double)(s[4] - s[3]);
         if (s[6] && s[7]) { e1 += (double)(s[6] - s[3]); e2 += (double)(s[7] - s[6]); e3 += (double)(s[4] - s[7]); }
         if (s[8] && s[11]) { for (int q = 0; q < 4; ++q) sub[q] += (double)(s[8 + q] - (q ? s[7 + q] : s[3])); sub[4] += (double)(s[6] - s[11]); }
@@ -227,6 +228,8 @@ int main(int argc, char** argv) {
       }
       if (cnt) printf("            stamps over %d waves: prologue %.0f  main %.0f  epilogue %.0f cycles (acc->LDS %.0f, stats %.0f, store %.0f); in-kernel clock %.0f MHz\n",
                       cnt, pro / cnt, mainl / cnt, epi / cnt, e1 / cnt, e2 / cnt, e3 / cnt, clk / cnt);
+      if (cnt && ph[0] > 0) printf("            main-loop phases (cycles summed over chunks): first group %.0f  staging %.0f  barrier %.0f  second group %.0f\n",
+                                  ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
       if (cnt && sub[0] > 0) printf("            output transform: tables+sync %.0f  pass A %.0f  pass B %.0f  pass C %.0f  bias/time %.0f\n",
                                    sub[0] / cnt, sub[1] / cnt, sub[2] / cnt, sub[3] / cnt, sub[4] / cnt);
 #endif
