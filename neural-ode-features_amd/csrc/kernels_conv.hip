@@ -969,15 +969,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
     qtab[tid] = q;
   }
 
-  // ---- staging descriptor: thread = (tile, channel quad, patch row r).  The patch pixels are fetched with raw
-  //      buffer loads through a descriptor covering this workgroup's samples: a pixel outside the image (or a
-  //      tile past the batch) gets an out-of-range offset and the range check returns the zero halo, so the
-  //      loads are branch-free and the compiler's vmcnt bookkeeping stays exact (with exec-masked loads it had
-  //      to assume none was issued and waited for the youngest request at every use). ----
+  // ---- staging descriptor: thread = (tile, channel quad, patch row r).  The four patch pixels are fetched with
+  //      global loads "scalar base + 32-bit lane offset": the base (workgroup's first sample + chunk) moves on
+  //      the scalar unit, the lane offsets are fixed for the whole kernel, and a pixel outside the image (or a
+  //      tile past the batch) points at the row of C zeros the host keeps behind the tensor -- so the requests
+  //      are branch-free (exact vmcnt bookkeeping; with exec-masked loads the compiler waited for the youngest
+  //      request at every use) and cost no VALU per chunk.  Range-checked buffer loads did the same but issued
+  //      ~100 cycles slower each (measured). ----
   const int sr = tid & 3, sq4 = (tid >> 2) & 3, stile = tid >> 4;
   const int slofs = stile * SST2 + (sr * 4) * ASTW + sq4 * 4;   // component (xi = sr, nu = 0)
-  constexpr unsigned OOB = 0x80000000u;
-  unsigned svoff[4] = {OOB, OOB, OOB, OOB};   // byte offsets of the four patch pixels of row sr
+  const float* abase = a.in + (size_t)n0 * d.HW * d.C;
+  const unsigned zoff = (unsigned)(((size_t)(d.N - n0) * d.HW * d.C + sq4 * 4) * sizeof(float));   // the zero row
+  unsigned svoff[4] = {zoff, zoff, zoff, zoff};   // byte offsets of the four patch pixels of row sr
   if (stile < tiles_valid) {
     const int s = stile / TPS, rem = stile - s * TPS;
     const int th = rem / TW, tw = rem - th * TW;
@@ -990,32 +993,28 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
       }
     }
   }
-  const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in + (size_t)n0 * d.HW * d.C), 0, nsamp * d.HW * d.C * 4, 0x00020000);
 
-  // ---- operand offsets: wave w = components 2w, 2w+1 ----
-  const int arow = l31 * SST2 + (2 * wave) * ASTW + 8 * hi;      // + ASTW for the second component, + 4 g
+  // ---- operand offsets: wave w = the four components (xi = w >> 1, nu = 0..3) of column half w & 1, so the
+  //      nu half of the output transform happens in registers before anything goes through LDS ----
+  const int wxi = wave >> 1, wnn = wave & 1;
+  const int arow = l31 * SST2 + (4 * wxi) * ASTW + 8 * hi;       // + nu * ASTW, + 4 g
   const int nchunk = (d.C + KCW - 1) / KCW;
   const float* wbase = a.wpacked + (size_t)nt * nchunk * (16 * BN * KCW);
-  const int bofs = ((2 * wave) * BN + l31) * KCW + 8 * hi;       // [comp][col][16]: + BN*KCW second component, + 32*KCW second column half, + 4 g
+  const int bofs = ((4 * wxi) * BN + wnn * 32 + l31) * KCW + 8 * hi;   // [comp][col][16]: + nu * BN*KCW, + 4 g
 
-  f32x16 acc[2][2];   // [component][column half]
+  f32x16 acc[4];   // [nu]
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][nn][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  for (int i = tid * 4; i < 3 * ABUF; i += THREADS * 4)
-    *reinterpret_cast<float4*>(smem + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  // no zero fill: every (tile, component, channel) slot is rewritten for each chunk and the pads are never read
 
-  float4 areg[4];
-  // channels past C (the last chunk of a ragged C, and the phantom chunk that evens out the piece count): the
-  // neighbouring pixel's values would meet zero filter taps, but a non-finite value there must not leak, so
-  // those quads are pushed out of range as well
+  float4 areg[2][4];   // patch rows of chunks q+1 and q+2 (set = chunk parity): requested two chunks ahead, the
+                       // activations come from HBM / MALL and one chunk (~2500 cycles) did not cover them
+  // CBASE is clamped by the callers (requests run up to three chunks ahead; C % 32 == 0 here: no ragged chunk)
 #define ALOAD1(DST, CBASE, I)                                                              \
-  DST[I] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (CBASE) + sq4 * 4 >= d.C ? OOB : svoff[I], (CBASE) * 4, 0));
+  DST[I] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(abase + (CBASE)) + svoff[I]);
   // x transform of this lane's patch row, then the y transform with ONE other row of the quad:
   //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(1) - e(3)    (lane r = xi owns e(r))
 #define QP(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
@@ -1031,11 +1030,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
         make_float4(so * e0 + sp * QP(e0), so * e1 + sp * QP(e1), so * e2 + sp * QP(e2), so * e3 + sp * QP(e3)); \
   }
 
-  // filter operands [register set][(component 2 x column half 2) x group 2]: the set of chunk q+1 fills while
+  // filter operands [register set][nu 4 x group 2]: the set of chunk q+1 fills while
   // chunk q computes
   float4 pb[2][8];
 #define BLOAD1(SET, PQ, G, J)                                                               \
-  pb[SET][(J) * 2 + (G)] = *reinterpret_cast<const float4*>(wbase + (size_t)(PQ) * (16 * BN * KCW) + bofs + 4 * (G) + (((J) >> 1) * BN + ((J) & 1) * 32) * KCW);
+  pb[SET][(J) * 2 + (G)] = *reinterpret_cast<const float4*>(wbase + (size_t)(PQ) * (16 * BN * KCW) + bofs + 4 * (G) + (J) * (BN * KCW));
 
 #define SB __builtin_amdgcn_sched_barrier(0)
   __syncthreads();  // zero fill + tables visible
@@ -1044,13 +1043,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   // cost a wait for the youngest request in every chunk.
   {
     float4 areg0[4];
+    const int cbl1 = min(KCW, d.C - KCW), cbl2 = min(2 * KCW, d.C - KCW);
     ALOAD1(areg0, 0, 0) ALOAD1(areg0, 0, 1) ALOAD1(areg0, 0, 2) ALOAD1(areg0, 0, 3)
+    ALOAD1(areg[1], cbl1, 0) ALOAD1(areg[1], cbl1, 1) ALOAD1(areg[1], cbl1, 2) ALOAD1(areg[1], cbl1, 3)
     SB;
     BLOAD1(0, 0, 0, 0) BLOAD1(0, 0, 0, 1) BLOAD1(0, 0, 0, 2) BLOAD1(0, 0, 0, 3)
     SB;
-    ALOAD1(areg, KCW, 0) ALOAD1(areg, KCW, 1) ALOAD1(areg, KCW, 2) ALOAD1(areg, KCW, 3)
-    SB;
     BLOAD1(0, 0, 1, 0) BLOAD1(0, 0, 1, 1) BLOAD1(0, 0, 1, 2) BLOAD1(0, 0, 1, 3)
+    SB;
+    ALOAD1(areg[0], cbl2, 0) ALOAD1(areg[0], cbl2, 1) ALOAD1(areg[0], cbl2, 2) ALOAD1(areg[0], cbl2, 3)
     SB;
     AWRITE1(areg0, Abuf, 0) AWRITE1(areg0, Abuf, 1) AWRITE1(areg0, Abuf, 2) AWRITE1(areg0, Abuf, 3)
     SB;
@@ -1058,19 +1059,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   __syncthreads();
   PSTAMP(a.stamps, 2, "s_memtime");
 
-  float4 pa0[2], pa1[2];
+  float4 pa0[4], pa1[4];
 #define LOADA2(PA, AB, G)                                                                  \
   do {                                                                                     \
-    PA[0] = *reinterpret_cast<const float4*>((AB) + arow + 4 * (G));                       \
-    PA[1] = *reinterpret_cast<const float4*>((AB) + arow + ASTW + 4 * (G));                \
+    _Pragma("unroll") for (int nu_ = 0; nu_ < 4; ++nu_)                                    \
+      PA[nu_] = *reinterpret_cast<const float4*>((AB) + arow + nu_ * ASTW + 4 * (G));      \
   } while (0)
-  // Half a k step: the two MFMAs of component CC (both column halves).  MFMA intrinsics carry no chain, so
+  // Half a k step: the two MFMAs of components nu = 2 CC, 2 CC + 1.  MFMA intrinsics carry no chain, so
   // instruction selection may float them past a sched_barrier and the memory operations behind it; the empty
   // asm that "uses" the accumulators ties the pair to its place.
 #define HSTEP(CC, PA, SET, G, E)                                                                                             \
-  acc[CC][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[CC].E, pb[SET][((CC) * 2 + 0) * 2 + (G)].E, acc[CC][0], 0, 0, 0);      \
-  acc[CC][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[CC].E, pb[SET][((CC) * 2 + 1) * 2 + (G)].E, acc[CC][1], 0, 0, 0);      \
-  asm volatile("" : "+v"(acc[CC][0]), "+v"(acc[CC][1]) :: "memory");
+  acc[2 * (CC)] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[2 * (CC)].E, pb[SET][(2 * (CC)) * 2 + (G)].E, acc[2 * (CC)], 0, 0, 0);                 \
+  acc[2 * (CC) + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(PA[2 * (CC) + 1].E, pb[SET][(2 * (CC) + 1) * 2 + (G)].E, acc[2 * (CC) + 1], 0, 0, 0); \
+  asm volatile("" : "+v"(acc[2 * (CC)]), "+v"(acc[2 * (CC) + 1]) :: "memory");
 
   LOADA2(pa0, Abuf, 0);
 #ifdef NODE_STAMPS
@@ -1086,42 +1087,57 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   // transform VALU come as a burst in which the matrix pipe idles:
   //   half steps  0- 3 (group 0, k = 0,1): the four group-0 filter requests of chunk q+1 (other register set)
   //   half steps  4- 7 (group 0, k = 2,3): transform + LDS write of the four columns of chunk q+1's patch row
-  //   half steps  8-11 (group 1, k = 0,1): the four activation requests of chunk q+2
+  //   half steps  8-11 (group 1, k = 0,1): the four activation requests of chunk q+3 (into the registers just freed)
   //   -- lgkmcnt(0) + barrier (the LDS writes have had four half steps to drain), group-0 operands of q+1 --
   //   half steps 12-15 (group 1, k = 2,3): the four group-1 filter requests of chunk q+1
   // Every request is unconditional and at least half a chunk ahead of its use; the in-order vmcnt waits the
   // compiler derives are exact (8 / 8 / 4 younger requests).  Buffer (q + 1) % 3 was last read in chunk q-2,
   // which every wave had left before anyone passed the previous barrier.  The pieces alternate between the two
   // filter register sets; an odd chunk count gets a phantom piece (activations out of range = zero).
+#ifdef W2_NO_BLOAD
+#define LB(...)
+#else
+#define LB(...) BLOAD1(__VA_ARGS__)
+#endif
+#ifdef W2_NO_ALOAD
+#define LA(...)
+#else
+#define LA(...) ALOAD1(__VA_ARGS__)
+#endif
+#ifdef W2_NO_AWRITE
+#define LW(...)
+#else
+#define LW(...) AWRITE1(__VA_ARGS__)
+#endif
 #define PIECE2(SET, NSET)                                                                  \
   {                                                                                        \
     float* Anxt = Abuf + abuf_n * ABUF;                                                    \
     const int q1 = min(chunk + 1, nchunk - 1);                                             \
-    const int cb2 = (chunk + 2) * KCW;                                                     \
+    const int cb2 = min((chunk + 3) * KCW, d.C - KCW);                                                   \
     LOADA2(pa1, Acur, 1); SB;                                                              \
-    HSTEP(0, pa0, SET, 0, x) BLOAD1(NSET, q1, 0, 0) SB;                                    \
-    HSTEP(1, pa0, SET, 0, x) BLOAD1(NSET, q1, 0, 1) SB;                                    \
-    HSTEP(0, pa0, SET, 0, y) BLOAD1(NSET, q1, 0, 2) SB;                                    \
-    HSTEP(1, pa0, SET, 0, y) BLOAD1(NSET, q1, 0, 3) SB;                                    \
+    HSTEP(0, pa0, SET, 0, x) LB(NSET, q1, 0, 0) SB;                                    \
+    HSTEP(1, pa0, SET, 0, x) LB(NSET, q1, 0, 1) SB;                                    \
+    HSTEP(0, pa0, SET, 0, y) LB(NSET, q1, 0, 2) SB;                                    \
+    HSTEP(1, pa0, SET, 0, y) LB(NSET, q1, 0, 3) SB;                                    \
     TICK(0);                                                                               \
-    HSTEP(0, pa0, SET, 0, z) AWRITE1(areg, Anxt, 0) SB;                                    \
-    HSTEP(1, pa0, SET, 0, z) AWRITE1(areg, Anxt, 1) SB;                                    \
-    HSTEP(0, pa0, SET, 0, w) AWRITE1(areg, Anxt, 2) SB;                                    \
-    HSTEP(1, pa0, SET, 0, w) AWRITE1(areg, Anxt, 3) SB;                                    \
+    HSTEP(0, pa0, SET, 0, z) LW(areg[NSET], Anxt, 0) SB;                                    \
+    HSTEP(1, pa0, SET, 0, z) LW(areg[NSET], Anxt, 1) SB;                                    \
+    HSTEP(0, pa0, SET, 0, w) LW(areg[NSET], Anxt, 2) SB;                                    \
+    HSTEP(1, pa0, SET, 0, w) LW(areg[NSET], Anxt, 3) SB;                                    \
     TICK(1);                                                                               \
-    HSTEP(0, pa1, SET, 1, x) ALOAD1(areg, cb2, 0) SB;                                      \
-    HSTEP(1, pa1, SET, 1, x) ALOAD1(areg, cb2, 1) SB;                                      \
-    HSTEP(0, pa1, SET, 1, y) ALOAD1(areg, cb2, 2) SB;                                      \
-    HSTEP(1, pa1, SET, 1, y) ALOAD1(areg, cb2, 3) SB;                                      \
+    HSTEP(0, pa1, SET, 1, x) LB(NSET, q1, 1, 0) SB;                                        \
+    HSTEP(1, pa1, SET, 1, x) LB(NSET, q1, 1, 1) SB;                                        \
+    HSTEP(0, pa1, SET, 1, y) LB(NSET, q1, 1, 2) SB;                                        \
+    HSTEP(1, pa1, SET, 1, y) LB(NSET, q1, 1, 3) SB;                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
     __builtin_amdgcn_s_barrier();                                                          \
     SB;                                                                                    \
     TICK(2);                                                                               \
     LOADA2(pa0, Anxt, 0); SB;                                                              \
-    HSTEP(0, pa1, SET, 1, z) BLOAD1(NSET, q1, 1, 0) SB;                                    \
-    HSTEP(1, pa1, SET, 1, z) BLOAD1(NSET, q1, 1, 1) SB;                                    \
-    HSTEP(0, pa1, SET, 1, w) BLOAD1(NSET, q1, 1, 2) SB;                                    \
-    HSTEP(1, pa1, SET, 1, w) BLOAD1(NSET, q1, 1, 3) SB;                                    \
+    HSTEP(0, pa1, SET, 1, z) LA(areg[NSET], cb2, 0) SB;                                    \
+    HSTEP(1, pa1, SET, 1, z) LA(areg[NSET], cb2, 1) SB;                                    \
+    HSTEP(0, pa1, SET, 1, w) LA(areg[NSET], cb2, 2) SB;                                    \
+    HSTEP(1, pa1, SET, 1, w) LA(areg[NSET], cb2, 3) SB;                                    \
     TICK(3);                                                                               \
     Acur = Anxt;                                                                           \
     abuf_n = abuf_n == 2 ? 0 : abuf_n + 1;                                                 \
@@ -1137,6 +1153,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
     }
   }
 #undef PIECE2
+#undef LB
+#undef LA
+#undef LW
 #ifdef NODE_STAMPS
   if (a.stamps != nullptr && (threadIdx.x & 63) == 0)
     for (int k = 0; k < 4; ++k)
@@ -1160,64 +1179,55 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   int ptl[4];
   {
     const int col = tid & 63;
-    const bool cok = fwd && col < ncols;
+    const int ccol = c0 + min(col, ncols - 1);   // clamped: the requests below stay unconditional (independent, one wait)
     const float tval = fwd ? eval_time(a.et) : 0.f;
-    const float bias = cok ? a.bias[c0 + col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tl = (tid >> 6) + 8 * i;
-      ptl[i] = ptab[tl];
-      const int q = qtab[tl];
+    for (int i = 0; i < 4; ++i) ptl[i] = ptab[(tid >> 6) + 8 * i];
+    if (fwd) {   // wave-uniform
+      const float bias = a.bias[ccol];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int qq = q + (e >> 1) * d.W + (e & 1);
-        tmv[4 * i + e] = cok ? bias + tval * a.tmap[(size_t)qq * d.C + c0 + col] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int q = qtab[(tid >> 6) + 8 * i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tmv[4 * i + e] = a.tmap[(size_t)(q + (e >> 1) * d.W + (e & 1)) * d.C + ccol];
       }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tmv[k] = bias + tval * tmv[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tmv[k] = 0.f;
     }
   }
 
-  // ---- output transform Y = A^T M A in two rounds of eight components (xi = 0,1 then xi = 2,3) ----
+  // ---- output transform Y = A^T M A: the nu half in registers, the xi half through LDS ----
   //   T[xi][0] = M[xi][0] + M[xi][1] + M[xi][2]     T[xi][1] = M[xi][1] - M[xi][2] - M[xi][3]
   //   Y[0][j] = T[0][j] + T[1][j] + T[2][j]         Y[1][j] = T[1][j] - T[2][j] - T[3][j]
   float* Ct = smem;  // [BM][CT2]
-  float* Mt = smem + 2 * BM * CT2 + 2 * d.S * BN + 32 * 64 * 2;   // [8][TT][CT2], behind the region the tail uses
+  float* Mt = smem + 2 * BM * CT2 + 2 * d.S * BN + 32 * 64 * 2;   // T [xi 4][j 2][TT][CT2], behind the region the tail uses
   float y[4][4];     // [tile i][pixel e = 2 * row + col]
+  {
 #pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    if ((wave >> 2) == round) {
-      const int cb = (wave & 3) * 2;   // component index within the round
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            Mt[((cb + c) * TT + (r & 3) + 8 * (r >> 2) + 4 * hi) * CT2 + nn * 32 + l31] = acc[c][nn][r];
+    for (int r = 0; r < 16; ++r) {
+      const float m12 = acc[1][r] + acc[2][r], d12 = acc[1][r] - acc[2][r];
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      Mt[((wxi * 2 + 0) * TT + row) * CT2 + wnn * 32 + l31] = acc[0][r] + m12;
+      Mt[((wxi * 2 + 1) * TT + row) * CT2 + wnn * 32 + l31] = d12 - acc[3][r];
     }
-    __syncthreads();
-    {
-      const int col = tid & 63;
+  }
+  __syncthreads();
+  {
+    const int col = tid & 63;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int tl = (tid >> 6) + 8 * i;
-        float t[2][2];
+    for (int i = 0; i < 4; ++i) {
+      const int tl = (tid >> 6) + 8 * i;
 #pragma unroll
-        for (int x2 = 0; x2 < 2; ++x2) {
-          const float m0 = Mt[((x2 * 4 + 0) * TT + tl) * CT2 + col], m1 = Mt[((x2 * 4 + 1) * TT + tl) * CT2 + col];
-          const float m2 = Mt[((x2 * 4 + 2) * TT + tl) * CT2 + col], m3 = Mt[((x2 * 4 + 3) * TT + tl) * CT2 + col];
-          t[x2][0] = (m0 + m1) + m2;
-          t[x2][1] = (m1 - m2) - m3;
-        }
-        if (round == 0) {   // xi = 0, 1
-          y[i][0] = t[0][0] + t[1][0]; y[i][1] = t[0][1] + t[1][1];
-          y[i][2] = t[1][0];           y[i][3] = t[1][1];
-        } else {            // xi = 2, 3
-          y[i][0] += t[0][0];             y[i][1] += t[0][1];
-          y[i][2] += -t[0][0] - t[1][0];  y[i][3] += -t[0][1] - t[1][1];
-        }
+      for (int j = 0; j < 2; ++j) {
+        const float t0 = Mt[((0 * 2 + j) * TT + tl) * CT2 + col], t1 = Mt[((1 * 2 + j) * TT + tl) * CT2 + col];
+        const float t2 = Mt[((2 * 2 + j) * TT + tl) * CT2 + col], t3 = Mt[((3 * 2 + j) * TT + tl) * CT2 + col];
+        y[i][j] = (t0 + t1) + t2;
+        y[i][2 + j] = (t1 - t2) - t3;
       }
     }
-    __syncthreads();
   }
   {
     const int col = tid & 63;

@@ -126,7 +126,9 @@ static int make_dims(const node_shape* sh, Dims* out) {
     if (wino_env == -2) { const char* e = getenv("NODE_TUNE_CONV_WINO"); wino_env = e ? atoi(e) : -1; }
     const int want = g_conv_wino >= 0 ? g_conv_wino : wino_env;
     d.wino = (d.W % 2 == 0) ? (want < 0 ? 2 : want) : 0;   // even widths: Winograd kernels (2-D where the tile fits, else 1-D); odd: direct kernel
-    if (d.wino == 2 && !(d.H % 2 == 0 && d.BM == 128 && 128 % d.HW == 0 && d.HW >= 16)) d.wino = 1;   // 2-D variant: whole samples in 32 tiles
+    if (d.wino == 2 && !(d.H % 2 == 0 && d.BM == 128 && 128 % d.HW == 0 && d.HW >= 16 && d.C % 32 == 0 &&
+                      ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32)))
+      d.wino = 1;   // 2-D variant: whole samples in 32 tiles
   }
   d.S = d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
@@ -228,8 +230,9 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   p.Y = b.take<float>(d.numel);
   p.Y1 = b.take<float>(d.numel);
   for (int i = 0; i < 7; ++i) p.KY[i] = b.take<float>(d.numel);
-  p.act1 = b.take<float>(d.numel);
-  p.act2 = b.take<float>(d.numel);
+  // conv inputs carry a tail of C zeros: the 2-D Winograd kernel reads its zero halo there
+  p.act1 = b.take<float>(d.numel + d.C);
+  p.act2 = b.take<float>(d.numel + d.C);
   p.TMP = b.take<float>(d.numel);
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
@@ -246,8 +249,8 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.r1 = b.take<float>((size_t)d.N * d.G);
     p.r2 = b.take<float>((size_t)d.N * d.G);
     p.r3 = b.take<float>((size_t)d.N * d.G);
-    p.dz1 = b.take<float>(d.numel);
-    p.dz2 = b.take<float>(d.numel);
+    p.dz1 = b.take<float>(d.numel + d.C);
+    p.dz2 = b.take<float>(d.numel + d.C);
     p.G = b.take<float>(d.numel);
     for (int i = 0; i < 2; ++i) {
       p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
@@ -313,6 +316,14 @@ struct Solver {
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
+    if (d.wino == 2) {   // zero tails of the conv inputs (see make_plan)
+      HIP_TRY(hipMemsetAsync(p.act1 + d.numel, 0, d.C * sizeof(float), st));
+      HIP_TRY(hipMemsetAsync(p.act2 + d.numel, 0, d.C * sizeof(float), st));
+      if (aug) {
+        HIP_TRY(hipMemsetAsync(p.dz1 + d.numel, 0, d.C * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(p.dz2 + d.numel, 0, d.C * sizeof(float), st));
+      }
+    }
     pack(d, prm.conv1_w, p.wf[0], 0, st);
     pack(d, prm.conv2_w, p.wf[1], 0, st);
     launch_tmap(d, prm.conv1_w, p.tmap[0], st);

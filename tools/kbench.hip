@@ -26,10 +26,11 @@ namespace node { int dims_for(const node_shape* sh, Dims* out); }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-static float* dev_rand(size_t n, std::mt19937& g, float scale = 1.f, float shift = 0.f) {
-  std::vector<float> h(n);
+static float* dev_rand(size_t n, std::mt19937& g, float scale = 1.f, float shift = 0.f, size_t zero_tail = 0) {
+  std::vector<float> h(n + zero_tail, 0.f);
   std::normal_distribution<float> nd(0.f, 1.f);
-  for (auto& v : h) v = shift + scale * nd(g);
+  for (size_t i = 0; i < n; ++i) h[i] = shift + scale * nd(g);
+  n += zero_tail;
   float* d;
   CK(hipMalloc(&d, n * sizeof(float)));
   CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
@@ -71,7 +72,7 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   const size_t numel = d.numel, C = d.C;
-  float* in = dev_rand(numel, gen);
+  float* in = dev_rand(numel, gen, 1.f, 0.f, C);   // conv inputs carry a tail of C zeros (2-D Winograd halo)
   float* wraw = dev_rand(C * (C + 1) * 9, gen, 0.02f);
   float* bias = dev_rand(C, gen, 0.1f);
   float* gamma = dev_rand(C, gen, 0.25f, 1.f);
