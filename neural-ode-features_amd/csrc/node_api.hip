@@ -153,9 +153,16 @@ static int make_dims(const node_shape* sh, Dims* out) {
     if (ww_env == -2) { const char* e = getenv("NODE_TUNE_WGRAD_WINO"); ww_env = e ? atoi(e) : -1; }
     const int want = g_wgrad_wino >= 0 ? g_wgrad_wino : (ww_env >= 0 ? ww_env : 1);
     d.wgrad_wino = 0;
+    d.wut = 0;
     if (want && ((d.W == 8 && d.H % 8 == 0) || (d.W == 16 && d.H % 2 == 0) || (d.W == 4 && d.H % 4 == 0))) {
       d.wgrad_wino = 1;
       d.RB = d.W == 8 ? 8 : d.W == 16 ? 2 : 4;
+    }
+    // 2-D Winograd domain: units of 8 (or 4) tiles that are whole tile rows of one sample
+    if (want >= 2 && d.H % 2 == 0 && d.W % 2 == 0 && ((size_t)d.N * d.HW * d.C + 2 * (size_t)d.C * (d.W + 2)) * sizeof(float) < ((size_t)1 << 32)) {
+      const int TW = d.W / 2, TPS = (d.H / 2) * TW;
+      const int ut = (TPS % 8 == 0 && 8 % TW == 0) ? 8 : (TPS % 4 == 0 && 4 % TW == 0) ? 4 : 0;
+      if (ut) { d.wgrad_wino = 2; d.wut = ut; }
     }
   }
   d.nbands = (d.H + d.RB - 1) / d.RB;
@@ -163,7 +170,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
     return fail(NODE_ERR_UNSUPPORTED, "W = %d: wgrad staging does not fit its registers", d.W);
   if (wgrad_lds_bytes(d) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "wgrad tile does not fit LDS");
   {
-    const int U = d.N * d.nbands;
+    const int U = d.wgrad_wino == 2 ? d.N * ((d.H / 2) * (d.W / 2) / d.wut) : d.N * d.nbands;
     const int ntc = (d.C + 63) / 64;
     int ns = 256 / (ntc * ntc);   // one workgroup per CU (307 VGPR+AGPR: one wave per SIMD)
     if (ns < 1) ns = 1;
@@ -316,7 +323,7 @@ struct Solver {
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
-    if (d.wino == 2) {   // zero tails of the conv inputs (see make_plan)
+    if (d.wino == 2 || d.wgrad_wino == 2) {   // zero tails of the conv inputs (see make_plan)
       HIP_TRY(hipMemsetAsync(p.act1 + d.numel, 0, d.C * sizeof(float), st));
       HIP_TRY(hipMemsetAsync(p.act2 + d.numel, 0, d.C * sizeof(float), st));
       if (aug) {

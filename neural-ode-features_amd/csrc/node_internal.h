@@ -26,6 +26,7 @@ struct Dims {
   int S;               // whole samples per M tile
   int wino;            // conv kernel: 0 direct, 1 Winograd F(2,3) along the rows (even W), 2 Winograd F(2x2,3x3) (even H, W; 128-pixel tiles)
   int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
+  int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
   int mtiles;          // ceil(N / S)
   // pointwise slab (combine+GN kernels)
   int cs;              // channels per slab (multiple of lcm(cpg,4))

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
   float* bias = dev_rand(C, gen, 0.1f);
   float* gamma = dev_rand(C, gen, 0.25f, 1.f);
   float* beta = dev_rand(C, gen, 0.1f);
-  float* act = dev_rand(numel, gen);
+  float* act = dev_rand(numel, gen, 1.f, 0.f, C);
   float* xhat = dev_rand(numel, gen);
   float* rstd = dev_rand((size_t)d.N * d.G, gen, 0.1f, 1.f);
   const size_t wsz = (size_t)d.ntile * d.nchunk * 9 * KCH * BN;
@@ -236,13 +236,13 @@ int main(int argc, char** argv) {
 #endif
     }
   } else if (what == "wgrad") {
-    // variant 0: generic kernel (k_wgrad_p); 1: geometry-templated kernel; 2: Winograd-domain kernel (k_wgrad_w)
+    // variant 0: generic kernel (k_wgrad_p); 1: geometry-templated kernel; 2: 1-D Winograd-domain kernel (k_wgrad_w); 3: 2-D (k_wgrad_w2)
     std::vector<float*> wp;
     std::vector<Dims> dv;
     std::vector<std::vector<double>> times(variants.size());
-    float* dz = dev_rand(numel, gen);
+    float* dz = dev_rand(numel, gen, 1.f, 0.f, C);
     for (size_t v = 0; v < variants.size(); ++v) {
-      g_wgrad_wino = variants[v] == 2 ? 1 : 0;
+      g_wgrad_wino = variants[v] == 3 ? 2 : variants[v] == 2 ? 1 : 0;
       Dims dd;
       if (dims_for(&sh, &dd) != 0) { fprintf(stderr, "bad shape: %s\n", node_last_error()); return 1; }
       dv.push_back(dd);
@@ -303,24 +303,27 @@ int main(int argc, char** argv) {
       double rmax;
       const double diff = max_abs_diff(reduced(v), refw_v0, &rmax);
       printf("variant %2d%s  median %8.2f us  min %8.2f us  %6.1f TF (median)  max|dW-first| %.3e (ref max %.3e)\n",
-             variants[v], dv[v].wgrad_wino ? " winograd" : "", med, mn, flops / (med * 1e-6) / 1e12, diff, rmax);
+             variants[v], dv[v].wgrad_wino == 2 ? " winograd-2d" : dv[v].wgrad_wino ? " winograd" : "", med, mn, flops / (med * 1e-6) / 1e12, diff, rmax);
 #ifdef NODE_STAMPS
       CK(hipMemset(stamps, 0, nstamp * sizeof(unsigned long long)));
       run(v, stamps);
       CK(hipStreamSynchronize(st));
       std::vector<unsigned long long> hs(nstamp);
       CK(hipMemcpy(hs.data(), stamps, nstamp * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      double pro = 0, mainl = 0, epi = 0, clk = 0;
+      double pro = 0, mainl = 0, epi = 0, clk = 0, ph[4] = {0, 0, 0, 0};
       int cnt = 0;
       for (size_t w = 0; w < nstamp / 16; ++w) {
         const unsigned long long* s = &hs[w * 16];
         if (s[1] == 0 || s[4] == 0) continue;
         pro += (double)(s[2] - s[1]); mainl += (double)(s[3] - s[2]); epi += (double)(s[4] - s[3]);
+        for (int q = 0; q < 4; ++q) ph[q] += (double)s[12 + q];
         if (s[5] > s[0]) clk += (double)(s[4] - s[1]) / (double)(s[5] - s[0]) * 100.0;
         ++cnt;
       }
       if (cnt) printf("            stamps over %d waves: prologue %.0f  main %.0f  store %.0f cycles; in-kernel clock %.0f MHz\n",
                       cnt, pro / cnt, mainl / cnt, epi / cnt, clk / cnt);
+      if (cnt && ph[1] > 0) printf("            main-loop phases (cycles summed over units): request %.0f  MFMA loop %.0f  transform+write %.0f  barrier %.0f\n",
+                                  ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
 #endif
     }
     // masked column sums
