@@ -383,35 +383,43 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w(WgradArgs a, Dims d) {
 //   Z = A dy A^T  of the 2x2 dz tile  (per dimension: z0 = y0, z1 = y0 + y1, z2 = y0 - y1, z3 = -y1),
 //   dW = G^T M G  before the slab leaves the registers (per dimension: w0 = m0 + (m1+m2)/2, w1 = (m1-m2)/2,
 //   w2 = m3 + (m1+m2)/2).  K = tiles (a quarter of the pixels) x 16 components: 16/36 of the direct MFMA work
-//   (the 1-D kernel above: 24/36).  Four waves x 32x32 x 16 accumulators (all 256 AGPRs); a unit is UT
-//   consecutive tiles of one sample (whole tile rows), images [tile][component][64 channels] with a component
-//   stride of 68 floats (conflict-free 16-B staging writes); operands by ds_read_b32 at immediate offsets,
-//   one step (tile pair) ahead; units double-buffered.  Requires even H, W; UT % (W/2) == 0.
+//   (the 1-D kernel above: 24/36).
+// Eight waves, two per SIMD: wave (h, wi, wj) holds the 32x32 block (wi, wj) of the eight components
+// a in {2h, 2h+1} (128 AGPRs).  With one wave per SIMD every staging instruction -- request, transform,
+// LDS write -- was paid in matrix-pipe time (measured: 7050 cycles per 4096-cycle unit); here each wave's
+// staging overlaps its partner's MFMAs, and all of it is cut into single items placed between the MFMAs:
+// the first half of a unit transforms and writes the next unit (its raw pixels were requested during the
+// previous unit), the second half requests the unit after that into the registers just freed.  A unit is UT
+// consecutive tiles of one sample (whole tile rows); images [tile][component][64 channels] with a component
+// stride of 68 floats (conflict-free 16-B staging writes); operands by ds_read_b32 at immediate offsets,
+// one step (tile pair) ahead; units double-buffered, one barrier per unit.  The two h halves meet through
+// LDS once, after the loop: each wave finishes (and stores) half of the 32x32 block.
+// Requires even H, W; UT % (W/2) == 0; a tail of C zeros behind act and dz.
 // ============================================================================
+constexpr int WG2_THREADS = 512;
 template <int UT>
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
+__global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
   constexpr int CS = 68;              // component stride
   constexpr int TS = 16 * CS;         // tile stride
   constexpr int IMG = UT * TS;        // one image (V or Z) of one unit
-  constexpr int NVU = UT / 4;         // V staging units (tile, quad, patch row) per thread
   static_assert(UT == 4 || UT == 8, "unit sizes with an instance");
   static_assert((UT * TS) * 4 < 65536, "LDS immediates");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  WgGeom g;
-  g.tid = tid; g.l31 = lane & 31; g.hi = lane >> 5; g.wi = wave >> 1; g.wj = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wh = wave >> 2, wi = (wave >> 1) & 1, wj = wave & 1;
   const int ntc = (d.C + 63) / 64;
   const int ci_t = blockIdx.x / ntc, co_t = blockIdx.x - ci_t * ntc;
-  g.ci0 = ci_t * 64; g.co0 = co_t * 64; g.sp = blockIdx.y; g.q16 = tid & 15;
+  const int ci0 = ci_t * 64, co0 = co_t * 64, sp = blockIdx.y;
 
   float* Vs0 = smem;             // 2 x IMG
   float* Zs0 = smem + 2 * IMG;   // 2 x IMG
 
-  f32x16 acc[16];
+  f32x16 acc[8];   // component (2 wh + (c >> 2)) * 4 + (c & 3) = 8 wh + c
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -419,149 +427,117 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
   const int groups = TPS / UT, rows_per_unit = UT / TW;
   const int U = d.N * groups;
   // wave-uniform by construction, but the 64-bit division leaves them in vector registers and the whole unit
-  // loop (counter, sample / group decode, base pointers) then runs on the VALU under an exec-mask loop:
-  // readfirstlane puts the loop on the scalar unit
-  const int u_begin = __builtin_amdgcn_readfirstlane((int)(((long long)g.sp * U) / d.nsplit));
-  const int u_end = __builtin_amdgcn_readfirstlane((int)(((long long)(g.sp + 1) * U) / d.nsplit));
+  // loop then runs on the VALU under an exec-mask loop: readfirstlane puts it on the scalar unit
+  const int u_begin = __builtin_amdgcn_readfirstlane((int)(((long long)sp * U) / d.nsplit));
+  const int u_end = __builtin_amdgcn_readfirstlane((int)(((long long)(sp + 1) * U) / d.nsplit));
 
-  // ---- staging descriptors ----
-  // Requests are "scalar base of the unit + fixed 32-bit lane offset": nothing but a handful of selects per
-  // unit (the first version, with per-request bounds checks and 64-bit address arithmetic, spent 1700 cycles
-  // per unit just issuing twelve loads).  Pixels outside the image read the row of C zeros the host keeps
-  // behind both tensors.
-  // V: thread = (tile tq + 4 uu, channel quad vq, patch row vr): lanes of a quad hold the four rows of one patch
-  const int vr = tid & 3, vq = (tid >> 2) & 15, tq = tid >> 6;
-  const int TH = d.H >> 1;
-  const size_t rowC = (size_t)d.W * d.C;
-  int v_thl[NVU];
-  unsigned v_off[NVU][4];   // byte offset from (unit base = pixel (2 th0 - 1, -1), channel ci0), valid columns
-  bool v_xok[NVU][4];
+  // ---- staging descriptors: the tile of a thread is its wave index (UT = 4: waves 4-7 stage nothing) ----
+  // Requests are "scalar base of the unit + fixed 32-bit lane offset"; pixels outside the image read the row of
+  // C zeros the host keeps behind both tensors.
+  // V: thread = (tile, channel quad vq, patch row vr): lanes of a quad hold the four rows of one patch
+  const int st = wave;   // staged tile
+  const bool st_on = st < UT;
+  const int vr = tid & 3, vq = (tid >> 2) & 15;
+  const int s_thl = st / TW, s_tw = st - s_thl * TW;
+  unsigned v_off[4];   // byte offset from (unit base = pixel (2 th0 - 1, -1), channel ci0)
+  bool v_xok[4];
 #pragma unroll
-  for (int uu = 0; uu < NVU; ++uu) {
-    const int tl = tq + 4 * uu;
-    v_thl[uu] = tl / TW;
-    const int tw = tl - v_thl[uu] * TW;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int x = 2 * tw - 1 + e;
-      v_xok[uu][e] = x >= 0 && x < d.W && g.ci0 + vq * 4 < d.C;
-      v_off[uu][e] = (unsigned)((((size_t)(2 * v_thl[uu] + vr) * d.W + (2 * tw + e)) * d.C + vq * 4) * sizeof(float));
-    }
+  for (int e = 0; e < 4; ++e) {
+    const int x = 2 * s_tw - 1 + e;
+    v_xok[e] = st_on && x >= 0 && x < d.W && ci0 + vq * 4 < d.C;
+    v_off[e] = (unsigned)((((size_t)(2 * s_thl + vr) * d.W + (2 * s_tw + e)) * d.C + vq * 4) * sizeof(float));
   }
-  // Z: thread = (tile zt, row-transform half zh, channel quad zq); always inside the image
-  const int zq = tid & 15, zh = (tid >> 4) & 1, zt = tid >> 5;
-  const bool z_on = zt < UT && g.co0 + zq * 4 < d.C;
-  const int z_thl = zt / TW, z_tw = zt - z_thl * TW;
+  const bool v_top = vr == 0 && s_thl == 0, v_bot = vr == 3 && s_thl == rows_per_unit - 1;
+  // Z: thread = (tile, row-transform index za, channel quad zq); always inside the image
+  const int zq = tid & 15, za = (tid >> 4) & 3;
+  const bool z_on = st_on && co0 + zq * 4 < d.C;
   unsigned z_off[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e)
-    z_off[e] = (unsigned)((((size_t)(2 * z_thl + (e >> 1)) * d.W + 2 * z_tw + (e & 1)) * d.C + zq * 4) * sizeof(float));
-  const float* act_zero = a.act + d.numel;   // C zeros
-  const float* dz_zero = a.dz + d.numel;
+    z_off[e] = (unsigned)((((size_t)(2 * s_thl + (e >> 1)) * d.W + 2 * s_tw + (e & 1)) * d.C + zq * 4) * sizeof(float));
+  const float zc0 = za == 3 ? 0.f : 1.f, zc1 = za == 0 ? 0.f : za == 1 ? 1.f : -1.f;   // R_a = zc0 * y0* + zc1 * y1*
 
-  float4 rv[NVU][4], rz[4];
-  // lanes whose patch row leaves the image in the first / last unit of a sample
-  bool v_top[NVU], v_bot[NVU];
-#pragma unroll
-  for (int uu = 0; uu < NVU; ++uu) {
-    v_top[uu] = vr == 0 && v_thl[uu] == 0;
-    v_bot[uu] = vr == 3 && v_thl[uu] == rows_per_unit - 1;
-  }
-  // Requests of the next unit: prepared once per unit on the scalar unit, then issued ONE AT A TIME between the
-  // MFMAs of the current unit (load_piece).  Issued as a burst, the 48 16-byte requests of the four waves
-  // queue behind the CU's 64 B/clk address path and each wave sat ~1500 cycles per unit in issue stalls with
-  // its matrix pipe idle (measured; the instruction count made no difference).
-  int ld_n = __builtin_amdgcn_readfirstlane(u_begin / groups);        // (sample, group) of the next unit to request,
-  int ld_g = __builtin_amdgcn_readfirstlane(u_begin - ld_n * groups); // advanced incrementally: no division per unit
+  // next unit to request: (sample, group), advanced incrementally on the scalar unit; requests past the last
+  // unit repeat it (harmless; every request and every write stays unconditional)
+  const int TH = d.H >> 1;
+  (void)TH;
+  int ld_u = u_begin;
+  int ld_n = __builtin_amdgcn_readfirstlane(u_begin / groups);
+  int ld_g = __builtin_amdgcn_readfirstlane(u_begin - ld_n * groups);
   const char* vb = nullptr;
   const char* zb = nullptr;
   unsigned vzero = 0, zzero = 0;
-  bool rbad[NVU];
+  bool rbad = false;
   auto stage_prepare = [&]() {
     const int n = ld_n, th0 = ld_g * rows_per_unit;
     const bool first = ld_g == 0, last = ld_g == groups - 1;
-    if (++ld_g == groups) { ld_g = 0; ++ld_n; }
-    // scalar bases (may point before the tensor for the halo row / column: never dereferenced there); the zero
-    // row as an offset from them: one VALU subtraction per tensor, one select per request
-    const ptrdiff_t vrel = (((ptrdiff_t)n * d.HW + (ptrdiff_t)(2 * th0 - 1) * d.W - 1) * d.C + g.ci0) * (ptrdiff_t)sizeof(float);
-    const ptrdiff_t zrel = (((ptrdiff_t)n * d.HW + (ptrdiff_t)(2 * th0) * d.W) * d.C + g.co0) * (ptrdiff_t)sizeof(float);
+    if (ld_u + 1 < u_end) {
+      ++ld_u;
+      if (++ld_g == groups) { ld_g = 0; ++ld_n; }
+    }
+    const ptrdiff_t vrel = (((ptrdiff_t)n * d.HW + (ptrdiff_t)(2 * th0 - 1) * d.W - 1) * d.C + ci0) * (ptrdiff_t)sizeof(float);
+    const ptrdiff_t zrel = (((ptrdiff_t)n * d.HW + (ptrdiff_t)(2 * th0) * d.W) * d.C + co0) * (ptrdiff_t)sizeof(float);
     vb = reinterpret_cast<const char*>(a.act) + vrel;
     zb = reinterpret_cast<const char*>(a.dz) + zrel;
     vzero = (unsigned)((ptrdiff_t)(d.numel * sizeof(float)) - vrel) + vq * 16;
     zzero = (unsigned)((ptrdiff_t)(d.numel * sizeof(float)) - zrel) + zq * 16;
-#pragma unroll
-    for (int uu = 0; uu < NVU; ++uu) rbad[uu] = (first && v_top[uu]) || (last && v_bot[uu]);
+    rbad = (first && v_top) || (last && v_bot);
   };
-  constexpr int NPIECE = 4 * NVU + 4;
+  float4 rv[4], rz[4];
   auto load_piece = [&](int k) {   // k is a compile-time constant at every call site
-    if (k < 4 * NVU) {
-      const int uu = k >> 2, e = k & 3;
-      rv[uu][e] = *reinterpret_cast<const float4*>(vb + ((!rbad[uu] && v_xok[uu][e]) ? v_off[uu][e] : vzero));
-    } else {
-      const int e = k - 4 * NVU;
-      rz[e] = *reinterpret_cast<const float4*>(zb + (z_on ? z_off[e] : zzero));
-    }
+    if (k < 4) rv[k] = *reinterpret_cast<const float4*>(vb + ((!rbad && v_xok[k]) ? v_off[k] : vzero));
+    else rz[k - 4] = *reinterpret_cast<const float4*>(zb + (z_on ? z_off[k - 4] : zzero));
   };
 #define QP2(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
-  const float so = vr == 3 ? -1.f : 1.f, sp = (vr == 0 || vr == 2) ? -1.f : 1.f;
+  const float so = vr == 3 ? -1.f : 1.f, sps = (vr == 0 || vr == 2) ? -1.f : 1.f;
   auto f4 = [](float x, float y, float z, float w) { return make_float4(x, y, z, w); };
-  auto stage_write = [&](int buf) {
-    float* Vs = Vs0 + buf * IMG;
-    float* Zs = Zs0 + buf * IMG;
-    // V = B^T d B: the x transform of this lane's patch row, then the y transform with ONE other row of the quad
-    //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(1) - e(3)    (lane r = xi owns e(r))
-#pragma unroll
-    for (int uu = 0; uu < NVU; ++uu) {
-      float* dst = Vs + (tq + 4 * uu) * TS + (vr * 4) * CS + vq * 4;
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        const float4 pl = nu == 0 ? rv[uu][0] : nu == 2 ? rv[uu][2] : rv[uu][1];
-        const float4 pr = nu == 0 ? rv[uu][2] : nu == 2 ? rv[uu][1] : nu == 1 ? rv[uu][2] : rv[uu][3];
-        const float sg = nu == 1 ? 1.f : -1.f;
-        const float e0 = pl.x + sg * pr.x, e1 = pl.y + sg * pr.y, e2 = pl.z + sg * pr.z, e3 = pl.w + sg * pr.w;
-        *reinterpret_cast<float4*>(dst + nu * CS) =
-            f4(so * e0 + sp * QP2(e0), so * e1 + sp * QP2(e1), so * e2 + sp * QP2(e2), so * e3 + sp * QP2(e3));
+  float4 zr0, zr1;   // the row-transformed dz pair of this thread (columns 0 / 1)
+  // one staging item: k = 0..3 column nu = k of V = B^T d B (x transform of this lane's patch row, then the y
+  // transform with ONE other row of the quad:  xi = 0: e(0) - e(2)  xi = 1: e(1) + e(2)  xi = 2: e(2) - e(1)
+  // xi = 3: e(1) - e(3), lane r = xi owns e(r));  k = 4..7 column b = k - 4 of Z = A dy A^T
+  auto write_piece = [&](int k, float* Vs, float* Zs) {
+    if (!st_on) return;   // wave-uniform
+    if (k < 4) {
+      const int nu = k;
+      const float4 pl = nu == 0 ? rv[0] : nu == 2 ? rv[2] : rv[1];
+      const float4 pr = nu == 0 ? rv[2] : nu == 2 ? rv[1] : nu == 1 ? rv[2] : rv[3];
+      const float sg = nu == 1 ? 1.f : -1.f;
+      const float e0 = pl.x + sg * pr.x, e1 = pl.y + sg * pr.y, e2 = pl.z + sg * pr.z, e3 = pl.w + sg * pr.w;
+      *reinterpret_cast<float4*>(Vs + st * TS + (vr * 4 + nu) * CS + vq * 4) =
+          f4(so * e0 + sps * QP2(e0), so * e1 + sps * QP2(e1), so * e2 + sps * QP2(e2), so * e3 + sps * QP2(e3));
+    } else {
+      const int b = k - 4;
+      if (b == 0) {
+        zr0 = f4(zc0 * rz[0].x + zc1 * rz[2].x, zc0 * rz[0].y + zc1 * rz[2].y, zc0 * rz[0].z + zc1 * rz[2].z, zc0 * rz[0].w + zc1 * rz[2].w);
+        zr1 = f4(zc0 * rz[1].x + zc1 * rz[3].x, zc0 * rz[1].y + zc1 * rz[3].y, zc0 * rz[1].z + zc1 * rz[3].z, zc0 * rz[1].w + zc1 * rz[3].w);
       }
-    }
-    // Z = A dy A^T: this thread's two row-transform indices a = 2 zh, 2 zh + 1, all four column indices
-    if (zt < UT) {
-      const float4 y00 = rz[0], y01 = rz[1], y10 = rz[2], y11 = rz[3];
-      float4 ra0, ra1, rb0, rb1;   // rows a = 2 zh (ra) and 2 zh + 1 (rb), columns 0 / 1
-      if (zh == 0) {
-        ra0 = y00; ra1 = y01;
-        rb0 = f4(y00.x + y10.x, y00.y + y10.y, y00.z + y10.z, y00.w + y10.w);
-        rb1 = f4(y01.x + y11.x, y01.y + y11.y, y01.z + y11.z, y01.w + y11.w);
-      } else {
-        ra0 = f4(y00.x - y10.x, y00.y - y10.y, y00.z - y10.z, y00.w - y10.w);
-        ra1 = f4(y01.x - y11.x, y01.y - y11.y, y01.z - y11.z, y01.w - y11.w);
-        rb0 = f4(-y10.x, -y10.y, -y10.z, -y10.w);
-        rb1 = f4(-y11.x, -y11.y, -y11.z, -y11.w);
-      }
-      float* dst = Zs + zt * TS + (zh * 8) * CS + zq * 4;
-      *reinterpret_cast<float4*>(dst + 0 * CS) = ra0;
-      *reinterpret_cast<float4*>(dst + 1 * CS) = f4(ra0.x + ra1.x, ra0.y + ra1.y, ra0.z + ra1.z, ra0.w + ra1.w);
-      *reinterpret_cast<float4*>(dst + 2 * CS) = f4(ra0.x - ra1.x, ra0.y - ra1.y, ra0.z - ra1.z, ra0.w - ra1.w);
-      *reinterpret_cast<float4*>(dst + 3 * CS) = f4(-ra1.x, -ra1.y, -ra1.z, -ra1.w);
-      *reinterpret_cast<float4*>(dst + 4 * CS) = rb0;
-      *reinterpret_cast<float4*>(dst + 5 * CS) = f4(rb0.x + rb1.x, rb0.y + rb1.y, rb0.z + rb1.z, rb0.w + rb1.w);
-      *reinterpret_cast<float4*>(dst + 6 * CS) = f4(rb0.x - rb1.x, rb0.y - rb1.y, rb0.z - rb1.z, rb0.w - rb1.w);
-      *reinterpret_cast<float4*>(dst + 7 * CS) = f4(-rb1.x, -rb1.y, -rb1.z, -rb1.w);
+      const float4 o = b == 0 ? zr0
+                     : b == 1 ? f4(zr0.x + zr1.x, zr0.y + zr1.y, zr0.z + zr1.z, zr0.w + zr1.w)
+                     : b == 2 ? f4(zr0.x - zr1.x, zr0.y - zr1.y, zr0.z - zr1.z, zr0.w - zr1.w)
+                              : f4(-zr1.x, -zr1.y, -zr1.z, -zr1.w);
+      *reinterpret_cast<float4*>(Zs + st * TS + (za * 4 + b) * CS + zq * 4) = o;
     }
   };
-#undef QP2
+#define SBW __builtin_amdgcn_sched_barrier(0)
 
-  if (u_begin < u_end) {
-    stage_prepare();
+  // prologue: unit u_begin -> buffer 0, unit u_begin + 1 -> registers
+  stage_prepare();
 #pragma unroll
-    for (int k = 0; k < NPIECE; ++k) load_piece(k);
-    stage_write(0);
-  }
+  for (int k = 0; k < 8; ++k) load_piece(k);
+  SBW;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) write_piece(k, Vs0, Zs0);
+  SBW;
+  stage_prepare();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) load_piece(k);
+  SBW;
   __syncthreads();
   WSTAMP(a.stamps, 2, "s_memtime");
 
-  // per-lane bases: step s covers tiles 2 s + hi; component c at + c * CS
-  const int vbase = g.hi * TS + g.wi * 32 + g.l31;
-  const int zbase = g.hi * TS + g.wj * 32 + g.l31;
+  // per-lane bases: step s covers tiles 2 s + hi; component 8 wh + c at + c * CS
+  const int vbase = hi * TS + (8 * wh) * CS + wi * 32 + l31;
+  const int zbase = hi * TS + (8 * wh) * CS + wj * 32 + l31;
   int buf = 0;
 #ifdef NODE_STAMPS
   unsigned long long tk_prev, tk_acc[4] = {0, 0, 0, 0};
@@ -575,40 +551,43 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
   for (int u = u_begin; u < u_end; ++u) {
     const float* Vs = Vs0 + buf * IMG + vbase;
     const float* Zs = Zs0 + buf * IMG + zbase;
-    const bool more = (u + 1) < u_end;
-    // unit u + 1 (the last unit re-requests its own successor-less position: harmless, and every request
-    // stays unconditional)
-    if (more) stage_prepare();
-    WTICK(0);
+    float* Vw = Vs0 + (buf ^ 1) * IMG;
+    float* Zw = Zs0 + (buf ^ 1) * IMG;
 
-    float av[2][16], bv[2][16];
+    float av[2][8], bv[2][8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < 8; ++c) {
       av[0][c] = Vs[c * CS];
       bv[0][c] = Zs[c * CS];
     }
     constexpr int NS = UT / 2;
-    constexpr int GAP = (NS * 16) / NPIECE >= 4 ? 2 : 1;   // MFMAs between two requests: all issued in the first half of
-                                                           // the unit, so that the last one has ~2000 cycles to land
+    constexpr int M = NS * 8;          // MFMAs per unit and wave
+    constexpr int WGAP = (M / 2) / 8;  // MFMAs between two staging items (2 for UT = 8, 1 for UT = 4)
+    WTICK(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
       const int sn = s + 1 < NS ? s + 1 : s;           // (last step re-reads itself: no branch)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
+      for (int c = 0; c < 8; ++c) {
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][c], bv[cur][c], acc[c], 0, 0, 0);
         av[nxt][c] = Vs[2 * sn * TS + c * CS];
         bv[nxt][c] = Zs[2 * sn * TS + c * CS];
-        const int m = s * 16 + c;
-        if (m % GAP == GAP / 2 && m / GAP < NPIECE) load_piece(m / GAP);
-        __builtin_amdgcn_sched_barrier(0);
+        const int m = s * 8 + c;
+        if (m < M / 2) {            // first half: unit u + 1 goes from the registers to the other buffer
+          if (m % WGAP == 0) write_piece(m / WGAP, Vw, Zw);
+        } else {                    // second half: unit u + 2 is requested into the registers just freed
+          if (m == M / 2) stage_prepare();
+          if ((m - M / 2) % WGAP == 0) load_piece((m - M / 2) / WGAP);
+        }
+        SBW;
       }
     }
     WTICK(1);
-    if (more) stage_write(buf ^ 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SBW;
     WTICK(2);
-    __syncthreads();
-    WTICK(3);
     buf ^= 1;
   }
 #ifdef NODE_STAMPS
@@ -618,29 +597,61 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
 #endif
 #undef WTICK0
 #undef WTICK
+#undef QP2
+#undef SBW
   WSTAMP(a.stamps, 3, "s_memtime");
-  // dW = G^T M G, element by element so that only nine results are live next to the sixteen accumulators
-  f32x16 wacc[9];
+
+  // ---- dW = G^T M G.  Column transform (b -> kw) and this wave's share of the row transform (a -> kh) in
+  //      registers; the two halves of a block meet in LDS: wave wh finishes and stores rows r in [8 wh, 8 wh + 8).
+  //      G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1] ----
+  float* X = smem + ((wi * 2 + wj) * 2) * (72 * 64);   // [destination half][9 taps x 8 rows][64 lanes]
+  float own[72];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float t[4][3];
+    float t[2][3];
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-      const float m0 = acc[aa * 4 + 0][r], m1 = acc[aa * 4 + 1][r], m2 = acc[aa * 4 + 2][r], m3 = acc[aa * 4 + 3][r];
+    for (int al = 0; al < 2; ++al) {
+      const float m0 = acc[al * 4 + 0][r], m1 = acc[al * 4 + 1][r], m2 = acc[al * 4 + 2][r], m3 = acc[al * 4 + 3][r];
       const float hs = 0.5f * (m1 + m2);
-      t[aa][0] = m0 + hs;
-      t[aa][1] = 0.5f * (m1 - m2);
-      t[aa][2] = m3 + hs;
+      t[al][0] = m0 + hs;
+      t[al][1] = 0.5f * (m1 - m2);
+      t[al][2] = m3 + hs;
     }
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const float hs = 0.5f * (t[1][kw] + t[2][kw]);
-      wacc[0 * 3 + kw][r] = t[0][kw] + hs;
-      wacc[1 * 3 + kw][r] = 0.5f * (t[1][kw] - t[2][kw]);
-      wacc[2 * 3 + kw][r] = t[3][kw] + hs;
+      float p0, p1, p2;
+      if (wh == 0) {   // a = 0, 1
+        p0 = t[0][kw] + 0.5f * t[1][kw]; p1 = 0.5f * t[1][kw]; p2 = 0.5f * t[1][kw];
+      } else {         // a = 2, 3
+        p0 = 0.5f * t[0][kw]; p1 = -0.5f * t[0][kw]; p2 = 0.5f * t[0][kw] + t[1][kw];
+      }
+      const bool mine = (r >> 3) == wh;   // wave-uniform per unrolled r
+      const int rr = r & 7;
+      if (mine) {
+        own[(0 * 3 + kw) * 8 + rr] = p0; own[(1 * 3 + kw) * 8 + rr] = p1; own[(2 * 3 + kw) * 8 + rr] = p2;
+      } else {
+        float* dst = X + (1 - wh) * (72 * 64) + lane;
+        dst[((0 * 3 + kw) * 8 + rr) * 64] = p0; dst[((1 * 3 + kw) * 8 + rr) * 64] = p1; dst[((2 * 3 + kw) * 8 + rr) * 64] = p2;
+      }
     }
   }
-  wg_store_slab<9>(a, d, g, wacc);
+  __syncthreads();
+  {
+    const size_t CC = (size_t)d.C * d.C;
+    float* wp = a.wpart + (size_t)sp * 9 * CC;
+    const int co = co0 + wj * 32 + l31;
+    const float* src = X + wh * (72 * 64) + lane;
+    if (co < d.C) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = 8 * wh + rr;
+          const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (ci < d.C) wp[(size_t)t * CC + (size_t)ci * d.C + co] = own[t * 8 + rr] + src[(t * 8 + rr) * 64];
+        }
+    }
+  }
   WSTAMP(a.stamps, 4, "s_memtime");
   WSTAMP(a.stamps, 5, "s_memrealtime");
 }
@@ -923,8 +934,8 @@ template <int UT>
 static void launch_wgrad_w2(const Dims& d, const WgradArgs& a, dim3 grid, hipStream_t s) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_w2<UT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  const size_t lds = (size_t)(4 * UT * 16 * 68) * sizeof(float);
-  hipLaunchKernelGGL((k_wgrad_w2<UT>), grid, dim3(WG_THREADS), lds, s, a, d);
+  const size_t lds_loop = (size_t)(4 * UT * 16 * 68) * sizeof(float), lds_x = (size_t)8 * 72 * 64 * sizeof(float);
+  hipLaunchKernelGGL((k_wgrad_w2<UT>), grid, dim3(WG2_THREADS), lds_loop > lds_x ? lds_loop : lds_x, s, a, d);
 }
 
 template <int W, int RB>

@@ -151,7 +151,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // weight gradient in the Winograd domain where an instance of k_wgrad_w exists (W % 4 == 0)
     static int ww_env = -2;
     if (ww_env == -2) { const char* e = getenv("NODE_TUNE_WGRAD_WINO"); ww_env = e ? atoi(e) : -1; }
-    const int want = g_wgrad_wino >= 0 ? g_wgrad_wino : (ww_env >= 0 ? ww_env : 1);
+    const int want = g_wgrad_wino >= 0 ? g_wgrad_wino : (ww_env >= 0 ? ww_env : 2);
     d.wgrad_wino = 0;
     d.wut = 0;
     if (want && ((d.W == 8 && d.H % 8 == 0) || (d.W == 16 && d.H % 2 == 0) || (d.W == 4 && d.H % 4 == 0))) {
