@@ -941,6 +941,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
+  // (An XCD-aware tile order was measured: one column tile per XCD keeps its filter slice L2-resident but
+  // fetches the activations four times; HBM traffic and time were unchanged -- 50.7 MB, 58 us -- so launch order
+  // stays: the four column tiles of a pixel tile share an XCD and read the activations once.)
   const int mtile = blockIdx.x, nt = blockIdx.y;
   const int n0 = mtile * d.S;
   const int c0 = nt * d.BNE;

@@ -630,50 +630,53 @@ void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {
 // by the wgrad GEMM and the GroupNorm-backward epilogues into one vector in the
 // internal theta layout, times osign (= tsign, the reverse-time negation).
 // ============================================================================
-// Bulk of the vector: the two conv-weight blocks, out[r] = osign * sum_sp wpart[sp][r], as float4 with
-// four slabs in flight per thread (the split-K slabs are 16 x 2.36 MB at C = 256: this pass is HBM-bound).
-__global__ __launch_bounds__(256) void k_theta_wsum(ThetaFinalizeArgs a, Dims d) {
-  const ThetaLayout L = theta_layout(d.C);
-  const size_t CC = (size_t)d.C * d.C;
-  const size_t n4 = 9 * CC / 4;   // C % 4 == 0
-  const int layer = blockIdx.y;
-  const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
-  float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int sp = 0;
-    for (; sp + 4 <= d.nsplit; sp += 4) {
-      const float4 v0 = wp[(size_t)sp * n4 + i], v1 = wp[(size_t)(sp + 1) * n4 + i];
-      const float4 v2 = wp[(size_t)(sp + 2) * n4 + i], v3 = wp[(size_t)(sp + 3) * n4 + i];
-      acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
-      acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
-    }
-    for (; sp < d.nsplit; ++sp) {
-      const float4 v = wp[(size_t)sp * n4 + i];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    out[i] = make_float4(a.osign * acc.x, a.osign * acc.y, a.osign * acc.z, a.osign * acc.w);
-  }
-}
-
-// The small pieces (26 C values): GroupNorm affine gradients, time-channel taps, conv biases -- column
-// sums of short matrices ([rows][2C] per-tile GroupNorm partials, [N][9C] per-sample masked dz sums).
-// blockIdx.y = job (0..2: GroupNorm layer; 3, 4: conv layer), blockIdx.x = 64-column chunk; the 256
-// threads are 64 columns x 4 row groups, four loads in flight each.
-__global__ __launch_bounds__(256) void k_theta_small(ThetaFinalizeArgs a, Dims d) {
+// ONE launch (a kernel on this box costs >= 5 us however little it does, and this used to be three):
+//   blockIdx.y = 0, 1: bulk of the vector, the two conv-weight blocks, out[r] = osign * sum_sp wpart[sp][r], as
+//     float4 with four slabs in flight per thread (the split-K slabs are 16 x 2.36 MB at C = 256: HBM-bound);
+//   blockIdx.y = 2..6: the small pieces (26 C values): GroupNorm affine gradients (jobs 0..2), time-channel taps
+//     and conv biases (jobs 3, 4) -- column sums of short matrices ([rows][2C] per-tile GroupNorm partials,
+//     [N][9C] per-sample masked dz sums); blockIdx.x = 64-column chunk, 64 columns x 4 row groups per workgroup;
+//   vjp_t = sum_layers sum_{tap,co} W[co][0][tap] * S[tap][co]  (d conv / d t = time-channel border map): each
+//     conv-job workgroup leaves the dot product of its 64 columns in a.sred's tail, the last one to arrive
+//     (agent-scope fences around a device counter) adds them in a fixed order -- deterministic.
+__global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dims d) {
   __shared__ float red[256];
+  __shared__ int s_last;
   const ThetaLayout L = theta_layout(d.C);
-  const int job = blockIdx.y;
   const int C = d.C;
+  if (blockIdx.y < 2) {
+    const size_t CC = (size_t)C * C;
+    const size_t n4 = 9 * CC / 4;   // C % 4 == 0
+    const int layer = blockIdx.y;
+    const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
+    float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int sp = 0;
+      for (; sp + 4 <= d.nsplit; sp += 4) {
+        const float4 v0 = wp[(size_t)sp * n4 + i], v1 = wp[(size_t)(sp + 1) * n4 + i];
+        const float4 v2 = wp[(size_t)(sp + 2) * n4 + i], v3 = wp[(size_t)(sp + 3) * n4 + i];
+        acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+        acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; sp < d.nsplit; ++sp) {
+        const float4 v = wp[(size_t)sp * n4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      out[i] = make_float4(a.osign * acc.x, a.osign * acc.y, a.osign * acc.z, a.osign * acc.w);
+    }
+    return;
+  }
+  const int job = blockIdx.y - 2;
   const bool gn = job < 3;
   const int layer = gn ? job : job - 3;
   const int ncol = gn ? 2 * C : 9 * C;
+  if ((int)blockIdx.x * 64 >= ncol) return;
   const int rows = gn ? a.gpart_rows[layer] : d.N;
   const float* src = gn ? a.gpart[layer] : a.spart[layer];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  if (blockIdx.x * 64 >= ncol) return;
   float v = 0.f;
   if (col < ncol) {
     int r = rg;
@@ -686,30 +689,38 @@ __global__ __launch_bounds__(256) void k_theta_small(ThetaFinalizeArgs a, Dims d
   }
   red[threadIdx.x] = v;
   __syncthreads();
-  if (rg != 0 || col >= ncol) return;
+  if (rg != 0) return;          // the first wave finishes the job
+  const bool on = col < ncol;
   v = (red[cl] + red[64 + cl]) + (red[128 + cl] + red[192 + cl]);
   if (gn) {   // columns [0, C) = dgamma, [C, 2C) = dbeta
-    const int which = col >= C ? 1 : 0;
-    a.theta_out[(which ? L.b[layer] : L.g[layer]) + (col - which * C)] = a.osign * v;
-  } else {    // column = tap * C + co
-    a.sred[(size_t)layer * 9 * C + col] = v;                         // reused by k_vjp_t
+    if (on) {
+      const int which = col >= C ? 1 : 0;
+      a.theta_out[(which ? L.b[layer] : L.g[layer]) + (col - which * C)] = a.osign * v;
+    }
+    return;
+  }
+  // column = tap * C + co
+  if (on) {
     a.theta_out[L.wt[layer] + col] = a.osign * (v * eval_time(a.et));  // time-channel taps: t * masked sums
     if (col >= 4 * C && col < 5 * C) a.theta_out[L.cb[layer] + (col - 4 * C)] = a.osign * v;  // conv bias = centre tap
   }
-}
-
-// vjp_t = sum_layers sum_{tap,co} W[co][0][tap] * S[tap][co]   (d conv / d t = time-channel border map)
-__global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
-  __shared__ float red[4];
-  float acc = 0.f;
-  const int C = d.C;
-  for (int layer = 0; layer < 2; ++layer) {
-    const float* sr = a.sred + (size_t)layer * 9 * C;
-    const float* wt = a.wtime[layer];   // [tap][co], gathered once per solve (k_wtime)
-    for (int i = threadIdx.x; i < 9 * C; i += 256) acc += sr[i] * wt[i];
+  const int nb = (9 * C + 63) / 64;                    // conv-job workgroups per layer
+  float* dotpart = a.sred + (size_t)2 * 9 * C;         // [2][nb] partial dot products, then the arrival counter
+  unsigned* counter = reinterpret_cast<unsigned*>(dotpart + 2 * nb);
+  const float part = wave_sum(on ? v * a.wtime[layer][col] : 0.f);   // wtime: [tap][co], gathered once per solve (k_wtime)
+  if (cl == 0) {
+    dotpart[layer * nb + blockIdx.x] = part;
+    __threadfence();                                   // release: the partial is out of this XCD's L2 before the count
+    s_last = atomicAdd(counter, 1u) == (unsigned)(2 * nb - 1);
   }
-  const float tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) {
+  __builtin_amdgcn_wave_barrier();
+  if (!s_last) return;                                  // (one wave: LDS write above is visible after the wave barrier)
+  __threadfence();                                      // acquire: drop stale lines before reading the others' partials
+  float tot = 0.f;
+  for (int i = cl; i < 2 * nb; i += 64) tot += __builtin_nontemporal_load(dotpart + i);
+  tot = wave_sum(tot);
+  if (cl == 0) {
+    *counter = 0u;                                      // ready for the next launch (stream order)
     if (a.write_scalar) a.ctrl->ts_k[a.kidx] = a.osign * tot;
     if (a.vjp_t_out) *a.vjp_t_out = a.osign * tot;
   }
@@ -718,9 +729,9 @@ __global__ __launch_bounds__(256) void k_vjp_t(ThetaFinalizeArgs a, Dims d) {
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s) {
   size_t wblocks = (9 * (size_t)d.C * d.C / 4 + 255) / 256;
   if (wblocks > 1024) wblocks = 1024;
-  hipLaunchKernelGGL(k_theta_wsum, dim3((unsigned)wblocks, 2), dim3(256), 0, s, a, d);
-  hipLaunchKernelGGL(k_theta_small, dim3((unsigned)((9 * d.C + 63) / 64), 5), dim3(256), 0, s, a, d);
-  hipLaunchKernelGGL(k_vjp_t, dim3(1), dim3(256), 0, s, a, d);
+  const size_t nsmall = (9 * (size_t)d.C + 63) / 64;
+  if (wblocks < nsmall) wblocks = nsmall;
+  hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)wblocks, 7), dim3(256), 0, s, a, d);
 }
 
 // out = y + scale * sum_j coef_j k_j   (flat; fixed-grid solver's end-of-step update)

@@ -263,7 +263,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
       p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
       p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
     }
-    p.sred = b.take<float>((size_t)2 * 9 * d.C);
+    p.sred = b.take<float>((size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64) + 4);   // + vjp_t partials + arrival counter
     for (int i = 0; i < 2; ++i) p.wtime[i] = b.take<float>((size_t)9 * d.C);
     p.gpart[0] = b.take<float>((size_t)d.mtiles * 2 * d.C);
     p.gpart[1] = b.take<float>((size_t)d.mtiles * 2 * d.C);
@@ -323,6 +323,8 @@ struct Solver {
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
+    if (aug)   // arrival counter of k_theta_finalize
+      HIP_TRY(hipMemsetAsync(p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64), 0, sizeof(unsigned), st));
     if (d.wino == 2 || d.wgrad_wino == 2) {   // zero tails of the conv inputs (see make_plan)
       HIP_TRY(hipMemsetAsync(p.act1 + d.numel, 0, d.C * sizeof(float), st));
       HIP_TRY(hipMemsetAsync(p.act2 + d.numel, 0, d.C * sizeof(float), st));
