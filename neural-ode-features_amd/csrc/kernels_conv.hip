@@ -267,7 +267,26 @@ __device__ inline void conv_epilogue_tail(const ConvArgs& a, const Dims& d, floa
           for (int i = 0; i < 4; ++i)
             if (okq[i]) a.out[off + i] = o[i];
         }
+        if (a.spart) {   // keep the finished tile for the column sums below (same thread read these four entries)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Ct[row * CT2 + colq + i] = okq[i] ? o[i] : 0.f;
+        }
       }
+    }
+    if (a.spart) {
+      // masked column sums of the data gradient this tile just produced (it is the next layer's dz): saves a
+      // k_colsum launch and its pass over the tensor.  Xt is free now: border flags, then the reduction scratch.
+      __syncthreads();
+      unsigned char* flg = reinterpret_cast<unsigned char*>(Xt);
+      float* red9 = Xt + 64;   // HW <= BM <= 256 bytes of flags
+      for (int p = tid; p < d.HW; p += THREADS) {
+        const int h = p / d.W, x = p - h * d.W;
+        flg[p] = (unsigned char)((h == 0 ? 1 : 0) | (h == d.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == d.W - 1 ? 8 : 0));
+      }
+      __syncthreads();
+      for (int s = 0; s < nsamp; ++s)
+        masked_colsum_tile(Ct + (s * d.HW) * CT2, CT2, d.HW, flg, ncols, max(1, min(min(THREADS / ncols, 8), (BM * CT2 - 64) / (9 * ncols))), tid, red9,
+                           a.spart + (size_t)(n0 + s) * 9 * d.C + c0, d.C);
     }
   }
 }

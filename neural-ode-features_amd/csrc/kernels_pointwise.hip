@@ -164,6 +164,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
   float* sm1 = xt + d.HW * d.cs;              // [cs]
   float* sm2 = sm1 + d.cs;                    // [cs]
   float* cred = sm2 + d.cs;                   // [256][2] channel partials
+  float* red9 = cred + 512;                   // [9 * 256] masked column sums across pixel groups
+  unsigned char* flg = reinterpret_cast<unsigned char*>(red9 + 9 * 256);   // [HW] border flags
+  if (a.spart)
+    for (int p = tid; p < d.HW; p += 256) {
+      const int h = p / d.W, x = p - h * d.W;
+      flg[p] = (unsigned char)((h == 0 ? 1 : 0) | (h == d.H - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == d.W - 1 ? 8 : 0));
+    }
 
   const float scale = comb_scale(a.comb, a.ctrl);
   float cf[7];
@@ -257,11 +264,20 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
       o[i] = r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]);
     }
     st4(a.dz_out + off, make_float4(o[0], o[1], o[2], o[3]));
+    if (a.spart) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums below
+  }
+  if (a.spart) {   // masked column sums of this sample's dz slab while it is still in LDS (replaces a k_colsum launch)
+    __syncthreads();
+    for (int cbase = 0; cbase < csl; cbase += 256) {
+      const int ncols = min(csl - cbase, 256);
+      masked_colsum_tile(gt + cbase, csl, d.HW, flg, ncols, max(1, 256 / ncols), tid, red9,
+                         a.spart + (size_t)n * 9 * d.C + c0 + cbase, d.C);
+    }
   }
 }
 
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
-  size_t lds = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs + 512) * sizeof(float);
+  size_t lds = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs + 512 + 9 * 256) * sizeof(float) + (size_t)d.HW + 16;
   hipLaunchKernelGGL(k_gn_bwd, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
 }
 

@@ -399,9 +399,12 @@ struct Solver {
     memset(&g, 0, sizeof(g));
     g.comb = ca; g.ctrl = p.ctrl; g.csign = csign; g.a_out = a_out;
     g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2];
+    static int fuse_colsum = -1;   // NODE_TUNE_FUSE_COLSUM=0: separate k_colsum launches (A/B measurements)
+    if (fuse_colsum < 0) { const char* e = getenv("NODE_TUNE_FUSE_COLSUM"); fuse_colsum = e ? atoi(e) : 1; }
+    g.spart = fuse_colsum ? p.spart[1] : nullptr;   // masked column sums of dz2, fused (k_colsum otherwise)
     launch_gn_bwd(d, g, st);
+    if (!fuse_colsum) launch_colsum(d, p.dz2, p.spart[1], st);
 
-    launch_colsum(d, p.dz2, p.spart[1], st);
     WgradArgs w2;
     memset(&w2, 0, sizeof(w2));
     w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
@@ -412,15 +415,17 @@ struct Solver {
     b2.in = p.dz2; b2.wpacked = p.wd[1]; b2.mode = CM_BWD_RELU_GN; b2.et = et;
     b2.gamma = prm.norm2_w; b2.osign = 1.f; b2.out = p.dz1;
     b2.act = p.act2; b2.xhat = p.xh2; b2.rstd = p.r2; b2.gpart = p.gpart[1];
+    b2.spart = fuse_colsum ? p.spart[0] : nullptr;   // masked column sums of dz1, fused into the epilogue
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b2, st); }
+    if (!fuse_colsum) launch_colsum(d, p.dz1, p.spart[0], st);
 
-    launch_colsum(d, p.dz1, p.spart[0], st);
     WgradArgs w1;
     memset(&w1, 0, sizeof(w1));
     w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0];
     { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
 
     ConvArgs b1 = b2;
+    b1.spart = nullptr;
     b1.in = p.dz1; b1.wpacked = p.wd[0];
     b1.gamma = prm.norm1_w; b1.osign = et.tsign; b1.out = kA_out;
     b1.act = p.act1; b1.xhat = p.xh1; b1.rstd = p.r1; b1.gpart = p.gpart[0];

@@ -131,6 +131,59 @@ struct CombineGnArgs {
 };
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s);
 
+// Masked column sums of one sample's [HW][cols] tile held in LDS (row stride `ld`):
+//   out[tap][c] = sum of v[p][c] over the pixels p whose tap neighbour p + tap lies inside the image
+// (the conv-bias gradient is tap 4; t x these are the time-channel weight gradients; their contraction with the
+// time-channel weights is d f / d t).  Nine inclusion-exclusion terms from: total, first/last row, first/last
+// column, four corners.  Producers of dz call it on the tile they are about to store, which saves a launch and
+// a pass over dz per layer (k_colsum is what runs otherwise).  `flg[p]`: bit0 first row, bit1 last row, bit2
+// first column, bit3 last column.  Threads = ncols x ngrp (column fastest); `red` holds ngrp * 9 * ncols floats.
+// Call with all threads of the workgroup; contains two barriers.
+__device__ inline void masked_colsum_tile(const float* tile, int ld, int HW, const unsigned char* flg, int ncols,
+                                          int ngrp, int tid, float* red, float* out, int out_ld) {
+  const int cl = tid % ncols, pg = tid / ncols;
+  if (pg < ngrp) {
+    float T = 0.f, rf = 0.f, rl = 0.f, cf = 0.f, cl_ = 0.f, k00 = 0.f, k01 = 0.f, k10 = 0.f, k11 = 0.f;
+    for (int p = pg; p < HW; p += ngrp) {
+      const float v = tile[p * ld + cl];
+      const int f = flg[p];
+      T += v;
+      if (f & 1) rf += v;
+      if (f & 2) rl += v;
+      if (f & 4) cf += v;
+      if (f & 8) cl_ += v;
+      if ((f & 5) == 5) k00 += v;
+      if ((f & 9) == 9) k01 += v;
+      if ((f & 6) == 6) k10 += v;
+      if ((f & 10) == 10) k11 += v;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {   // tap (kh, kw) excludes the first (k == 0) / last (k == 2) row and column
+      const int kh = t / 3, kw = t % 3;
+      float o = T;
+      if (kh == 0) o -= rf;
+      if (kh == 2) o -= rl;
+      if (kw == 0) o -= cf;
+      if (kw == 2) o -= cl_;
+      if (kh == 0 && kw == 0) o += k00;
+      if (kh == 0 && kw == 2) o += k01;
+      if (kh == 2 && kw == 0) o += k10;
+      if (kh == 2 && kw == 2) o += k11;
+      red[(pg * 9 + t) * ncols + cl] = o;
+    }
+  }
+  __syncthreads();
+  if (pg == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float o = red[t * ncols + cl];
+      for (int r = 1; r < ngrp; ++r) o += red[(r * 9 + t) * ncols + cl];
+      out[(size_t)t * out_ld + cl] = o;
+    }
+  }
+  __syncthreads();
+}
+
 struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN_bwd(g)
   Comb comb;
   const Ctrl* ctrl;
@@ -141,6 +194,7 @@ struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN
   const float* gamma;
   float* dz_out;
   float* gpart;        // [N][2][C] per-sample (dgamma, dbeta) partials
+  float* spart;        // nullable: [N][9][C] masked column sums of dz_out (see masked_colsum_tile)
 };
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s);
 
@@ -214,6 +268,7 @@ struct ConvArgs {
   const float* xhat;      // [N,HW,C]
   const float* rstd;      // [N][G]
   float* gpart;           // [mtiles][2][C]
+  float* spart;           // bwd, nullable: [N][9][C] masked column sums of the output (see masked_colsum_tile)
   unsigned long long* stamps;  // diagnostics only (NODE_STAMPS builds); nullptr otherwise
   int ablate;                  // diagnostics only (NODE_STAMPS builds): timing-only ablation bits
 };
