@@ -647,11 +647,11 @@ void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {
 // internal theta layout, times osign (= tsign, the reverse-time negation).
 // ============================================================================
 // ONE launch (a kernel on this box costs >= 5 us however little it does, and this used to be three):
-//   blockIdx.y = 0, 1: bulk of the vector, the two conv-weight blocks, out[r] = osign * sum_sp wpart[sp][r], as
+//   bulk of the vector (the last 2 x wb workgroups): the two conv-weight blocks, out[r] = osign * sum_sp wpart[sp][r], as
 //     float4 with four slabs in flight per thread (the split-K slabs are 16 x 2.36 MB at C = 256: HBM-bound);
-//   blockIdx.y = 2..6: the small pieces (26 C values): GroupNorm affine gradients (jobs 0..2), time-channel taps
+//   the small pieces (the first 5 x nsm workgroups; 26 C values): GroupNorm affine gradients (jobs 0..2), time-channel taps
 //     and conv biases (jobs 3, 4) -- column sums of short matrices ([rows][2C] per-tile GroupNorm partials,
-//     [N][9C] per-sample masked dz sums); blockIdx.x = 64-column chunk, 64 columns x 4 row groups per workgroup;
+//     [N][9C] per-sample masked dz sums); one 64-column chunk, 64 columns x 4 row groups, per workgroup;
 //   vjp_t = sum_layers sum_{tap,co} W[co][0][tap] * S[tap][co]  (d conv / d t = time-channel border map): each
 //     conv-job workgroup leaves the dot product of its 64 columns in a.sred's tail, the last one to arrive
 //     (agent-scope fences around a device counter) adds them in a fixed order -- deterministic.
@@ -660,14 +660,19 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
   __shared__ int s_last;
   const ThetaLayout L = theta_layout(d.C);
   const int C = d.C;
-  if (blockIdx.y < 2) {
+  // linear grid: [5 jobs x nsm column chunks of the small pieces][2 layers x wb blocks of the bulk sums] -- the small
+  // jobs first, so that their arrival chain overlaps the bulk; no workgroup is launched just to exit
+  const int nsm = (9 * C + 63) / 64;
+  const int bx_all = blockIdx.x;
+  const int wb = ((int)gridDim.x - 5 * nsm) / 2;
+  if (bx_all >= 5 * nsm) {
+    const int layer = (bx_all - 5 * nsm) / wb, bx = (bx_all - 5 * nsm) - layer * wb;
     const size_t CC = (size_t)C * C;
     const size_t n4 = 9 * CC / 4;   // C % 4 == 0
-    const int layer = blockIdx.y;
     const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
     float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const size_t stride = (size_t)wb * 256;
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n4; i += stride) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       int sp = 0;
       for (; sp + 4 <= d.nsplit; sp += 4) {
@@ -684,15 +689,15 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
     }
     return;
   }
-  const int job = blockIdx.y - 2;
+  const int job = bx_all / nsm, bxs = bx_all - job * nsm;
   const bool gn = job < 3;
   const int layer = gn ? job : job - 3;
   const int ncol = gn ? 2 * C : 9 * C;
-  if ((int)blockIdx.x * 64 >= ncol) return;
+  if (bxs * 64 >= ncol) return;
   const int rows = gn ? a.gpart_rows[layer] : d.N;
   const float* src = gn ? a.gpart[layer] : a.spart[layer];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cl;
+  const int col = bxs * 64 + cl;
   float v = 0.f;
   if (col < ncol) {
     int r = rg;
@@ -724,19 +729,21 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
   float* dotpart = a.sred + (size_t)2 * 9 * C;         // [2][nb] partial dot products, then the arrival counter
   unsigned* counter = reinterpret_cast<unsigned*>(dotpart + 2 * nb);
   const float part = wave_sum(on ? v * a.wtime[layer][col] : 0.f);   // wtime: [tap][co], gathered once per solve (k_wtime)
+  // Hand-off without fences: an agent-scope release here would write back this XCD's whole L2, which is full of
+  // the wgrad slabs' dirty lines (measured: +12 us on the launch).  The partial is an agent-scope (write-through)
+  // store, acknowledged (vmcnt(0)) before the agent-scope count; the last arriver reads with agent-scope loads.
   if (cl == 0) {
-    dotpart[layer * nb + blockIdx.x] = part;
-    __threadfence();                                   // release: the partial is out of this XCD's L2 before the count
-    s_last = atomicAdd(counter, 1u) == (unsigned)(2 * nb - 1);
+    __hip_atomic_store(dotpart + layer * nb + bxs, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(2 * nb - 1);
   }
   __builtin_amdgcn_wave_barrier();
   if (!s_last) return;                                  // (one wave: LDS write above is visible after the wave barrier)
-  __threadfence();                                      // acquire: drop stale lines before reading the others' partials
   float tot = 0.f;
-  for (int i = cl; i < 2 * nb; i += 64) tot += __builtin_nontemporal_load(dotpart + i);
+  for (int i = cl; i < 2 * nb; i += 64) tot += __hip_atomic_load(dotpart + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   tot = wave_sum(tot);
   if (cl == 0) {
-    *counter = 0u;                                      // ready for the next launch (stream order)
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order)
     if (a.write_scalar) a.ctrl->ts_k[a.kidx] = a.osign * tot;
     if (a.vjp_t_out) *a.vjp_t_out = a.osign * tot;
   }
@@ -746,8 +753,7 @@ void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_
   size_t wblocks = (9 * (size_t)d.C * d.C / 4 + 255) / 256;
   if (wblocks > 1024) wblocks = 1024;
   const size_t nsmall = (9 * (size_t)d.C + 63) / 64;
-  if (wblocks < nsmall) wblocks = nsmall;
-  hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)wblocks, 7), dim3(256), 0, s, a, d);
+  hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)(5 * nsmall + 2 * wblocks)), dim3(256), 0, s, a, d);
 }
 
 // out = y + scale * sum_j coef_j k_j   (flat; fixed-grid solver's end-of-step update)
