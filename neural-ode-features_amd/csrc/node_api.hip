@@ -117,7 +117,10 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // co-resident 64-row workgroups run in lockstep and hide nothing of each other.
     const int s128 = 128 / d.HW < d.N ? 128 / d.HW : d.N;
     const long wg128 = (long)((d.N + s128 - 1) / s128) * d.ntile;
-    const bool want64 = g_conv_bm > 0 ? g_conv_bm == 64 : wg128 < 256;
+    static int bm_env = -2;   // NODE_TUNE_CONV_BM=64|128 forces the M tile (tests: the 2-D Winograd kernel on small batches)
+    if (bm_env == -2) { const char* e = getenv("NODE_TUNE_CONV_BM"); bm_env = e ? atoi(e) : -1; }
+    const int force_bm = g_conv_bm > 0 ? g_conv_bm : bm_env;
+    const bool want64 = force_bm > 0 ? force_bm == 64 : wg128 < 256;
     if (want64) d.BM = 64;
   }
   if (d.W > 64) return fail(NODE_ERR_UNSUPPORTED, "W = %d > 64", d.W);
