@@ -326,6 +326,9 @@ struct Solver {
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
+    if (aug)   // stage-2 parameter derivative: read with weight zero by the error norm / dense output, never written
+               // by dopri5 steps (the initial-step probe does write it) -- must hold finite values
+      HIP_TRY(hipMemsetAsync(p.KT[1], 0, d.P * sizeof(float), st));
     if (aug)   // arrival counter of k_theta_finalize
       HIP_TRY(hipMemsetAsync(p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64), 0, sizeof(unsigned), st));
     if (d.wino == 2 || d.wgrad_wino == 2) {   // zero tails of the conv inputs (see make_plan)
@@ -394,8 +397,13 @@ struct Solver {
 
   // augmented dynamics: (f, csign*a^T df/dy, csign*a^T df/dt, csign*a^T df/dtheta) * tsign
   //   upstream adjoint: csign = -1.   kT_out / scalar ts_k[kidx] optional.
+  // need_theta = false: the parameter / time components of this stage derivative are never consumed (dopri5
+  // stage 2: b_2 = b^_2 = c_mid,2 = 0 and no stage STATE of those segments is ever formed, since f does not depend
+  // on them), so the two weight-gradient GEMMs and the finalize are skipped; kT_out / ts_k[kidx] keep their
+  // (finite, zero-weighted) contents.
   int eval_aug(const Comb& cy, const Comb& ca, float* y_out, float* a_out, const EvalTime& et,
-               float* kY_out, float* kA_out, float* kT_out, int kidx, float csign, float* vjp_t_out) {
+               float* kY_out, float* kA_out, float* kT_out, int kidx, float csign, float* vjp_t_out,
+               bool need_theta = true) {
     TRY(eval_fwd(cy, y_out, et, kY_out, true));
 
     GnBwdArgs g;
@@ -408,10 +416,12 @@ struct Solver {
     launch_gn_bwd(d, g, st);
     if (!fuse_colsum) launch_colsum(d, p.dz2, p.spart[1], st);
 
-    WgradArgs w2;
-    memset(&w2, 0, sizeof(w2));
-    w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
-    { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
+    if (need_theta) {
+      WgradArgs w2;
+      memset(&w2, 0, sizeof(w2));
+      w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
+      { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
+    }
 
     ConvArgs b2;
     memset(&b2, 0, sizeof(b2));
@@ -422,10 +432,12 @@ struct Solver {
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b2, st); }
     if (!fuse_colsum) launch_colsum(d, p.dz1, p.spart[0], st);
 
-    WgradArgs w1;
-    memset(&w1, 0, sizeof(w1));
-    w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0];
-    { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
+    if (need_theta) {
+      WgradArgs w1;
+      memset(&w1, 0, sizeof(w1));
+      w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0];
+      { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
+    }
 
     ConvArgs b1 = b2;
     b1.spart = nullptr;
@@ -434,6 +446,7 @@ struct Solver {
     b1.act = p.act1; b1.xhat = p.xh1; b1.rstd = p.r1; b1.gpart = p.gpart[0];
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b1, st); }
 
+    if (!need_theta) return check_launch("augmented dynamics");
     ThetaFinalizeArgs tf;
     memset(&tf, 0, sizeof(tf));
     tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
@@ -451,12 +464,13 @@ struct Solver {
   EvalTime et_probe() const { EvalTime e; e.ctrl = p.ctrl; e.alpha = 0.f; e.tsign = tsign; e.mode = TM_PROBE; return e; }
 
   // evaluate the system at (state + scale * sum coef_j k_j) into k[kout]
-  int eval_sys(int kout, const double* coef, int ncoef, int scale_mode, const EvalTime& et, bool write_new) {
+  int eval_sys(int kout, const double* coef, int ncoef, int scale_mode, const EvalTime& et, bool write_new,
+               bool need_theta = true) {
     Comb cy = make_comb(p.Y, p.KY, coef, ncoef, scale_mode);
     if (!aug) return eval_fwd(cy, write_new ? p.Y1 : nullptr, et, p.KY[kout], false);
     Comb ca = make_comb(p.A, p.KA, coef, ncoef, scale_mode);
     return eval_aug(cy, ca, write_new ? p.Y1 : nullptr, write_new ? p.A1 : nullptr, et,
-                    p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr);
+                    p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr, need_theta);
   }
 
   int readback() {
@@ -486,7 +500,11 @@ struct Solver {
 
   // one dopri5 step on the device; host learns the outcome from hctrl afterwards
   int dopri5_step(bool forced, double forced_next) {
-    for (int s = 0; s < 6; ++s) TRY(eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5));
+    // stage 2 (s == 0): its parameter / time derivative has zero weight everywhere (see eval_aug)
+    static int skip_k2 = -1;
+    if (skip_k2 < 0) { const char* e = getenv("NODE_TUNE_SKIP_K2_THETA"); skip_k2 = e ? atoi(e) : 1; }
+    for (int s = 0; s < 6; ++s)
+      TRY(eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5, !(skip_k2 && s == 0)));
     const int nseg = aug ? 3 : 1;
     ErrSeg e0;
     e0.y0 = p.Y; e0.y1 = p.Y1; e0.n = d.numel; e0.compute_y1 = 0;
