@@ -40,3 +40,41 @@ def test_2d_winograd_conv_on_small_batches():
     env = dict(os.environ, NODE_TUNE_CONV_BM='128', NODE_TUNE_CONV_WINO='2')
     r = subprocess.run([sys.executable, '-c', CHILD, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+GRAD_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.nn.functional as F
+import neural_ode_features_amd as nof
+torch.manual_seed(23)
+net = nof.ODENet(3, out=10, n_filters=32, downsample='residual', method='dopri5', tol=1e-3, adjoint=True, t1=1, dropout=0).cuda()
+gen = torch.Generator().manual_seed(3)
+x = torch.randn(6, 3, 32, 32, generator=gen).cuda()
+y = torch.randint(0, 10, (6,), generator=gen).cuda()
+loss = F.cross_entropy(net(x), y)
+loss.backward()
+torch.save({k: v.grad.cpu() for k, v in net.named_parameters()}, sys.argv[2])
+'''
+
+
+def test_skipping_the_zero_weight_stage_derivative_is_bit_identical(tmp_path):
+    """dopri5 stage 2 has zero weight in the solution, the error estimate and the dense output, and the
+    parameter / time segments never form stage states: leaving their stage-2 derivative uncomputed
+    (NODE_TUNE_SKIP_K2_THETA=1, the default) must not change a single bit of any gradient."""
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for skip in ('0', '1'):
+        out = str(tmp_path / ('g%s.pt' % skip))
+        env = dict(os.environ, NODE_TUNE_SKIP_K2_THETA=skip)
+        r = subprocess.run([sys.executable, '-c', GRAD_CHILD, root, out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(out))
+    # the ODE block's gradients come from this library alone: bit-identical.  The stem's pass through
+    # PyTorch-ROCm / MIOpen backward kernels, which are not run-to-run deterministic: compared to rounding.
+    for k in outs[0]:
+        if 'odeblock' in k:
+            assert torch.equal(outs[0][k], outs[1][k]), k
+        else:
+            assert float((outs[0][k] - outs[1][k]).abs().max()) <= 1e-5 * float(outs[0][k].abs().max()) + 1e-9, k
