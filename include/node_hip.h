@@ -160,6 +160,22 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params,
                        node_stats* stats,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Classifier head behind the ODE block, up to (not including) the Linear layer
+ *   -- model.py:231-250 (FCClassifier): GroupNorm(min(32,C), C) [model.py:268-271] -> ReLU ->
+ *      AdaptiveAvgPool2d((1,1)) -> [Dropout] -> Flatten.
+ * z: [n, c, h, w] (NCHW); gamma, beta: [c]; scale: [n, c] dropout mask / (1 - p) as the
+ * caller's RNG produced it, or NULL (eval mode / no dropout); pooled: [n, c];
+ * stats: [n, groups, 2] (mean, 1/sigma), kept by the caller for the backward.
+ * No workspace; one launch each on `stream`. */
+int node_head_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
+                  const float* scale, float* pooled, float* stats, void* stream);
+
+/* Backward of node_head_fwd: g_pooled [n, c] = dL/dpooled.  Outputs dz [n, c, h, w] and
+ * per-sample partials gpart [n, 2, c] of (dL/dgamma, dL/dbeta) -- summed over n by the caller. */
+int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
+                  const float* scale, const float* stats, const float* g_pooled,
+                  float* dz, float* gpart, void* stream);
+
 /* Event-based per-kernel-class timing (off by default; adds two event records
  * per profiled launch).  begin() resets the counters; end() synchronises the
  * recorded events and fills `out`. */

@@ -896,6 +896,30 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   return status_to_rc(stt.status);
 }
 
+int node_head_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* scale,
+                  float* pooled, float* stats, void* stream) {
+  char why[200];
+  const int rc = head_check(shape, why, sizeof(why));
+  if (rc != NODE_OK) return fail(rc, "%s", why);
+  if (!z || !gamma || !beta || !pooled || !stats) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  launch_head_fwd(*shape, z, gamma, beta, scale, pooled, stats, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_head_fwd failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
+int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* scale,
+                  const float* stats, const float* g_pooled, float* dz, float* gpart, void* stream) {
+  char why[200];
+  const int rc = head_check(shape, why, sizeof(why));
+  if (rc != NODE_OK) return fail(rc, "%s", why);
+  if (!z || !gamma || !beta || !stats || !g_pooled || !dz || !gpart) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  launch_head_bwd(*shape, z, gamma, beta, scale, stats, g_pooled, dz, gpart, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_head_bwd failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
 int node_profile_begin(void) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }

@@ -311,4 +311,14 @@ struct ThetaFinalizeArgs {
 };
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s);
 
+// classifier head (kernels_head.hip); node_shape is the public struct of include/node_hip.h
+}  // namespace node
+struct node_shape;
+namespace node {
+int head_check(const node_shape* sh, char* why, size_t why_len);
+void launch_head_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
+                     float* pooled, float* stats, hipStream_t s);
+void launch_head_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
+                     const float* stats, const float* gpool, float* dz, float* gpart, hipStream_t s);
+
 }  // namespace node

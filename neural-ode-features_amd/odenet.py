@@ -3,9 +3,9 @@
 Mirrors the observable semantics and state_dict keys of the reference's
 `ODENet.forward` (`/root/reference/model.py:6-62`), its stems (`model.py:119-178`)
 and head (`model.py:231-250`) so checkpoints load unchanged (`utils.py:248-270`).
-The stem and head are a handful of plain convolutions run once per batch
-(~1 ODEfunc-eval of FLOPs): they stay on
-PyTorch-ROCm/MIOpen.  Only the ODE block is the accelerated path.
+The stem is a handful of plain convolutions run once per batch (~1 ODEfunc-eval of
+FLOPs) and stays on PyTorch-ROCm/MIOpen; the head's
+GroupNorm -> ReLU -> pool -> Dropout is one fused HIP launch each way (head.py).
 """
 from __future__ import annotations
 
@@ -80,6 +80,24 @@ class FCClassifier(_Wrapped):
             layers.append(nn.Dropout(dropout))
         layers += [Flatten(), nn.Linear(in_ch, out)]
         super().__init__(nn.Sequential(*layers))
+
+    def forward(self, x):
+        """CUDA fp32 inputs take the fused HIP head (head.py: one launch forward, one backward) for everything
+        in front of the last layer; anything else -- CPU tensors, a body someone has edited beyond what
+        `ODENet.to_features_extractor` does -- runs the plain module sequence."""
+        body = list(self.module.children())
+        fusable = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and len(body) in (5, 6)
+                   and isinstance(body[0], nn.GroupNorm) and body[0].affine and isinstance(body[1], nn.ReLU)
+                   and isinstance(body[2], nn.AdaptiveAvgPool2d) and isinstance(body[-2], Flatten)
+                   and (len(body) == 5 or isinstance(body[3], nn.Dropout)))
+        if not fusable:
+            return self.module(x)
+        from .head import head_pool
+        gn = body[0]
+        drop = body[3] if len(body) == 6 else None
+        pooled = head_pool(x, gn.weight, gn.bias, gn.num_groups, gn.eps,
+                           p=drop.p if drop is not None else 0.0, training=self.training and drop is not None)
+        return body[-1](pooled)
 
 
 class ODENet(nn.Module):

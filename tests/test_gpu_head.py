@@ -1,0 +1,73 @@
+"""GPU parity of the fused classifier head (node_head_fwd / node_head_bwd) against the CPU oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+# vector kernels: 8x8 (16 lanes per channel), 4x4 (4), 16x16 (64), 2x2 (1); per-channel fallback: 7x7, 5x6, C = 1024 at 8x8
+SHAPES = [(128, 256, 8, 8), (5, 64, 7, 7), (3, 96, 4, 4), (2, 8, 5, 6), (2, 1024, 4, 4), (7, 16, 2, 2), (3, 32, 16, 16),
+          (2, 1024, 8, 8), (4, 64, 16, 16)]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('with_scale', [False, True])
+def test_head_pool_forward_backward_match_oracle(shape, with_scale):
+    from neural_ode_features_amd.head import _HeadPool
+    from oracle.head import head_pool as oracle_head
+    N, C, H, W = shape
+    G = min(32, C)
+    gen = torch.Generator().manual_seed(C + H)
+    z = torch.randn(N, C, H, W, generator=gen)
+    gamma = 1.0 + 0.25 * torch.randn(C, generator=gen)
+    beta = 0.3 * torch.randn(C, generator=gen)
+    scale = (torch.rand(N, C, generator=gen) > 0.5).float() * 2.0 if with_scale else None
+    cot = torch.randn(N, C, generator=gen)
+
+    zr, gr, br = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    want = oracle_head(zr, gr, br, G, 1e-5, scale)
+    want.backward(cot)
+
+    zg, gg, bg = (t.cuda().requires_grad_(True) for t in (z, gamma, beta))
+    got = _HeadPool.apply(zg, gg, bg, None if scale is None else scale.cuda(), G, 1e-5)
+    got.backward(cot.cuda())
+    assert rel_err(got, want) < 1e-5
+    assert rel_err(zg.grad, zr.grad) < 2e-5
+    assert rel_err(gg.grad, gr.grad) < 2e-5 and rel_err(bg.grad, br.grad) < 2e-5
+
+
+def test_fcclassifier_fused_matches_plain_modules_and_dropout_stream():
+    """The module-level switch: same logits / gradients as the plain nn.Sequential on the same device, and the
+    dropout mask is the one nn.Dropout draws from the same generator state."""
+    import neural_ode_features_amd as nof
+    torch.manual_seed(5)
+    head = nof.FCClassifier(in_ch=64, out=10, dropout=0.5).cuda().train()
+    x = torch.randn(9, 64, 8, 8, device='cuda')
+    for train in (True, False):
+        head.train(train)
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        torch.manual_seed(77)
+        fused = head(xa)
+        torch.manual_seed(77)
+        plain = head.module(xb)
+        assert rel_err(fused, plain) < 1e-5
+        w = torch.randn_like(fused)
+        head.zero_grad()
+        (fused * w).sum().backward()
+        gf = {k: v.grad.clone() for k, v in head.named_parameters()}
+        head.zero_grad()
+        (plain * w).sum().backward()
+        assert rel_err(xa.grad, xb.grad) < 2e-5
+        for k, v in head.named_parameters():
+            assert rel_err(gf[k], v.grad) < 2e-5, k
+
+
+def test_head_errors():
+    from neural_ode_features_amd._lib import NodeHipError
+    from neural_ode_features_amd.head import _HeadPool
+    z = torch.randn(2, 12, 4, 4, device='cuda')
+    with pytest.raises(NodeHipError):
+        _HeadPool.apply(z, torch.ones(12, device='cuda'), torch.zeros(12, device='cuda'), None, 5, 1e-5)   # 5 does not divide 12
