@@ -176,6 +176,16 @@ int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, c
                   const float* scale, const float* stats, const float* g_pooled,
                   float* dz, float* gpart, void* stream);
 
+/* GroupNorm (+ReLU) of the stem's residual blocks -- model.py:284-310 (`relu(norm(x))` in front of every
+ * conv; normalization('group') = nn.GroupNorm(min(32,C), C), model.py:268-271), forward and backward.
+ * z, out, g_out, dz: [n, c, h, w] (NCHW); stats: [n, groups, 2] (mean, 1/sigma) from the forward;
+ * gpart: [n, 2, c] per-sample partials of (dL/dgamma, dL/dbeta), summed over n by the caller.
+ * relu != 0: out = relu(GN(z)); relu == 0: out = GN(z).  No workspace; one launch each. */
+int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
+                     int relu, float* out, float* stats, void* stream);
+int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
+                     const float* stats, int relu, const float* g_out, float* dz, float* gpart, void* stream);
+
 /* Event-based per-kernel-class timing (off by default; adds two event records
  * per profiled launch).  begin() resets the counters; end() synchronises the
  * recorded events and fills `out`. */

@@ -26,7 +26,7 @@ ERRORS = {
 EXPORTS = [
     'node_abi_version', 'node_last_error', 'node_param_count', 'node_workspace_bytes',
     'node_odefunc_fwd', 'node_odefunc_vjp', 'node_solve_fwd', 'node_solve_adjoint',
-    'node_head_fwd', 'node_head_bwd',
+    'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
     'node_profile_begin', 'node_profile_end',
 ]
 
@@ -102,6 +102,10 @@ def load():
     lib.node_head_fwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp]
     lib.node_head_bwd.restype = i32
     lib.node_head_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.node_gn_relu_fwd.restype = i32
+    lib.node_gn_relu_fwd.argtypes = [P(NodeShape), vp, vp, vp, i32, vp, vp, vp]
+    lib.node_gn_relu_bwd.restype = i32
+    lib.node_gn_relu_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.node_profile_begin.restype = i32
     lib.node_profile_begin.argtypes = []
     lib.node_profile_end.restype = i32

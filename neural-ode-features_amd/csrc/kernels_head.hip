@@ -50,6 +50,15 @@ __device__ inline void groups_from_channels(const float* chv, float* grp, int G,
   __syncthreads();
 }
 
+// 256-thread block sum, result in every thread (red: 4 floats of LDS; safe to call back to back)
+__device__ inline float block_sum_256h(float v, float* red) {
+  v = lanes_sum<64>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // sum of `v` over the channels of this thread's group (thread = channel; fallback kernels)
 __device__ inline float group_sum(float v, float* ch, int c, int c_lo, int cpg, bool on) {
   __syncthreads();               // previous use of `ch` finished
@@ -267,6 +276,93 @@ __global__ __launch_bounds__(256) void k_head_bwd_g(const float* __restrict__ z,
         dz[base + p] = rstd * (gu * gm - m1 - xh * m2);
       }
   }
+}
+
+// ----------------------------------------------------------------------------
+// GroupNorm (+ReLU) of the stem's residual blocks (model.py:284-310: `relu(norm(x))` in front of every conv),
+// forward and backward, NCHW.  One workgroup per (sample, group): in NCHW a group is ONE contiguous run of
+// cpg * HW floats.  Three passes over that run (it stays in L1/L2); per-channel (dgamma, dbeta) partials per
+// sample for the caller to sum.  Replaces PyTorch's 3 + 5 kernels per GroupNorm-ReLU pair, among them a
+// 56-us GammaBetaBackward.
+//   forward:  out = [relu]((z - mean) * rstd * gamma + beta)
+//   backward: gu = g_out * [(u > 0)];  dz = rstd * (gu*gamma - mean_g(gu*gamma) - xhat * mean_g(gu*gamma*xhat))
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_relu_fwd(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ out,
+                                                     float* __restrict__ stats, int C, int HW, int G, float eps, int relu) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G, cpg = C / G;
+  const int M = cpg * HW;
+  const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+  const float* zg = z + base;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) s += zg[i];
+  const float mean = block_sum_256h(s, red) / (float)M;
+  float s2 = 0.f;
+  for (int i = threadIdx.x; i < M; i += 256) { const float dv = zg[i] - mean; s2 += dv * dv; }
+  const float rstd = 1.0f / sqrtf(block_sum_256h(s2, red) / (float)M + eps);
+  if (threadIdx.x == 0) { stats[(size_t)blockIdx.x * 2] = mean; stats[(size_t)blockIdx.x * 2 + 1] = rstd; }
+  for (int cc = 0; cc < cpg; ++cc) {
+    const float gm = gamma[g * cpg + cc], bt = beta[g * cpg + cc];
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      float v = ((zg[cc * HW + p] - mean) * rstd) * gm + bt;
+      if (relu) v = fmaxf(v, 0.f);
+      out[base + cc * HW + p] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gn_relu_bwd(const float* __restrict__ z, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ stats,
+                                                     const float* __restrict__ gout, float* __restrict__ dz,
+                                                     float* __restrict__ gpart, int C, int HW, int G, int relu) {
+  __shared__ float red[4];
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G, cpg = C / G;
+  const int M = cpg * HW;
+  const size_t base = ((size_t)n * C + (size_t)g * cpg) * HW;
+  const float mean = stats[(size_t)blockIdx.x * 2], rstd = stats[(size_t)blockIdx.x * 2 + 1];
+  float s1 = 0.f, s2 = 0.f;   // sums over the group of dxhat and dxhat * xhat
+  for (int cc = 0; cc < cpg; ++cc) {
+    const int c = g * cpg + cc;
+    const float gm = gamma[c], bt = beta[c];
+    float dg = 0.f, db = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const float xh = (z[base + cc * HW + p] - mean) * rstd;
+      float gu = gout[base + cc * HW + p];
+      if (relu && !(xh * gm + bt > 0.f)) gu = 0.f;
+      dg += gu * xh;
+      db += gu;
+    }
+    dg = block_sum_256h(dg, red);
+    db = block_sum_256h(db, red);
+    if (threadIdx.x == 0) {
+      gpart[((size_t)n * 2 + 0) * C + c] = dg;
+      gpart[((size_t)n * 2 + 1) * C + c] = db;
+    }
+    s1 += db * gm;
+    s2 += dg * gm;
+  }
+  const float m1 = s1 / (float)M, m2 = s2 / (float)M;
+  for (int cc = 0; cc < cpg; ++cc) {
+    const float gm = gamma[g * cpg + cc], bt = beta[g * cpg + cc];
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const float xh = (z[base + cc * HW + p] - mean) * rstd;
+      float gu = gout[base + cc * HW + p];
+      if (relu && !(xh * gm + bt > 0.f)) gu = 0.f;
+      dz[base + cc * HW + p] = rstd * (gu * gm - m1 - xh * m2);
+    }
+  }
+}
+
+void launch_gn_relu_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, int relu, float* out,
+                        float* stats, hipStream_t s) {
+  hipLaunchKernelGGL(k_gn_relu_fwd, dim3(sh.n * sh.groups), dim3(256), 0, s, z, gamma, beta, out, stats, sh.c, sh.h * sh.w,
+                     sh.groups, sh.eps, relu);
+}
+void launch_gn_relu_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* stats,
+                        int relu, const float* gout, float* dz, float* gpart, hipStream_t s) {
+  hipLaunchKernelGGL(k_gn_relu_bwd, dim3(sh.n * sh.groups), dim3(256), 0, s, z, gamma, beta, stats, gout, dz, gpart, sh.c,
+                     sh.h * sh.w, sh.groups, relu);
 }
 
 int head_check(const node_shape* sh, char* why, size_t why_len) {

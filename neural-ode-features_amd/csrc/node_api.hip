@@ -896,6 +896,30 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   return status_to_rc(stt.status);
 }
 
+int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, int relu, float* out,
+                     float* stats, void* stream) {
+  char why[200];
+  const int rc = head_check(shape, why, sizeof(why));
+  if (rc != NODE_OK && rc != NODE_ERR_UNSUPPORTED) return fail(rc, "%s", why);   // (the per-group kernels take any C)
+  if (!z || !gamma || !beta || !out || !stats) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  launch_gn_relu_fwd(*shape, z, gamma, beta, relu, out, stats, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_gn_relu_fwd failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
+int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* stats,
+                     int relu, const float* g_out, float* dz, float* gpart, void* stream) {
+  char why[200];
+  const int rc = head_check(shape, why, sizeof(why));
+  if (rc != NODE_OK && rc != NODE_ERR_UNSUPPORTED) return fail(rc, "%s", why);
+  if (!z || !gamma || !beta || !stats || !g_out || !dz || !gpart) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  launch_gn_relu_bwd(*shape, z, gamma, beta, stats, relu, g_out, dz, gpart, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_gn_relu_bwd failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
 int node_head_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* scale,
                   float* pooled, float* stats, void* stream) {
   char why[200];

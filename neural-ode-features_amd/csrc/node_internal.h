@@ -318,6 +318,10 @@ namespace node {
 int head_check(const node_shape* sh, char* why, size_t why_len);
 void launch_head_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      float* pooled, float* stats, hipStream_t s);
+void launch_gn_relu_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, int relu, float* out,
+                        float* stats, hipStream_t s);
+void launch_gn_relu_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* stats,
+                        int relu, const float* gout, float* dz, float* gpart, hipStream_t s);
 void launch_head_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      const float* stats, const float* gpool, float* dz, float* gpart, hipStream_t s);
 

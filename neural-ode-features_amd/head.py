@@ -58,3 +58,45 @@ def head_pool(z: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
         scale = F.dropout(torch.ones(z.shape[0], z.shape[1], 1, 1, device=z.device, dtype=torch.float32), p, True)
         scale = scale.reshape(z.shape[0], z.shape[1]).contiguous()
     return _HeadPool.apply(z, gamma, beta, scale, groups, eps)
+
+
+class _GnRelu(torch.autograd.Function):
+    """out = [relu](GroupNorm(z)) -- the stem's `relu(norm(x))` pairs (model.py:304-307), one launch each way."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, groups, eps, relu):
+        lib = _lib.load()
+        z = z.contiguous()
+        n, c, h, w = z.shape
+        shape = _lib.NodeShape(n, c, h, w, groups, eps)
+        out = torch.empty_like(z)
+        stats = torch.empty(n, groups, 2, device=z.device, dtype=torch.float32)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        _lib.check(lib.node_gn_relu_fwd(shape, _ptr(z), _ptr(g), _ptr(b), int(relu), _ptr(out), _ptr(stats), stream))
+        ctx.save_for_backward(z, g, b, stats)
+        ctx.shape = (n, c, h, w, groups, eps, int(relu))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        z, g, b, stats = ctx.saved_tensors
+        n, c, h, w, groups, eps, relu = ctx.shape
+        shape = _lib.NodeShape(n, c, h, w, groups, eps)
+        g_out = g_out.contiguous()
+        dz = torch.empty_like(z)
+        gpart = torch.empty(n, 2, c, device=z.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(z.device).cuda_stream
+        _lib.check(lib.node_gn_relu_bwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(stats), relu, _ptr(g_out), _ptr(dz),
+                                        _ptr(gpart), stream))
+        gsum = gpart.sum(0)
+        return dz, gsum[0], gsum[1], None, None, None
+
+
+def gn_relu(z: torch.Tensor, norm: torch.nn.GroupNorm, relu: bool = True) -> torch.Tensor:
+    """`relu(norm(z))` for CUDA fp32 4-D inputs through the fused HIP kernels; the plain modules otherwise."""
+    if z.is_cuda and z.dtype == torch.float32 and z.dim() == 4 and isinstance(norm, torch.nn.GroupNorm) and norm.affine:
+        return _GnRelu.apply(z, norm.weight, norm.bias, norm.num_groups, norm.eps, relu)
+    out = norm(z)
+    return F.relu(out) if relu else out

@@ -30,9 +30,10 @@ class ResBlock(nn.Module):
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
 
     def forward(self, x):
-        pre = self.relu(self.norm1(x))
+        from .head import gn_relu   # fused GroupNorm + ReLU (one HIP launch each way) for CUDA fp32 inputs
+        pre = gn_relu(x, self.norm1)
         skip = x if self.downsample is None else self.downsample(pre)
-        h = self.conv2(self.relu(self.norm2(self.conv1(pre))))
+        h = self.conv2(gn_relu(self.conv1(pre), self.norm2))
         return h + skip
 
 

@@ -71,3 +71,53 @@ def test_head_errors():
     z = torch.randn(2, 12, 4, 4, device='cuda')
     with pytest.raises(NodeHipError):
         _HeadPool.apply(z, torch.ones(12, device='cuda'), torch.zeros(12, device='cuda'), None, 5, 1e-5)   # 5 does not divide 12
+
+
+GN_SHAPES = [(128, 64, 30, 30), (16, 64, 15, 15), (9, 256, 8, 8), (3, 96, 5, 7), (2, 8, 3, 3), (2, 1024, 4, 4)]
+
+
+@pytest.mark.parametrize('shape', GN_SHAPES)
+@pytest.mark.parametrize('relu', [True, False])
+def test_gn_relu_forward_backward_match_torch(shape, relu):
+    """The stem's `relu(norm(x))` pairs (model.py:304-307): fused HIP op vs F.group_norm (+ F.relu) on the CPU."""
+    from neural_ode_features_amd.head import _GnRelu
+    N, C, H, W = shape
+    G = min(32, C)
+    gen = torch.Generator().manual_seed(C + H)
+    z = torch.randn(N, C, H, W, generator=gen) * 1.5 + 0.3
+    gamma = 1.0 + 0.25 * torch.randn(C, generator=gen)
+    beta = 0.3 * torch.randn(C, generator=gen)
+    cot = torch.randn(N, C, H, W, generator=gen)
+    zr, gr, br = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    want = F.group_norm(zr, G, gr, br, 1e-5)
+    if relu:
+        want = F.relu(want)
+    want.backward(cot)
+    zg, gg, bg = (t.cuda().requires_grad_(True) for t in (z, gamma, beta))
+    got = _GnRelu.apply(zg, gg, bg, G, 1e-5, relu)
+    got.backward(cot.cuda())
+    assert rel_err(got, want) < 1e-5
+    assert rel_err(zg.grad, zr.grad) < 2e-5
+    assert rel_err(gg.grad, gr.grad) < 2e-5 and rel_err(bg.grad, br.grad) < 2e-5
+
+
+def test_resblock_fused_matches_plain_modules():
+    import neural_ode_features_amd as nof
+    from torch import nn
+    torch.manual_seed(3)
+    blk = nof.ResBlock(64, 256, stride=2, downsample=nn.Conv2d(64, 256, 1, 2, bias=False)).cuda()
+    x = torch.randn(8, 64, 15, 15, device='cuda')
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    fused = blk(xa)
+    pre = blk.relu(blk.norm1(xb))
+    plain = blk.conv2(blk.relu(blk.norm2(blk.conv1(pre)))) + blk.downsample(pre)
+    assert rel_err(fused, plain) < 2e-5
+    w = torch.randn_like(fused)
+    blk.zero_grad()
+    (fused * w).sum().backward()
+    gf = {k: v.grad.clone() for k, v in blk.named_parameters()}
+    blk.zero_grad()
+    (plain * w).sum().backward()
+    assert rel_err(xa.grad, xb.grad) < 5e-5
+    for k, v in blk.named_parameters():
+        assert rel_err(gf[k], v.grad) < 5e-5, k
