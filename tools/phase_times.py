@@ -15,6 +15,9 @@ opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-
 gen = torch.Generator().manual_seed(1234)
 x = torch.randn(128, 3, 32, 32, generator=gen).to(dev)
 y = torch.randint(0, 10, (128,), generator=gen).to(dev)
+if os.environ.get('GRAPH_HEAD'):
+    sample = torch.randn(128, 256, 8, 8, device=dev, requires_grad=True)
+    model.classifier = torch.cuda.make_graphed_callables(model.classifier, (sample,))
 ev = lambda: torch.cuda.Event(enable_timing=True)
 names = ['stem fwd', 'ode fwd', 'head+loss', 'head bwd', 'ode adjoint', 'stem bwd', 'optimizer']
 tot = [0.0] * len(names)
