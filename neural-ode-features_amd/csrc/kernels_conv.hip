@@ -964,12 +964,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   // fetches the activations four times; HBM traffic and time were unchanged -- 50.7 MB, 58 us -- so launch order
   // stays: the four column tiles of a pixel tile share an XCD and read the activations once.)
   const int mtile = blockIdx.x, nt = blockIdx.y;
-  const int n0 = mtile * d.S;
+  // whole samples per tile, or (Dims::csplit workgroups per sample, images larger than 128 pixels) one 32-tile
+  // band of ONE sample: whole tile rows, 128 consecutive pixels; GroupNorm is then a separate pointwise pass and
+  // this kernel stores its raw tile
+  const int csp = d.csplit;
+  const int n0 = csp ? mtile / csp : mtile * d.S;
+  const int band = csp ? mtile - n0 * csp : 0;
   const int c0 = nt * d.BNE;
-  const int nsamp = min(d.S, d.N - n0);
+  const int nsamp = csp ? 1 : min(d.S, d.N - n0);
   const int TW = d.W >> 1, TH = d.H >> 1;
   const int TPS = TH * TW;           // tiles per sample
-  const int tiles_valid = nsamp * TPS;
+  const int tiles_valid = csp ? TT : nsamp * TPS;
   const bool fwd = a.mode != CM_BWD_RELU_GN;
   const int ncols = min(d.BNE, d.C - c0);
 
@@ -981,7 +986,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   int* qtab = ptab + TT;                                  // [TT] the same pixel's index inside its sample
   if (tid < TT) {
     int pr = -1, q = 0;
-    if (tid < d.S * TPS) {
+    if (csp) {
+      const int thl = tid / TW, tw = tid - thl * TW;
+      pr = (2 * thl) * d.W + 2 * tw;
+      q = band * BM + pr;
+    } else if (tid < d.S * TPS) {
       const int s = tid / TPS, rem = tid - s * TPS;
       const int th = rem / TW, tw = rem - th * TW;
       q = (2 * th) * d.W + 2 * tw;
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   const unsigned zoff = (unsigned)(((size_t)(d.N - n0) * d.HW * d.C + sq4 * 4) * sizeof(float));   // the zero row
   unsigned svoff[4] = {zoff, zoff, zoff, zoff};   // byte offsets of the four patch pixels of row sr
   if (stile < tiles_valid) {
-    const int s = stile / TPS, rem = stile - s * TPS;
+    const int s = csp ? 0 : stile / TPS, rem = csp ? band * TT + stile : stile - s * TPS;
     const int th = rem / TW, tw = rem - th * TW;
     const int sy = 2 * th - 1 + sr;
     if (sy >= 0 && sy < d.H) {
@@ -1262,6 +1271,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   }
   __syncthreads();
   PSTAMP(a.stamps, 6, "s_memtime");
+  if (a.raw_out) {   // split mode: the band's 128 pixels x ncols, as they are (conv + bias + t * tmap, or the raw data gradient)
+    const int colq = (tid & 15) * 4, rr = tid >> 4;
+    const bool vec_ok = ((c0 & 3) == 0) && ((ncols & 3) == 0);
+    for (int p = rr; p < BM; p += THREADS / 16) {
+      const float* src = Ct + p * CT2 + colq;
+      const size_t off = ((size_t)n0 * d.HW + (size_t)band * BM + p) * d.C + c0 + colq;
+      if (vec_ok) {
+        if (colq < ncols) *reinterpret_cast<float4*>(a.raw_out + off) = make_float4(src[0], src[1], src[2], src[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (colq + i < ncols) a.raw_out[off + i] = src[i];
+      }
+    }
+    PSTAMP(a.stamps, 4, "s_memtime");
+    PSTAMP(a.stamps, 5, "s_memrealtime");
+    return;
+  }
   conv_epilogue_tail<THREADS, BM>(a, d, smem, n0, c0, nsamp, ncols, mtile);
   PSTAMP(a.stamps, 4, "s_memtime");
   PSTAMP(a.stamps, 5, "s_memrealtime");

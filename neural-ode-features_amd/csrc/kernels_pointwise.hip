@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
     for (int i = 0; i < 4; ++i) {
       const int gl = (4 * q + i) / d.cpg;
       xh[i] = (x[i] - smean[gl]) * srstd[gl];
-      o[i] = fmaxf(xh[i] * g[i] + b[i], 0.f);
+      float vv = xh[i] * g[i] + b[i];
+      if (a.relu) vv = fmaxf(vv, 0.f);
+      o[i] = a.osign * vv;
     }
     st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
     if (a.xhat_out) st4(a.xhat_out + off, make_float4(xh[0], xh[1], xh[2], xh[3]));
@@ -194,7 +196,13 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
       av.x += s.x; av.y += s.y; av.z += s.z; av.w += s.w;
     }
     if (a.a_out) st4(a.a_out + off, av);
-    st4(gt + p * csl + 4 * q, make_float4(a.csign * av.x, a.csign * av.y, a.csign * av.z, a.csign * av.w));
+    float4 gq = make_float4(a.csign * av.x, a.csign * av.y, a.csign * av.z, a.csign * av.w);
+    if (a.mask_act) {
+      const float4 mk = ld4(a.mask_act + off);
+      gq.x = mk.x > 0.f ? gq.x : 0.f; gq.y = mk.y > 0.f ? gq.y : 0.f;
+      gq.z = mk.z > 0.f ? gq.z : 0.f; gq.w = mk.w > 0.f ? gq.w : 0.f;
+    }
+    st4(gt + p * csl + 4 * q, gq);
     st4(xt + p * csl + 4 * q, ld4(a.xhat + off));
   }
   __syncthreads();
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
     for (int i = 0; i < 4; ++i) {
       const int gl = (4 * q + i) / d.cpg;
       const float r = a.rstd[(size_t)n * d.G + c0 / d.cpg + gl];
-      o[i] = r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]);
+      o[i] = a.osign * (r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]));
     }
     st4(a.dz_out + off, make_float4(o[0], o[1], o[2], o[3]));
     if (a.spart) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums below

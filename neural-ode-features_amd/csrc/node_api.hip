@@ -107,6 +107,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
   d.BNE = (64 / d.cpg) * d.cpg;
   d.ntile = (d.C + d.BNE - 1) / d.BNE;
   d.nchunk = (d.C + KCH - 1) / KCH;
+  d.csplit = 0;
   if (d.HW <= 128) d.BM = 128;
   else if (d.HW <= 256) d.BM = 256;
   else return fail(NODE_ERR_UNSUPPORTED, "H*W = %d > 256 is not tiled yet", d.HW);
@@ -132,12 +133,21 @@ static int make_dims(const node_shape* sh, Dims* out) {
     if (d.wino == 2 && !(d.H % 2 == 0 && d.BM == 128 && 128 % d.HW == 0 && d.HW >= 16 && d.C % 32 == 0 &&
                       ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32)))
       d.wino = 1;   // 2-D variant: whole samples in 32 tiles
+    // ... or, for 256-pixel images, two workgroups per sample (32 tiles = whole tile rows = 128 consecutive
+    // pixels each) with the GroupNorm as a pointwise pass behind the conv: 16x16 at C = 256 runs the 1-D kernel
+    // at 109 algorithmic TFLOP/s (one sample per 256-pixel tile), the 2-D kernel + pass is ~1.5x faster
+    if ((want < 0 || want == 2) && d.HW == 256 && d.H % 2 == 0 && d.W % 2 == 0 && 32 % (d.W / 2) == 0 && d.C % 32 == 0 &&
+        ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32)) {
+      d.wino = 2;
+      d.BM = 128;
+      d.csplit = d.HW / 128;
+    }
   }
-  d.S = d.BM / d.HW;
+  d.S = d.csplit ? 1 : d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
   while (d.wino != 2 && d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
   if (conv_lds_bytes(d, 0) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "conv tile does not fit LDS");
-  d.mtiles = (d.N + d.S - 1) / d.S;
+  d.mtiles = d.csplit ? d.N * d.csplit : (d.N + d.S - 1) / d.S;
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
   static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels
   if (slab_elems < 0) { const char* e = getenv("NODE_TUNE_SLAB"); slab_elems = e ? atoi(e) : 2048; }
@@ -205,6 +215,7 @@ struct Plan {
   float* tmap[2];
   float *Y, *Y1, *KY[7];
   float *act1, *act2, *TMP;
+  float* RAW;               // split-conv mode (Dims::csplit): the conv's raw output, consumed by the GroupNorm pass
   // adjoint
   float *A, *A1, *KA[7];
   float *TH, *TH1, *THTMP, *KT[7];
@@ -244,6 +255,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   p.act1 = b.take<float>(d.numel + d.C);
   p.act2 = b.take<float>(d.numel + d.C);
   p.TMP = b.take<float>(d.numel);
+  if (d.csplit) p.RAW = b.take<float>(d.numel);
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
     p.A = b.take<float>(d.numel);
@@ -369,12 +381,32 @@ struct Solver {
   }
 
   // f(t, y_i) with y_i = comb; writes k_out = tsign * f  (and y_i to y_out if asked)
+  // split-conv mode: GroupNorm (+ReLU) of the conv's raw output as a pointwise pass (k_combine_gn with an empty
+  // Butcher row), and the ReLU-mask + GroupNorm backward of a raw data gradient (k_gn_bwd)
+  void gn_pass_fwd(const float* gamma, const float* beta, int relu, float osign, float* out, float* xhat_out, float* rstd_out) {
+    CombineGnArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.comb.y = p.RAW; ca.comb.nk = 0; ca.comb.scale_mode = SC_ABS; ca.ctrl = p.ctrl;
+    ca.act_out = out; ca.xhat_out = xhat_out; ca.rstd_out = rstd_out;
+    ca.gamma = gamma; ca.beta = beta; ca.relu = relu; ca.osign = osign;
+    launch_combine_gn(d, ca, st);
+  }
+  void gn_pass_bwd(const float* act, const float* xhat, const float* rstd, const float* gamma, float osign, float* out,
+                   float* gpart, float* spart) {
+    GnBwdArgs g;
+    memset(&g, 0, sizeof(g));
+    g.comb.y = p.RAW; g.comb.nk = 0; g.comb.scale_mode = SC_ABS; g.ctrl = p.ctrl; g.csign = 1.f;
+    g.xhat = xhat; g.rstd = rstd; g.gamma = gamma; g.dz_out = out; g.gpart = gpart; g.spart = spart;
+    g.mask_act = act; g.osign = osign;
+    launch_gn_bwd(d, g, st);
+  }
+
   int eval_fwd(const Comb& cy, float* y_out, const EvalTime& et, float* k_out, bool train) {
     CombineGnArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
     ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
-    ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b;
+    ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
     launch_combine_gn(d, ca, st);
 
     ConvArgs c1;
@@ -383,7 +415,9 @@ struct Solver {
     c1.bias = prm.conv1_b; c1.tmap = p.tmap[0]; c1.et = et;
     c1.gamma = prm.norm2_w; c1.beta = prm.norm2_b; c1.osign = 1.f;
     c1.out = p.act2; c1.xhat_out = train ? p.xh2 : nullptr; c1.rstd_out = train ? p.r2 : nullptr;
+    c1.raw_out = d.csplit ? p.RAW : nullptr;
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, c1, st); }
+    if (d.csplit) gn_pass_fwd(prm.norm2_w, prm.norm2_b, 1, 1.f, p.act2, train ? p.xh2 : nullptr, train ? p.r2 : nullptr);
 
     ConvArgs c2 = c1;
     c2.in = p.act2; c2.wpacked = p.wf[1]; c2.mode = CM_FWD_GN;
@@ -391,6 +425,7 @@ struct Solver {
     c2.gamma = prm.norm3_w; c2.beta = prm.norm3_b; c2.osign = et.tsign;
     c2.out = k_out; c2.xhat_out = train ? p.xh3 : nullptr; c2.rstd_out = train ? p.r3 : nullptr;
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, c2, st); }
+    if (d.csplit) gn_pass_fwd(prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr, train ? p.r3 : nullptr);
     nfe += 1;
     return check_launch("odefunc forward");
   }
@@ -409,7 +444,7 @@ struct Solver {
     GnBwdArgs g;
     memset(&g, 0, sizeof(g));
     g.comb = ca; g.ctrl = p.ctrl; g.csign = csign; g.a_out = a_out;
-    g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2];
+    g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2]; g.osign = 1.f;
     static int fuse_colsum = -1;   // NODE_TUNE_FUSE_COLSUM=0: separate k_colsum launches (A/B measurements)
     if (fuse_colsum < 0) { const char* e = getenv("NODE_TUNE_FUSE_COLSUM"); fuse_colsum = e ? atoi(e) : 1; }
     g.spart = fuse_colsum ? p.spart[1] : nullptr;   // masked column sums of dz2, fused (k_colsum otherwise)
@@ -429,7 +464,9 @@ struct Solver {
     b2.gamma = prm.norm2_w; b2.osign = 1.f; b2.out = p.dz1;
     b2.act = p.act2; b2.xhat = p.xh2; b2.rstd = p.r2; b2.gpart = p.gpart[1];
     b2.spart = fuse_colsum ? p.spart[0] : nullptr;   // masked column sums of dz1, fused into the epilogue
+    b2.raw_out = d.csplit ? p.RAW : nullptr;
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b2, st); }
+    if (d.csplit) gn_pass_bwd(p.act2, p.xh2, p.r2, prm.norm2_w, 1.f, p.dz1, p.gpart[1], fuse_colsum ? p.spart[0] : nullptr);
     if (!fuse_colsum) launch_colsum(d, p.dz1, p.spart[0], st);
 
     if (need_theta) {
@@ -445,6 +482,7 @@ struct Solver {
     b1.gamma = prm.norm1_w; b1.osign = et.tsign; b1.out = kA_out;
     b1.act = p.act1; b1.xhat = p.xh1; b1.rstd = p.r1; b1.gpart = p.gpart[0];
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, b1, st); }
+    if (d.csplit) gn_pass_bwd(p.act1, p.xh1, p.r1, prm.norm1_w, et.tsign, kA_out, p.gpart[0], nullptr);
 
     if (!need_theta) return check_launch("augmented dynamics");
     ThetaFinalizeArgs tf;
@@ -452,7 +490,8 @@ struct Solver {
     tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
     tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
     tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
-    tf.gpart_rows[0] = d.mtiles; tf.gpart_rows[1] = d.mtiles; tf.gpart_rows[2] = d.N;
+    tf.gpart_rows[0] = tf.gpart_rows[1] = d.csplit ? d.N : d.mtiles;   // (split-conv mode: per-sample partials from the GroupNorm pass)
+    tf.gpart_rows[2] = d.N;
     tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
     tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
     tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;

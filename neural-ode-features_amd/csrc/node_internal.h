@@ -27,6 +27,8 @@ struct Dims {
   int wino;            // conv kernel: 0 direct, 1 Winograd F(2,3) along the rows (even W), 2 Winograd F(2x2,3x3) (even H, W; 128-pixel tiles)
   int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
+  int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
+                    // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)
   int mtiles;          // ceil(N / S)
   // pointwise slab (combine+GN kernels)
   int cs;              // channels per slab (multiple of lcm(cpg,4))
@@ -128,6 +130,8 @@ struct CombineGnArgs {
   float* rstd_out;     // nullable [N][G]
   const float* gamma;
   const float* beta;
+  int relu;            // 1: act = relu(GN(y_i)); 0: act = GN(y_i)   (split-conv GroupNorm pass)
+  float osign;         // output multiplier (1 for the stage combine)
 };
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s);
 
@@ -195,6 +199,8 @@ struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN
   float* dz_out;
   float* gpart;        // [N][2][C] per-sample (dgamma, dbeta) partials
   float* spart;        // nullable: [N][9][C] masked column sums of dz_out (see masked_colsum_tile)
+  const float* mask_act;   // nullable: g is zeroed where this activation is <= 0 (ReLU mask of a split-conv data gradient)
+  float osign;         // output multiplier (1 for GroupNorm-3's backward)
 };
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s);
 
@@ -269,6 +275,7 @@ struct ConvArgs {
   const float* rstd;      // [N][G]
   float* gpart;           // [mtiles][2][C]
   float* spart;           // bwd, nullable: [N][9][C] masked column sums of the output (see masked_colsum_tile)
+  float* raw_out;         // split mode (Dims::csplit): conv + bias + t*tmap (fwd) or the raw data gradient (bwd), no GroupNorm
   unsigned long long* stamps;  // diagnostics only (NODE_STAMPS builds); nullptr otherwise
   int ablate;                  // diagnostics only (NODE_STAMPS builds): timing-only ablation bits
 };

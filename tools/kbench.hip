@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
       a.act = act; a.xhat = xhat; a.rstd = rstd; a.gpart = gp[v];
       a.stamps = stp;
       a.ablate = variants[v] >> 12;
+      if (dv[v].csplit) a.raw_out = outs[v];   // split mode: raw conv output (GroupNorm is a separate pass): timing only
       launch_conv(dv[v], a, st);
     };
     for (size_t v = 0; v < variants.size(); ++v) for (int i = 0; i < 3; ++i) run(v, nullptr);
