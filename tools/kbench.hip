@@ -230,6 +230,15 @@ int main(int argc, char** argv) {
       }
       if (cnt) printf("            stamps over %d waves: prologue %.0f  main %.0f  epilogue %.0f cycles (acc->LDS %.0f, stats %.0f, store %.0f); in-kernel clock %.0f MHz\n",
                       cnt, pro / cnt, mainl / cnt, epi / cnt, e1 / cnt, e2 / cnt, e3 / cnt, clk / cnt);
+      {
+        double q0 = 0, q1 = 0, q2 = 0, q3 = 0; int c2 = 0;
+        for (size_t w = 0; w < nstamp / 16; ++w) {
+          const unsigned long long* s = &hs[w * 16];
+          if (s[1] == 0 || s[4] == 0 || s[8] == 0 || s[10] == 0 || s[8] < s[1] || s[8] > s[2]) continue;
+          q0 += (double)(s[8] - s[1]); q1 += (double)(s[9] - s[8]); q2 += (double)(s[10] - s[9]); q3 += (double)(s[2] - s[10]); ++c2;
+        }
+        if (c2) printf("            prologue: setup %.0f  requests issued %.0f  first chunk landed + transformed %.0f  barrier %.0f\n", q0 / c2, q1 / c2, q2 / c2, q3 / c2);
+      }
       if (cnt && ph[0] > 0) printf("            main-loop phases (cycles summed over chunks): first group %.0f  staging %.0f  barrier %.0f  second group %.0f\n",
                                   ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt);
       if (cnt && sub[0] > 0) printf("            output transform: tables+sync %.0f  pass A %.0f  pass B %.0f  pass C %.0f  bias/time %.0f\n",
