@@ -1181,6 +1181,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
     for (int chunk = 0; chunk < nchunk;) {
       PIECE2(0, 1)
       PIECE2(1, 0)
+#ifdef NODE_STAMPS
+      if (chunk == 2) PSTAMP(a.stamps, 11, "s_memtime");   // end of the first loop iteration (cold instruction cache)
+#endif
     }
   }
 #undef PIECE2

@@ -237,6 +237,14 @@ int main(int argc, char** argv) {
           if (s[1] == 0 || s[4] == 0 || s[8] == 0 || s[10] == 0 || s[8] < s[1] || s[8] > s[2]) continue;
           q0 += (double)(s[8] - s[1]); q1 += (double)(s[9] - s[8]); q2 += (double)(s[10] - s[9]); q3 += (double)(s[2] - s[10]); ++c2;
         }
+        {
+          double f1 = 0; int c3 = 0;
+          for (size_t w = 0; w < nstamp / 16; ++w) {
+            const unsigned long long* s = &hs[w * 16];
+            if (s[2] && s[11] > s[2] && s[3] > s[11]) { f1 += (double)(s[11] - s[2]); ++c3; }
+          }
+          if (c3) printf("            first loop iteration (2 chunks) %.0f cycles\n", f1 / c3);
+        }
         if (c2) printf("            prologue: setup %.0f  requests issued %.0f  first chunk landed + transformed %.0f  barrier %.0f\n", q0 / c2, q1 / c2, q2 / c2, q3 / c2);
       }
       if (cnt && ph[0] > 0) printf("            main-loop phases (cycles summed over chunks): first group %.0f  staging %.0f  barrier %.0f  second group %.0f\n",
