@@ -1008,7 +1008,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   //      request at every use) and cost no VALU per chunk.  Range-checked buffer loads did the same but issued
   //      ~100 cycles slower each (measured). ----
   const int sr = tid & 3, sq4 = (tid >> 2) & 3, stile = tid >> 4;
-  const int slofs = stile * SST2 + (sr * 4) * ASTW + sq4 * 4;   // component (xi = sr, nu = 0)
+  // component (xi = sr, nu = 0).  ds_write_b128 is serviced in groups of 8 contiguous lanes with banks (a/4) % 32:
+  // the four patch rows of a quad sit 80 floats apart (= 16 banks), so rows 0/2 and 1/3 collided (2-way, measured
+  // as 31 % of all LDS cycles); the channel quad of rows 2 and 3 is stored at position sq4 ^ 2 instead, and the
+  // readers of those components (xi = 2, 3) swap their lane halves to match.
+  const int slofs = stile * SST2 + (sr * 4) * ASTW + ((sq4 ^ (sr & 2)) * 4);
   const float* abase = a.in + (size_t)n0 * d.HW * d.C;
   const unsigned zoff = (unsigned)(((size_t)(d.N - n0) * d.HW * d.C + sq4 * 4) * sizeof(float));   // the zero row
   unsigned svoff[4] = {zoff, zoff, zoff, zoff};   // byte offsets of the four patch pixels of row sr
@@ -1028,7 +1032,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   // ---- operand offsets: wave w = the four components (xi = w >> 1, nu = 0..3) of column half w & 1, so the
   //      nu half of the output transform happens in registers before anything goes through LDS ----
   const int wxi = wave >> 1, wnn = wave & 1;
-  const int arow = l31 * SST2 + (4 * wxi) * ASTW + 8 * hi;       // + nu * ASTW, + 4 g
+  const int arow = l31 * SST2 + (4 * wxi) * ASTW + 8 * (hi ^ (wxi >> 1));   // + nu * ASTW, + 4 g  (xi >= 2: quads 0,1 <-> 2,3, see slofs)
   const int nchunk = (d.C + KCW - 1) / KCW;
   const float* wbase = a.wpacked + (size_t)nt * nchunk * (16 * BN * KCW);
   const int bofs = ((4 * wxi) * BN + wnn * 32 + l31) * KCW + 8 * hi;   // [comp][col][16]: + nu * BN*KCW, + 4 g

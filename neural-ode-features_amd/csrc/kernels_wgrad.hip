@@ -515,7 +515,9 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
       const float4 pr = nu == 0 ? rv[2] : nu == 2 ? rv[1] : nu == 1 ? rv[2] : rv[3];
       const float sg = nu == 1 ? 1.f : -1.f;
       const float e0 = pl.x + sg * pr.x, e1 = pl.y + sg * pr.y, e2 = pl.z + sg * pr.z, e3 = pl.w + sg * pr.w;
-      *reinterpret_cast<float4*>(Vs + st * TS + (vr * 4 + nu) * CS + vq * 4) =
+      // (channel quad of patch rows 2, 3 stored at vq ^ 2: ds_write_b128 groups are 8 contiguous lanes on 32 banks and the
+      //  rows of a quad sit 16 banks apart -- rows 0/2 and 1/3 collided; the readers of components a >= 2 flip channel bit 3)
+      *reinterpret_cast<float4*>(Vs + st * TS + (vr * 4 + nu) * CS + (vq ^ (vr & 2)) * 4) =
           f4(so * e0 + sps * QP2(e0), so * e1 + sps * QP2(e1), so * e2 + sps * QP2(e2), so * e3 + sps * QP2(e3));
     } else {
       const int b = k - 4;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
   WSTAMP(a.stamps, 2, "s_memtime");
 
   // per-lane bases: step s covers tiles 2 s + hi; component 8 wh + c at + c * CS
-  const int vbase = hi * TS + (8 * wh) * CS + wi * 32 + l31;
+  const int vbase = hi * TS + (8 * wh) * CS + ((wi * 32 + l31) ^ (8 * wh));   // (wave half wh holds a = 2 wh, 2 wh + 1: see the staging write)
   const int zbase = hi * TS + (8 * wh) * CS + wj * 32 + l31;
   int buf = 0;
 #ifdef NODE_STAMPS
