@@ -1051,9 +1051,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
 #define ALOAD1(DST, CBASE, I)                                                              \
   DST[I] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(abase + (CBASE)) + svoff[I]);
   // x transform of this lane's patch row, then the y transform with ONE other row of the quad:
-  //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(1) - e(3)    (lane r = xi owns e(r))
-#define QP(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
-  const float so = sr == 3 ? -1.f : 1.f, sp = (sr == 0 || sr == 2) ? -1.f : 1.f;
+  //   xi = 0: e(0) - e(2)   xi = 1: e(1) + e(2)   xi = 2: e(2) - e(1)   xi = 3: e(3) - e(1)    (lane r = xi owns e(r))
+  // Row xi = 3 is the NEGATIVE of the textbook B^T row (e(1) - e(3)); k_pack_weights_w2 negates the same row of the
+  // filter transform, so the products are unchanged.  That makes every lane's result "own + (+/-) the other row":
+  // two instructions per element -- a DPP-fused XOR that fetches the other row and sets its sign, and an add --
+  // instead of four (mov_dpp, two multiplies by +/-1, fma).  The transform is the main loop's VALU bill, and a
+  // VALU instruction costs ~11 cycles of this wave's issue time next to the partner's MFMA stream.
+#define QPX(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true) ^ spmask)
+  const int spmask = sr == 1 ? 0 : (int)0x80000000;   // the other row enters negated except for xi = 1
   // one transformed column nu of the patch row: 4 channels, one 16-B LDS write
 #define AWRITE1(SRC, ABASE, NU)                                                            \
   {                                                                                        \
@@ -1062,7 +1067,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
     const float sg = (NU) == 1 ? 1.f : -1.f;                                               \
     const float e0 = pl.x + sg * pr.x, e1 = pl.y + sg * pr.y, e2 = pl.z + sg * pr.z, e3 = pl.w + sg * pr.w; \
     *reinterpret_cast<float4*>((ABASE) + slofs + (NU) * ASTW) =                            \
-        make_float4(so * e0 + sp * QP(e0), so * e1 + sp * QP(e1), so * e2 + sp * QP(e2), so * e3 + sp * QP(e3)); \
+        make_float4(e0 + QPX(e0), e1 + QPX(e1), e2 + QPX(e2), e3 + QPX(e3));              \
   }
 
   // filter operands [register set][nu 4 x group 2]: the set of chunk q+1 fills while
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
 #undef ALOAD1
 #undef AWRITE1
 #undef BLOAD1
-#undef QP
+#undef QPX
   PSTAMP(a.stamps, 3, "s_memtime");
 
   // bias + t * tmap of the pixel-tile elements this thread finalises (column tid & 63, tiles (tid >> 6) + 8 i, 2x2
@@ -1336,6 +1341,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_w2(const float* __restrict
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) v += G(xi, kh) * g[kh][kw] * G(nu, kw);
+      if (xi == 3) v = -v;   // the kernel's input transform uses the negated row xi = 3 (see AWRITE1)
     }
     packed[idx] = v;
   }
