@@ -467,7 +467,9 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     z_off[e] = (unsigned)((((size_t)(2 * s_thl + (e >> 1)) * d.W + 2 * s_tw + (e & 1)) * d.C + zq * 4) * sizeof(float));
-  const float zc0 = za == 3 ? 0.f : 1.f, zc1 = za == 0 ? 0.f : za == 1 ? 1.f : -1.f;   // R_a = zc0 * y0* + zc1 * y1*
+  // R_a = zc0 * y0* + zc1 * y1*  (rows 1, -1 apart; row a = 3 is +y1*, the NEGATIVE of A's textbook row -y1*, to
+  // match the negated row 3 of the V transform below: the product V[3][b] * Z[3][b] is unchanged)
+  const float zc0 = za == 3 ? 0.f : 1.f, zc1 = za == 0 ? 0.f : za == 2 ? -1.f : 1.f;
 
   // next unit to request: (sample, group), advanced incrementally on the scalar unit; requests past the last
   // unit repeat it (harmless; every request and every write stays unconditional)
@@ -500,13 +502,14 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
     if (k < 4) rv[k] = *reinterpret_cast<const float4*>(vb + ((!rbad && v_xok[k]) ? v_off[k] : vzero));
     else rz[k - 4] = *reinterpret_cast<const float4*>(zb + (z_on ? z_off[k - 4] : zzero));
   };
-#define QP2(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true))
-  const float so = vr == 3 ? -1.f : 1.f, sps = (vr == 0 || vr == 2) ? -1.f : 1.f;
+  // (as in k_conv3x3_w2: row 3 negated -> every lane is "own + (+/-) other row": one DPP-fused XOR + one add per element)
+  const int spmask = vr == 1 ? 0 : (int)0x80000000;
+#define QP2(v) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), 0x5A /* quad_perm [2,2,1,1] */, 0xf, 0xf, true) ^ spmask)
   auto f4 = [](float x, float y, float z, float w) { return make_float4(x, y, z, w); };
   float4 zr0, zr1;   // the row-transformed dz pair of this thread (columns 0 / 1)
   // one staging item: k = 0..3 column nu = k of V = B^T d B (x transform of this lane's patch row, then the y
   // transform with ONE other row of the quad:  xi = 0: e(0) - e(2)  xi = 1: e(1) + e(2)  xi = 2: e(2) - e(1)
-  // xi = 3: e(1) - e(3), lane r = xi owns e(r));  k = 4..7 column b = k - 4 of Z = A dy A^T
+  // xi = 3: e(3) - e(1), lane r = xi owns e(r));  k = 4..7 column b = k - 4 of Z = A dy A^T
   auto write_piece = [&](int k, float* Vs, float* Zs) {
     if (!st_on) return;   // wave-uniform
     if (k < 4) {
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
       // (channel quad of patch rows 2, 3 stored at vq ^ 2: ds_write_b128 groups are 8 contiguous lanes on 32 banks and the
       //  rows of a quad sit 16 banks apart -- rows 0/2 and 1/3 collided; the readers of components a >= 2 flip channel bit 3)
       *reinterpret_cast<float4*>(Vs + st * TS + (vr * 4 + nu) * CS + (vq ^ (vr & 2)) * 4) =
-          f4(so * e0 + sps * QP2(e0), so * e1 + sps * QP2(e1), so * e2 + sps * QP2(e2), so * e3 + sps * QP2(e3));
+          f4(e0 + QP2(e0), e1 + QP2(e1), e2 + QP2(e2), e3 + QP2(e3));
     } else {
       const int b = k - 4;
       if (b == 0) {

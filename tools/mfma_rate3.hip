@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // bit3: VALU in all waves (symmetric staging); bit4: dependent VALU chain (else 8 independent chains)
 template <int MODE, int NV>
 __global__ __launch_bounds__(512) void k_rate(float* out, unsigned long long* cyc, int chunks) {
+  __shared__ __attribute__((aligned(16))) float lds[16384];
   f32x16 acc[4];
   for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int tid = threadIdx.x;
@@ -33,7 +34,16 @@ __global__ __launch_bounds__(512) void k_rate(float* out, unsigned long long* cy
     if (do_valu) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        if (MODE & 16) v[0] = __builtin_fmaf(v[0], 1.0001f, 0.5f);
+        if (MODE & 32) {          // DPP quad permutes (the input transform's cross-row exchange)
+          v[i & 7] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i & 7]), 0x5A, 0xf, 0xf, true) ^ (int)(i * 77));
+        } else if (MODE & 64) {   // 16-byte LDS writes
+          *reinterpret_cast<float4*>(lds + ((tid * 4 + (i & 7) * 2048) & 16383)) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (MODE & 128) {  // packed fp32 adds
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          f2 x = {v[(2 * i) & 6], v[((2 * i) & 6) + 1]}, y = {0.5f, 0.25f};
+          x = x + y;
+          v[(2 * i) & 6] = x.x; v[((2 * i) & 6) + 1] = x.y;
+        } else if (MODE & 16) v[0] = __builtin_fmaf(v[0], 1.0001f, 0.5f);
         else v[i & 7] = __builtin_fmaf(v[i & 7], 1.0001f, 0.5f);
       }
     }
@@ -83,5 +93,12 @@ int main() {
   run<1 + 8, 100>("all waves MFMA+VALU (symmetric), barrier");
   run<1, 400>("stagers MFMA+VALU, partners MFMA, barrier");
   run<1, 100>("stagers MFMA+VALU, partners MFMA, barrier");
+  run<1 + 8, 50>("all waves MFMA + 50 fma, barrier");
+  run<1 + 8 + 32, 50>("all waves MFMA + 50 DPP-xor, barrier");
+  run<1 + 8 + 128, 50>("all waves MFMA + 50 packed adds, barrier");
+  run<1 + 8 + 64, 8>("all waves MFMA + 8 ds_write_b128, barrier");
+  run<1 + 32, 100>("stagers MFMA + 100 DPP-xor, partners MFMA, barrier");
+  run<2 + 32, 200>("stagers DPP-xor only, partners MFMA only");
+  run<2 + 64, 32>("stagers ds_write_b128 only, partners MFMA only");
   return 0;
 }
