@@ -37,7 +37,7 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None for other shapes."""
-    path = os.path.join(ROOT, 'profiles', 'r01_i_pmc_eval_cfg2.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_k_pmc_eval_cfg2.json')
     if not (args.batch == 128 and args.filters == 256 and os.path.exists(path)):
         return None
     try:
