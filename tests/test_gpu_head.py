@@ -121,3 +121,17 @@ def test_resblock_fused_matches_plain_modules():
     assert rel_err(xa.grad, xb.grad) < 5e-5
     for k, v in blk.named_parameters():
         assert rel_err(gf[k], v.grad) < 5e-5, k
+
+
+def test_stem_and_head_on_gpu_match_the_reference_logits():
+    """tests/golden/odenet_t0.pt: logits of the REFERENCE's own ODENet with the ODE block switched off (t1 = 0,
+    model.py:363-364), i.e. stem + head only.  On the GPU both run through the fused GroupNorm / head kernels."""
+    import os
+    import neural_ode_features_amd as nof
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'odenet_t0.pt'))
+    net = nof.ODENet(1, out=10, n_filters=8, downsample='residual', t1=0)
+    net.load_state_dict(g['state_dict'])
+    net = net.cuda().eval()
+    with torch.no_grad():
+        got = net(g['x'].cuda())
+    assert rel_err(got, g['logits']) < 2e-5
