@@ -960,10 +960,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  // (An XCD-aware tile order was measured: one column tile per XCD keeps its filter slice L2-resident but
-  // fetches the activations four times; HBM traffic and time were unchanged -- 50.7 MB, 58 us -- so launch order
-  // stays: the four column tiles of a pixel tile share an XCD and read the activations once.)
-  const int mtile = blockIdx.x, nt = blockIdx.y;
+  // XCD-aware tile order (speed-neutral, traffic only): blocks b and b + 8 share an XCD and its 4 MB L2.  In launch
+  // order an XCD sees every column tile, i.e. the whole packed filter (4.2 MB at C = 256: 8 copies = 33.6 MB of
+  // the 50.9 MB this kernel fetched per launch); giving each XCD two column tiles x a quarter of the pixel tiles
+  // fetches the filter 4 x and the activations 2 x instead: the minimum over such partitions.
+  int mtile = blockIdx.x, nt = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, L = blockIdx.x + gx * blockIdx.y;
+    if (gy == 4 && (gx & 3) == 0) {
+      const int xcd = L & 7, slot = L >> 3;      // slot 0 .. gx/2 - 1
+      nt = (xcd & 1) * 2 + (slot & 1);
+      mtile = (xcd >> 1) * (gx >> 2) + (slot >> 1);
+    }
+  }
   // whole samples per tile, or (Dims::csplit workgroups per sample, images larger than 128 pixels) one 32-tile
   // band of ONE sample: whole tile rows, 128 consecutive pixels; GroupNorm is then a separate pointwise pass and
   // this kernel stores its raw tile
