@@ -1,63 +1,140 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec (forward + adjoint backward + SGD step) of the
-CIFAR-10 ODE-ResNet, dopri5 tol=1e-3, bs=128 per GPU (BASELINE.json configs[1];
-with --gpus N the batch shards data-parallel, N x 128 = configs[3] at N=8).
+CIFAR-10 ODE-ResNet, dopri5, bs=128 per GPU (BASELINE.json configs[1]; with --gpus N
+the batch shards data-parallel, N x 128 = configs[3] at N=8).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # cfg 2, one GPU
+    python bench.py --config 3                       # tol 1e-5 (configs[2])
+    python bench.py --config 5                       # 64x64 input, 1024 filters, 3 stacked blocks, 64 images / GPU
+    python bench.py --gpus N --steps K --warmup W    # spawns N ranks itself (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          # ... or runs as one rank of a launcher
+
+`--gpus N` never runs at a smaller world size: without a launcher's environment the
+script starts N child ranks (before anything touches the GPU); if the box has fewer
+than N devices, or the launcher's WORLD_SIZE disagrees, it exits non-zero.
 
 A "step" is the loop body of the reference's train.py:40-58 on device-resident
 synthetic tensors: p = model(x); loss = CE(p, y); loss.backward(); optimizer.step();
-optimizer.zero_grad().  Stem/head run on PyTorch-ROCm (MIOpen); the ODE block --
-the hot path -- runs in libnode_hip.so through the C ABI.
+optimizer.zero_grad().  The ODE block(s) -- the hot path -- run in libnode_hip.so
+through the C ABI.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
-(k_conv3x3, fp32-MFMA implicit GEMM): algorithmic FLOPs per launch / average launch
-duration from HIP events recorded by the library on the launch stream, over a
-repeat of the timed steps.  `cpu_baseline` is the oracle (CPU restatement of the
-torchdiffeq path driving PyTorch-CPU conv/group_norm) on this box's host cores.
+Prints ONE JSON line (rank 0).  `value` = images of all ranks / wall time of exactly
+K steps (barrier + synchronize on both sides, max over ranks); `step_ms` holds the
+per-step median / min / max from HIP events on the compute stream.  `roofline` is
+for the dominant kernel (the 3x3 conv, fp32 MFMA): `achieved` = MFMA FLOPs the kernel
+ISSUES per launch / average launch duration from HIP events recorded by the library
+on the launch stream over a repeat of the timed steps, `frac` = achieved / the fp32
+matrix peak -- the utilisation of the matrix pipe.  The kernel is a Winograd
+F(2x2,3x3) convolution, so it issues 16/36 of the direct-convolution FLOPs SURVEY.md
+8(d) counts; that algorithmic rate is reported under `roofline.algorithmic` and is
+NOT a utilisation.  `cpu_baseline` is the oracle (CPU restatement of the torchdiffeq
+path driving PyTorch-CPU conv/group_norm) on this box's host cores.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 
+# BASELINE.json configs (1-based like SURVEY.md 8d); per-GPU batch
+CONFIGS = {
+    2: dict(filters=256, tol=1e-3, batch=128, image=32, blocks=1,
+            name='CIFAR-10 ODE-ResNet (odenet, residual stem, 256 filters), dopri5 tol=1e-3, adjoint backward'),
+    3: dict(filters=256, tol=1e-5, batch=128, image=32, blocks=1,
+            name='CIFAR-10 ODE-ResNet (odenet, residual stem, 256 filters), dopri5 tol=1e-5, adjoint backward'),
+    5: dict(filters=1024, tol=1e-3, batch=64, image=64, blocks=3,
+            name='synthetic 64x64x3 input, 4x-widened ODE-ResNet (1024 filters), 3 stacked ODE blocks, dopri5 tol=1e-3, '
+                 'adjoint backward'),
+}
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
-    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
-    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None for other shapes."""
-    path = os.path.join(ROOT, 'profiles', 'r01_k_pmc_eval_cfg2.json')
-    if not (args.batch == 128 and args.filters == 256 and os.path.exists(path)):
-        return None
+
+# ---------------------------------------------------------------------------
+# self-launcher: one child process per GPU, started before any GPU call
+# ---------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(world, argv, env_extra=None, timeout=None):
+    """Start `world` copies of `argv` as ranks 0..world-1 of one node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    in the environment, rendezvous on 127.0.0.1), wait for all of them, return the worst exit code.  Children are
+    fresh processes: the parent must not have initialised the GPU (it only counts devices)."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen(list(argv), env=env))
+    rc = 0
+    deadline = None if timeout is None else time.time() + timeout
     try:
-        with open(path) as fh:
-            pmc = json.load(fh)
-        k = next(v for n, v in pmc.items() if 'k_conv3x3' in n)
-        return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
-    except Exception:
-        return None
+        for p in procs:
+            left = None if deadline is None else max(1.0, deadline - time.time())
+            code = p.wait(timeout=left)
+            rc = rc or code
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
-def build_model(device, filters, tol, method):
+def resolve_world(args):
+    """(world, rank, local_rank) from the launcher's environment, or None after this process acted as the launcher."""
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is not None:
+        world = int(env_world)
+        if world != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+        return world, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus == 1:
+        return 1, 0, 0
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < args.gpus:
+        raise SystemExit('bench.py: --gpus %d requested but this node exposes %d HIP device(s); refusing to run at a '
+                         'smaller world size' % (args.gpus, have))
+    rc = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+    raise SystemExit(rc)
+
+
+# ---------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------
+def build_model(device, cfg, method):
+    import torch
     import neural_ode_features_amd as nof
     torch.manual_seed(23)       # train.py:224,227
-    model = nof.ODENet(3, out=10, n_filters=filters, downsample='residual', method=method, tol=tol,
-                       adjoint=True, t1=1, dropout=0.5)
+    if cfg['blocks'] == 1:
+        model = nof.ODENet(3, out=10, n_filters=cfg['filters'], downsample='residual', method=method, tol=cfg['tol'],
+                           adjoint=True, t1=1, dropout=0.5)
+    else:
+        model = nof.StackedODENet(3, out=10, n_filters=cfg['filters'], n_blocks=cfg['blocks'], downsample='residual',
+                                  method=method, tol=cfg['tol'], adjoint=True, t1=1, dropout=0.5)
     return model.to(device)
 
 
 def train_step(model, opt, x, y, reducer=None):
+    import torch.nn.functional as F
     p = model(x)
     loss = F.cross_entropy(p, y)
     nfe_f = model.nfe(reset=True)
@@ -65,14 +142,19 @@ def train_step(model, opt, x, y, reducer=None):
     nfe_b = model.nfe(reset=True)
     if reducer is not None:
         reducer.finish()
-    opt.step()
-    opt.zero_grad()
+        opt.step()
+        reducer.zero_grad()
+    else:
+        opt.step()
+        opt.zero_grad()
     return loss, nfe_f, nfe_b
 
 
-def cpu_baseline(state_dict, filters, tol, method, bs, iters, min_seconds=12.0):
-    """The reference-equivalent CPU path: same ODENet, the oracle standing in for
-    torchdiffeq (which cannot be installed here), all host cores."""
+def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
+    """The reference-equivalent CPU path: same net, the oracle standing in for torchdiffeq (which cannot be
+    installed here), on a BOUNDED sample of the workload: whole training iterations at a batch sized so that
+    one iteration takes a few seconds, repeated for about `min_seconds`."""
+    import torch
     import neural_ode_features_amd as nof
     from oracle import torchdiffeq_restated as tdq
     # threads actually used: the GPU box exposes every host core but gives one GPU slot a 16-core
@@ -85,29 +167,58 @@ def cpu_baseline(state_dict, filters, tol, method, bs, iters, min_seconds=12.0):
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(23)
-    model = nof.ODENet(3, out=10, n_filters=filters, downsample='residual', method=method, tol=tol,
-                       adjoint=True, t1=1, dropout=0.5)
-    model.load_state_dict(state_dict)
-    model.odeblock.odeint = tdq.odeint_adjoint       # CPU solver = the checker, timed as the baseline
+    if cfg['blocks'] == 1:
+        model = nof.ODENet(3, out=10, n_filters=cfg['filters'], downsample='residual', method=method, tol=cfg['tol'],
+                           adjoint=True, t1=1, dropout=0.5)
+        model.load_state_dict(state_dict)
+        model.odeblock.odeint = tdq.odeint_adjoint       # CPU solver = the checker, timed as the baseline
+        bs = cfg['batch']
+    else:
+        model = nof.StackedODENet(3, out=10, n_filters=cfg['filters'], n_blocks=cfg['blocks'], downsample='residual',
+                                  method=method, tol=cfg['tol'], adjoint=True, t1=1, dropout=0.5)
+        model.load_state_dict(state_dict)
+        for b in model.odeblocks:
+            b.odeint = tdq.odeint_adjoint
+        bs = 2                                            # cfg 5: ~0.6 TFLOP per image and iteration
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     gen = torch.Generator().manual_seed(1234)
-    xw = torch.randn(8, 3, 32, 32, generator=gen)
-    yw = torch.randint(0, 10, (8,), generator=gen)
-    train_step(model, opt, xw, yw)                    # warm-up (thread pool, oneDNN primitives)
-    x = torch.randn(bs, 3, 32, 32, generator=gen)
+    img = cfg['image']
+    if cfg['blocks'] == 1:
+        xw = torch.randn(8, 3, img, img, generator=gen)
+        yw = torch.randint(0, 10, (8,), generator=gen)
+        train_step(model, opt, xw, yw)                    # warm-up (thread pool, oneDNN primitives)
+    x = torch.randn(bs, 3, img, img, generator=gen)
     y = torch.randint(0, 10, (bs,), generator=gen)
     t0 = time.perf_counter()
     nf = nb = 0
     done = 0
-    while done < iters or (time.perf_counter() - t0 < min_seconds and done < 64):
-        _, a, b = train_step(model, opt, x, y)
-        nf, nb = a, b
+    while done < 1 or (time.perf_counter() - t0 < min_seconds and done < 64):
+        _, nf, nb = train_step(model, opt, x, y)
         done += 1
-    iters = done
+        if time.perf_counter() - t0 > max_seconds:
+            break
     dt = time.perf_counter() - t0
-    return {'value': iters * bs / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': done * bs / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'sample': '%d training iterations at bs=%d (fwd + adjoint + SGD), last NFE-F %d NFE-B %d, %.1f s'
-                      % (iters, bs, nf, nb, dt)}
+                      % (done, bs, nf, nb, dt)}
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None where no pass is committed."""
+    for name in ('r02_pmc_eval_cfg%d.json' % config, 'r01_k_pmc_eval_cfg%d.json' % config):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as fh:
+                pmc = json.load(fh)
+            k = next(v for n, v in pmc.items() if 'k_conv3x3' in n)
+            return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+        except Exception:
+            continue
+    return None
 
 
 def main():
@@ -115,31 +226,39 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (bs=128: BASELINE.json)')
-    ap.add_argument('--filters', type=int, default=256)
-    ap.add_argument('--tol', type=float, default=1e-3)
+    ap.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS), help='BASELINE.json config (1-based)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override')
+    ap.add_argument('--filters', type=int, default=None)
+    ap.add_argument('--tol', type=float, default=None)
     ap.add_argument('--method', default='dopri5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=1)
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    if args.batch is not None:
+        cfg['batch'] = args.batch
+    if args.filters is not None:
+        cfg['filters'] = args.filters
+    if args.tol is not None:
+        cfg['tol'] = args.tol
 
+    world, rank, local_rank = resolve_world(args)
+
+    import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (there is no CPU fallback for the product path)')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py: LOCAL_RANK %d but only %d HIP device(s)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
-    model = build_model(device, args.filters, args.tol, args.method)
+    model = build_model(device, cfg, args.method)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     reducer = None
     if world > 1:
@@ -149,8 +268,8 @@ def main():
     model.train()
 
     gen = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(args.batch, 3, 32, 32, generator=gen).to(device)      # normalised CIFAR-shaped
-    y = torch.randint(0, 10, (args.batch,), generator=gen).to(device)
+    x = torch.randn(cfg['batch'], 3, cfg['image'], cfg['image'], generator=gen).to(device)   # normalised CIFAR-shaped
+    y = torch.randint(0, 10, (cfg['batch'],), generator=gen).to(device)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -160,22 +279,29 @@ def main():
 
     for _ in range(args.warmup):
         train_step(model, opt, x, y, reducer)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync()
     t0 = time.perf_counter()
     nfe_f = nfe_b = 0
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         _, a, b = train_step(model, opt, x, y, reducer)
+        ev[i + 1].record()
         nfe_f += a
         nfe_b += b
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    fstats = model.odeblock.odefunc.last_forward_stats
-    bstats = model.odeblock.odefunc.last_backward_stats
+    blocks = list(model.odeblocks) if hasattr(model, 'odeblocks') else [model.odeblock]
+    fstats = [b.odefunc.last_forward_stats for b in blocks]
+    bstats = [b.odefunc.last_backward_stats for b in blocks]
 
+    side = cfg['image'] // 4
+    state = [cfg['batch'], cfg['filters'], side, side]
     roofline = None
     if not args.no_roofline:
         # repeat of the timed steps with per-launch HIP events on the launch stream
@@ -187,34 +313,32 @@ def main():
         k = prof['conv3x3_implicit_gemm']
         if k['launches'] > 0:
             avg_ms = k['total_ms'] / k['launches']
-            flops_per_launch = k['flops'] / k['launches']
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            # `achieved` counts ALGORITHMIC FLOPs (direct 3x3 conv: 2*9*C^2*N*H*W) and `frac` is
-            # achieved / peak as the contract defines it.  The kernel reaches those FLOPs through a Winograd
-            # transform (2-D F(2x2,3x3): 16/36 of them are issued as MFMA work; 1-D F(2,3): 2/3), which is
-            # why `frac` can exceed 1; `mfma_pipe` prices the MFMA work actually issued -- that is the
-            # utilisation of the matrix pipe and the number to raise.
+            algo_per_launch = k['flops'] / k['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
             wino = os.environ.get('NODE_TUNE_CONV_WINO', '2')
             issued = {'2': 16.0 / 36.0, '1': 2.0 / 3.0}.get(wino, 1.0)
             kname = {'2': 'k_conv3x3_w2 (fp32 MFMA, 2-D Winograd F(2x2,3x3), fwd+dgrad)',
                      '1': 'k_conv3x3_w (fp32 MFMA, 1-D Winograd F(2,3), fwd+dgrad)'}.get(wino, 'k_conv3x3 (fp32 MFMA implicit GEMM, fwd+dgrad)')
+            algo = algo_per_launch / (avg_ms * 1e-3) / 1e12
+            ach = algo * issued
             roofline = {'bound': 'mfma', 'kernel': kname,
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args),
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args.config),
                         'avg_launch_us': avg_ms * 1e3, 'launches': k['launches'],
-                        'flops_per_launch': flops_per_launch,
-                        'mfma_pipe': {'flops_per_launch': flops_per_launch * issued,
-                                      'achieved': ach * issued, 'frac': ach * issued / MFMA_F32_PEAK_TFLOPS},
-                        'note': 'achieved/frac count direct-convolution FLOPs; the Winograd kernel issues %.3f of '
-                                'them on the MFMA pipe (mfma_pipe)' % issued}
+                        'flops_per_launch': algo_per_launch * issued,
+                        'algorithmic': {'flops_per_launch': algo_per_launch, 'achieved': algo,
+                                        'speedup_vs_peak': algo / MFMA_F32_PEAK_TFLOPS},
+                        'note': 'achieved/frac = MFMA FLOPs issued (%.3f of the direct-convolution FLOPs: Winograd) over the '
+                                'fp32 matrix peak, i.e. matrix-pipe utilisation; `algorithmic` counts direct-convolution '
+                                'FLOPs (SURVEY.md 8d) and is not a utilisation' % issued}
             w = prof['wgrad_gemm']
             if w['launches'] > 0:
                 wavg = w['total_ms'] / w['launches']
-                roofline['wgrad'] = {'achieved': w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12,
-                                     'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
+                walgo = w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12
+                roofline['wgrad'] = {'achieved': walgo * issued, 'frac': walgo * issued / MFMA_F32_PEAK_TFLOPS,
+                                     'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
 
     if rank == 0:
-        global_batch = args.batch * world
+        global_batch = cfg['batch'] * world
         result = {
             'metric': 'images/sec (fwd+adjoint) CIFAR-10 ODE-ResNet bs=128 at 1/2/4/8 GPU',
             'value': args.steps * global_batch / elapsed,
@@ -223,26 +347,26 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
+            'step_ms': {'median': statistics.median(per_step), 'min': min(per_step), 'max': max(per_step),
+                        'source': 'HIP events on the compute stream of rank 0, one per step'},
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': 'CIFAR-10 ODE-ResNet (odenet, residual stem, %d filters), %s tol=%g, adjoint backward, '
-                            'bs=%d per GPU, SGD step' % (args.filters, args.method, args.tol, args.batch),
-                'global_batch': global_batch, 'state': [args.batch, args.filters, 8, 8],
+                'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
+                'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
                 'parallelism': 'dp%d' % world,
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
-                'last_forward_steps': [fstats['accepted'], fstats['rejected']],
-                'last_backward_steps': [bstats['accepted'], bstats['rejected']],
+                'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
+                'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],
             },
         }
         if roofline is not None:
             result['roofline'] = roofline
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(init_state, args.filters, args.tol, args.method,
-                                                  args.batch, args.cpu_iters)
+            result['cpu_baseline'] = cpu_baseline(init_state, cfg, args.method)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

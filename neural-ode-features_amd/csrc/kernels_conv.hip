@@ -1413,15 +1413,15 @@ void launch_pack_weights_w(const Dims& d, const float* w, float* packed, int dgr
 
 template <int MT>
 static void launch_conv_w_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_w<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_conv3x3_w<MT>, attr);
   hipLaunchKernelGGL((k_conv3x3_w<MT>), dim3(d.mtiles, d.ntile), dim3(512), conv_w_lds_bytes(d), s, a, d);
 }
 
 template <int WM, int MT>
 static void launch_conv_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3<WM, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_conv3x3<WM, MT>, attr);
   hipLaunchKernelGGL((k_conv3x3<WM, MT>), dim3(d.mtiles, d.ntile), dim3(WM * 128), conv_lds_bytes(d, a.mode), s, a, d);
 }
 
@@ -1429,8 +1429,8 @@ static void launch_conv_t(const Dims& d, const ConvArgs& a, hipStream_t s) {
 // barriers / prologue / epilogue when the grid is small; 128 / 256 = eight waves.
 void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
   if (d.wino == 2) {   // 2-D Winograd (128-pixel tiles, even H and W); weights packed by launch_pack_weights_w2
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_conv3x3_w2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static bool attr[MAX_DEVICES];
+    allow_full_lds((const void*)k_conv3x3_w2, attr);
     hipLaunchKernelGGL(k_conv3x3_w2, dim3(d.mtiles, d.ntile), dim3(512), conv_w2_lds_bytes(d), s, a, d);
     return;
   }

@@ -941,24 +941,24 @@ int wgrad_variant() {
 
 template <int W, int RB>
 static void launch_wgrad_w(const Dims& d, const WgradArgs& a, dim3 grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_w<W, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_wgrad_w<W, RB>, attr);
   const size_t lds = (size_t)(2 * (RB + 2) * (W / 2) * 256 + 2 * RB * (W / 2) * 256) * sizeof(float);
   hipLaunchKernelGGL((k_wgrad_w<W, RB>), grid, dim3(WG_THREADS), lds, s, a, d);
 }
 
 template <int UT>
 static void launch_wgrad_w2(const Dims& d, const WgradArgs& a, dim3 grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_w2<UT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_wgrad_w2<UT>, attr);
   const size_t lds_loop = (size_t)(4 * UT * 16 * 68) * sizeof(float), lds_x = (size_t)8 * 72 * 64 * sizeof(float);
   hipLaunchKernelGGL((k_wgrad_w2<UT>), grid, dim3(WG2_THREADS), lds_loop > lds_x ? lds_loop : lds_x, s, a, d);
 }
 
 template <int W, int RB>
 static void launch_wgrad_t(const Dims& d, const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_t<W, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_wgrad_t<W, RB>, attr);
   hipLaunchKernelGGL((k_wgrad_t<W, RB>), grid, dim3(WG_THREADS), lds, s, a, d);
 }
 
@@ -983,8 +983,8 @@ void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
     if (d.W == 7 && d.RB == 7) { launch_wgrad_t<7, 7>(d, a, grid, lds, s); return; }
     if (d.W == 4 && d.RB == 4) { launch_wgrad_t<4, 4>(d, a, grid, lds, s); return; }
   }
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)k_wgrad_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static bool attr[MAX_DEVICES];
+  allow_full_lds((const void*)k_wgrad_p, attr);
   hipLaunchKernelGGL(k_wgrad_p, grid, dim3(WG_THREADS), lds, s, a, d);
 }
 

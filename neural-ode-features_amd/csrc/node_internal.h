@@ -109,6 +109,18 @@ __device__ inline float comb_scale(const Comb& c, const Ctrl* ctrl) {
   return c.scale_mode == SC_ABS ? 1.0f : (c.scale_mode == SC_DT ? (float)ctrl->dt : ctrl->h0);
 }
 
+// Kernels that stage more than 64 KB of LDS need the opt-in attribute, and the attribute is PER DEVICE: a process
+// that drives several GPUs must set it on each (one flag per device ordinal; benign if two threads race to set it).
+constexpr int MAX_DEVICES = 64;
+inline void allow_full_lds(const void* fn, bool (&done)[MAX_DEVICES]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool tracked = dev >= 0 && dev < MAX_DEVICES;
+  if (tracked && done[dev]) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (tracked) done[dev] = true;
+}
+
 // ----------------------------------------------------------------------------
 // kernel launchers (defined in the kernels_*.hip units)
 // ----------------------------------------------------------------------------

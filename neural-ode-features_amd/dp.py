@@ -7,6 +7,10 @@ no cross-sample op (GroupNorm is per-sample), so each rank integrates its own
 shard with its own adaptive steps ("local-norm" mode -- exactly what wrapping the
 reference in DDP would do) and the only exchange step is the gradient sum.
 
+Layout: every bucket owns ONE persistent flat fp32 buffer and each parameter's
+`.grad` is a view into it, so the all-reduce runs in place on the buffer autograd
+accumulated into -- no gather before, no scatter after.
+
 Overlap: parameters are grouped into buckets in *reverse* registration order
 (head first -- its gradients are ready before the adjoint solve starts).  A
 post-accumulate-grad hook launches the bucket's all-reduce asynchronously as
@@ -15,9 +19,19 @@ the adjoint ODE solve runs, and the ODE block's bucket (only final once the
 reverse solve reaches t0) travels during the stem's backward.  On a fully
 connected 8-GPU xGMI node each all-reduce is per-link bound; the ODE bucket
 (4.75 MB at C=256) is kept whole so RCCL can split it over all 7 links.
+
+    reducer = GradientReducer(model)          # after dist.init_process_group
+    loss.backward()                           # hooks launch async all-reduces
+    reducer.finish()                          # wait, average in place
+    optimizer.step()
+    reducer.zero_grad()                       # one memset per bucket, views stay installed
+
+One backward per `finish()`; micro-batches that accumulate (`train.py:56-58`) run
+under `with reducer.accumulate():` for all but the last backward.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -35,32 +49,43 @@ def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 
 class _Bucket:
-    def __init__(self, params: List[nn.Parameter]):
+    def __init__(self, index: int, params: List[nn.Parameter]):
+        self.index = index
         self.params = params
-        self.pending = len(params)
-        self.flat: Optional[torch.Tensor] = None
+        self.flat: Optional[torch.Tensor] = None      # persistent [sum numel] buffer; .grad of every param views it
+        self.views: List[torch.Tensor] = []
+        self.fired = 0            # hooks seen since the last finish() (outside accumulate())
         self.work = None
+        self.launched = False
+
+    def ensure_flat(self):
+        if self.flat is not None and self.flat.device == self.params[0].device:
+            return
+        p0 = self.params[0]
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        self.views = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.views.append(self.flat[off:off + n].view_as(p))
+            off += n
 
     def reset(self):
-        self.pending = len(self.params)
+        self.fired = 0
         self.work = None
+        self.launched = False
 
 
 class GradientReducer:
-    """Bucketed, overlapped gradient averaging.
-
-        reducer = GradientReducer(model)          # after dist.init_process_group
-        loss.backward()                           # hooks launch async all-reduces
-        reducer.finish()                          # wait + scatter averaged grads back
-        optimizer.step()
-    """
+    """Bucketed, overlapped, in-place gradient averaging (see the module docstring)."""
 
     def __init__(self, model: nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
                  boundaries: Optional[Iterable[nn.Module]] = None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         params = [p for p in model.parameters() if p.requires_grad]
-        # cut buckets at sub-module boundaries (head | ode block | stem) first, then by size
+        # cut buckets at sub-module boundaries (head | ode block | stem) first, then by size and dtype/device
         owner = {}
         if boundaries is None:
             boundaries = [m for _, m in model.named_children()]
@@ -68,55 +93,94 @@ class GradientReducer:
             for p in m.parameters():
                 owner[id(p)] = bi
         self.buckets: List[_Bucket] = []
-        cur, cur_bytes, cur_owner = [], 0, None
+        cur, cur_bytes, cur_key = [], 0, None
         for p in reversed(params):
-            o = owner.get(id(p), -1)
+            key = (owner.get(id(p), -1), p.dtype, p.device)
             nbytes = p.numel() * p.element_size()
-            if cur and (o != cur_owner or cur_bytes + nbytes > bucket_bytes):
-                self.buckets.append(_Bucket(cur))
+            if cur and (key != cur_key or cur_bytes + nbytes > bucket_bytes):
+                self.buckets.append(_Bucket(len(self.buckets), cur))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
-            cur_owner = o
+            cur_key = key
         if cur:
-            self.buckets.append(_Bucket(cur))
-        self._bucket_of = {}
+            self.buckets.append(_Bucket(len(self.buckets), cur))
+        self._slot = {}
         self._hooks = []
         for b in self.buckets:
-            for p in b.params:
-                self._bucket_of[id(p)] = b
+            for i, p in enumerate(b.params):
+                self._slot[id(p)] = (b, i)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.launch_order: List[int] = []   # bucket indices in the order their all-reduce was issued
+        self._accumulating = False
+        self.install_views()
 
+    # -- flat-buffer plumbing ------------------------------------------------
+    def install_views(self):
+        """Point every parameter's `.grad` at its slice of the bucket buffer (keeping what it held)."""
+        for b in self.buckets:
+            b.ensure_flat()
+            for p, v in zip(b.params, b.views):
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def zero_grad(self):
+        """`optimizer.zero_grad()` for reducer-managed parameters: one memset per bucket; the views stay
+        installed, so the next backward accumulates straight into the all-reduce buffers."""
+        for b in self.buckets:
+            b.ensure_flat()
+            b.flat.zero_()
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+
+    @contextlib.contextmanager
+    def accumulate(self):
+        """Backward passes inside this context only accumulate locally (micro-batching, train.py:56-58)."""
+        prev, self._accumulating = self._accumulating, True
+        try:
+            yield
+        finally:
+            self._accumulating = prev
+
+    # -- hooks ---------------------------------------------------------------
     def _on_grad(self, p: nn.Parameter):
-        b = self._bucket_of[id(p)]
-        b.pending -= 1
-        if b.pending == 0:
+        b, i = self._slot[id(p)]
+        b.ensure_flat()
+        v = b.views[i]
+        if p.grad is not v and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+            # `.grad` was reset to None (optimizer.zero_grad()) and autograd installed a fresh tensor
+            if p.grad is not None:
+                v.copy_(p.grad)
+            p.grad = v
+        if self._accumulating:
+            return
+        if b.launched:
+            raise RuntimeError('GradientReducer: a gradient of bucket %d arrived after its all-reduce was launched -- '
+                               'two backward() calls per finish(); wrap all but the last in `reducer.accumulate()`'
+                               % b.index)
+        b.fired += 1
+        if b.fired == len(b.params):
             self._launch(b)
 
     def _launch(self, b: _Bucket):
+        b.launched = True
         if self.world == 1:
             return
-        grads = [q.grad if q.grad is not None else torch.zeros_like(q) for q in b.params]
-        b.flat = torch.cat([g.reshape(-1) for g in grads])
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self.launch_order.append(self.buckets.index(b))
+        self.launch_order.append(b.index)
 
     def finish(self):
-        """Wait for every in-flight all-reduce, write the averaged gradients back."""
-        for b in self.buckets:
-            if self.world > 1:
-                if b.work is None:          # a bucket whose hooks did not all fire (unused params)
+        """Wait for every in-flight all-reduce and average in place.  Buckets whose hooks did not all fire
+        (parameters unused this step) are launched here, in bucket order -- the same order on every rank."""
+        if self.world > 1:
+            for b in self.buckets:
+                if not b.launched:
                     self._launch(b)
+            for b in self.buckets:
                 b.work.wait()
-                flat = b.flat / self.world
-                off = 0
-                for q in b.params:
-                    n = q.numel()
-                    if q.grad is None:
-                        q.grad = torch.empty_like(q)
-                    q.grad.copy_(flat[off:off + n].view_as(q))
-                    off += n
+                b.flat.div_(self.world)
+        for b in self.buckets:
             b.reset()
         self.launch_order = []
 

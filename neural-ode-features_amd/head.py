@@ -28,7 +28,8 @@ class _HeadPool(torch.autograd.Function):
         stats = torch.empty(n, groups, 2, device=z.device, dtype=torch.float32)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         stream = torch.cuda.current_stream(z.device).cuda_stream
-        _lib.check(lib.node_head_fwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(scale), _ptr(pooled), _ptr(stats), stream))
+        with torch.cuda.device(z.device):
+            _lib.check(lib.node_head_fwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(scale), _ptr(pooled), _ptr(stats), stream))
         ctx.save_for_backward(z, g, b, scale, stats)
         ctx.shape = (n, c, h, w, groups, eps)
         return pooled
@@ -43,7 +44,8 @@ class _HeadPool(torch.autograd.Function):
         dz = torch.empty_like(z)
         gpart = torch.empty(n, 2, c, device=z.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(z.device).cuda_stream
-        _lib.check(lib.node_head_bwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(scale), _ptr(stats), _ptr(g_pooled),
+        with torch.cuda.device(z.device):
+            _lib.check(lib.node_head_bwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(scale), _ptr(stats), _ptr(g_pooled),
                                      _ptr(dz), _ptr(gpart), stream))
         gsum = gpart.sum(0)
         return dz, gsum[0], gsum[1], None, None, None
@@ -73,7 +75,8 @@ class _GnRelu(torch.autograd.Function):
         stats = torch.empty(n, groups, 2, device=z.device, dtype=torch.float32)
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         stream = torch.cuda.current_stream(z.device).cuda_stream
-        _lib.check(lib.node_gn_relu_fwd(shape, _ptr(z), _ptr(g), _ptr(b), int(relu), _ptr(out), _ptr(stats), stream))
+        with torch.cuda.device(z.device):
+            _lib.check(lib.node_gn_relu_fwd(shape, _ptr(z), _ptr(g), _ptr(b), int(relu), _ptr(out), _ptr(stats), stream))
         ctx.save_for_backward(z, g, b, stats)
         ctx.shape = (n, c, h, w, groups, eps, int(relu))
         return out
@@ -88,7 +91,8 @@ class _GnRelu(torch.autograd.Function):
         dz = torch.empty_like(z)
         gpart = torch.empty(n, 2, c, device=z.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(z.device).cuda_stream
-        _lib.check(lib.node_gn_relu_bwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(stats), relu, _ptr(g_out), _ptr(dz),
+        with torch.cuda.device(z.device):
+            _lib.check(lib.node_gn_relu_bwd(shape, _ptr(z), _ptr(g), _ptr(b), _ptr(stats), relu, _ptr(g_out), _ptr(dz),
                                         _ptr(gpart), stream))
         gsum = gpart.sum(0)
         return dz, gsum[0], gsum[1], None, None, None

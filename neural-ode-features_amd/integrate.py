@@ -10,6 +10,8 @@ that are not the reference's Conv-GroupNorm-ReLU `ODEfunc` raise.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -77,28 +79,47 @@ def _method_id(method) -> int:
     return _lib.METHODS[method]
 
 
-_T_CACHE: Dict[Tuple[int, int, int], List[float]] = {}
+HOST_TIMES_ATTR = '_node_host_times'
+
+
+def tag_host_times(t: torch.Tensor, times) -> torch.Tensor:
+    """Attach the host copy of a time grid to the tensor that carries it (`ODEBlock.t1`'s setter builds
+    the grid from host values, so the solve never has to read the device tensor back)."""
+    setattr(t, HOST_TIMES_ATTR, (t._version, [float(v) for v in times]))
+    return t
+
+
+# Untagged device tensors (the reference's own `ODEBlock` run on top of this package, model.py:366): read back
+# once per tensor OBJECT.  The entry holds a weak reference and the tensor's version counter; identity of the
+# object is what is compared, never its address -- a freed-and-reallocated grid can share `data_ptr()` with a
+# dead one (a `t1` sweep, evaluate.py:116-117, does exactly that), but not a live Python object.
+_T_SEEN: Dict[int, tuple] = {}
 
 
 def _host_times(t: torch.Tensor) -> List[float]:
-    """Time grid as host floats.  A device tensor is read back once and cached by
-    (storage, version): `ODEBlock` re-passes the same tensor every iteration."""
+    """Time grid as host floats."""
     if not torch.is_tensor(t):
         raise TypeError('t must be a tensor')
     if not torch.is_floating_point(t):
         raise TypeError('`t` must be a floating point Tensor but is a {}'.format(t.type()))
     if t.dim() != 1 or t.numel() < 2:
         raise ValueError('t must be one-dimensional with at least two points')
+    tag = getattr(t, HOST_TIMES_ATTR, None)
+    if tag is not None and tag[0] == t._version and len(tag[1]) == t.numel():
+        return list(tag[1])
     if t.device.type == 'cpu':
         return [float(v) for v in t.detach().to(torch.float32).tolist()]
-    key = (t.data_ptr(), t._version, t.numel())
-    hit = _T_CACHE.get(key)
-    if hit is None:
-        if len(_T_CACHE) > 256:
-            _T_CACHE.clear()
-        hit = [float(v) for v in t.detach().to(torch.float32).cpu().tolist()]
-        _T_CACHE[key] = hit
-    return hit
+    hit = _T_SEEN.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return list(hit[2])
+    vals = [float(v) for v in t.detach().to(torch.float32).cpu().tolist()]     # one read-back per tensor object
+    if len(_T_SEEN) > 64:
+        for k in [k for k, v in _T_SEEN.items() if v[0]() is None]:
+            del _T_SEEN[k]
+        if len(_T_SEEN) > 64:
+            _T_SEEN.clear()
+    _T_SEEN[id(t)] = (weakref.ref(t), t._version, vals)
+    return list(vals)
 
 
 _WS: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -254,12 +275,13 @@ class _HipOdeint(torch.autograd.Function):
     (continuous adjoint, what `odeint_adjoint` does upstream)."""
 
     @staticmethod
-    def forward(ctx, func, rec, times, rtol, atol, method_id, options, y0, *params):
+    def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, y0, *params):
         out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
         func.nfe = getattr(func, 'nfe', 0) + st['nfe']          # model.py:340 convention
         func.last_forward_stats = st
         ctx.func, ctx.rec, ctx.times = func, rec, times
         ctx.rtol, ctx.atol, ctx.method_id, ctx.options = rtol, atol, method_id, options
+        ctx.adjoint = adjoint
         ctx.save_for_backward(out, *params)
         return out
 
@@ -268,7 +290,10 @@ class _HipOdeint(torch.autograd.Function):
         out, *params = ctx.saved_tensors
         gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
                                        ctx.method_id, ctx.options)
-        ctx.func.nfe = getattr(ctx.func, 'nfe', 0) + st['nfe']
+        if ctx.adjoint:       # upstream's non-adjoint backward is plain autograd: it never calls func.forward
+            ctx.func.nfe = getattr(ctx.func, 'nfe', 0) + st['nfe']
+        else:
+            _warn_nonadjoint_once()
         ctx.func.last_backward_stats = st
         grads = []
         off = 0
@@ -276,10 +301,22 @@ class _HipOdeint(torch.autograd.Function):
             n = p.numel()
             grads.append(gp[off:off + n].view_as(p))
             off += n
-        return (None, None, None, None, None, None, None, gy0, *grads)
+        return (None, None, None, None, None, None, None, None, gy0, *grads)
 
 
-def _odeint_impl(func, y0, t, rtol, atol, method, options):
+_WARNED_NONADJOINT = False
+
+
+def _warn_nonadjoint_once():
+    global _WARNED_NONADJOINT
+    if not _WARNED_NONADJOINT:
+        _WARNED_NONADJOINT = True
+        warnings.warn('neural-ode-features_amd: `odeint` (adjoint=False) was differentiated; its gradient is produced by '
+                      'the continuous-adjoint HIP solve, which agrees with backpropagation through the solver steps '
+                      '(what torchdiffeq.odeint does) to O(tol), not to rounding.', RuntimeWarning, stacklevel=3)
+
+
+def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
     _check_state(y0)
     if not isinstance(func, nn.Module):
         raise ValueError('func is required to be an instance of nn.Module.')
@@ -290,7 +327,7 @@ def _odeint_impl(func, y0, t, rtol, atol, method, options):
     dec = all(b < a for a, b in zip(times[:-1], times[1:]))
     if not (inc or dec):
         raise ValueError('t must be strictly increasing or strictly decreasing')
-    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, y0, *rec.params)
+    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, y0, *rec.params)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
@@ -306,8 +343,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-12, method=None, options=None):
     Forward values are identical to `odeint_adjoint`.  Deviation (documented in
     DESIGN.md): upstream `odeint` is differentiated by autograd through the
     solver's own ops; here a requested gradient is produced by the same HIP
-    continuous-adjoint solve, which agrees to O(tol)."""
-    return _odeint_impl(func, y0, t, rtol, atol, method, options)
+    continuous-adjoint solve, which agrees to O(tol) (a RuntimeWarning says so once); like
+    upstream's autograd backward it adds nothing to `func.nfe`."""
+    return _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=False)
 
 
 # ---------------------------------------------------------------------------

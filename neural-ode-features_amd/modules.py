@@ -83,7 +83,16 @@ class ODEBlock(nn.Module):
     def forward(self, x):
         if self.integration_time is None:      # t1 == 0: identity (model.py:363-364)
             return x
-        self.integration_time = self.integration_time.type_as(x)
+        t = self.integration_time
+        if t.device != x.device or t.dtype != x.dtype:
+            # model.py:366.  The host copy of the grid that the `t1` setter attached travels with it, so the
+            # solve never reads the device tensor back (a grid assigned to `integration_time` directly carries
+            # no tag and is read back once per tensor object, integrate._host_times)
+            moved = t.type_as(x)
+            tag = getattr(t, integrate.HOST_TIMES_ATTR, None)
+            if tag is not None and tag[0] == t._version:
+                integrate.tag_host_times(moved, tag[1])
+            self.integration_time = moved
         out = self.odeint(self.odefunc, x, self.integration_time,
                           method=self.method, rtol=self.tol, atol=self.tol)
         return out[-1] if self.return_last_only else out
@@ -97,6 +106,11 @@ class ODEBlock(nn.Module):
     def nfe(self, value):
         self.odefunc.nfe = value
 
+    @staticmethod
+    def _grid(points):
+        t = torch.tensor(points, dtype=torch.float32)
+        return integrate.tag_host_times(t, t.tolist())      # fp32-rounded: what the device copy will hold
+
     @property
     def t1(self):
         return self.integration_time[1]
@@ -104,13 +118,13 @@ class ODEBlock(nn.Module):
     @t1.setter
     def t1(self, value):
         if isinstance(value, (int, float)):
-            self.integration_time = None if value == 0 else torch.tensor([0, value], dtype=torch.float32)
+            self.integration_time = None if value == 0 else self._grid([0, value])
             return
         if isinstance(value, (list, tuple, torch.Tensor)):
             points = value.tolist() if isinstance(value, torch.Tensor) else list(value)
             if points[0] != 0:
                 print(points[0])               # the reference prints the first point it prepends 0 to
                 points = [0] + points
-            self.integration_time = torch.tensor(points, dtype=torch.float32)
+            self.integration_time = self._grid(points)
             return
         raise ValueError('Argument must be a scalar, a list, or a tensor')

@@ -4,8 +4,11 @@ Mirrors the observable semantics and state_dict keys of the reference's
 `ODENet.forward` (`/root/reference/model.py:6-62`), its stems (`model.py:119-178`)
 and head (`model.py:231-250`) so checkpoints load unchanged (`utils.py:248-270`).
 The stem is a handful of plain convolutions run once per batch (~1 ODEfunc-eval of
-FLOPs) and stays on PyTorch-ROCm/MIOpen; the head's
-GroupNorm -> ReLU -> pool -> Dropout is one fused HIP launch each way (head.py).
+FLOPs); the head's GroupNorm -> ReLU -> pool -> Dropout
+is one fused HIP launch each way (head.py).  The stems that embed a second ODE block
+(`ODEDownsample`, `ODEDownsample2`, model.py:181-223) run that block through the same
+HIP solver; `StackedODENet` chains several blocks behind one stem (BASELINE.json
+configs[4], a synthetic extension -- the reference stacks at most two).
 """
 from __future__ import annotations
 
@@ -53,7 +56,50 @@ def _stem(kind, in_ch, out_ch, norm):
             nn.Conv2d(in_ch, mid, 3, 1), make_norm(mid), nn.ReLU(inplace=True),
             nn.Conv2d(mid, mid, 4, 2, 1), make_norm(mid), nn.ReLU(inplace=True),
             nn.Conv2d(mid, out_ch, 4, 2, 1))
-    raise NotImplementedError("downsample=%r (the ODE stems 'ode'/'ode2' are a later row, SURVEY.md 8f)" % (kind,))
+    raise NotImplementedError('downsample=%r' % (kind,))
+
+
+class ODEDownsample(nn.Module):
+    """conv 4x4/2 -> ODE block -> max-pool 4x4/2 (model.py:181-196).  With `return_last_only` off the block
+    returns its whole trajectory and this stem returns (trajectory, pooled last state)."""
+
+    def __init__(self, in_ch, out_ch=64, method='dopri5', adjoint=False, t1=1, tol=1e-3, norm='group'):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 4, 2, 1)
+        self.odeblock = ODEBlock(n_filters=out_ch, adjoint=adjoint, t1=t1, tol=tol, method=method, norm=norm)
+        self.maxpool = nn.MaxPool2d(4, 2, 1)
+
+    def forward(self, x):
+        x = self.odeblock(self.conv1(x))
+        if x.dim() > 4:
+            return x, self.maxpool(x[-1])
+        return self.maxpool(x)
+
+
+class ODEDownsample2(nn.Module):
+    """conv 4x4/2 -> ODE block -> GroupNorm -> ReLU -> conv 4x4/2 (model.py:199-223)."""
+
+    def __init__(self, in_ch, out_ch=64, method='dopri5', adjoint=False, t1=1, tol=1e-3, norm='group'):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_ch, out_ch, 4, 2, 1)
+        self.odeblock = ODEBlock(n_filters=out_ch, adjoint=adjoint, t1=t1, tol=tol, method=method, norm=norm)
+        self.norm = nn.Sequential(normalization(norm)(out_ch), nn.ReLU(inplace=True))
+        self.conv2 = nn.Conv2d(out_ch, out_ch, 4, 2, 1)
+        self.apply_conv = False
+
+    def _norm(self, x):
+        from .head import gn_relu
+        return gn_relu(x, self.norm[0])
+
+    def forward(self, x):
+        x = self.odeblock(self.conv1(x))
+        if x.dim() > 4:
+            x = torch.stack([self._norm(xi) for xi in x])
+            if self.apply_conv:
+                x = torch.stack([self.conv2(xi) for xi in x])
+                return x, x[-1]
+            return x, self.conv2(x[-1])
+        return self.conv2(self._norm(x))
 
 
 class _Wrapped(nn.Module):
@@ -105,20 +151,39 @@ class ODENet(nn.Module):
     def __init__(self, in_ch, out=10, n_filters=64, downsample='residual', method='dopri5', tol=1e-3,
                  adjoint=False, t1=1, dropout=0, norm='group'):
         super().__init__()
-        self.downsample = _Wrapped(_stem(downsample, in_ch, n_filters, norm))
+        if downsample == 'ode':          # model.py:18-21
+            self.downsample = ODEDownsample(in_ch, out_ch=n_filters, adjoint=adjoint, t1=t1, tol=tol, method=method, norm=norm)
+        elif downsample == 'ode2':
+            self.downsample = ODEDownsample2(in_ch, out_ch=n_filters, adjoint=adjoint, t1=t1, tol=tol, method=method, norm=norm)
+        else:
+            self.downsample = _Wrapped(_stem(downsample, in_ch, n_filters, norm))
         self.odeblock = ODEBlock(n_filters=n_filters, tol=tol, adjoint=adjoint, t1=t1, method=method, norm=norm)
         self.classifier = FCClassifier(in_ch=n_filters, out=out, dropout=dropout, norm=norm)
 
     def forward(self, x):
-        x = self.odeblock(self.downsample(x))
+        out = []
+        x = self.downsample(x)
+        if isinstance(x, (tuple, list)):     # an ODE stem in feature-extraction mode: (trajectory, continuation)
+            f, x = x
+            if isinstance(self.classifier.module[-1], nn.Sequential):   # classification layer removed: pool only
+                f = torch.stack([fi.mean(-1).mean(-1) for fi in f])
+            else:
+                f = torch.stack([self.classifier(fi) for fi in f])
+            out.append(f)
+        x = self.odeblock(x)
         if x.dim() > 4:   # [T, N, C, H, W]: head applied per time slice (model.py:39-40)
             x = torch.stack([self.classifier(xi) for xi in x])
         else:
             x = self.classifier(x)
-        return x
+        if not out:
+            return x
+        out.append(x)
+        return torch.cat(out)
 
     def to_features_extractor(self, keep_pool=True):
         """model.py:48-56: expose the trajectory and drop the classification layer."""
+        if isinstance(self.downsample, (ODEDownsample, ODEDownsample2)):
+            self.downsample.odeblock.return_last_only = False
         self.odeblock.return_last_only = False
         if keep_pool:
             self.classifier.module[-1] = nn.Sequential()
@@ -129,4 +194,36 @@ class ODENet(nn.Module):
         count = self.odeblock.nfe
         if reset:
             self.odeblock.nfe = 0
+        return count
+
+
+class StackedODENet(nn.Module):
+    """Residual stem -> `n_blocks` ODE blocks in series -> classifier head: BASELINE.json configs[4]
+    ("4x-widened ODE-ResNet, 3 stacked ODE blocks").  A synthetic extension of `ODENet` (model.py:6-62; the
+    reference stacks at most two blocks, through `ODEDownsample`); every block is the reference's `ODEBlock`
+    and runs as its own HIP solve, keys `odeblocks.<i>.odefunc...`."""
+
+    def __init__(self, in_ch, out=10, n_filters=64, n_blocks=3, downsample='residual', method='dopri5', tol=1e-3,
+                 adjoint=False, t1=1, dropout=0, norm='group'):
+        super().__init__()
+        self.downsample = _Wrapped(_stem(downsample, in_ch, n_filters, norm))
+        self.odeblocks = nn.ModuleList([ODEBlock(n_filters=n_filters, tol=tol, adjoint=adjoint, t1=t1, method=method,
+                                                 norm=norm) for _ in range(n_blocks)])
+        self.classifier = FCClassifier(in_ch=n_filters, out=out, dropout=dropout, norm=norm)
+
+    @property
+    def odeblock(self):       # the last block: what `ODENet` users read statistics from
+        return self.odeblocks[-1]
+
+    def forward(self, x):
+        x = self.downsample(x)
+        for blk in self.odeblocks:
+            x = blk(x)
+        return self.classifier(x)
+
+    def nfe(self, reset=False):
+        count = sum(b.nfe for b in self.odeblocks)
+        if reset:
+            for b in self.odeblocks:
+                b.nfe = 0
         return count

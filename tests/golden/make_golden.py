@@ -18,6 +18,12 @@ name first.  What the fixtures pin:
   odenet_rk4.pt /         reference ``ODENet`` driven end-to-end (forward, CE loss, backward) with the
   odenet_dopri5.pt        oracle standing in for torchdiffeq: logits, loss, NFE-F/NFE-B, selected grads
 
+  odenet_ode_features.pt  reference ``ODENet(3, downsample='ode', t1=[.1,.2,.3,1])`` in feature-extractor mode -- the
+                          reference's own smoke (model.py:416-421): a second ODE block inside the stem
+                          (``ODEDownsample``, model.py:181-196), both trajectories pooled and concatenated
+  odenet_ode2_train.pt    reference ``ODENet(3, downsample='ode2')`` (``ODEDownsample2``, model.py:199-223) trained one
+                          step end-to-end (two adjoint solves per backward), oracle standing in for torchdiffeq
+
 Fixtures are data (tensors / json).  No reference source text is stored.
 """
 import json
@@ -141,8 +147,49 @@ def make_odenet_e2e(ref, name, method, tol, in_ch, filters, hw, bs, t1, seed):
     print(name, 'loss %.5f nfe_f %d nfe_b %d' % (loss, nfe_f, nfe_b))
 
 
+def make_ode_stem_features(ref):
+    torch.manual_seed(31)
+    net = ref.ODENet(3, out=10, n_filters=16, downsample='ode', t1=[.1, .2, .3, 1], tol=1e-3, adjoint=True)
+    gen = torch.Generator().manual_seed(32)
+    randomize_(net, gen)
+    net.eval()
+    net.to_features_extractor()
+    x = torch.rand(2, 3, 32, 32, generator=gen)
+    with torch.no_grad():
+        feats = net(x)
+    torch.save({'x': x, 'features': feats, 'state_dict': net.state_dict(), 'keys': list(net.state_dict().keys()),
+                't1': [.1, .2, .3, 1], 'filters': 16, 'tol': 1e-3, 'nfe_main': net.nfe(),
+                'nfe_stem': net.downsample.odeblock.nfe},
+               os.path.join(HERE, 'odenet_ode_features.pt'))
+    print('odenet_ode_features', tuple(feats.shape), 'nfe stem/main', net.downsample.odeblock.nfe, net.nfe())
+
+
+def make_ode2_train(ref):
+    torch.manual_seed(33)
+    net = ref.ODENet(3, out=10, n_filters=16, downsample='ode2', method='dopri5', tol=1e-3, adjoint=True, t1=1, dropout=0)
+    gen = torch.Generator().manual_seed(34)
+    randomize_(net, gen)
+    net.train()
+    x = torch.rand(2, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, (2,), generator=gen)
+    p = net(x)
+    loss = F.cross_entropy(p, y)
+    nfe_f = (net.downsample.odeblock.nfe, net.nfe())
+    loss.backward()
+    nfe_b = (net.downsample.odeblock.nfe - nfe_f[0], net.nfe() - nfe_f[1])
+    torch.save({'x': x, 'y': y, 'logits': p.detach(), 'loss': loss.detach(), 'nfe_f': nfe_f, 'nfe_b': nfe_b,
+                'state_dict': net.state_dict(), 'keys': list(net.state_dict().keys()), 'filters': 16, 'tol': 1e-3,
+                'grads': {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}},
+               os.path.join(HERE, 'odenet_ode2_train.pt'))
+    print('odenet_ode2_train loss %.5f nfe_f %s nfe_b %s' % (loss, nfe_f, nfe_b))
+
+
 def main():
     ref = import_reference_model()
+    if 'stems' in sys.argv[1:]:        # only the fixtures added in round 2
+        make_ode_stem_features(ref)
+        make_ode2_train(ref)
+        return
     make_odefunc(ref, 8, 2, 7, 7, seed=23)
     make_odefunc(ref, 16, 3, 5, 6, seed=24)
     make_odefunc(ref, 64, 2, 8, 8, seed=25)
@@ -151,6 +198,8 @@ def main():
     # config-1-like plumbing case (MNIST-shaped, rk4, one 3/8 step) and a small dopri5 case
     make_odenet_e2e(ref, 'odenet_rk4.pt', 'rk4', 1e-3, 1, 8, 28, 4, 1, seed=23)
     make_odenet_e2e(ref, 'odenet_dopri5.pt', 'dopri5', 1e-3, 3, 8, 32, 2, 1, seed=29)
+    make_ode_stem_features(ref)
+    make_ode2_train(ref)
 
 
 if __name__ == '__main__':

@@ -47,3 +47,39 @@ def robust_grad_err(a, b):
     l2 = float((a - b).norm() / (b.norm() + 1e-30))
     frac = float(((a - b).abs() > 1e-3 * b.abs().max()).double().mean())
     return l2, frac
+
+
+class ProbedODEfunc(OracleODEfunc):
+    """The oracle dynamics, additionally recording per SAMPLE the smallest |pre-activation| either ReLU saw over
+    every evaluation made through it (forward solve, and the recomputed forwards of the adjoint solve).  A sample
+    whose record stays above the fp32 disagreement of two correct implementations (~1e-6) cannot have had a ReLU
+    mask flip: its gradient must agree tightly.  Same ops in the same order as `oracle.dynamics.odefunc_forward`."""
+
+    def __init__(self, dim):
+        super().__init__(dim)
+        self.min_abs = None
+
+    def _note(self, z):
+        m = z.detach().abs().flatten(1).amin(dim=1)
+        self.min_abs = m if self.min_abs is None or self.min_abs.shape != m.shape else torch.minimum(self.min_abs, m)
+
+    def forward(self, t, x):
+        import torch.nn.functional as F
+        from oracle.dynamics import concat_conv2d, n_groups
+        self.nfe += 1
+        p = dict(self.named_parameters())
+        g = n_groups(x.shape[1])
+        z1 = F.group_norm(x, g, p['norm1.weight'], p['norm1.bias'], 1e-5)
+        self._note(z1)
+        out = concat_conv2d(t, F.relu(z1), p['conv1._layer.weight'], p['conv1._layer.bias'])
+        z2 = F.group_norm(out, g, p['norm2.weight'], p['norm2.bias'], 1e-5)
+        self._note(z2)
+        out = concat_conv2d(t, F.relu(z2), p['conv2._layer.weight'], p['conv2._layer.bias'])
+        return F.group_norm(out, g, p['norm3.weight'], p['norm3.bias'], 1e-5)
+
+
+def per_sample_err(a, b):
+    """max |a - b| of every sample, relative to the largest |b| of the whole tensor."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return (a - b).abs().flatten(1).amax(dim=1) / (b.abs().max() + 1e-30)

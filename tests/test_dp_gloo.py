@@ -101,3 +101,74 @@ def test_shard_batch_and_single_process_reducer():
     red.finish()
     assert torch.equal(lin.weight.grad, g)
     red.remove()
+
+
+def _single_process_reference(steps, world):
+    import bench
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    torch.manual_seed(23)
+    net = nof.ODENet(1, out=10, n_filters=8, downsample='residual', method='rk4', tol=1e-3, adjoint=True, dropout=0)
+    net.odeblock.odeint = tdq.odeint_adjoint
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    x, y = _data(4 * world)
+    for _ in range(steps):
+        bench.train_step(net, opt, x, y)
+    return net
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('accumulate', [0, 1])
+def test_bench_train_step_through_self_launcher(tmp_path, accumulate):
+    """bench.py's launcher (`--gpus N` without torchrun) + its train step + the in-place reducer, world size 2 over
+    gloo: after 3 optimizer steps every rank holds the parameters a single process gets from the full batch
+    (rk4: fixed steps, so sharding / micro-batching does not change the arithmetic beyond summation order)."""
+    import bench
+    world, steps = 2, 3
+    rc = bench.spawn_ranks(world, [sys.executable, os.path.join(ROOT, 'tests', 'dp_child.py'), str(tmp_path), str(steps),
+                                   str(accumulate)], timeout=500)
+    assert rc == 0
+    r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'), weights_only=False)
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    ref = _single_process_reference(steps, world)
+    for k, v in ref.named_parameters():
+        assert torch.allclose(r0['params'][k], v.detach(), rtol=5e-4, atol=5e-6), k
+
+
+def test_bench_refuses_smaller_world():
+    """`python bench.py --gpus 2` must never measure one GPU: no devices here -> non-zero exit, no JSON line;
+    a launcher environment that disagrees with --gpus is refused too."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'refusing' in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+    env['WORLD_SIZE'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_reducer_rejects_unannounced_second_backward():
+    import neural_ode_features_amd as nof
+    lin = torch.nn.Linear(3, 2)
+    red = nof.dp.GradientReducer(lin)
+    lin(torch.ones(1, 3)).sum().backward()
+    with pytest.raises(RuntimeError, match='accumulate'):
+        lin(torch.ones(1, 3)).sum().backward()
+    red.finish()
+    red.zero_grad()
+    with red.accumulate():
+        lin(torch.ones(1, 3)).sum().backward()
+    lin(torch.ones(1, 3)).sum().backward()
+    red.finish()
+    assert torch.equal(lin.weight.grad, 2 * torch.ones(2, 3))
+    # optimizer.zero_grad() (set_to_none) between steps is tolerated: the hook re-installs the bucket views
+    lin.zero_grad()
+    lin(torch.ones(1, 3)).sum().backward()
+    red.finish()
+    assert torch.equal(lin.weight.grad, torch.ones(2, 3))
+    assert lin.weight.grad.data_ptr() in [v.data_ptr() for v in red.buckets[0].views]
+    red.remove()

@@ -1,0 +1,309 @@
+"""GPU parity, round 2: the holes the round-1 review listed.
+
+* whole adjoint solves at BASELINE configs[1]/[2] size ([128,256,8,8], tol 1e-3 / 1e-5) against the oracle, with
+  per-sample accounting of ReLU-kink exposure (tests/helpers.py:ProbedODEfunc);
+* 16x16 states (the reference's one-shot / 'ode' stems, cfg 5): split-conv path at several column-tile counts and
+  channels-per-group, forward + VJP + an adjoint solve; C = 1024 (cpg = 32);
+* run-time mutation of a live block (`t1`, `tol`, `return_last_only`; evaluate.py:62,80,116-117) and
+  `ODENet.to_features_extractor()` end to end (evaluate.py:56-94, model.py:39-56);
+* ODE stems (`downsample='ode'/'ode2'`, model.py:181-223) against fixtures generated from the reference;
+* three stacked blocks (BASELINE configs[4]).
+"""
+import contextlib
+import io
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torchdiffeq_restated as tdq
+from oracle.dynamics import odefunc_vjp as oracle_vjp
+from tests.helpers import ProbedODEfunc, make_func, per_sample_err, rel_err, robust_grad_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
+
+
+def _adjoint_both(shape, tol, seed, kink_free, probe=False, tpts=(0.0, 1.0)):
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=seed, device='cuda', kink_free=kink_free)
+    if probe:
+        probed = ProbedODEfunc(C)
+        probed.load_state_dict(twin.state_dict())
+        twin = probed
+    gen = torch.Generator().manual_seed(seed + 1)
+    y = torch.randn(N, C, H, W, generator=gen)
+    wgt = torch.randn(len(tpts), N, C, H, W, generator=gen) / (C * H * W) ** 0.5
+    t = torch.tensor(tpts)
+    yo = y.clone().requires_grad_(True)
+    fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
+    out_o = tdq.odeint_adjoint(twin, yo, t, rtol=tol, atol=tol, method='dopri5', fwd_stats=fs_o, bwd_stats=bs_o)
+    (out_o * wgt).sum().backward()
+    gp_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
+    yh = y.cuda().requires_grad_(True)
+    f.nfe = 0
+    out_h = nof.odeint_adjoint(f, yh, t.cuda(), rtol=tol, atol=tol, method='dopri5')
+    (out_h * wgt.cuda()).sum().backward()
+    gp_h = torch.cat([p.grad.reshape(-1) for p in f.parameters()])
+    fs_h, bs_h = f.last_forward_stats, f.last_backward_stats
+    same = (fs_h['accepted'], fs_h['rejected'], bs_h['accepted'], bs_h['rejected']) == \
+           (fs_o.accepted, fs_o.rejected, bs_o.accepted, bs_o.rejected)
+    print(shape, tol, 'kink_free', kink_free, 'fwd steps', (fs_h['accepted'], fs_h['rejected']), (fs_o.accepted, fs_o.rejected),
+          'bwd steps', (bs_h['accepted'], bs_h['rejected']), (bs_o.accepted, bs_o.rejected))
+    return dict(out_o=out_o.detach(), out_h=out_h.detach(), gy_o=yo.grad, gy_h=yh.grad, gp_o=gp_o, gp_h=gp_h, same=same,
+                twin=twin, nfe_b=bs_h['nfe'], steps_b=bs_h['accepted'] + bs_h['rejected'])
+
+
+@pytest.mark.parametrize('tol', [1e-3, 1e-5])
+def test_full_size_adjoint_solve_kink_free(tol):
+    """configs[1] / configs[2] state [128,256,8,8]: forward + whole adjoint solve vs the oracle, max-norm, on the
+    parameter set whose ReLUs never switch (so no mask can flip between two correct fp32 implementations)."""
+    r = _adjoint_both((128, 256, 8, 8), tol, seed=51, kink_free=True)
+    assert float((r['out_h'].cpu() - r['out_o']).abs().max()) <= 10 * tol
+    assert r['nfe_b'] == 3 + 6 * r['steps_b']
+    e_y, e_p = rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print('full-size kink-free adjoint: grad_y rel', e_y, 'grad_theta rel', e_p, 'same history', r['same'])
+    if r['same']:
+        assert rel_err(r['out_h'], r['out_o']) < 2e-4
+        assert e_y < 1e-3 and e_p < 1e-3
+    else:       # an accept/reject flip moves both trajectories by O(tol)
+        assert e_y < 5e-2 and e_p < 5e-2
+
+
+@pytest.mark.parametrize('tol', [1e-3, 1e-5])
+def test_full_size_adjoint_solve_per_sample_accounting(tol):
+    """Ordinary parameters (ReLUs switch).  The oracle records per sample how close any pre-activation of the whole
+    solve came to zero; samples that stayed further than 4e-6 away cannot have had a mask flip and must agree to
+    1e-3 (max-norm, relative to the largest gradient); the exposed ones are counted and bounded."""
+    r = _adjoint_both((128, 256, 8, 8), tol, seed=52, kink_free=False, probe=True)
+    assert float((r['out_h'].cpu() - r['out_o']).abs().max()) <= 10 * tol
+    es = per_sample_err(r['gy_h'], r['gy_o'])
+    exposed = r['twin'].min_abs < 4e-6
+    clean = ~exposed
+    l2_y, _ = robust_grad_err(r['gy_h'], r['gy_o'])
+    l2_p, _ = robust_grad_err(r['gp_h'], r['gp_o'])
+    print('tol', tol, 'exposed samples', int(exposed.sum()), 'of', es.numel(), '| clean: max err %.3e' %
+          (float(es[clean].max()) if clean.any() else 0.0), '| exposed: max err %.3e median %.3e' %
+          ((float(es[exposed].max()), float(es[exposed].median())) if exposed.any() else (0.0, 0.0)),
+          '| samples over 1e-3:', int((es > 1e-3).sum()), '| L2 grad_y %.3e grad_theta %.3e' % (l2_y, l2_p),
+          'same history', r['same'])
+    if r['same']:
+        if clean.any():
+            assert float(es[clean].max()) < 1e-3
+        # every sample over the tight bound must be one the oracle saw within rounding of a kink
+        assert int(((es > 1e-3) & clean).sum()) == 0
+        assert float(es.max()) < 0.25 and l2_y < 3e-2 and l2_p < 3e-2
+    else:
+        assert l2_y < 0.1 and l2_p < 0.1
+
+
+@pytest.mark.parametrize('shape', [(4, 256, 16, 16), (2, 64, 16, 16), (2, 1024, 16, 16), (3, 96, 16, 16)])
+def test_16x16_split_conv_forward_and_vjp(shape):
+    """256-pixel images: two workgroups per sample, GroupNorm as a pointwise pass behind the conv.  C = 256: four
+    column tiles, 8 channels per group; C = 64: one tile, 2 per group; C = 1024: sixteen tiles, 32 per group
+    (cfg 5); C = 96: 3 per group, ragged last column tile."""
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    gen = torch.Generator().manual_seed(61)
+    y = torch.randn(N, C, H, W, generator=gen)
+    cot = torch.randn(N, C, H, W, generator=gen)
+    f, twin = make_func(C, seed=62, device='cuda', kink_free=True)
+    fo, vy, vt, vp = nof.odefunc_vjp(f, 0.4, y.cuda(), cot.cuda())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.4, y, dict(twin.named_parameters()), cot)
+    print(shape, 'f', rel_err(fo, f_ref), 'vjp_y', rel_err(vy, vy_ref), 'vjp_theta', rel_err(vp, vp_ref),
+          'vjp_t', float(vt), float(vt_ref))
+    assert rel_err(fo, f_ref) < 2e-5 and rel_err(vy, vy_ref) < 5e-5 and rel_err(vp, vp_ref) < 5e-5
+    assert abs(float(vt) - float(vt_ref)) < 1e-4 * abs(float(vt_ref)) + 1e-3
+    assert rel_err(nof.odefunc_forward(f, 0.4, y.cuda()), f_ref) < 2e-5
+    # ordinary parameters: forward tight, the ReLU-mask path of the backward per sample
+    f, twin = make_func(C, seed=63, device='cuda')
+    fo, vy, vt, vp = nof.odefunc_vjp(f, 0.4, y.cuda(), cot.cuda())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.4, y, dict(twin.named_parameters()), cot)
+    assert rel_err(fo, f_ref) < 2e-5
+    es = per_sample_err(vy, vy_ref)
+    assert int((es > 5e-5).sum()) <= 1, es
+    assert robust_grad_err(vp, vp_ref)[0] < 5e-2
+
+
+@pytest.mark.parametrize('shape,tol', [((4, 256, 16, 16), 1e-3), ((2, 64, 16, 16), 1e-4)])
+def test_16x16_adjoint_solve(shape, tol):
+    r = _adjoint_both(shape, tol, seed=64, kink_free=True)
+    assert float((r['out_h'].cpu() - r['out_o']).abs().max()) <= 10 * tol
+    e_y, e_p = rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print(shape, 'grad_y rel', e_y, 'grad_theta rel', e_p, 'same history', r['same'])
+    if r['same']:
+        assert rel_err(r['out_h'], r['out_o']) < 2e-4 and e_y < 1e-3 and e_p < 1e-3
+    else:
+        assert e_y < 5e-2 and e_p < 5e-2
+
+
+def test_live_block_t1_tol_sweep():
+    """evaluate.py:116-117,167-168: `model.odeblock.t1 = t1` / `.tol = tol` between forwards of the SAME block.
+    Every forward must integrate the grid that is set NOW (a freed time tensor's address is readily reused)."""
+    import neural_ode_features_amd as nof
+    f, twin = make_func(32, seed=71, device='cpu')
+    blk = nof.ODEBlock(n_filters=32, tol=1e-3, method='dopri5', adjoint=True, t1=1)
+    blk.odefunc.load_state_dict(f.state_dict())
+    blk = blk.cuda()
+    x = torch.randn(3, 32, 8, 8, generator=torch.Generator().manual_seed(72))
+    xg = x.cuda()
+
+    def want(tpts, tol):
+        with torch.no_grad():
+            return tdq.odeint(twin, x, torch.tensor(tpts), rtol=tol, atol=tol, method='dopri5')
+
+    outs = {}
+    for rep in range(3):
+        for t1 in (0.5, 1.0, 0.25, 0.75):
+            blk.t1 = t1
+            with torch.no_grad():
+                got = blk(xg)
+            assert float(blk.t1) == t1
+            ref = want([0.0, t1], 1e-3)[-1]
+            assert float((got.cpu() - ref).abs().max()) <= 1e-2, (rep, t1)
+            assert rel_err(got, ref) < 2e-4, (rep, t1)
+            if t1 in outs:
+                assert torch.equal(outs[t1], got)            # same grid -> same bits, every time round
+            outs[t1] = got
+    assert not torch.equal(outs[0.5], outs[1.0])
+    # list-valued t1 + whole trajectory + a tolerance sweep up to 100 (evaluate.py:423)
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk.t1 = [.1, .2, 1]
+    blk.return_last_only = False
+    for tol in (1e-3, 1e-1, 100):
+        blk.tol = tol
+        blk.nfe = 0
+        with torch.no_grad():
+            got = blk(xg)
+        ref = want([0.0, .1, .2, 1.0], tol)
+        assert got.shape == (4, 3, 32, 8, 8)
+        # (at tol 100 the first step is accepted whatever its error: both sides take the same giant steps)
+        assert rel_err(got, ref) < 1e-3, tol
+        st = blk.odefunc.last_forward_stats
+        assert blk.nfe == 2 + 6 * (st['accepted'] + st['rejected'])
+    blk.t1 = 0
+    assert blk(xg) is xg                                     # identity block (model.py:363-364)
+    # a grid assigned to `integration_time` directly (no setter): read back from the device, not from a stale tag
+    blk.integration_time = torch.tensor([0.0, 0.3]).cuda()
+    blk.return_last_only = True
+    blk.tol = 1e-3
+    with torch.no_grad():
+        a = blk(xg)
+    blk.integration_time = torch.tensor([0.0, 0.6]).cuda()
+    with torch.no_grad():
+        b = blk(xg)
+    assert rel_err(a, want([0.0, 0.3], 1e-3)[-1]) < 2e-4 and rel_err(b, want([0.0, 0.6], 1e-3)[-1]) < 2e-4
+    blk.integration_time[1] = 0.9                            # in-place edit bumps the version counter
+    with torch.no_grad():
+        c = blk(xg)
+    assert rel_err(c, want([0.0, 0.9], 1e-3)[-1]) < 2e-4
+
+
+def test_features_extractor_end_to_end():
+    """evaluate.py:56-94: to_features_extractor(), t1 = 21 points, tol swept -- [21, N, C] pooled features per
+    time slice, package net + HIP solver vs the same net + oracle solver on the CPU."""
+    import copy
+    import neural_ode_features_amd as nof
+    torch.manual_seed(81)
+    net = nof.ODENet(3, out=10, n_filters=32, downsample='residual', method='dopri5', tol=1e-3, adjoint=False, t1=1)
+    net.eval()
+    net.to_features_extractor()
+    cpu = copy.deepcopy(net)
+    cpu.odeblock.odeint = tdq.odeint
+    net = net.cuda()
+    x = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(82))
+    t1 = torch.arange(0, 1.05, .05).tolist()                 # evaluate.py:424
+    for tol in (1e-3, 1e-1, 100.0):
+        for m in (net, cpu):
+            m.odeblock.t1 = t1
+            m.odeblock.tol = tol
+        with torch.no_grad():
+            got = net(x.cuda())
+            ref = cpu(x)
+        assert got.shape == ref.shape == (21, 4, 32)
+        print('features tol', tol, 'max abs err', float((got.cpu() - ref).abs().max()), 'nfe', net.nfe(), cpu.nfe())
+        assert net.nfe(reset=True) == cpu.nfe(reset=True)
+        assert torch.allclose(got.cpu(), ref, rtol=1e-3, atol=2e-4)
+        assert torch.equal(got[0].cpu(), ref[0]) or torch.allclose(got[0].cpu(), ref[0], rtol=1e-5, atol=1e-6)
+
+
+def test_ode_stem_fixtures_on_gpu(golden_dir):
+    """`downsample='ode'` as a feature extractor (the reference's own smoke, model.py:416-421) and `'ode2'` trained
+    one step: fixtures from the reference's modules + oracle solver vs package modules + HIP solver."""
+    import neural_ode_features_amd as nof
+    g = _load(golden_dir, 'odenet_ode_features.pt')
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = nof.ODENet(3, out=10, n_filters=g['filters'], downsample='ode', tol=g['tol'], adjoint=True, t1=g['t1'])
+    net.to_features_extractor()
+    net.load_state_dict(g['state_dict'])
+    net = net.cuda().eval()
+    with torch.no_grad():
+        feats = net(g['x'].cuda())
+    assert feats.shape == g['features'].shape
+    print('ode stem features max abs err', float((feats.cpu() - g['features']).abs().max()))
+    assert (net.downsample.odeblock.nfe, net.nfe()) == (g['nfe_stem'], g['nfe_main'])
+    assert torch.allclose(feats.cpu(), g['features'], rtol=1e-3, atol=2e-4)
+
+    g = _load(golden_dir, 'odenet_ode2_train.pt')
+    net = nof.ODENet(3, out=10, n_filters=g['filters'], downsample='ode2', method='dopri5', tol=g['tol'], adjoint=True,
+                     t1=1, dropout=0)
+    net.load_state_dict(g['state_dict'])
+    net = net.cuda().train()
+    p = net(g['x'].cuda())
+    loss = F.cross_entropy(p, g['y'].cuda())
+    nfe_f = (net.downsample.odeblock.nfe, net.nfe())
+    loss.backward()
+    nfe_b = (net.downsample.odeblock.nfe - nfe_f[0], net.nfe() - nfe_f[1])
+    assert nfe_f == tuple(g['nfe_f']) and nfe_b == tuple(g['nfe_b'])
+    assert float((p.detach().cpu() - g['logits']).abs().max()) <= 10 * g['tol']
+    assert rel_err(p, g['logits']) < 1e-3
+    gmax = max(float(v.abs().max()) for v in g['grads'].values())
+    worst = 0.0
+    for k, v in net.named_parameters():
+        ref = g['grads'][k]
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        worst = max(worst, float((v.grad.detach().cpu() - ref).abs().max()) / scale)
+    print('ode2 training step: worst per-tensor gradient error', worst)
+    assert worst < 2e-2
+
+
+def test_three_stacked_blocks():
+    """BASELINE configs[4] topology at a small width: stem -> 3 ODE blocks -> head, forward + adjoint backward."""
+    import copy
+    import neural_ode_features_amd as nof
+    torch.manual_seed(91)
+    net = nof.StackedODENet(3, out=10, n_filters=32, n_blocks=3, method='dopri5', tol=1e-3, adjoint=True, dropout=0)
+    gen = torch.Generator().manual_seed(92)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if 'odefunc.norm' in name and name.endswith('bias') and 'norm3' not in name:
+                p.add_(8.0)                                   # kink-free dynamics (tests/helpers.py)
+    cpu = copy.deepcopy(net)
+    for b in cpu.odeblocks:
+        b.odeint = tdq.odeint_adjoint
+    net = net.cuda().train()
+    cpu.train()
+    x = torch.randn(2, 3, 64, 64, generator=gen)
+    y = torch.randint(0, 10, (2,), generator=gen)
+    p = net(x.cuda())
+    loss = F.cross_entropy(p, y.cuda())
+    nfe_f = net.nfe(reset=True)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    pr = cpu(x)
+    lr = F.cross_entropy(pr, y)
+    nfe_fr = cpu.nfe(reset=True)
+    lr.backward()
+    nfe_br = cpu.nfe(reset=True)
+    print('stacked: nfe', (nfe_f, nfe_b), (nfe_fr, nfe_br), 'logits err', float((p.detach().cpu() - pr).abs().max()))
+    assert (nfe_f, nfe_b) == (nfe_fr, nfe_br)
+    assert torch.allclose(p.detach().cpu(), pr.detach(), rtol=1e-3, atol=1e-4)
+    gmax = max(float(v.grad.abs().max()) for v in cpu.parameters())
+    for (k, v), (_, w) in zip(net.named_parameters(), cpu.named_parameters()):
+        scale = max(float(w.grad.abs().max()), 1e-3 * gmax)
+        assert float((v.grad.cpu() - w.grad).abs().max()) / scale < 2e-2, k
