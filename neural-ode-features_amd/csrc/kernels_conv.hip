@@ -293,6 +293,8 @@ __device__ inline void conv_epilogue_tail(const ConvArgs& a, const Dims& d, floa
 
 template <int WM, int MT>
 __global__ __launch_bounds__(WM * 128) void k_conv3x3(ConvArgs a, Dims d) {
+  if (a.et.ctrl != nullptr && a.et.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   PSTAMP(a.stamps, 0, "s_memrealtime");
   PSTAMP(a.stamps, 1, "s_memtime");
   constexpr int THREADS = WM * 128;        // WM waves in M x 2 in N
@@ -593,6 +595,8 @@ constexpr int BBUFW = 4 * BN * BSTW;
 
 template <int MT>
 __global__ __launch_bounds__(512) void k_conv3x3_w(ConvArgs a, Dims d) {
+  if (a.et.ctrl != nullptr && a.et.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   PSTAMP(a.stamps, 0, "s_memrealtime");
   PSTAMP(a.stamps, 1, "s_memtime");
   constexpr int THREADS = 512;
@@ -949,6 +953,8 @@ static size_t conv_w_lds_bytes(const Dims& d) {
 constexpr int SST2 = 16 * ASTW + 4;   // floats per tile of the A image: 16 components x 20, + 4: 81 16-B units (odd)
 
 __global__ __launch_bounds__(512) void k_conv3x3_w2(ConvArgs a, Dims d) {
+  if (a.et.ctrl != nullptr && a.et.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   PSTAMP(a.stamps, 0, "s_memrealtime");
   PSTAMP(a.stamps, 1, "s_memtime");
   constexpr int THREADS = 512;

@@ -57,6 +57,7 @@ __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) =
 // written to HBM unless the caller asks for it (last stage -> y1).
 // ============================================================================
 __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
+  if (a.ctrl->done) return;   // a step enqueued past the end of the interval (see Ctrl)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x, c0 = blockIdx.y * d.cs;
@@ -155,6 +156,7 @@ void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s) {
 //   per-sample partials of dgamma = sum g*xhat, dbeta = sum g
 // ============================================================================
 __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
+  if (a.ctrl->done) return;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x, c0 = blockIdx.y * d.cs;
@@ -296,6 +298,7 @@ void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
 // pass also forms y1 = y0 + dt * sum_j b_j k_j.
 // ============================================================================
 __global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl, float rtol, float atol, float* partial) {
+  if (ctrl->done) return;
   __shared__ float red[4];
   const float dtf = (float)ctrl->dt;
   float ce[7], cb[7];
@@ -369,6 +372,7 @@ void launch_error_norm(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float at
 // squared error ratio <= 1; dt <- dt / clamp(sqrt(max ratio)^(1/5)/0.9, 0.1, 1/dfactor).
 // t / dt are float64 like upstream's adaptive solvers.
 // ============================================================================
+__device__ inline float interp_one(float y0, float y1, const float* k, float dt, float x);
 __device__ inline float reduce_partials_512(const float* p, float* red) {
   float v = p[threadIdx.x] + p[threadIdx.x + 256];
   return block_sum_256(v, red);
@@ -377,6 +381,10 @@ __device__ inline float reduce_partials_512(const float* p, float* red) {
 __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   __shared__ float red[4];
   __shared__ float ratios[4];
+  if (a.ctrl->done) {   // a step enqueued past the end of the interval: nothing was computed, nothing is emitted
+    if (threadIdx.x == 0) a.ctrl->j0 = a.ctrl->j1 = a.ctrl->j;
+    return;
+  }
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
     const float tot = reduce_partials_512(a.partial[sgi], red);
     if (threadIdx.x == 0) ratios[sgi] = (float)((double)tot / a.numel[sgi]);
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   Ctrl* c = a.ctrl;
   const double t = c->t, dt = c->dt;
   const float dtf = (float)dt;
+  const int step = c->step_idx;
   int nr = a.nseg;
   if (a.has_scalar) {
     float e = (dtf * c_CERR[0]) * c->ts_k[0];
@@ -408,12 +417,15 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   }
   for (int i = nr; i < 4; ++i) c->ratio[i] = 0.f;
   double dt_next;
-  if (a.forced) {
+  int done = 0;
+  if (a.forced != nullptr) {   // replay: every step accepted, sizes from the list (the last one repeats)
     accept = true;
-    dt_next = a.forced_next;
+    const double nd = step + 1 < a.n_forced ? a.forced[step + 1] : -1.0;
+    dt_next = nd > 0.0 ? nd : dt;
   } else if (nan) {
     c->status = NODE_ERR_NONFINITE;
     dt_next = dt;
+    done = 1;
   } else if (maxr == 0.f) {
     dt_next = dt * 10.0;
   } else {
@@ -427,8 +439,15 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   c->t_prev = t;
   c->dt_used = dt;
   c->accept = accept ? 1 : 0;
+  if (step == 0) c->first_dt = dt;
+  if (a.dt_log != nullptr && step < a.dt_log_cap) a.dt_log[step] = accept ? dt : -dt;
+  c->step_idx = step + 1;
+  const int j0 = c->j;
+  int j1 = j0;
+  double t_now = t;
   if (accept) {
-    c->t = t + dt;
+    t_now = t + dt;
+    c->t = t_now;
     c->n_acc += 1;
     if (a.has_scalar) {  // keep the step's (y0, f0) for dense output, then FSAL
       c->ts_y0_prev = c->ts_cur;
@@ -436,10 +455,31 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
       c->ts_cur = c->ts_new;
       c->ts_k[0] = c->ts_k[6];
     }
+    // targets passed by this step (upstream advances until t >= target, no clamping, then interpolates)
+    while (j1 < a.n_targets && !(a.targets[j1] > t_now)) ++j1;
+    if (j1 == a.n_targets) {
+      done = 1;
+      if (a.has_scalar && a.interp_scalar && j1 > j0) {   // scalar segment of the augmented state at the interval's end
+        const float t0f = (float)t, t1f = (float)t_now, tjf = (float)a.targets[a.n_targets - 1];
+        const float x = (tjf - t0f) / (t1f - t0f);
+        float kk[7];
+        for (int q = 0; q < 7; ++q) kk[q] = c->ts_k[q];
+        kk[0] = c->ts_f0_prev;
+        c->ts_cur = interp_one(c->ts_y0_prev, c->ts_new, kk, dtf, x);
+      }
+    }
   } else {
     c->n_rej += 1;
   }
+  c->j0 = j0;
+  c->j1 = j1;
+  c->j = j1;
   c->dt = dt_next;
+  if (!done && !(t_now + dt_next > t_now)) {   // upstream: 'underflow in dt'
+    c->status = NODE_ERR_DT_UNDERFLOW;
+    done = 1;
+  }
+  c->done = done;
 }
 
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
@@ -537,6 +577,7 @@ __global__ void k_set_ctrl(Ctrl* c, double t, double dt, int reset) {
   c->dt = dt;
   c->t_prev = t;
   c->dt_used = 0.0;
+  c->done = 0; c->step_idx = 0; c->j = 0; c->j0 = 0; c->j1 = 0; c->first_dt = 0.0;
   if (reset) {
     c->accept = 0; c->status = 0; c->n_acc = 0; c->n_rej = 0; c->h0 = 0.f; c->d0 = 0.f; c->d1 = 0.f;
     for (int i = 0; i < 4; ++i) c->ratio[i] = 0.f;
@@ -603,6 +644,97 @@ void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s) {
   hipLaunchKernelGGL(k_interp_scalar, dim3(1), dim3(1), 0, s, ctrl, dt, x);
 }
 
+// ----------------------------------------------------------------------------
+// Device-resident stepping: what the host used to do between two steps after reading `Ctrl` back.
+// ----------------------------------------------------------------------------
+// Dense output of the forward solve for the targets [j0, j1) the finished step passed, written straight into the
+// caller's NCHW trajectory: workgroup = (64 channels x 64 pixels of one sample) through an LDS tile, reads
+// coalesced along the channels (NHWC state), writes coalesced along the pixels.
+__global__ __launch_bounds__(256) void k_emit_outputs(EmitArgs a, Dims d) {
+  const Ctrl* c = a.ctrl;
+  const int j0 = c->j0, j1 = c->j1;
+  if (j1 <= j0) return;
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, c0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  const float dt = (float)c->dt_used;
+  const float t0f = (float)c->t_prev, t1f = (float)c->t;
+  const size_t sample = (size_t)n * d.HW * d.C;
+  for (int j = j0; j < j1; ++j) {
+    const float x = ((float)a.targets[j] - t0f) / (t1f - t0f);   // upstream rounds t0, t1, t to the state dtype first
+    for (int i = ty; i < 64; i += 4) {
+      const int p = p0 + i, ch = c0 + tx;
+      if (p < d.HW && ch < d.C) {
+        const size_t idx = sample + (size_t)p * d.C + ch;
+        float kk[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) kk[q] = (q == 1) ? 0.f : a.k[q][idx];
+        tile[i][tx] = interp_one(a.y0[idx], a.y1[idx], kk, dt, x);
+      }
+    }
+    __syncthreads();
+    float* out = a.y_out + (size_t)j * d.N * d.C * d.HW + sample;
+    for (int i = ty; i < 64; i += 4) {
+      const int ch = c0 + i, p = p0 + tx;
+      if (p < d.HW && ch < d.C) out[(size_t)ch * d.HW + p] = tile[tx][i];
+    }
+    __syncthreads();
+  }
+}
+void launch_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s) {
+  dim3 grid((d.C + 63) / 64, (d.HW + 63) / 64, d.N);
+  hipLaunchKernelGGL(k_emit_outputs, grid, dim3(256), 0, s, a, d);
+}
+
+// Accepted step, interval not finished: y <- y1, k0 <- k6 (FSAL) for every tensor segment.  Augmented solve at the
+// end of its interval: every segment <- dense output at the interval's end time, in place (element-wise).
+__global__ __launch_bounds__(256) void k_commit(CommitArgs a) {
+  const Ctrl* c = a.ctrl;
+  if (!c->accept || c->step_idx == 0) return;
+  const bool fin = c->done != 0;
+  if (fin && !(a.interp_final && c->j1 > c->j0 && c->status == 0)) return;
+  // (a step enqueued past the end: the controller left j0 == j1, so nothing happens here either)
+  const size_t stride = (size_t)gridDim.x * 256, start = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (!fin) {
+    for (int sg = 0; sg < a.nseg; ++sg) {
+      const size_t n4 = a.n[sg] >> 2;
+      float4* y = reinterpret_cast<float4*>(a.y[sg]);
+      const float4* y1 = reinterpret_cast<const float4*>(a.y1[sg]);
+      float4* k0 = reinterpret_cast<float4*>(a.k0[sg]);
+      const float4* k6 = reinterpret_cast<const float4*>(a.k6[sg]);
+      for (size_t i = start; i < n4; i += stride) { y[i] = y1[i]; k0[i] = k6[i]; }
+      for (size_t i = (n4 << 2) + start; i < a.n[sg]; i += stride) { a.y[sg][i] = a.y1[sg][i]; a.k0[sg][i] = a.k6[sg][i]; }
+    }
+    return;
+  }
+  const float dt = (float)c->dt_used;
+  const float t0f = (float)c->t_prev, t1f = (float)c->t;
+  const float x = ((float)a.targets[0] - t0f) / (t1f - t0f);
+  for (int sg = 0; sg < a.nseg; ++sg)
+    for (size_t i = start; i < a.n[sg]; i += stride) {
+      float kk[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) kk[q] = (q == 1) ? 0.f : a.k[sg][q][i];
+      a.y[sg][i] = interp_one(a.y[sg][i], a.y1[sg][i], kk, dt, x);
+    }
+}
+void launch_commit(const CommitArgs& a, hipStream_t s) {
+  size_t nmax = 0;
+  for (int i = 0; i < a.nseg; ++i) nmax = a.n[i] > nmax ? a.n[i] : nmax;
+  size_t blocks = (nmax / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_commit, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
+
+__global__ void k_set_interval(Ctrl* c, double t, double dt) {
+  c->t = t; c->dt = dt; c->t_prev = t; c->dt_used = 0.0;
+  c->done = 0; c->step_idx = 0; c->j = 0; c->j0 = 0; c->j1 = 0; c->first_dt = 0.0; c->accept = 0;
+}
+void launch_set_interval(Ctrl* ctrl, double t, double dt, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_interval, dim3(1), dim3(1), 0, s, ctrl, t, dt);
+}
+
 __global__ __launch_bounds__(256) void k_axpy(float* y, const float* x, float alpha, size_t n) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] += alpha * x[i];
@@ -664,6 +796,7 @@ void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s) {
 //     conv-job workgroup leaves the dot product of its 64 columns in a.sred's tail, the last one to arrive
 //     (agent-scope fences around a device counter) adds them in a fixed order -- deterministic.
 __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dims d) {
+  if (a.ctrl->done) return;
   __shared__ float red[256];
   __shared__ int s_last;
   const ThetaLayout L = theta_layout(d.C);

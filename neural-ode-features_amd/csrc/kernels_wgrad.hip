@@ -83,6 +83,8 @@ __device__ inline void wg_store_slab(const WgradArgs& a, const Dims& d, const Wg
 // ============================================================================
 template <int W, int RB>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_t(WgradArgs a, Dims d) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
   constexpr int WP = W + 2;
@@ -217,6 +219,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_t(WgradArgs a, Dims d) {
 // ============================================================================
 template <int W, int RB>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w(WgradArgs a, Dims d) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
   constexpr int NT = W / 2;                  // column pairs per image row
@@ -399,6 +403,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_w(WgradArgs a, Dims d) {
 constexpr int WG2_THREADS = 512;
 template <int UT>
 __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
   constexpr int CS = 68;              // component stride
@@ -677,6 +683,8 @@ __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
 // k_wgrad_p: geometry-generic fallback (slot table; five VALU instructions per step)
 // ============================================================================
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_p(WgradArgs a, Dims d) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -223,8 +223,13 @@ struct Plan {
   float *dz1, *dz2, *G;
   float *wpart[2], *spart[2], *gpart[3], *sred, *wtime[2];
   float* dots;              // [n_t] time vjps scratch
+  // device-resident stepping
+  double* targets;          // [n_t] output times of the current interval (solver orientation)
+  double* forced;           // [STEP_LIST_CAP] replay-mode step sizes
+  double* dtlog;            // [STEP_LIST_CAP] dt tried per step of the current interval (negative: rejected)
   size_t bytes;
 };
+constexpr int STEP_LIST_CAP = 4096;   // replay lists / dt logs longer than this are refused / truncated
 
 struct Bump {
   char* base;
@@ -244,6 +249,9 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   memset(&p, 0, sizeof(p));
   Bump b(base);
   p.ctrl = b.take<Ctrl>(1);
+  p.targets = b.take<double>((size_t)(n_t > 0 ? n_t : 1));
+  p.forced = b.take<double>(STEP_LIST_CAP);
+  p.dtlog = b.take<double>(STEP_LIST_CAP);
   for (int i = 0; i < 3; ++i) p.partial[i] = b.take<float>(ERR_BLOCKS * 2);
   const size_t wsz = conv_packed_elems(d);
   for (int i = 0; i < 2; ++i) p.wf[i] = b.take<float>(wsz);
@@ -289,19 +297,46 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   return p;
 }
 
-// pinned host mirror of Ctrl for the per-step read-back
-struct HostMirror {
-  Ctrl* h = nullptr;
-  ~HostMirror() { /* process-lifetime */ }
+// pinned host staging: the mirror of Ctrl for the read-backs and the small lists that travel to / from the device
+// (target times, replay list, dt log).  One per host thread; every solve ends with a stream synchronisation, so
+// the staging is free again when the next solve of this thread starts.
+struct HostStage {
+  Ctrl* ctrl = nullptr;
+  double* lists = nullptr;
+  size_t cap = 0;      // doubles
 };
-thread_local HostMirror g_mirror;
+thread_local HostStage g_stage;
 
-int get_mirror(Ctrl** out) {
-  if (!g_mirror.h) {
-    HIP_TRY(hipHostMalloc((void**)&g_mirror.h, sizeof(Ctrl), hipHostMallocDefault));
+int get_stage(size_t doubles, HostStage** out) {
+  if (!g_stage.ctrl) HIP_TRY(hipHostMalloc((void**)&g_stage.ctrl, sizeof(Ctrl), hipHostMallocDefault));
+  if (g_stage.cap < doubles) {
+    if (g_stage.lists) (void)hipHostFree(g_stage.lists);
+    g_stage.lists = nullptr;
+    g_stage.cap = 0;
+    const size_t want = doubles < 16384 ? 16384 : doubles;
+    HIP_TRY(hipHostMalloc((void**)&g_stage.lists, want * sizeof(double), hipHostMallocDefault));
+    g_stage.cap = want;
   }
-  *out = g_mirror.h;
+  *out = &g_stage;
   return NODE_OK;
+}
+
+// How many steps the last solve of the same problem took: the number enqueued blind before the first read-back.
+struct StepGuess { int N, C, H, W, aug, forced; float rtol, atol; double t0, t1; int steps; };
+thread_local std::vector<StepGuess> g_guess;
+int guess_steps(const StepGuess& k) {
+  for (const auto& g : g_guess)
+    if (g.N == k.N && g.C == k.C && g.H == k.H && g.W == k.W && g.aug == k.aug && g.forced == k.forced && g.rtol == k.rtol &&
+        g.atol == k.atol && g.t0 == k.t0 && g.t1 == k.t1)
+      return g.steps;
+  return 1;
+}
+void remember_steps(const StepGuess& k) {
+  for (auto& g : g_guess)
+    if (g.N == k.N && g.C == k.C && g.H == k.H && g.W == k.W && g.aug == k.aug && g.forced == k.forced && g.rtol == k.rtol &&
+        g.atol == k.atol && g.t0 == k.t0 && g.t1 == k.t1) { g.steps = k.steps; return; }
+  if (g_guess.size() >= 64) g_guess.erase(g_guess.begin());
+  g_guess.push_back(k);
 }
 
 const double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
@@ -326,6 +361,7 @@ struct Solver {
   float tsign = 1.f;
   float rtol = 0.f, atol = 0.f;
   int nfe = 0;
+  bool count_nfe = true;   // off while steps are enqueued blind: those evaluations are counted from the device's step counter
   Ctrl* hctrl = nullptr;
 
   double conv_flops() const { return 2.0 * 9.0 * d.C * d.C * (double)d.N * d.HW; }
@@ -426,7 +462,7 @@ struct Solver {
     c2.out = k_out; c2.xhat_out = train ? p.xh3 : nullptr; c2.rstd_out = train ? p.r3 : nullptr;
     { ProfScope ps(0, conv_flops(), st); launch_conv(d, c2, st); }
     if (d.csplit) gn_pass_fwd(prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr, train ? p.r3 : nullptr);
-    nfe += 1;
+    if (count_nfe) nfe += 1;
     return check_launch("odefunc forward");
   }
 
@@ -454,7 +490,7 @@ struct Solver {
     if (need_theta) {
       WgradArgs w2;
       memset(&w2, 0, sizeof(w2));
-      w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
+      w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1]; w2.ctrl = p.ctrl;
       { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
     }
 
@@ -472,7 +508,7 @@ struct Solver {
     if (need_theta) {
       WgradArgs w1;
       memset(&w1, 0, sizeof(w1));
-      w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0];
+      w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.ctrl = p.ctrl;
       { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
     }
 
@@ -537,13 +573,28 @@ struct Solver {
     return check_launch("initial step");
   }
 
-  // one dopri5 step on the device; host learns the outcome from hctrl afterwards
-  int dopri5_step(bool forced, double forced_next) {
+  // Where a run of dopri5 steps writes: the interval's target times, the replay list, the dt log (device arrays),
+  // and -- forward solve -- the caller's trajectory.
+  struct StepIO {
+    int n_targets = 0;
+    int n_forced = 0;        // > 0: replay mode
+    int log_cap = 0;         // > 0: dt log wanted
+    float* y_out = nullptr;  // forward: [n_targets][N][C][H][W], slot j <-> target j
+  };
+
+  // one dopri5 step, entirely on the device: six stages, error norms, controller (accept / dt / targets passed),
+  // dense output, commit.  The host learns nothing here; see run_steps().
+  int enqueue_step(const StepIO& io) {
     // stage 2 (s == 0): its parameter / time derivative has zero weight everywhere (see eval_aug)
     static int skip_k2 = -1;
     if (skip_k2 < 0) { const char* e = getenv("NODE_TUNE_SKIP_K2_THETA"); skip_k2 = e ? atoi(e) : 1; }
-    for (int s = 0; s < 6; ++s)
-      TRY(eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5, !(skip_k2 && s == 0)));
+    const bool was_counting = count_nfe;
+    count_nfe = false;
+    for (int s = 0; s < 6; ++s) {
+      const int rc = eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5, !(skip_k2 && s == 0));
+      if (rc != NODE_OK) { count_nfe = was_counting; return rc; }
+    }
+    count_nfe = was_counting;
     const int nseg = aug ? 3 : 1;
     ErrSeg e0;
     e0.y0 = p.Y; e0.y1 = p.Y1; e0.n = d.numel; e0.compute_y1 = 0;
@@ -565,21 +616,57 @@ struct Solver {
     sc.partial[0] = p.partial[0]; sc.partial[1] = p.partial[1]; sc.partial[2] = p.partial[2];
     sc.numel[0] = (double)d.numel; sc.numel[1] = (double)d.numel; sc.numel[2] = (double)d.P;
     sc.nseg = nseg; sc.has_scalar = aug ? 1 : 0; sc.rtol = rtol; sc.atol = atol;
-    sc.forced = forced ? 1 : 0; sc.forced_next = forced_next;
+    sc.targets = p.targets; sc.n_targets = io.n_targets;
+    sc.forced = io.n_forced > 0 ? p.forced : nullptr; sc.n_forced = io.n_forced;
+    sc.dt_log = io.log_cap > 0 ? p.dtlog : nullptr; sc.dt_log_cap = io.log_cap;
+    sc.interp_scalar = aug ? 1 : 0;
     launch_step_controller(sc, st);
-    TRY(check_launch("dopri5 step"));
-    return readback();
+    if (!aug) {
+      EmitArgs ea;
+      ea.ctrl = p.ctrl; ea.targets = p.targets; ea.y0 = p.Y; ea.y1 = p.Y1;
+      for (int j = 0; j < 7; ++j) ea.k[j] = p.KY[j];
+      ea.y_out = io.y_out;
+      launch_emit_outputs(d, ea, st);
+    }
+    CommitArgs cm;
+    memset(&cm, 0, sizeof(cm));
+    cm.ctrl = p.ctrl; cm.targets = p.targets; cm.nseg = nseg; cm.interp_final = aug ? 1 : 0;
+    cm.y[0] = p.Y; cm.y1[0] = p.Y1; cm.k0[0] = p.KY[0]; cm.k6[0] = p.KY[6]; cm.n[0] = d.numel;
+    for (int j = 0; j < 7; ++j) cm.k[0][j] = p.KY[j];
+    if (aug) {
+      // (the y segment is reloaded from the forward trajectory at every interval: its dense output is not needed,
+      //  but it is cheap and keeps the three segments uniform)
+      cm.y[1] = p.A; cm.y1[1] = p.A1; cm.k0[1] = p.KA[0]; cm.k6[1] = p.KA[6]; cm.n[1] = d.numel;
+      cm.y[2] = p.TH; cm.y1[2] = p.TH1; cm.k0[2] = p.KT[0]; cm.k6[2] = p.KT[6]; cm.n[2] = d.P;
+      for (int j = 0; j < 7; ++j) { cm.k[1][j] = p.KA[j]; cm.k[2][j] = p.KT[j]; }
+    }
+    launch_commit(cm, st);
+    return check_launch("dopri5 step");
   }
 
-  void swap_on_accept() {
-    std::swap(p.Y, p.Y1);
-    std::swap(p.KY[0], p.KY[6]);
-    if (aug) {
-      std::swap(p.A, p.A1);
-      std::swap(p.KA[0], p.KA[6]);
-      std::swap(p.TH, p.TH1);
-      std::swap(p.KT[0], p.KT[6]);
+  // Advance the current interval to its last target.  `guess` steps are enqueued before the first read-back (what the
+  // previous solve of the same problem needed: one synchronisation per solve in steady state), then two at a time;
+  // steps enqueued past the end return at once on the device (Ctrl::done).  On return *hctrl holds the final record.
+  int run_steps(const StepIO& io, long long max_steps, int guess, int* status) {
+    long long enq = 0;
+    long long batch = guess > 0 ? guess : 1;
+    for (;;) {
+      if (batch > max_steps - enq) batch = max_steps - enq;
+      for (long long i = 0; i < batch; ++i) TRY(enqueue_step(io));
+      enq += batch;
+      TRY(readback());
+      if (hctrl->status != 0) { *status = hctrl->status; return NODE_OK; }
+      if (hctrl->done) return NODE_OK;
+      if (enq >= max_steps) { *status = NODE_ERR_MAX_STEPS; return NODE_OK; }
+      batch = 2;
     }
+  }
+
+  // host -> device: the interval's target times (and, once per solve, the replay list)
+  int upload(double* dst, const double* src, int n, double* stage) {
+    for (int i = 0; i < n; ++i) stage[i] = src[i];
+    HIP_TRY(hipMemcpyAsync(dst, stage, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    return NODE_OK;
   }
 
   // one interval of the fixed-grid RK4 (3/8 rule): state advanced in place
@@ -718,7 +805,11 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   Solver S;
   TRY(check_common(shape, params, ws, ws_bytes, 0, n_t, &S.d, &S.p));
   S.prm = *params; S.st = (hipStream_t)stream; S.aug = false; S.rtol = rtol; S.atol = atol;
-  TRY(get_mirror(&S.hctrl));
+  const bool forced = method == NODE_METHOD_DOPRI5 && opts && opts->n_forced_dt > 0 && opts->forced_dt;
+  if (forced && opts->n_forced_dt > STEP_LIST_CAP) return fail(NODE_ERR_ARG, "replay list longer than %d", STEP_LIST_CAP);
+  HostStage* hs = nullptr;
+  TRY(get_stage((size_t)n_t + 2 * STEP_LIST_CAP, &hs));
+  S.hctrl = hs->ctrl;
   const bool decreasing = t_pts[1] < t_pts[0];
   S.tsign = decreasing ? -1.f : 1.f;
   std::vector<double> ts(n_t);
@@ -746,66 +837,39 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     return S.check_launch("node_solve_fwd(rk4)");
   }
 
-  // ---- dopri5 ----
-  const bool forced = opts && opts->n_forced_dt > 0 && opts->forced_dt;
-  int forced_idx = 0;
+  // ---- dopri5: every decision of the step loop is taken on the device ----
   const long long max_steps = (opts && opts->max_num_steps > 0) ? opts->max_num_steps : 2147483647LL;
+  Solver::StepIO io;
+  io.n_targets = n_t - 1;
+  io.n_forced = forced ? opts->n_forced_dt : 0;
+  io.log_cap = (opts && opts->record_dt > 0 && opts->dt_log) ? (opts->record_dt < STEP_LIST_CAP ? opts->record_dt : STEP_LIST_CAP) : 0;
+  io.y_out = y_out + numel;
+  TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
+  if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
-  if (forced) forced_idx = 1;
-  else TRY(S.initial_step());
-  bool first = true;
-  int j = 1;
-  long long steps = 0;
-  double cur_t = ts[0], cur_dt = forced ? opts->forced_dt[0] : 0.0;
-  while (j < n_t) {
-    if (steps >= max_steps) { stt.status = NODE_ERR_MAX_STEPS; break; }
-    double fnext = 0.0;
-    if (forced) { fnext = forced_idx < opts->n_forced_dt ? opts->forced_dt[forced_idx] : -1.0; }
-    // (replay: when the list is exhausted keep the last dt, like the oracle)
-    TRY(S.dopri5_step(forced, 0.0));
-    ++steps;
-    const Ctrl& h = *S.hctrl;
-    if (first) { stt.first_dt = h.dt_used; first = false; }
-    if (h.status != 0) { stt.status = h.status; break; }
-    dlog.add(h.dt_used, h.accept != 0);
-    if (forced) {  // overwrite the controller's proposal with the forced sequence
-      const double nd = fnext > 0.0 ? fnext : h.dt_used;
-      launch_set_ctrl(S.p.ctrl, h.t, nd, 0, S.st);
-      if (fnext > 0.0) ++forced_idx;
-      cur_dt = nd;
-    } else {
-      cur_dt = h.dt;
-    }
-    cur_t = h.t;
-    if (h.accept) {
-      stt.accepted += 1;
-      const double t0 = h.t_prev, t1 = h.t;
-      while (j < n_t && !(ts[j] > t1)) {
-        InterpArgs ia;
-        ia.y0 = S.p.Y; ia.y1 = S.p.Y1;
-        for (int q = 0; q < 7; ++q) ia.k[q] = S.p.KY[q];
-        ia.out = S.p.TMP; ia.n = numel; ia.dt = (float)h.dt_used;
-        {  // upstream rounds t0, t1, t to the state dtype before forming x
-          const float t0f = (float)t0, t1f = (float)t1, tjf = (float)ts[j];
-          ia.x = (tjf - t0f) / (t1f - t0f);
-        }
-        launch_interp(ia, S.st);
-        launch_nhwc_to_nchw(S.d, S.p.TMP, y_out + (size_t)j * numel, S.st);
-        ++j;
-      }
-      S.swap_on_accept();
-    } else {
-      stt.rejected += 1;
-    }
-    if (j < n_t && !(cur_t + cur_dt > cur_t)) { stt.status = NODE_ERR_DT_UNDERFLOW; break; }
+  if (!forced) TRY(S.initial_step());
+  StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 0, forced ? 1 : 0, rtol, atol, ts[0], ts[n_t - 1], 0};
+  int status = 0;
+  TRY(S.run_steps(io, max_steps, guess_steps(key), &status));
+  const Ctrl& h = *S.hctrl;
+  key.steps = h.step_idx;
+  if (status == 0) remember_steps(key);
+  stt.status = status;
+  stt.accepted = h.n_acc; stt.rejected = h.n_rej;
+  stt.nfe = S.nfe + 6 * h.step_idx;     // f0 (+ the initial-step probe) + six stages per step tried (show.py:199)
+  stt.first_dt = h.first_dt; stt.t_final = h.t; stt.last_dt = h.dt;
+  if (io.log_cap > 0) {
+    const int n = h.step_idx < io.log_cap ? h.step_idx : io.log_cap;
+    double* stage = hs->lists;
+    HIP_TRY(hipMemcpyAsync(stage, S.p.dtlog, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, S.st));
+    HIP_TRY(hipStreamSynchronize(S.st));
+    for (int i = 0; i < n; ++i) dlog.add(fabs(stage[i]), stage[i] > 0.0);
   }
-  HIP_TRY(hipStreamSynchronize(S.st));
-  stt.nfe = S.nfe; stt.t_final = cur_t; stt.last_dt = cur_dt;
   if (stats) *stats = stt;
   TRY(S.check_launch("node_solve_fwd(dopri5)"));
   if (stt.status == NODE_ERR_MAX_STEPS) return fail(NODE_ERR_MAX_STEPS, "max_num_steps exceeded");
-  if (stt.status == NODE_ERR_DT_UNDERFLOW) return fail(NODE_ERR_DT_UNDERFLOW, "underflow in dt %g", cur_dt);
+  if (stt.status == NODE_ERR_DT_UNDERFLOW) return fail(NODE_ERR_DT_UNDERFLOW, "underflow in dt %g", h.dt);
   return status_to_rc(stt.status);
 }
 
@@ -819,21 +883,29 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   Solver S;
   TRY(check_common(shape, params, ws, ws_bytes, 1, n_t, &S.d, &S.p));
   S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.rtol = rtol; S.atol = atol;
-  TRY(get_mirror(&S.hctrl));
+  const bool forced = opts && opts->n_forced_dt > 0 && opts->forced_dt && method == NODE_METHOD_DOPRI5;
+  if (forced && opts->n_forced_dt > STEP_LIST_CAP) return fail(NODE_ERR_ARG, "replay list longer than %d", STEP_LIST_CAP);
+  HostStage* hs = nullptr;
+  TRY(get_stage((size_t)n_t + 2 * STEP_LIST_CAP, &hs));
+  S.hctrl = hs->ctrl;
   node_stats stt;
   memset(&stt, 0, sizeof(stt));
   DtLog dlog(opts);
   const size_t numel = S.d.numel;
-  const bool forced = opts && opts->n_forced_dt > 0 && opts->forced_dt && method == NODE_METHOD_DOPRI5;
-  int forced_idx = 0;
   const long long max_steps = (opts && opts->max_num_steps > 0) ? opts->max_num_steps : 2147483647LL;
+  Solver::StepIO io;
+  io.n_targets = 1;
+  io.n_forced = forced ? opts->n_forced_dt : 0;
+  io.log_cap = (opts && opts->record_dt > 0 && opts->dt_log) ? (opts->record_dt < STEP_LIST_CAP ? opts->record_dt : STEP_LIST_CAP) : 0;
 
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
   launch_nchw_to_nhwc(S.d, grad_out + (size_t)(n_t - 1) * numel, S.p.A, S.st);  // adj_y = grad_output[-1]
+  if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   double cur_t = 0.0, cur_dt = 0.0;
   bool first = true;
+  int steps_total = 0;
 
   for (int i = n_t - 1; i >= 1 && stt.status == 0; --i) {
     // the interval is integrated from t_i to t_{i-1}; upstream negates time when that is decreasing
@@ -857,62 +929,32 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       dlog.add(s1 - s0, true);
       cur_t = s1; cur_dt = s1 - s0;
     } else {
-      forced_idx = 0;  // replay list restarts per interval (one odeint call each upstream)
-      launch_set_ctrl(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, 0, S.st);
-      if (forced) forced_idx = 1;
+      // replay list restarts per interval (one odeint call each upstream)
+      launch_set_interval(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, S.st);
+      TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
       launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], S.p.G, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
-      long long steps = 0;
-      bool done = false;
-      while (!done) {
-        if (steps >= max_steps) { stt.status = NODE_ERR_MAX_STEPS; break; }
-        double fnext = -1.0;
-        if (forced) fnext = forced_idx < opts->n_forced_dt ? opts->forced_dt[forced_idx] : -1.0;
-        TRY(S.dopri5_step(forced, 0.0));
-        ++steps;
-        const Ctrl& h = *S.hctrl;
-        if (first) { stt.first_dt = h.dt_used; first = false; }
-        if (h.status != 0) { stt.status = h.status; break; }
-        dlog.add(h.dt_used, h.accept != 0);
-        if (forced) {
-          const double nd = fnext > 0.0 ? fnext : h.dt_used;
-          launch_set_ctrl(S.p.ctrl, h.t, nd, 0, S.st);
-          if (fnext > 0.0) ++forced_idx;
-          cur_dt = nd;
-        } else {
-          cur_dt = h.dt;
-        }
-        cur_t = h.t;
-        if (h.accept) {
-          stt.accepted += 1;
-          if (!(s1 > h.t)) {
-            // dense output at s1 for the adjoint, parameter and time segments (y is reloaded per interval)
-            const double t0 = h.t_prev, t1 = h.t;
-            const float t0f = (float)t0, t1f = (float)t1, s1f = (float)s1;
-            const float x = (s1f - t0f) / (t1f - t0f);
-            InterpArgs ia;
-            ia.y0 = S.p.A; ia.y1 = S.p.A1;
-            for (int q = 0; q < 7; ++q) ia.k[q] = S.p.KA[q];
-            ia.out = S.p.TMP; ia.n = numel; ia.dt = (float)h.dt_used; ia.x = x;
-            launch_interp(ia, S.st);
-            InterpArgs it = ia;
-            it.y0 = S.p.TH; it.y1 = S.p.TH1;
-            for (int q = 0; q < 7; ++q) it.k[q] = S.p.KT[q];
-            it.out = S.p.THTMP; it.n = S.d.P;
-            launch_interp(it, S.st);
-            launch_interp_scalar(S.p.ctrl, (float)h.dt_used, x, S.st);
-            std::swap(S.p.A, S.p.TMP);
-            std::swap(S.p.TH, S.p.THTMP);
-            done = true;
-          } else {
-            S.swap_on_accept();
-          }
-        } else {
-          stt.rejected += 1;
-        }
-        if (!done && !(cur_t + cur_dt > cur_t)) { stt.status = NODE_ERR_DT_UNDERFLOW; break; }
+      StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 1, forced ? 1 : 0, rtol, atol, s0, s1, 0};
+      int status = 0;
+      // the dense output of the adjoint, parameter and time segments at s1 happens on the device with the last step
+      TRY(S.run_steps(io, max_steps, guess_steps(key), &status));
+      const Ctrl& h = *S.hctrl;
+      key.steps = h.step_idx;
+      if (status == 0) remember_steps(key);
+      stt.status = status;
+      if (first) { stt.first_dt = h.first_dt; first = false; }
+      steps_total += h.step_idx;
+      stt.accepted = h.n_acc; stt.rejected = h.n_rej;     // cumulative over the intervals
+      cur_t = h.t; cur_dt = h.dt;
+      if (io.log_cap > 0) {
+        const int n = h.step_idx < io.log_cap ? h.step_idx : io.log_cap;
+        double* stage = hs->lists + n_t + STEP_LIST_CAP;
+        HIP_TRY(hipMemcpyAsync(stage, S.p.dtlog, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, S.st));
+        HIP_TRY(hipStreamSynchronize(S.st));
+        for (int q = 0; q < n; ++q) dlog.add(fabs(stage[q]), stage[q] > 0.0);
       }
+      if (stt.status != 0) break;
     }
     // adj_y += grad_output[i-1]
     launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
@@ -927,7 +969,8 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     HIP_TRY(hipMemcpyAsync(grad_t, S.p.dots, (size_t)n_t * sizeof(float), hipMemcpyDeviceToDevice, S.st));
   }
   HIP_TRY(hipStreamSynchronize(S.st));
-  stt.nfe = S.nfe; stt.t_final = cur_t; stt.last_dt = cur_dt;
+  stt.nfe = S.nfe + 6 * steps_total;
+  stt.t_final = cur_t; stt.last_dt = cur_dt;
   if (stats) *stats = stt;
   TRY(S.check_launch("node_solve_adjoint"));
   if (stt.status == NODE_ERR_MAX_STEPS) return fail(NODE_ERR_MAX_STEPS, "max_num_steps exceeded");

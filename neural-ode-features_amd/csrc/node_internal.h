@@ -79,6 +79,14 @@ struct Ctrl {
   float ts_y0_prev; // value at the start of the last accepted step (dense output)
   float ts_f0_prev; // derivative at the start of the last accepted step
   float pad;
+  // device-resident stepping: the host enqueues steps without reading anything back; once `done` is set every
+  // kernel of a later step returns at once, so steps enqueued past the end of the interval cost launch time only
+  int done;        // the interval reached its last target time (or stopped with `status`)
+  int step_idx;    // steps tried in this interval (accepted + rejected)
+  int j;           // next target time not yet passed
+  int j0, j1;      // targets [j0, j1) were passed by the step just finished (dense output is emitted for them)
+  int pad2;
+  double first_dt; // step size of the interval's first step
 };
 
 enum TimeMode { TM_STAGE = 0, TM_PROBE = 1 };
@@ -233,10 +241,37 @@ struct StepCtlArgs {
   int nseg;            // tensor segments (1 fwd, 3 aug: y, a, theta)
   int has_scalar;      // adj_t segment present
   float rtol, atol;
-  int forced;          // replay mode
-  double forced_next;
+  const double* targets;   // device: times (in solver orientation) at which output is wanted, increasing
+  int n_targets;
+  const double* forced;    // device, nullable: replay mode -- step k takes forced[k] (the last one repeats)
+  int n_forced;
+  double* dt_log;          // device, nullable: dt tried at step k (negative: rejected)
+  int dt_log_cap;
+  int interp_scalar;       // aug: when the last target is passed, ts_cur <- dense output at that time
 };
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s);
+
+// After the controller, on the device (no host decision):
+//   forward solve: dense output for the targets [j0, j1) of the step just finished, straight into y_out (NCHW);
+//   then, if the step was accepted and the interval goes on, y <- y1 and k0 <- k6 (FSAL) for every segment.
+struct EmitArgs {
+  const Ctrl* ctrl;
+  const double* targets;
+  const float* y0; const float* y1; const float* k[7];   // NHWC
+  float* y_out;        // [n_targets][N][C][HW] (NCHW), slot j <-> targets[j]
+};
+void launch_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
+struct CommitArgs {
+  const Ctrl* ctrl;
+  const double* targets;   // aug: the interval's end time (targets[0]) for the in-place dense output
+  int nseg;
+  float* y[3]; const float* y1[3]; float* k0[3]; const float* k6[3];
+  const float* k[3][7];    // aug only: all stage derivatives (dense output at the interval's end)
+  size_t n[3];
+  int interp_final;        // aug: when the interval's end is passed, y[s] <- dense output at targets[0] (in place)
+};
+void launch_commit(const CommitArgs& a, hipStream_t s);
+void launch_set_interval(Ctrl* ctrl, double t, double dt, hipStream_t s);   // new interval: t, dt, done = 0, counters of the interval
 
 // initial step (Hairer)
 struct InitSeg { const float* y0; const float* f0; const float* f1; size_t n; };
@@ -305,6 +340,7 @@ void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dg
 struct WgradArgs {
   const float* act;       // [N,HW,C] conv input activation
   const float* dz;        // [N,HW,C] cotangent of conv output
+  const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done (see Ctrl)
   float* wpart;           // [nsplit][9][C][C]
   unsigned long long* stamps;  // diagnostics only (NODE_STAMPS builds)
 };

@@ -1,7 +1,7 @@
 """GPU parity, round 2: the holes the round-1 review listed.
 
-* whole adjoint solves at BASELINE configs[1]/[2] size ([128,256,8,8], tol 1e-3 / 1e-5) against the oracle, with
-  per-sample accounting of ReLU-kink exposure (tests/helpers.py:ProbedODEfunc);
+* whole adjoint solves at BASELINE configs[1]/[2] size ([128,256,8,8], tol 1e-3 / 1e-5) against the oracle: max-norm on
+  the kink-free parameter set, and under an fp64 arbiter with ordinary parameters (per sample / tensor / channel);
 * 16x16 states (the reference's one-shot / 'ode' stems, cfg 5): split-conv path at several column-tile counts and
   channels-per-group, forward + VJP + an adjoint solve; C = 1024 (cpg = 32);
 * run-time mutation of a live block (`t1`, `tol`, `return_last_only`; evaluate.py:62,80,116-117) and
@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from oracle import torchdiffeq_restated as tdq
 from oracle.dynamics import odefunc_vjp as oracle_vjp
-from tests.helpers import ProbedODEfunc, make_func, per_sample_err, rel_err, robust_grad_err
+from tests.helpers import make_func, per_sample_err, rel_err, robust_grad_err
 
 pytestmark = pytest.mark.gpu
 
@@ -28,14 +28,10 @@ def _load(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
 
 
-def _adjoint_both(shape, tol, seed, kink_free, probe=False, tpts=(0.0, 1.0)):
+def _adjoint_both(shape, tol, seed, kink_free, tpts=(0.0, 1.0)):
     import neural_ode_features_amd as nof
     N, C, H, W = shape
     f, twin = make_func(C, seed=seed, device='cuda', kink_free=kink_free)
-    if probe:
-        probed = ProbedODEfunc(C)
-        probed.load_state_dict(twin.state_dict())
-        twin = probed
     gen = torch.Generator().manual_seed(seed + 1)
     y = torch.randn(N, C, H, W, generator=gen)
     wgt = torch.randn(len(tpts), N, C, H, W, generator=gen) / (C * H * W) ** 0.5
@@ -75,31 +71,89 @@ def test_full_size_adjoint_solve_kink_free(tol):
         assert e_y < 5e-2 and e_p < 5e-2
 
 
-@pytest.mark.parametrize('tol', [1e-3, 1e-5])
-def test_full_size_adjoint_solve_per_sample_accounting(tol):
-    """Ordinary parameters (ReLUs switch).  The oracle records per sample how close any pre-activation of the whole
-    solve came to zero; samples that stayed further than 4e-6 away cannot have had a mask flip and must agree to
-    1e-3 (max-norm, relative to the largest gradient); the exposed ones are counted and bounded."""
-    r = _adjoint_both((128, 256, 8, 8), tol, seed=52, kink_free=False, probe=True)
-    assert float((r['out_h'].cpu() - r['out_o']).abs().max()) <= 10 * tol
-    es = per_sample_err(r['gy_h'], r['gy_o'])
-    exposed = r['twin'].min_abs < 4e-6
-    clean = ~exposed
-    l2_y, _ = robust_grad_err(r['gy_h'], r['gy_o'])
-    l2_p, _ = robust_grad_err(r['gp_h'], r['gp_o'])
-    print('tol', tol, 'exposed samples', int(exposed.sum()), 'of', es.numel(), '| clean: max err %.3e' %
-          (float(es[clean].max()) if clean.any() else 0.0), '| exposed: max err %.3e median %.3e' %
-          ((float(es[exposed].max()), float(es[exposed].median())) if exposed.any() else (0.0, 0.0)),
-          '| samples over 1e-3:', int((es > 1e-3).sum()), '| L2 grad_y %.3e grad_theta %.3e' % (l2_y, l2_p),
-          'same history', r['same'])
-    if r['same']:
-        if clean.any():
-            assert float(es[clean].max()) < 1e-3
-        # every sample over the tight bound must be one the oracle saw within rounding of a kink
-        assert int(((es > 1e-3) & clean).sum()) == 0
-        assert float(es.max()) < 0.25 and l2_y < 3e-2 and l2_p < 3e-2
-    else:
-        assert l2_y < 0.1 and l2_p < 0.1
+def _replay_triplet(shape, tol, seed, t_end):
+    """Ordinary parameters (ReLUs switch inside the solve) under an fp64 ARBITER.  A free-running HIP solve supplies
+    the accepted step sizes (forward and backward); the same discrete scheme is then integrated three times in replay
+    mode: HIP (fp32), oracle fp32, oracle fp64.  Returns the three gradient sets."""
+    import copy
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=seed, device='cuda', kink_free=False)
+    gen = torch.Generator().manual_seed(seed + 1)
+    y = torch.randn(N, C, H, W, generator=gen)
+    wgt = torch.randn(2, N, C, H, W, generator=gen) / (C * H * W) ** 0.5
+    t = torch.tensor([0.0, t_end])
+    # 1. free-running HIP solve: the step sizes the controller accepts on this problem
+    yh = y.cuda().requires_grad_(True)
+    out = nof.odeint_adjoint(f, yh, t.cuda(), rtol=tol, atol=tol, method='dopri5', options={'record_dt': 1024})
+    (out * wgt.cuda()).sum().backward()
+    fs, bs = f.last_forward_stats, f.last_backward_stats
+    fd = [d for d, a in zip(fs['dts'], fs['accepts']) if a]
+    bd = [d for d, a in zip(bs['dts'], bs['accepts']) if a]
+    assert len(fd) == fs['accepted'] and len(bd) == bs['accepted']
+    free = dict(gy=yh.grad.clone(), gp=torch.cat([p.grad.reshape(-1) for p in f.parameters()]))
+    opts = {'forced_dts': fd, 'forced_dts_bwd': bd}
+    print(shape, tol, 'free-running HIP: forward', (fs['accepted'], fs['rejected']), 'backward', (bs['accepted'], bs['rejected']))
+    # 2. replay on the GPU
+    for p in f.parameters():
+        p.grad = None
+    yh = y.cuda().requires_grad_(True)
+    out_h = nof.odeint_adjoint(f, yh, t.cuda(), rtol=tol, atol=tol, method='dopri5', options=opts)
+    (out_h * wgt.cuda()).sum().backward()
+    hip = dict(out=out_h.detach().cpu(), gy=yh.grad.cpu(), gp=torch.cat([p.grad.reshape(-1) for p in f.parameters()]).cpu())
+    # 3. replay by the oracle in fp32 and in fp64
+    res = {}
+    for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        tw = copy.deepcopy(twin).to(dt)
+        yo = y.to(dt).requires_grad_(True)
+        out_o = tdq.odeint_adjoint(tw, yo, t.to(dt), rtol=tol, atol=tol, method='dopri5', options=dict(opts))
+        (out_o * wgt.to(dt)).sum().backward()
+        res[name] = dict(out=out_o.detach(), gy=yo.grad, gp=torch.cat([p.grad.reshape(-1) for p in tw.parameters()]))
+    return hip, res['f32'], res['f64'], free
+
+
+@pytest.mark.parametrize('tol,t_end', [(1e-3, 1.0), (1e-5, 0.3)])
+def test_full_size_adjoint_solve_fp64_arbiter(tol, t_end):
+    """configs[1] / configs[2] state [128,256,8,8], ordinary parameters: the ReLU masks DO switch inside the solve, so
+    two correct fp32 implementations disagree wherever a pre-activation lands within rounding of zero (measured: every
+    one of the 128 samples has such an element somewhere in the ~50 evaluations of a solve; per-sample max-norm
+    disagreement ~3e-2 between the oracle and the HIP path, L2 4e-3).  A max-norm bound between the two is therefore
+    either vacuous or false.  The fp64 oracle arbitrates instead: on the SAME step sequence, the HIP result must be
+    as close to the fp64 result as the fp32 oracle is (a wrong scale on a few channels, a wrong mask, a missing term
+    would put it far outside) -- per sample for grad_y0, per parameter tensor and per conv output channel for
+    grad_theta."""
+    hip, o32, o64, free = _replay_triplet((128, 256, 8, 8), tol, seed=52, t_end=t_end)
+    assert float((hip['out'][-1].double() - o64['out'][-1]).abs().max()) <= 10 * tol
+
+    def dist(a, ref):       # per-sample max-norm distance relative to the largest reference gradient
+        return (a.double() - ref).abs().flatten(1).amax(dim=1) / ref.abs().max()
+
+    e_hip, e_cpu = dist(hip['gy'], o64['gy']), dist(o32['gy'], o64['gy'])
+    print('tol', tol, 'grad_y0 per-sample distance to fp64: HIP median %.3e max %.3e | fp32 oracle median %.3e max %.3e'
+          % (float(e_hip.median()), float(e_hip.max()), float(e_cpu.median()), float(e_cpu.max())))
+    assert float(e_hip.median()) <= 3.0 * float(e_cpu.median()) + 1e-5
+    assert float(e_hip.max()) <= 3.0 * float(e_cpu.max()) + 1e-5
+    l2_hip = float((hip['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
+    l2_cpu = float((o32['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
+    print('grad_y0 relative L2 distance to fp64: HIP %.3e  fp32 oracle %.3e' % (l2_hip, l2_cpu))
+    assert l2_hip <= 3.0 * l2_cpu + 1e-6
+    # parameter gradients: every tensor, and every output channel of the two conv weights, on its own scale
+    C = 256
+    sizes = [C, C, C * (C + 1) * 9, C, C, C, C * (C + 1) * 9, C, C, C]
+    off = 0
+    for i, n in enumerate(sizes):
+        h, a, r = hip['gp'][off:off + n].double(), o32['gp'][off:off + n].double(), o64['gp'][off:off + n]
+        off += n
+        rows = C if n > C else 1                      # conv weights: one row per output channel
+        h, a, r = h.view(rows, -1), a.view(rows, -1), r.view(rows, -1)
+        scale = r.abs().amax(dim=1).clamp_min(1e-3 * float(r.abs().max()))
+        eh, ea = (h - r).abs().amax(dim=1) / scale, (a - r).abs().amax(dim=1) / scale
+        print('  theta tensor %d (%d rows): HIP worst %.3e median %.3e | fp32 oracle worst %.3e median %.3e'
+              % (i, rows, float(eh.max()), float(eh.median()), float(ea.max()), float(ea.median())))
+        assert float(eh.max()) <= 3.0 * float(ea.max()) + 1e-5, i
+        assert float(eh.median()) <= 3.0 * float(ea.median()) + 1e-5, i
+    # the free-running solve took exactly these steps: it must reproduce the replay to rounding
+    assert rel_err(free['gy'], hip['gy']) < 1e-4 and rel_err(free['gp'], hip['gp']) < 1e-4
 
 
 @pytest.mark.parametrize('shape', [(4, 256, 16, 16), (2, 64, 16, 16), (2, 1024, 16, 16), (3, 96, 16, 16)])
