@@ -142,11 +142,8 @@ def train_step(model, opt, x, y, reducer=None):
     nfe_b = model.nfe(reset=True)
     if reducer is not None:
         reducer.finish()
-        opt.step()
-        reducer.zero_grad()
-    else:
-        opt.step()
-        opt.zero_grad()
+    opt.step()
+    opt.zero_grad()
     return loss, nfe_f, nfe_b
 
 
@@ -261,10 +258,12 @@ def main():
     model = build_model(device, cfg, args.method)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     reducer = None
+    # SGD lr .1 momentum .9 wd 1e-4 (reproduce.sh:3-6, train.py:136): one fused launch for all parameter tensors
+    opt = nof.FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     if world > 1:
         nof.dp.broadcast_parameters(model, 0)
-        reducer = nof.dp.GradientReducer(model)
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)  # reproduce.sh:3-6, train.py:136
+        reducer = nof.dp.GradientReducer(model, average=False)   # all-reduce SUM in the bucket buffers ...
+        opt.grad_scale = 1.0 / world                             # ... its 1/world folded into the optimizer step
     model.train()
 
     gen = torch.Generator().manual_seed(1234 + rank)

@@ -160,6 +160,20 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params,
                        node_stats* stats,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Backward of torchdiffeq.odeint with adjoint=False (the constructor default, model.py:7; selected at model.py:359):
+ * upstream backpropagates through the solver's operations.  The accepted steps of the forward solve are replayed
+ * from y0 (`step_dt`: their sizes as node_solve_fwd logged them through node_solve_opts.dt_log, accepted ones only,
+ * `n_steps` of them; ignored for rk4, whose grid is t_pts), all stage derivatives are kept, and the cotangent
+ * grad_out [n_t, n, c, h, w] is carried back through every step: grad_y0 [n, c, h, w], grad_params flat in
+ * parameters() order.  Step sizes are constants of the differentiation.  Workspace: node_backprop_workspace_bytes
+ * (it holds the tape: 7 state-sized tensors per step). */
+size_t node_backprop_workspace_bytes(const node_shape* shape, int method, int n_t, int n_steps);
+int node_solve_backprop(const node_shape* shape, const node_params* params,
+                        const float* y0, const float* t_pts, int n_t,
+                        const double* step_dt, int n_steps, int method,
+                        const float* grad_out, float* grad_y0, float* grad_params,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* Classifier head behind the ODE block, up to (not including) the Linear layer
  *   -- model.py:231-250 (FCClassifier): GroupNorm(min(32,C), C) [model.py:268-271] -> ReLU ->
  *      AdaptiveAvgPool2d((1,1)) -> [Dropout] -> Flatten.
@@ -185,6 +199,22 @@ int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma
                      int relu, float* out, float* stats, void* stream);
 int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
                      const float* stats, int relu, const float* g_out, float* dz, float* gpart, void* stream);
+
+/* The optimizer step of the training loop -- train.py:136 (`torch.optim.SGD(params, lr, momentum=0.9, weight_decay=wd)`)
+ * stepped at train.py:56-58 -- for ALL parameter tensors of the model in one launch (per 64 tensors):
+ *   g = grad_scale * grad + weight_decay * p;  buf = momentum * buf + g;  p -= lr * buf
+ * (dampening 0, no Nesterov: the reference's settings).  `tensors` is a HOST array of `count` records of device
+ * pointers; gradients are read where autograd / the data-parallel reducer left them.  grad_scale folds the
+ * 1/world of a data-parallel gradient SUM into the step.  momentum_buf must start at zero (the first step then
+ * equals PyTorch's buf = g). */
+typedef struct node_sgd_tensor {
+  float* param;
+  const float* grad;
+  float* momentum_buf;
+  size_t n;
+} node_sgd_tensor;
+int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float momentum, float weight_decay,
+                  float grad_scale, void* stream);
 
 /* Event-based per-kernel-class timing (off by default; adds two event records
  * per profiled launch).  begin() resets the counters; end() synchronises the

@@ -26,8 +26,9 @@ ERRORS = {
 EXPORTS = [
     'node_abi_version', 'node_last_error', 'node_param_count', 'node_workspace_bytes',
     'node_odefunc_fwd', 'node_odefunc_vjp', 'node_solve_fwd', 'node_solve_adjoint',
+    'node_backprop_workspace_bytes', 'node_solve_backprop',
     'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
-    'node_profile_begin', 'node_profile_end',
+    'node_sgd_step', 'node_profile_begin', 'node_profile_end',
 ]
 
 
@@ -57,6 +58,10 @@ class NodeSolveOpts(C.Structure):
 
 class NodeProfile(C.Structure):
     _fields_ = [('launches', C.c_int64 * 3), ('total_ms', C.c_double * 3), ('flops', C.c_double * 3)]
+
+
+class NodeSgdTensor(C.Structure):
+    _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('momentum_buf', C.c_void_p), ('n', C.c_size_t)]
 
 
 class NodeHipError(RuntimeError):
@@ -98,6 +103,11 @@ def load():
     lib.node_solve_adjoint.restype = i32
     lib.node_solve_adjoint.argtypes = [P(NodeShape), P(NodeParams), vp, vp, P(C.c_float), i32, f32, f32, i32,
                                        P(NodeSolveOpts), vp, vp, vp, P(NodeStats), vp, sz, vp]
+    lib.node_backprop_workspace_bytes.restype = sz
+    lib.node_backprop_workspace_bytes.argtypes = [P(NodeShape), i32, i32, i32]
+    lib.node_solve_backprop.restype = i32
+    lib.node_solve_backprop.argtypes = [P(NodeShape), P(NodeParams), vp, P(C.c_float), i32, P(C.c_double), i32, i32,
+                                        vp, vp, vp, vp, sz, vp]
     lib.node_head_fwd.restype = i32
     lib.node_head_fwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp]
     lib.node_head_bwd.restype = i32
@@ -106,6 +116,8 @@ def load():
     lib.node_gn_relu_fwd.argtypes = [P(NodeShape), vp, vp, vp, i32, vp, vp, vp]
     lib.node_gn_relu_bwd.restype = i32
     lib.node_gn_relu_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.node_sgd_step.restype = i32
+    lib.node_sgd_step.argtypes = [P(NodeSgdTensor), i32, f32, f32, f32, f32, vp]
     lib.node_profile_begin.restype = i32
     lib.node_profile_begin.argtypes = []
     lib.node_profile_end.restype = i32

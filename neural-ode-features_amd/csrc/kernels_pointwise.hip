@@ -744,6 +744,30 @@ void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s)
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_axpy, dim3((unsigned)blocks), dim3(256), 0, s, y, x, alpha, n);
 }
+__global__ __launch_bounds__(256) void k_scatter_axpy(ScatterArgs a) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t n4 = a.n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(a.src)[i];
+    for (int q = 0; q < a.nt; ++q) {
+      float4* d = reinterpret_cast<float4*>(a.dst[q]) + i;
+      float4 o = *d;
+      const float c = a.coef[q];
+      o.x += c * v.x; o.y += c * v.y; o.z += c * v.z; o.w += c * v.w;
+      *d = o;
+    }
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = (n4 << 2) + threadIdx.x; i < a.n; i += 256)
+      for (int q = 0; q < a.nt; ++q) a.dst[q][i] += a.coef[q] * a.src[i];
+}
+void launch_scatter_axpy(const ScatterArgs& a, hipStream_t s) {
+  if (a.nt <= 0 || a.n == 0) return;
+  size_t blocks = (a.n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_scatter_axpy, dim3((unsigned)blocks), dim3(256), 0, s, a);
+}
 __global__ __launch_bounds__(256) void k_fill(float* p, float v, size_t n) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;

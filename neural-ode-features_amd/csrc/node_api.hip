@@ -340,6 +340,9 @@ void remember_steps(const StepGuess& k) {
 }
 
 const double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
+const double DP_CMID[7] = {6025192743.0 / 30085553152.0 / 2.0, 0.0, 51252292925.0 / 65400821598.0 / 2.0,
+                           -2691868925.0 / 45128329728.0 / 2.0, 187940372067.0 / 1594534317056.0 / 2.0,
+                           -1776094331.0 / 19743644256.0 / 2.0, 11237099.0 / 235043384.0 / 2.0};
 const double DP_BETA[6][6] = {
     {1.0 / 5, 0, 0, 0, 0, 0},
     {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
@@ -978,6 +981,219 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   return status_to_rc(stt.status);
 }
 
+// ----------------------------------------------------------------------------
+// Backward of the NON-adjoint `odeint` (model.py:359 with adjoint=False, the constructor default model.py:7):
+// upstream differentiates through the solver's own operations.  Here: the accepted steps are replayed from y0 with
+// the recorded step sizes (same kernels, bit-identical stage values), every stage derivative is kept on a tape, and
+// the cotangents walk the steps backwards -- one VJP of the dynamics per stage evaluation, the Butcher rows and the
+// dense-output polynomial transposed.  Step sizes are treated as constants (upstream's 2019 controller is itself
+// differentiable; that sensitivity is O(local error) and is not reproduced -- DESIGN.md).
+// ----------------------------------------------------------------------------
+namespace {
+struct Tape {
+  std::vector<float*> Y;   // state at the start of step n (n = 0..S), NHWC
+  std::vector<float*> K;   // stage derivatives: dopri5 K[6 n + i], i = 0..6 (k6 of step n IS k0 of step n + 1); rk4 K[4 n + i]
+  float* KB[7];            // cotangents of the stage derivatives of the step being processed
+  float* YB;               // cotangent of the step's end state
+  float* Y0B;              // cotangent of the step's start state (being assembled)
+  float* G;                // one slice of grad_out, NHWC
+};
+size_t backprop_tensors(int method, int n_steps) {
+  return (size_t)(method == NODE_METHOD_DOPRI5 ? 7 * n_steps + 2 : 5 * n_steps + 1) + 10;
+}
+}  // namespace
+
+extern "C" size_t node_backprop_workspace_bytes(const node_shape* shape, int method, int n_t, int n_steps) {
+  Dims d;
+  if (make_dims(shape, &d) != NODE_OK || n_steps < 1) return 0;
+  Plan p = make_plan(d, 1, n_t, nullptr);
+  return p.bytes + backprop_tensors(method, n_steps) * (((d.numel * sizeof(float)) + 255) & ~(size_t)255) + 256;
+}
+
+extern "C" int node_solve_backprop(const node_shape* shape, const node_params* params, const float* y0, const float* t_pts,
+                                   int n_t, const double* step_dt, int n_steps, int method, const float* grad_out,
+                                   float* grad_y0, float* grad_params, void* ws, size_t ws_bytes, void* stream) {
+  if (!y0 || !grad_out || !grad_y0 || !grad_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
+  TRY(check_times(t_pts, n_t));
+  const bool dopri = method == NODE_METHOD_DOPRI5;
+  if (dopri && (!step_dt || n_steps < 1)) return fail(NODE_ERR_ARG, "dopri5 backprop needs the forward solve's accepted step sizes");
+  if (!dopri) n_steps = n_t - 1;
+  Solver S;
+  TRY(check_common(shape, params, ws, ws_bytes, 1, n_t, &S.d, &S.p));
+  const size_t need = node_backprop_workspace_bytes(shape, method, n_t, n_steps);
+  if (ws_bytes < need) return fail(NODE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.rtol = 0.f; S.atol = 0.f;
+  const Dims& d = S.d;
+  const size_t numel = d.numel;
+  const bool decreasing = t_pts[1] < t_pts[0];
+  S.tsign = decreasing ? -1.f : 1.f;
+  std::vector<double> ts(n_t);
+  for (int i = 0; i < n_t; ++i) ts[i] = (double)(decreasing ? -t_pts[i] : t_pts[i]);
+
+  Tape tp;
+  {
+    Bump b((char*)ws + S.p.bytes);
+    tp.Y.resize(n_steps + 1);
+    for (auto& q : tp.Y) q = b.take<float>(numel);
+    tp.K.resize(dopri ? 6 * n_steps + 1 : 4 * n_steps);
+    for (auto& q : tp.K) q = b.take<float>(numel);
+    for (int i = 0; i < 7; ++i) tp.KB[i] = b.take<float>(numel);
+    tp.YB = b.take<float>(numel);
+    tp.Y0B = b.take<float>(numel);
+    tp.G = b.take<float>(numel);
+  }
+  TRY(S.prepare());
+  S.count_nfe = false;
+
+  // ---- replay: the forward solve's accepted steps, every stage derivative kept ----
+  std::vector<double> tn(n_steps + 1), dtn(n_steps);
+  std::vector<int> out_step(n_t, -1);          // which step's dense output produced y_out[j]
+  std::vector<float> out_x(n_t, 0.f);
+  launch_nchw_to_nhwc(d, y0, tp.Y[0], S.st);
+  const double c2[1] = {1.0 / 3}, c3[2] = {-1.0 / 3, 1.0}, c4[3] = {1.0, -1.0, 1.0};
+  const double* rk4_rows[3] = {c2, c3, c4};
+  const double rk4_alpha[3] = {1.0 / 3, 2.0 / 3, 1.0};
+  const double rk4_b[4] = {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8};
+  auto comb_of = [&](const float* y, float* const* k, const double* coef, int nc) { return Solver::make_comb(y, k, coef, nc, SC_DT); };
+  tn[0] = ts[0];
+  if (dopri) {
+    launch_set_ctrl(S.p.ctrl, ts[0], 0.0, 1, S.st);
+    TRY(S.eval_fwd(Solver::make_comb(tp.Y[0], nullptr, nullptr, 0, SC_ABS), nullptr, S.et_stage(0.0), tp.K[0], false));
+    int j = 1;
+    for (int n = 0; n < n_steps; ++n) {
+      dtn[n] = step_dt[n];
+      if (!(dtn[n] > 0.0)) return fail(NODE_ERR_ARG, "step size %d is not positive", n);
+      launch_set_ctrl(S.p.ctrl, tn[n], dtn[n], 0, S.st);
+      for (int s = 0; s < 6; ++s)
+        TRY(S.eval_fwd(comb_of(tp.Y[n], &tp.K[6 * n], DP_BETA[s], s + 1), s == 5 ? tp.Y[n + 1] : nullptr, S.et_stage(DP_ALPHA[s]),
+                       tp.K[6 * n + s + 1], false));
+      tn[n + 1] = tn[n] + dtn[n];
+      while (j < n_t && !(ts[j] > tn[n + 1])) {
+        out_step[j] = n;
+        const float t0f = (float)tn[n], t1f = (float)tn[n + 1], tjf = (float)ts[j];
+        out_x[j] = (tjf - t0f) / (t1f - t0f);
+        ++j;
+      }
+    }
+    if (j < n_t) return fail(NODE_ERR_ARG, "the %d recorded steps end at t = %g, before the last output time", n_steps, tn[n_steps]);
+  } else {
+    launch_set_ctrl(S.p.ctrl, ts[0], 0.0, 1, S.st);
+    for (int n = 0; n < n_steps; ++n) {
+      const float t0f = (float)ts[n], t1f = (float)ts[n + 1];
+      tn[n] = (double)t0f; dtn[n] = (double)(t1f - t0f); tn[n + 1] = (double)t1f;
+      launch_set_ctrl(S.p.ctrl, tn[n], dtn[n], 0, S.st);
+      float* const* K = &tp.K[4 * n];
+      TRY(S.eval_fwd(Solver::make_comb(tp.Y[n], nullptr, nullptr, 0, SC_ABS), nullptr, S.et_stage(0.0), K[0], false));
+      for (int s = 0; s < 3; ++s)
+        TRY(S.eval_fwd(comb_of(tp.Y[n], K, rk4_rows[s], s + 1), nullptr, S.et_stage(rk4_alpha[s]), K[s + 1], false));
+      launch_lincomb(comb_of(tp.Y[n], K, rk4_b, 4), S.p.ctrl, tp.Y[n + 1], numel, S.st);
+      out_step[n + 1] = n;
+      out_x[n + 1] = 1.f;
+    }
+  }
+
+  // ---- reverse ----
+  launch_fill(S.p.TH, 0.f, d.P, S.st);
+  launch_fill(tp.YB, 0.f, numel, S.st);
+  launch_fill(tp.Y0B, 0.f, numel, S.st);
+  for (int i = 0; i < 7; ++i) launch_fill(tp.KB[i], 0.f, numel, S.st);
+  // VJP of the dynamics at (stage time, stage state) with cotangent `cot`: vjp_y -> p.KA[0], vjp_theta added to p.TH
+  auto vjp = [&](const Comb& state, double alpha, const float* cot) -> int {
+    Comb ca = Solver::make_comb(cot, nullptr, nullptr, 0, SC_ABS);
+    TRY(S.eval_aug(state, ca, nullptr, nullptr, S.et_stage(alpha), S.p.KY[0], S.p.KA[0], S.p.KT[0], -1, +1.f, nullptr, true));
+    launch_axpy(S.p.TH, S.p.KT[0], 1.f, d.P, S.st);
+    return NODE_OK;
+  };
+  const int nst = dopri ? 6 : 4;     // stage derivatives per step that feed y1
+  bool k6_live = false;              // dopri5: does KB[6] hold anything?
+  for (int n = n_steps - 1; n >= 0; --n) {
+    const float dtf = (float)dtn[n];
+    float* const* K = dopri ? &tp.K[6 * n] : &tp.K[4 * n];
+    launch_set_ctrl(S.p.ctrl, tn[n], dtn[n], 0, S.st);
+    // dense-output contributions of the outputs this step produced (transposed quartic)
+    for (int j = n_t - 1; j >= 1; --j) {
+      if (out_step[j] != n) continue;
+      launch_nchw_to_nhwc(d, grad_out + (size_t)j * numel, tp.G, S.st);
+      ScatterArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.src = tp.G; sa.n = numel;
+      const double x = (double)out_x[j];
+      if (!dopri || x == 1.0) {        // the output IS the end state
+        sa.dst[0] = tp.YB; sa.coef[0] = 1.f; sa.nt = 1;
+      } else {
+        const double x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        const double wy0 = 1 - 11 * x2 + 18 * x3 - 8 * x4, wy1 = -5 * x2 + 14 * x3 - 8 * x4;
+        const double wf0 = x - 4 * x2 + 5 * x3 - 2 * x4, wf1 = x2 - 3 * x3 + 2 * x4, wm = 16 * x2 - 32 * x3 + 16 * x4;
+        int q = 0;
+        sa.dst[q] = tp.Y0B; sa.coef[q++] = (float)(wy0 + wm);
+        sa.dst[q] = tp.YB; sa.coef[q++] = (float)wy1;
+        for (int i = 0; i < 7; ++i) {
+          double c = wm * DP_CMID[i];
+          if (i == 0) c += wf0;
+          if (i == 6) c += wf1;
+          if (c == 0.0) continue;
+          sa.dst[q] = tp.KB[i]; sa.coef[q++] = (float)(dtn[n] * c);
+        }
+        sa.nt = q;
+        k6_live = true;
+      }
+      launch_scatter_axpy(sa, S.st);
+    }
+    if (dopri && k6_live) {   // k6 = f(t + dt, y1): the evaluation the next step reused as its k0 (FSAL)
+      TRY(vjp(Solver::make_comb(tp.Y[n + 1], nullptr, nullptr, 0, SC_ABS), 1.0, tp.KB[6]));
+      launch_axpy(tp.YB, S.p.KA[0], 1.f, numel, S.st);
+    }
+    {   // y1 = y0 + dt sum b_i k_i
+      ScatterArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.src = tp.YB; sa.n = numel;
+      int q = 0;
+      sa.dst[q] = tp.Y0B; sa.coef[q++] = 1.f;
+      for (int i = 0; i < nst; ++i) {
+        const double bi = dopri ? DP_BETA[5][i] : rk4_b[i];
+        if (bi == 0.0) continue;
+        sa.dst[q] = tp.KB[i]; sa.coef[q++] = dtf * (float)bi;
+      }
+      sa.nt = q;
+      launch_scatter_axpy(sa, S.st);
+    }
+    for (int i = nst - 1; i >= 1; --i) {   // stage i: state y0 + dt sum_{j<i} beta_ij k_j
+      const double* row = dopri ? DP_BETA[i - 1] : rk4_rows[i - 1];
+      const double alpha = dopri ? DP_ALPHA[i - 1] : rk4_alpha[i - 1];
+      TRY(vjp(comb_of(tp.Y[n], K, row, i), alpha, tp.KB[i]));
+      ScatterArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.src = S.p.KA[0]; sa.n = numel;
+      int q = 0;
+      sa.dst[q] = tp.Y0B; sa.coef[q++] = 1.f;
+      for (int jj = 0; jj < i; ++jj) {
+        if (row[jj] == 0.0) continue;
+        sa.dst[q] = tp.KB[jj]; sa.coef[q++] = dtf * (float)row[jj];
+      }
+      sa.nt = q;
+      launch_scatter_axpy(sa, S.st);
+    }
+    if (!dopri || n == 0) {   // k0 = f(t, y0) evaluated by this step itself
+      TRY(vjp(Solver::make_comb(tp.Y[n], nullptr, nullptr, 0, SC_ABS), 0.0, tp.KB[0]));
+      launch_axpy(tp.Y0B, S.p.KA[0], 1.f, numel, S.st);
+    } else {                  // FSAL: it is the previous step's k6
+      std::swap(tp.KB[0], tp.KB[6]);
+      k6_live = true;
+    }
+    std::swap(tp.YB, tp.Y0B);
+    launch_fill(tp.Y0B, 0.f, numel, S.st);
+    for (int i = 0; i < (dopri ? 6 : 4); ++i) launch_fill(tp.KB[i], 0.f, numel, S.st);
+  }
+  // out[0] = y0
+  launch_nchw_to_nhwc(d, grad_out, tp.G, S.st);
+  launch_axpy(tp.YB, tp.G, 1.f, numel, S.st);
+  launch_nhwc_to_nchw(d, tp.YB, grad_y0, S.st);
+  launch_theta_to_torch(d, S.p.TH, grad_params, S.st);
+  HIP_TRY(hipStreamSynchronize(S.st));
+  return S.check_launch("node_solve_backprop");
+}
+
 int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, int relu, float* out,
                      float* stats, void* stream) {
   char why[200];
@@ -1023,6 +1239,34 @@ int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, c
   launch_head_bwd(*shape, z, gamma, beta, scale, stats, g_pooled, dz, gpart, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_head_bwd failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
+int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float momentum, float weight_decay, float grad_scale,
+                  void* stream) {
+  if (count < 0) return fail(NODE_ERR_ARG, "count < 0");
+  if (count == 0) return NODE_OK;
+  if (!tensors) return fail(NODE_ERR_NULL, "tensors is NULL");
+  if (!(lr >= 0.f) || !(momentum >= 0.f) || !(weight_decay >= 0.f)) return fail(NODE_ERR_ARG, "lr / momentum / weight_decay must be >= 0");
+  for (int i = 0; i < count; ++i) {
+    if (!tensors[i].param || !tensors[i].grad || !tensors[i].momentum_buf) return fail(NODE_ERR_NULL, "tensor %d: a pointer is NULL", i);
+    if ((((uintptr_t)tensors[i].param) | ((uintptr_t)tensors[i].grad) | ((uintptr_t)tensors[i].momentum_buf)) & 3)
+      return fail(NODE_ERR_ARG, "tensor %d: pointers must be 4-byte aligned", i);
+  }
+  for (int base = 0; base < count; base += SGD_TABLE) {
+    SgdTable tb;
+    memset(&tb, 0, sizeof(tb));
+    const int m = count - base < SGD_TABLE ? count - base : SGD_TABLE;
+    size_t max_n = 0;
+    for (int i = 0; i < m; ++i) {
+      tb.e[i].p = tensors[base + i].param; tb.e[i].g = tensors[base + i].grad; tb.e[i].m = tensors[base + i].momentum_buf;
+      tb.e[i].n = tensors[base + i].n;
+      if (tb.e[i].n > max_n) max_n = tb.e[i].n;
+    }
+    launch_sgd_multi(tb, m, max_n, lr, momentum, weight_decay, grad_scale, (hipStream_t)stream);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_sgd_step failed: %s", hipGetErrorString(e));
   return NODE_OK;
 }
 

@@ -297,6 +297,9 @@ void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s)
 // ctrl->ts_cur -= sign * <a, b>;  *out_dot = sign * <a, b>
 void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float sign, float* partial, float* out_dot, hipStream_t s);
 void launch_fill(float* p, float v, size_t n, hipStream_t s);
+// dst[q][i] += coef[q] * src[i] for q < nt: a cotangent fanned out over the tensors it feeds (backprop through a step)
+struct ScatterArgs { const float* src; float* dst[8]; float coef[8]; int nt; size_t n; };
+void launch_scatter_axpy(const ScatterArgs& a, hipStream_t s);
 void launch_lincomb(const Comb& c, const Ctrl* ctrl, float* out, size_t n, hipStream_t s);
 void launch_copy_scalar_out(const Ctrl* ctrl, float* dst, hipStream_t s);
 
@@ -377,6 +380,11 @@ void launch_gn_relu_fwd(const node_shape& sh, const float* z, const float* gamma
                         float* stats, hipStream_t s);
 void launch_gn_relu_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* stats,
                         int relu, const float* gout, float* dz, float* gpart, hipStream_t s);
+// fused multi-tensor SGD (kernels_optim.hip)
+constexpr int SGD_TABLE = 64;
+struct SgdEntry { float* p; const float* g; float* m; size_t n; };
+struct SgdTable { SgdEntry e[SGD_TABLE]; };
+void launch_sgd_multi(const SgdTable& tb, int count, size_t max_n, float lr, float momentum, float wd, float gscale, hipStream_t s);
 void launch_head_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      const float* stats, const float* gpool, float* dz, float* gpart, hipStream_t s);
 

@@ -7,9 +7,10 @@ no cross-sample op (GroupNorm is per-sample), so each rank integrates its own
 shard with its own adaptive steps ("local-norm" mode -- exactly what wrapping the
 reference in DDP would do) and the only exchange step is the gradient sum.
 
-Layout: every bucket owns ONE persistent flat fp32 buffer and each parameter's
-`.grad` is a view into it, so the all-reduce runs in place on the buffer autograd
-accumulated into -- no gather before, no scatter after.
+Layout: every bucket owns ONE persistent flat fp32 buffer.  When the last gradient of a bucket lands, the bucket's
+gradients (which autograd left wherever it allocated them) are packed into that buffer with one launch, each
+parameter's `.grad` is re-pointed at its slice (host only), and the all-reduce runs in place -- nothing is copied
+back: the optimizer reads the reduced gradients from the bucket (`optim.FusedSGD` takes raw pointers).
 
 Overlap: parameters are grouped into buckets in *reverse* registration order
 (head first -- its gradients are ready before the adjoint solve starts).  A
@@ -21,10 +22,9 @@ connected 8-GPU xGMI node each all-reduce is per-link bound; the ODE bucket
 (4.75 MB at C=256) is kept whole so RCCL can split it over all 7 links.
 
     reducer = GradientReducer(model)          # after dist.init_process_group
-    loss.backward()                           # hooks launch async all-reduces
-    reducer.finish()                          # wait, average in place
-    optimizer.step()
-    reducer.zero_grad()                       # one memset per bucket, views stay installed
+    loss.backward()                           # hooks pack + launch async all-reduces
+    reducer.finish()                          # wait (and average, unless the optimizer folds 1/world in)
+    optimizer.step(); optimizer.zero_grad()
 
 One backward per `finish()`; micro-batches that accumulate (`train.py:56-58`) run
 under `with reducer.accumulate():` for all but the last backward.
@@ -78,12 +78,15 @@ class _Bucket:
 
 
 class GradientReducer:
-    """Bucketed, overlapped, in-place gradient averaging (see the module docstring)."""
+    """Bucketed, overlapped gradient reduction without a copy-back (see the module docstring)."""
 
     def __init__(self, model: nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
-                 boundaries: Optional[Iterable[nn.Module]] = None):
+                 boundaries: Optional[Iterable[nn.Module]] = None, average: bool = True):
+        """`average=False` leaves the SUM in the buckets for an optimizer that folds 1/world into its step
+        (`optim.FusedSGD.grad_scale`)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
         params = [p for p in model.parameters() if p.requires_grad]
         # cut buckets at sub-module boundaries (head | ode block | stem) first, then by size and dtype/device
         owner = {}
@@ -113,26 +116,13 @@ class GradientReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.launch_order: List[int] = []   # bucket indices in the order their all-reduce was issued
         self._accumulating = False
-        self.install_views()
-
-    # -- flat-buffer plumbing ------------------------------------------------
-    def install_views(self):
-        """Point every parameter's `.grad` at its slice of the bucket buffer (keeping what it held)."""
-        for b in self.buckets:
-            b.ensure_flat()
-            for p, v in zip(b.params, b.views):
-                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
-                p.grad = v
 
     def zero_grad(self):
-        """`optimizer.zero_grad()` for reducer-managed parameters: one memset per bucket; the views stay
-        installed, so the next backward accumulates straight into the all-reduce buffers."""
+        """`optimizer.zero_grad()` (set to None) for the reducer's parameters: no kernel; the next backward's
+        gradients land in fresh tensors and are packed into the bucket buffers again."""
         for b in self.buckets:
-            b.ensure_flat()
-            b.flat.zero_()
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            for p in b.params:
+                p.grad = None
 
     @contextlib.contextmanager
     def accumulate(self):
@@ -145,16 +135,9 @@ class GradientReducer:
 
     # -- hooks ---------------------------------------------------------------
     def _on_grad(self, p: nn.Parameter):
-        b, i = self._slot[id(p)]
-        b.ensure_flat()
-        v = b.views[i]
-        if p.grad is not v and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
-            # `.grad` was reset to None (optimizer.zero_grad()) and autograd installed a fresh tensor
-            if p.grad is not None:
-                v.copy_(p.grad)
-            p.grad = v
         if self._accumulating:
             return
+        b, _ = self._slot[id(p)]
         if b.launched:
             raise RuntimeError('GradientReducer: a gradient of bucket %d arrived after its all-reduce was launched -- '
                                'two backward() calls per finish(); wrap all but the last in `reducer.accumulate()`'
@@ -167,19 +150,35 @@ class GradientReducer:
         b.launched = True
         if self.world == 1:
             return
+        b.ensure_flat()
+        # pack: gradients that already live in their slice (a caller that zeroes in place instead of dropping them)
+        # stay; the rest go in with ONE launch when none is in place, one copy each otherwise
+        loose = [(p, v) for p, v in zip(b.params, b.views) if p.grad is None or p.grad.data_ptr() != v.data_ptr()]
+        if len(loose) == len(b.params) and all(p.grad is not None for p in b.params):
+            torch.cat([p.grad.reshape(-1) for p in b.params], out=b.flat)
+        else:
+            for p, v in loose:
+                if p.grad is None:
+                    v.zero_()            # parameter unused this step
+                else:
+                    v.copy_(p.grad)
+        for p, v in zip(b.params, b.views):
+            p.grad = v                   # host only: the reduced gradient is read where the all-reduce leaves it
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launch_order.append(b.index)
 
     def finish(self):
-        """Wait for every in-flight all-reduce and average in place.  Buckets whose hooks did not all fire
-        (parameters unused this step) are launched here, in bucket order -- the same order on every rank."""
+        """Wait for every in-flight all-reduce (and average in place unless `average=False`).  Buckets whose hooks
+        did not all fire (parameters unused this step) are launched here, in bucket order -- the same order on
+        every rank."""
         if self.world > 1:
             for b in self.buckets:
                 if not b.launched:
                     self._launch(b)
             for b in self.buckets:
                 b.work.wait()
-                b.flat.div_(self.world)
+                if self.average:
+                    b.flat.div_(self.world)
         for b in self.buckets:
             b.reset()
         self.launch_order = []

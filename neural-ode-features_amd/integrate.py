@@ -10,7 +10,6 @@ that are not the reference's Conv-GroupNorm-ReLU `ODEfunc` raise.
 from __future__ import annotations
 
 import ctypes as C
-import warnings
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -270,31 +269,74 @@ def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Ten
     return grad_y0, grad_p, grad_t, _stats_dict(stats, keep_o)
 
 
+def solve_backprop(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor, grad_out: torch.Tensor,
+                   times: List[float], step_dts: List[float], method_id: int):
+    """Backward of the non-adjoint `odeint`: backpropagation through the forward solve's accepted steps."""
+    lib = _lib.load()
+    y0 = y0.detach().contiguous()
+    grad_out = grad_out.detach().contiguous()
+    dev = y0.device
+    shape = _shape_struct(y0, rec)
+    pstruct, keep_p = _params_struct(params, dev)
+    n_t = len(times)
+    n_steps = len(step_dts) if method_id == _lib.METHOD_DOPRI5 else n_t - 1
+    with torch.cuda.device(dev):
+        ws_bytes = lib.node_backprop_workspace_bytes(C.byref(shape), method_id, n_t, n_steps)
+        if ws_bytes == 0:
+            raise _lib.NodeHipError(-3, lib.node_last_error().decode())
+        ws = _workspace(dev, ws_bytes)
+        grad_y0 = torch.empty_like(y0)
+        grad_p = torch.empty(lib.node_param_count(C.byref(shape)), dtype=torch.float32, device=dev)
+        tarr = (C.c_float * n_t)(*times)
+        darr = (C.c_double * max(1, len(step_dts)))(*step_dts)
+        rc = lib.node_solve_backprop(C.byref(shape), C.byref(pstruct), y0.data_ptr(), tarr, n_t, darr, n_steps, method_id,
+                                     grad_out.data_ptr(), grad_y0.data_ptr(), grad_p.data_ptr(), _aligned_ptr(ws), ws_bytes,
+                                     torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(rc)
+    del keep_p
+    return grad_y0, grad_p
+
+
+BACKPROP_LOG = 4096      # step sizes the forward solve can record for the non-adjoint backward (csrc: STEP_LIST_CAP)
+
+
 class _HipOdeint(torch.autograd.Function):
     """Forward = node_solve_fwd under no_grad; backward = node_solve_adjoint
     (continuous adjoint, what `odeint_adjoint` does upstream)."""
 
     @staticmethod
     def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, y0, *params):
+        if not adjoint and (y0.requires_grad or any(p.requires_grad for p in params)):
+            options = dict(options or {})          # the backward replays the accepted steps: log their sizes
+            options['record_dt'] = max(int(options.get('record_dt', 0) or 0), BACKPROP_LOG)
         out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
         func.nfe = getattr(func, 'nfe', 0) + st['nfe']          # model.py:340 convention
         func.last_forward_stats = st
         ctx.func, ctx.rec, ctx.times = func, rec, times
         ctx.rtol, ctx.atol, ctx.method_id, ctx.options = rtol, atol, method_id, options
         ctx.adjoint = adjoint
+        ctx.step_dts = None
+        if not adjoint and 'dts' in st:
+            if st['accepted'] + st['rejected'] > len(st['dts']):
+                raise RuntimeError('the forward solve took more than %d steps: too many for the non-adjoint backward; '
+                                   'use odeint_adjoint' % BACKPROP_LOG)
+            ctx.step_dts = [d for d, a in zip(st['dts'], st['accepts']) if a]
         ctx.save_for_backward(out, *params)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         out, *params = ctx.saved_tensors
-        gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
-                                       ctx.method_id, ctx.options)
-        if ctx.adjoint:       # upstream's non-adjoint backward is plain autograd: it never calls func.forward
+        if ctx.adjoint:
+            gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
+                                           ctx.method_id, ctx.options)
             ctx.func.nfe = getattr(ctx.func, 'nfe', 0) + st['nfe']
+            ctx.func.last_backward_stats = st
         else:
-            _warn_nonadjoint_once()
-        ctx.func.last_backward_stats = st
+            # upstream's non-adjoint backward is plain autograd through the solver's operations: it never calls
+            # func.forward, so the reference's NFE counter does not move (model.py:340)
+            gy0, gp = solve_backprop(ctx.rec, params, out[0], grad_out, ctx.times, ctx.step_dts or [], ctx.method_id)
+            ctx.func.last_backward_stats = {'nfe': 0, 'accepted': len(ctx.step_dts or []), 'rejected': 0, 'status': 0}
         grads = []
         off = 0
         for p in params:
@@ -302,18 +344,6 @@ class _HipOdeint(torch.autograd.Function):
             grads.append(gp[off:off + n].view_as(p))
             off += n
         return (None, None, None, None, None, None, None, None, gy0, *grads)
-
-
-_WARNED_NONADJOINT = False
-
-
-def _warn_nonadjoint_once():
-    global _WARNED_NONADJOINT
-    if not _WARNED_NONADJOINT:
-        _WARNED_NONADJOINT = True
-        warnings.warn('neural-ode-features_amd: `odeint` (adjoint=False) was differentiated; its gradient is produced by '
-                      'the continuous-adjoint HIP solve, which agrees with backpropagation through the solver steps '
-                      '(what torchdiffeq.odeint does) to O(tol), not to rounding.', RuntimeWarning, stacklevel=3)
 
 
 def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
@@ -340,11 +370,11 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
 def odeint(func, y0, t, rtol=1e-7, atol=1e-12, method=None, options=None):
     """Drop-in for `torchdiffeq.odeint` on the reference's call (model.py:359,367).
 
-    Forward values are identical to `odeint_adjoint`.  Deviation (documented in
-    DESIGN.md): upstream `odeint` is differentiated by autograd through the
-    solver's own ops; here a requested gradient is produced by the same HIP
-    continuous-adjoint solve, which agrees to O(tol) (a RuntimeWarning says so once); like
-    upstream's autograd backward it adds nothing to `func.nfe`."""
+    Forward values are identical to `odeint_adjoint`.  The gradient is what upstream's
+    autograd produces by differentiating through the solver: backpropagation through
+    the accepted steps (`node_solve_backprop`: stage derivatives on a tape, one VJP of
+    the dynamics per stage evaluation), with the step sizes held constant; like upstream's
+    backward it adds nothing to `func.nfe`."""
     return _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=False)
 
 

@@ -41,11 +41,14 @@ def main():
             loss.backward()
             reducer.finish()
             opt.step()
-            reducer.zero_grad()
+            opt.zero_grad()
         else:
             loss, _, _ = bench.train_step(net, opt, xs, ys, reducer)
         losses.append(float(loss))
-    # every gradient still lives in its bucket's flat buffer (in-place all-reduce, no copies)
+    # one more backward + reduce, not stepped: the reduced gradients are read where the all-reduce left them
+    import torch.nn.functional as F
+    F.cross_entropy(net(xs), ys).backward()
+    reducer.finish()
     for b in reducer.buckets:
         for p, v in zip(b.params, b.views):
             assert p.grad.data_ptr() == v.data_ptr()

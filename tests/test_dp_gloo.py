@@ -160,15 +160,10 @@ def test_reducer_rejects_unannounced_second_backward():
         lin(torch.ones(1, 3)).sum().backward()
     red.finish()
     red.zero_grad()
+    assert lin.weight.grad is None
     with red.accumulate():
         lin(torch.ones(1, 3)).sum().backward()
     lin(torch.ones(1, 3)).sum().backward()
     red.finish()
     assert torch.equal(lin.weight.grad, 2 * torch.ones(2, 3))
-    # optimizer.zero_grad() (set_to_none) between steps is tolerated: the hook re-installs the bucket views
-    lin.zero_grad()
-    lin(torch.ones(1, 3)).sum().backward()
-    red.finish()
-    assert torch.equal(lin.weight.grad, torch.ones(2, 3))
-    assert lin.weight.grad.data_ptr() in [v.data_ptr() for v in red.buckets[0].views]
     red.remove()

@@ -1,0 +1,80 @@
+"""GPU: the fused SGD step (`node_sgd_step` through the C ABI, optim.FlatSGD) against torch.optim.SGD -- the
+reference's optimizer (train.py:136), stepped and zeroed per iteration (train.py:56-58)."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_flat_sgd_matches_torch_sgd_on_random_gradients():
+    import neural_ode_features_amd as nof
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 7, 3), torch.nn.GroupNorm(7, 7), torch.nn.Flatten(), torch.nn.Linear(7 * 36, 5)).cuda()
+    ref = copy.deepcopy(net)
+    opt = nof.FusedSGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator(device='cuda').manual_seed(4)
+    big = torch.empty(4096, device='cuda')
+    for step in range(5):
+        off = 1                                   # gradients at odd offsets of a shared buffer: the unaligned path
+        for i, (p, q) in enumerate(zip(net.parameters(), ref.parameters())):
+            g = torch.randn(p.shape, generator=gen, device='cuda')
+            if step % 2 and p.numel() < 512:
+                view = big[off:off + p.numel()].view(p.shape)
+                view.copy_(g)
+                p.grad = view
+                off += p.numel() + 1
+            else:
+                p.grad = g.clone()
+            q.grad = g.clone()
+        if step == 3:
+            list(net.parameters())[1].grad = None          # a parameter without gradient is skipped, like torch.optim.SGD
+            list(ref.parameters())[1].grad = None
+        opt.step()
+        opt.zero_grad()
+        ropt.step()
+        ropt.zero_grad()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), step
+            assert p.grad is None
+
+
+def test_flat_sgd_training_steps_match_torch_sgd():
+    """Three whole training steps of a small ODE-Net (HIP solver both sides): FlatParams + FlatSGD vs plain SGD."""
+    import bench
+    import neural_ode_features_amd as nof
+    torch.manual_seed(5)
+    a = nof.ODENet(3, out=10, n_filters=32, downsample='residual', method='rk4', tol=1e-3, adjoint=True, dropout=0).cuda()
+    b = copy.deepcopy(a)
+    oa = nof.FusedSGD(a.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(b.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(8, 3, 32, 32, generator=gen).cuda()
+    y = torch.randint(0, 10, (8,), generator=gen).cuda()
+    for step in range(3):
+        la, _, _ = bench.train_step(a, oa, x, y)
+        lb, _, _ = bench.train_step(b, ob, x, y)
+        assert abs(float(la) - float(lb)) < 1e-4 * max(1.0, abs(float(lb))), step
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=2e-4, atol=2e-6), k
+    # learning-rate schedulers drive it through param_groups like a torch optimizer (train.py:158-163)
+    oa.param_groups[0]['lr'] = 0.0
+    before = [p.detach().clone() for p in a.parameters()]
+    bench.train_step(a, oa, x, y)
+    for p, q in zip(a.parameters(), before):
+        assert torch.equal(p, q)
+
+
+def test_sgd_step_argument_checks():
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(64, device='cuda')
+    row = _lib.NodeSgdTensor(t.data_ptr(), t.data_ptr(), t.data_ptr(), 64)
+    assert lib.node_sgd_step(None, 1, 0.1, 0.9, 0.0, 1.0, None) == -1
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr(), None, t.data_ptr(), 64)), 1, 0.1, 0.9, 0.0, 1.0, None) == -1
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr() + 2, t.data_ptr(), t.data_ptr(), 8)), 1, 0.1, 0.9, 0.0, 1.0, None) == -9
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 1, -0.1, 0.9, 0.0, 1.0, None) == -9
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 0, 0.1, 0.9, 0.0, 1.0, None) == 0

@@ -105,7 +105,7 @@ def _replay_triplet(shape, tol, seed, t_end):
     res = {}
     for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
         tw = copy.deepcopy(twin).to(dt)
-        yo = y.to(dt).requires_grad_(True)
+        yo = y.detach().to(dt).clone().requires_grad_(True)
         out_o = tdq.odeint_adjoint(tw, yo, t.to(dt), rtol=tol, atol=tol, method='dopri5', options=dict(opts))
         (out_o * wgt.to(dt)).sum().backward()
         res[name] = dict(out=out_o.detach(), gy=yo.grad, gp=torch.cat([p.grad.reshape(-1) for p in tw.parameters()]))

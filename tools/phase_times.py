@@ -11,10 +11,13 @@ torch.manual_seed(23)
 if os.environ.get('BENCHMARK'): torch.backends.cudnn.benchmark = True
 dev = torch.device('cuda:0')
 model = nof.ODENet(3, out=10, n_filters=256, downsample='residual', method='dopri5', tol=1e-3, adjoint=True, t1=1, dropout=0.5).to(dev)
-opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=bool(os.environ.get('FUSED_SGD')))
 gen = torch.Generator().manual_seed(1234)
 x = torch.randn(128, 3, 32, 32, generator=gen).to(dev).requires_grad_(bool(os.environ.get('GRAPH_STEM')))
 y = torch.randint(0, 10, (128,), generator=gen).to(dev)
+if os.environ.get('CHANNELS_LAST'):
+    model.downsample = model.downsample.to(memory_format=torch.channels_last)
+    x = x.detach().contiguous(memory_format=torch.channels_last).requires_grad_(x.requires_grad)
 if os.environ.get('GRAPH_STEM'):
     model.downsample = torch.cuda.make_graphed_callables(model.downsample, (torch.randn(128, 3, 32, 32, device=dev, requires_grad=True),))
 if os.environ.get('GRAPH_HEAD'):
