@@ -230,6 +230,7 @@ def main():
     ap.add_argument('--method', default='dopri5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true', help='eager stem / head instead of the captured hipGraphs')
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.batch is not None:
@@ -249,14 +250,21 @@ def main():
         raise SystemExit('bench.py: LOCAL_RANK %d but only %d HIP device(s)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
     model = build_model(device, cfg, args.method)
     init_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(cfg['batch'], 3, cfg['image'], cfg['image'], generator=gen).to(device)   # normalised CIFAR-shaped
+    y = torch.randint(0, 10, (cfg['batch'],), generator=gen).to(device)
+    model.train()
+    if not args.no_graphs:
+        # stem and head (forward and backward) as hipGraphs, captured before RCCL's watchdog thread exists
+        nof.graphs.capture_static_parts(model, x)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     reducer = None
     # SGD lr .1 momentum .9 wd 1e-4 (reproduce.sh:3-6, train.py:136): one fused launch for all parameter tensors
     opt = nof.FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
@@ -264,11 +272,6 @@ def main():
         nof.dp.broadcast_parameters(model, 0)
         reducer = nof.dp.GradientReducer(model, average=False)   # all-reduce SUM in the bucket buffers ...
         opt.grad_scale = 1.0 / world                             # ... its 1/world folded into the optimizer step
-    model.train()
-
-    gen = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(cfg['batch'], 3, cfg['image'], cfg['image'], generator=gen).to(device)   # normalised CIFAR-shaped
-    y = torch.randint(0, 10, (cfg['batch'],), generator=gen).to(device)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -356,7 +359,7 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
-                'parallelism': 'dp%d' % world,
+                'parallelism': 'dp%d' % world, 'stem_head': 'eager' if args.no_graphs else 'hipGraph',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
                 'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],

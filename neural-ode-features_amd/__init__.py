@@ -10,7 +10,7 @@ reference's `model.py` runs unchanged on top of the HIP library:
 from .integrate import odeint, odeint_adjoint, odefunc_forward, odefunc_vjp  # noqa: F401
 from .modules import ConcatConv2d, ODEBlock, ODEfunc, normalization  # noqa: F401
 from .odenet import FCClassifier, ODEDownsample, ODEDownsample2, ODENet, ResBlock, StackedODENet  # noqa: F401
-from . import dp, optim  # noqa: F401
+from . import dp, graphs, optim  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 
 __all__ = ['odeint', 'odeint_adjoint', 'ODEBlock', 'ODEfunc', 'ConcatConv2d', 'ODENet', 'StackedODENet',

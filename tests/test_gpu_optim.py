@@ -54,12 +54,16 @@ def test_flat_sgd_training_steps_match_torch_sgd():
     gen = torch.Generator().manual_seed(6)
     x = torch.randn(8, 3, 32, 32, generator=gen).cuda()
     y = torch.randint(0, 10, (8,), generator=gen).cuda()
+    start = [p.detach().clone() for p in a.parameters()]
     for step in range(3):
         la, _, _ = bench.train_step(a, oa, x, y)
         lb, _, _ = bench.train_step(b, ob, x, y)
         assert abs(float(la) - float(lb)) < 1e-4 * max(1.0, abs(float(lb))), step
-    for (k, p), q in zip(a.named_parameters(), b.parameters()):
-        assert torch.allclose(p, q, rtol=2e-4, atol=2e-6), k
+    # the UPDATES agree (MIOpen's weight-gradient kernels accumulate with atomics: gradients of two identical
+    # runs differ in the last bits, and three steps at lr 0.05 amplify that a little)
+    for (k, p), q, p0 in zip(a.named_parameters(), b.parameters(), start):
+        da, db = (p - p0), (q - p0)
+        assert float((da - db).abs().max()) <= 2e-3 * float(db.abs().max()) + 1e-7, k
     # learning-rate schedulers drive it through param_groups like a torch optimizer (train.py:158-163)
     oa.param_groups[0]['lr'] = 0.0
     before = [p.detach().clone() for p in a.parameters()]
