@@ -260,8 +260,11 @@ def main():
     y = torch.randint(0, 10, (cfg['batch'],), generator=gen).to(device)
     model.train()
     if not args.no_graphs:
-        # stem and head (forward and backward) as hipGraphs, captured before RCCL's watchdog thread exists
-        nof.graphs.capture_static_parts(model, x)
+        # the classifier head (forward and backward) as hipGraphs, captured before RCCL's watchdog thread exists.
+        # Same-process A/B at cfg 2 (tools/ab_step.py, medians of 60 steps): eager 8.93 ms, head graphed 8.80 ms,
+        # stem graphed 9.16 ms (its backward replays on the capture's side stream and pays cross-stream
+        # synchronisation with the eager optimizer), both 8.98 ms -> only the head is captured.
+        nof.graphs.capture_static_parts(model, x, stem=False, head=True)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
@@ -359,7 +362,7 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
-                'parallelism': 'dp%d' % world, 'stem_head': 'eager' if args.no_graphs else 'hipGraph',
+                'parallelism': 'dp%d' % world, 'head': 'eager' if args.no_graphs else 'hipGraph', 'stem': 'eager (MIOpen)',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
                 'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],

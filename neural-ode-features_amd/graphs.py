@@ -4,8 +4,10 @@ stream-ordered launches (their step count is data dependent; see csrc/node_api.h
 
 Why: after each solve the host has just synchronised with the GPU, so everything it dispatches next is exposed --
 ~30 eager launches for the stem's backward, ~15 for head + loss.  Replaying a captured graph is one launch each
-(measured at cfg 2, tools/phase_times.py: head + loss 0.22 -> 0.09 ms, head backward 0.35 -> 0.21 ms, stem forward
-0.55 -> 0.45 ms per step).
+(measured at cfg 2, tools/phase_times.py: head + loss 0.22 -> 0.09 ms, head backward 0.35 -> 0.21 ms per step; whole
+step, same-process A/B with tools/ab_step.py: 8.93 -> 8.80 ms with the head captured.  Capturing the stem made the
+step SLOWER, 9.16 ms: its backward graph replays on the capture's side stream and the eager optimizer behind it
+pays a cross-stream synchronisation per parameter -- so `bench.py` captures the head only).
 
 Capture BEFORE `torch.distributed.init_process_group`: RCCL's watchdog thread polls events, which is not allowed
 while a stream of the process is capturing.  Parameters keep their storages (in-place updates, `load_state_dict`
