@@ -110,7 +110,7 @@ def resolve_world(args):
         return 1, 0, 0
     import torch
     have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if have < args.gpus:
+    if have < args.gpus and not (args.share_gpu and have >= 1):
         raise SystemExit('bench.py: --gpus %d requested but this node exposes %d HIP device(s); refusing to run at a '
                          'smaller world size' % (args.gpus, have))
     rc = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
@@ -204,7 +204,8 @@ def pmc_traffic(config):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None where no pass is committed."""
-    for name in ('r02_pmc_eval_cfg%d.json' % config, 'r01_k_pmc_eval_cfg%d.json' % config):
+    shape_of = {2: 2, 3: 2, 5: 5}.get(config, config)       # cfg 3 runs cfg 2's kernels at cfg 2's state shape
+    for name in ('r02_pmc_eval_cfg%d.json' % shape_of, 'r01_k_pmc_eval_cfg%d.json' % shape_of):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -231,6 +232,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='eager stem / head instead of the captured hipGraphs')
+    ap.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
+                    help='collective backend (nccl = RCCL; gloo only for the shared-GPU smoke test)')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='TESTING ONLY: ranks share the devices that exist (rank %% device_count); exercises the N-rank code '
+                         'path on a 1-GPU box, the number it prints is not a measurement')
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     if args.batch is not None:
@@ -246,6 +252,10 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (there is no CPU fallback for the product path)')
+    if args.share_gpu:
+        if args.dist_backend != 'gloo':
+            raise SystemExit('bench.py: --share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)')
+        local_rank = local_rank % torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise SystemExit('bench.py: LOCAL_RANK %d but only %d HIP device(s)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -267,7 +277,10 @@ def main():
         nof.graphs.capture_static_parts(model, x, stem=False, head=True)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
     reducer = None
     # SGD lr .1 momentum .9 wd 1e-4 (reproduce.sh:3-6, train.py:136): one fused launch for all parameter tensors
     opt = nof.FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
@@ -362,7 +375,7 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
-                'parallelism': 'dp%d' % world, 'head': 'eager' if args.no_graphs else 'hipGraph', 'stem': 'eager (MIOpen)',
+                'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'eager' if args.no_graphs else 'hipGraph', 'stem': 'eager (MIOpen)',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
                 'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],

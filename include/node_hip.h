@@ -27,8 +27,13 @@
  *    reference's layouts: conv weights are [C, C+1, 3, 3] with input channel 0
  *    being the time channel (model.py:321-322);
  *  - all work is enqueued on the caller's HIP stream (`hipStream_t` passed as
- *    void*); solve calls synchronise that stream once per adaptive step to read
- *    the accept flag, and once at the end, so `stats` is valid on return;
+ *    void*).  The adaptive step loop runs WITHOUT host decisions: accept /
+ *    reject, the next step size, which output times a step passed, dense
+ *    output and the end of the interval are all decided by kernels; the host
+ *    enqueues as many steps as the previous solve of the same problem needed,
+ *    then synchronises once to read the controller record (and tops up two
+ *    steps at a time if the interval is not finished; steps enqueued past the
+ *    end return at once on the device).  `stats` is valid on return;
  *  - return 0 on success, a negative NODE_ERR_* otherwise; the message is
  *    available from node_last_error() (thread-local).  No exceptions, no abort.
  */

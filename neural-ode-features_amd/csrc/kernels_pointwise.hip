@@ -897,6 +897,12 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
   // Hand-off without fences: an agent-scope release here would write back this XCD's whole L2, which is full of
   // the wgrad slabs' dirty lines (measured: +12 us on the launch).  The partial is an agent-scope (write-through)
   // store, acknowledged (vmcnt(0)) before the agent-scope count; the last arriver reads with agent-scope loads.
+  // This leans on gfx950's memory system (agent-scope stores write through the XCD's L2; s_waitcnt vmcnt(0) waits
+  // for the write acknowledgement), not on the HIP memory model -- so it is tied to the architecture at compile
+  // time, and tests/test_gpu_parity.py::test_vjp_t_is_deterministic_over_repeated_launches watches it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_theta_finalize's fence-free hand-off is only valid on gfx950: use release/acquire on the counter elsewhere"
+#endif
   if (cl == 0) {
     __hip_atomic_store(dotpart + layer * nb + bxs, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

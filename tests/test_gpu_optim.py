@@ -82,3 +82,25 @@ def test_sgd_step_argument_checks():
     assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr() + 2, t.data_ptr(), t.data_ptr(), 8)), 1, 0.1, 0.9, 0.0, 1.0, None) == -9
     assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 1, -0.1, 0.9, 0.0, 1.0, None) == -9
     assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 0, 0.1, 0.9, 0.0, 1.0, None) == 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_through_self_launcher_on_one_gpu():
+    """The N-rank path of bench.py end to end on a 1-GPU box: `--gpus 2` spawns two ranks itself (they share cuda:0,
+    collectives over gloo because RCCL refuses two ranks on one device): head captured as hipGraphs, reducer packing
+    the gradients into bucket buffers, all-reduce, FusedSGD reading them in place with 1/world folded in.  The JSON
+    line must say n_gpus = 2; its throughput is not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--share-gpu',
+                        '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--no-roofline', '--batch', '32'],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
+    assert 'SHARE' in d['config']['parallelism']

@@ -59,3 +59,20 @@ def test_odefunc_vjp_matches_oracle(shape):
                 vt=abs(float(vt) - float(vt_ref)) / (abs(float(vt_ref)) + 1e-6))
     print('vjp', shape, errs)
     assert errs['f'] < 2e-5 and errs['vy'] < 5e-5 and errs['vp'] < 5e-5 and errs['vt'] < 1e-4, errs
+
+
+def test_vjp_t_is_deterministic_over_repeated_launches():
+    """d f / d t comes out of k_theta_finalize's last-arrival reduction (fence-free hand-off, see the kernel): 200
+    back-to-back launches at the cfg-2 state must all give the SAME bits, and the arrival counter must be back at
+    zero each time (a stale partial or a lost count would show as a different sum sooner or later)."""
+    import neural_ode_features_amd as nof
+    f, _ = make_func(256, seed=3, device='cuda')
+    gen = torch.Generator().manual_seed(12)
+    y = torch.randn(128, 256, 8, 8, generator=gen).cuda()
+    cot = torch.randn(128, 256, 8, 8, generator=gen).cuda()
+    _, vy0, vt0, vp0 = nof.odefunc_vjp(f, 0.3, y, cot)
+    vt0 = float(vt0)
+    for _ in range(200):
+        _, vy, vt, vp = nof.odefunc_vjp(f, 0.3, y, cot)
+        assert float(vt) == vt0
+    assert torch.equal(vp, vp0) and torch.equal(vy, vy0)

@@ -364,3 +364,41 @@ def test_three_stacked_blocks():
     for (k, v), (_, w) in zip(net.named_parameters(), cpu.named_parameters()):
         scale = max(float(w.grad.abs().max()), 1e-3 * gmax)
         assert float((v.grad.cpu() - w.grad).abs().max()) / scale < 2e-2, k
+
+
+def test_blind_step_enqueue_over_and_under_prediction():
+    """The step loop enqueues as many steps as the previous solve of the same problem class took before it reads
+    anything back.  Alternating inputs that need more / fewer steps exercises both outcomes: steps enqueued past the
+    end must be no-ops on the device (fewer needed), and a short guess must be topped up (more needed) -- every solve
+    is checked against the oracle, forward and adjoint, and twice in a row."""
+    import neural_ode_features_amd as nof
+    f, twin = make_func(32, seed=111, device='cuda', kink_free=True)
+    t = torch.tensor([0.0, 1.0])
+    gen = torch.Generator().manual_seed(112)
+    base = torch.randn(4, 32, 8, 8, generator=gen)
+    seen = set()
+    for scale in (0.05, 30.0, 0.05, 30.0, 30.0, 0.05):
+        y = base * scale
+        yo = y.clone().requires_grad_(True)
+        fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
+        out_o = tdq.odeint_adjoint(twin, yo, t, rtol=1e-4, atol=1e-4, method='dopri5', fwd_stats=fs_o, bwd_stats=bs_o)
+        out_o[-1].square().sum().backward()
+        gp_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
+        for p in twin.parameters():
+            p.grad = None
+        yh = y.cuda().requires_grad_(True)
+        f.nfe = 0
+        out_h = nof.odeint_adjoint(f, yh, t.cuda(), rtol=1e-4, atol=1e-4, method='dopri5')
+        nfe_f = f.nfe
+        out_h[-1].square().sum().backward()
+        gp_h = torch.cat([p.grad.reshape(-1) for p in f.parameters()])
+        for p in f.parameters():
+            p.grad = None
+        fs, bs = f.last_forward_stats, f.last_backward_stats
+        steps = (fs['accepted'] + fs['rejected'], bs['accepted'] + bs['rejected'])
+        seen.add(steps)
+        print('scale', scale, 'steps fwd/bwd', steps, 'oracle', (fs_o.accepted + fs_o.rejected, bs_o.accepted + bs_o.rejected))
+        assert nfe_f == 2 + 6 * steps[0] and f.nfe - nfe_f == 3 + 6 * steps[1]
+        assert steps == (fs_o.accepted + fs_o.rejected, bs_o.accepted + bs_o.rejected)
+        assert rel_err(out_h, out_o) < 2e-4 and rel_err(yh.grad, yo.grad) < 1e-3 and rel_err(gp_h, gp_o) < 1e-3
+    assert len(seen) >= 2, seen          # the two inputs really need different numbers of steps
