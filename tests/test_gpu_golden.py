@@ -53,10 +53,14 @@ def test_hip_end_to_end_matches_reference_run(golden_dir, name):
     # (~1e-9 against a largest gradient of ~0.2), so each tensor is compared relative to
     # max(its own scale, 1e-4 x the largest gradient of the net).
     gmax = max(float(v.abs().max()) for v in g['grads'].values())
+    # The stem's convolutions are MIOpen's: its backward kernels were measured to differ by up to 4e-3 relative between
+    # algorithm choices on a fresh box (tests/test_gpu_head.py), so the stem's parameters get a wider bound than the
+    # ODE block's and the head's, whose gradients come out of this package's kernels.
     for k, v in net.named_parameters():
         ref = g['grads'][k]
         scale = max(float(ref.abs().max()), 1e-4 * gmax)
-        assert float((v.grad.detach().cpu() - ref).abs().max()) / scale < 5e-3, k
+        bound = 2e-2 if k.startswith('downsample') else 5e-3
+        assert float((v.grad.detach().cpu() - ref).abs().max()) / scale < bound, k
 
 
 def test_full_size_cifar_state_forward_and_vjp_vs_oracle():

@@ -402,3 +402,29 @@ def test_blind_step_enqueue_over_and_under_prediction():
         assert steps == (fs_o.accepted + fs_o.rejected, bs_o.accepted + bs_o.rejected)
         assert rel_err(out_h, out_o) < 2e-4 and rel_err(yh.grad, yo.grad) < 1e-3 and rel_err(gp_h, gp_o) < 1e-3
     assert len(seen) >= 2, seen          # the two inputs really need different numbers of steps
+
+
+def test_device_loop_reports_non_finite_and_underflow():
+    """Status decided by the controller kernel must come back as the C ABI's error codes (upstream: assertions
+    'non-finite values in state' / 'underflow in dt')."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd._lib import NodeHipError
+    f, _ = make_func(16, seed=121, device='cuda')
+    t = torch.tensor([0.0, 1.0]).cuda()
+    y = torch.randn(2, 16, 4, 4).cuda()
+    y[0, 0, 0, 0] = float('inf')
+    with pytest.raises(NodeHipError, match='NONFINITE'):
+        nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+    # a solve right after a failed one starts from a clean controller
+    y = torch.randn(2, 16, 4, 4).cuda()
+    out = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+    assert bool(torch.isfinite(out).all())
+    # steps enqueued after the failure did nothing: the statistics say one step
+    with pytest.raises(NodeHipError):
+        nof.odeint(f, y * float('nan'), t, rtol=1e-3, atol=1e-3)
+    # max_num_steps counts steps TRIED in an interval, whatever the guess from earlier solves was
+    for _ in range(2):
+        with pytest.raises(NodeHipError, match='MAX_STEPS'):
+            nof.odeint(f, y, t, rtol=1e-9, atol=1e-9, options={'max_num_steps': 3})
+    out2 = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+    assert torch.equal(out, out2)
