@@ -232,6 +232,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-graphs', action='store_true', help='eager stem / head instead of the captured hipGraphs')
+    ap.add_argument('--no-deferred', action='store_true',
+                    help='every solve ends with a read-back of the device controller (the drop-in default) instead of '
+                         'deferred completion with a device-predicated optimizer step (integrate.Deferred)')
     ap.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
                     help='collective backend (nccl = RCCL; gloo only for the shared-GPU smoke test)')
     ap.add_argument('--share-gpu', action='store_true',
@@ -295,20 +298,40 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        train_step(model, opt, x, y, reducer)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    sync()
-    t0 = time.perf_counter()
-    nfe_f = nfe_b = 0
-    ev[0].record()
-    for i in range(args.steps):
-        _, a, b = train_step(model, opt, x, y, reducer)
-        ev[i + 1].record()
-        nfe_f += a
-        nfe_b += b
-    sync()
-    elapsed = time.perf_counter() - t0
+    # Deferred completion: the solves enqueue the step count of the previous iteration and return without a
+    # read-back; a miss (wrong count) bumps a device flag on which the optimizer step is predicated, so a step with
+    # a miss commits nothing.  A timed region that contains a miss did less than K full steps and is measured again.
+    import contextlib
+    deferred = None if args.no_deferred else integrate.Deferred(device)
+    if deferred is not None:
+        opt.use_deferred(deferred, reducer)
+    scope = deferred if deferred is not None else contextlib.nullcontext()
+    with scope:
+        for _ in range(args.warmup):
+            train_step(model, opt, x, y, reducer)
+        for attempt in range(3):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            sync()
+            if deferred is not None:
+                deferred.resolve()
+            misses0 = deferred.misses if deferred is not None else 0
+            t0 = time.perf_counter()
+            nfe_f = nfe_b = 0
+            ev[0].record()
+            for i in range(args.steps):
+                _, a, b = train_step(model, opt, x, y, reducer)
+                ev[i + 1].record()
+                nfe_f += a
+                nfe_b += b
+            sync()
+            elapsed = time.perf_counter() - t0
+            timed_misses = (deferred.resolve() - misses0) if deferred is not None else 0
+            if world > 1:
+                mm = torch.tensor([float(timed_misses)], device=device)
+                dist.all_reduce(mm)
+                timed_misses = int(mm.item())
+            if timed_misses == 0:
+                break
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -324,8 +347,9 @@ def main():
     if not args.no_roofline:
         # repeat of the timed steps with per-launch HIP events on the launch stream
         integrate.profile_begin()
-        for _ in range(min(args.steps, 5)):
-            train_step(model, opt, x, y, reducer)
+        with scope:
+            for _ in range(min(args.steps, 5)):
+                train_step(model, opt, x, y, reducer)
         torch.cuda.synchronize(device)
         prof = integrate.profile_end()
         k = prof['conv3x3_implicit_gemm']
@@ -375,6 +399,9 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
+                'solver_completion': 'read-back per solve' if deferred is None else
+                                     'deferred (device-predicated optimizer step; %d blind solves, %d misses in the timed region)'
+                                     % (deferred.blind_solves, timed_misses),
                 'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'eager' if args.no_graphs else 'hipGraph', 'stem': 'eager (MIOpen)',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],

@@ -65,6 +65,7 @@ enum {
   NODE_ERR_HIP = -8,          /* a HIP runtime call failed                        */
   NODE_ERR_ARG = -9           /* bad scalar argument (method, n_t, time order...) */
 };
+#define NODE_PENDING 1        /* node_stats.status of a solve enqueued with node_solve_opts.blind_steps */
 
 /* State shape [n, c, h, w]; groups = min(32, c) (model.py:271); eps = 1e-5. */
 typedef struct node_shape {
@@ -100,6 +101,14 @@ typedef struct node_stats {
   double first_dt;  /* initial step chosen (dopri5) */
 } node_stats;
 
+/* What a solve that was enqueued WITHOUT a final synchronisation (node_solve_opts.blind_steps) leaves in device
+ * memory, written on the stream behind its last step.  `miss` != 0: the steps enqueued were not exactly the steps
+ * the solve needed (unfinished, finished early, or stopped with `status`), i.e. its outputs must not be used. */
+typedef struct node_step_record {
+  int32_t done, status, steps, accepted, rejected, miss;
+  double t, dt, first_dt;
+} node_step_record;
+
 /* Optional knobs (pass NULL for upstream behaviour). */
 typedef struct node_solve_opts {
   int32_t max_num_steps;    /* <=0: 2^31-1 like upstream                          */
@@ -108,6 +117,14 @@ typedef struct node_solve_opts {
   int32_t record_dt;        /* >0: capacity of dt_log                             */
   double* dt_log;           /* host: dt tried at each step (<0 => rejected)       */
   int32_t* n_dt_log;        /* host: number of entries written                    */
+  /* Deferred completion (dopri5, n_t == 2, no replay / dt log): enqueue exactly `blind_steps` steps and RETURN
+   * WITHOUT SYNCHRONISING.  The caller keeps its queue fed across the solve and learns the outcome later from
+   * `record` (device memory, filled on the stream); `miss_flag` (device float, nullable) is incremented when the
+   * record says miss, so that work which commits results (node_sgd_step's skip flag) can be predicated on the
+   * device.  stats then hold the PREDICTED counts (nfe = 2 + 6 blind_steps ...), status NODE_PENDING. */
+  int32_t blind_steps;
+  node_step_record* record; /* device */
+  float* miss_flag;         /* device, nullable */
 } node_solve_opts;
 
 /* Per-kernel-class timing collected with HIP events on the caller's stream
@@ -211,7 +228,8 @@ int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma
  * (dampening 0, no Nesterov: the reference's settings).  `tensors` is a HOST array of `count` records of device
  * pointers; gradients are read where autograd / the data-parallel reducer left them.  grad_scale folds the
  * 1/world of a data-parallel gradient SUM into the step.  momentum_buf must start at zero (the first step then
- * equals PyTorch's buf = g). */
+ * equals PyTorch's buf = g).  `skip_if_nonzero` (device float, nullable): the launch leaves everything untouched
+ * when it reads a non-zero value there -- the commit point of a step whose solves ran with deferred completion. */
 typedef struct node_sgd_tensor {
   float* param;
   const float* grad;
@@ -219,7 +237,7 @@ typedef struct node_sgd_tensor {
   size_t n;
 } node_sgd_tensor;
 int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float momentum, float weight_decay,
-                  float grad_scale, void* stream);
+                  float grad_scale, const float* skip_if_nonzero, void* stream);
 
 /* Event-based per-kernel-class timing (off by default; adds two event records
  * per profiled launch).  begin() resets the counters; end() synchronises the

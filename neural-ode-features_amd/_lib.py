@@ -51,9 +51,18 @@ class NodeStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class NodeStepRecord(C.Structure):
+    _fields_ = [('done', C.c_int32), ('status', C.c_int32), ('steps', C.c_int32), ('accepted', C.c_int32),
+                ('rejected', C.c_int32), ('miss', C.c_int32), ('t', C.c_double), ('dt', C.c_double), ('first_dt', C.c_double)]
+
+
 class NodeSolveOpts(C.Structure):
     _fields_ = [('max_num_steps', C.c_int32), ('n_forced_dt', C.c_int32), ('forced_dt', C.POINTER(C.c_double)),
-                ('record_dt', C.c_int32), ('dt_log', C.POINTER(C.c_double)), ('n_dt_log', C.POINTER(C.c_int32))]
+                ('record_dt', C.c_int32), ('dt_log', C.POINTER(C.c_double)), ('n_dt_log', C.POINTER(C.c_int32)),
+                ('blind_steps', C.c_int32), ('record', C.c_void_p), ('miss_flag', C.c_void_p)]
+
+
+NODE_PENDING = 1
 
 
 class NodeProfile(C.Structure):
@@ -117,7 +126,7 @@ def load():
     lib.node_gn_relu_bwd.restype = i32
     lib.node_gn_relu_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.node_sgd_step.restype = i32
-    lib.node_sgd_step.argtypes = [P(NodeSgdTensor), i32, f32, f32, f32, f32, vp]
+    lib.node_sgd_step.argtypes = [P(NodeSgdTensor), i32, f32, f32, f32, f32, vp, vp]
     lib.node_profile_begin.restype = i32
     lib.node_profile_begin.argtypes = []
     lib.node_profile_end.restype = i32

@@ -10,7 +10,8 @@
 
 namespace node {
 
-__global__ __launch_bounds__(256) void k_sgd_multi(SgdTable tb, float lr, float momentum, float wd, float gscale) {
+__global__ __launch_bounds__(256) void k_sgd_multi(SgdTable tb, float lr, float momentum, float wd, float gscale, const float* skip) {
+  if (skip != nullptr && *skip != 0.f) return;   // a solve of this step reported a miss: nothing is committed
   const SgdEntry e = tb.e[blockIdx.y];
   float* __restrict__ p = e.p;
   const float* __restrict__ g = e.g;
@@ -47,11 +48,12 @@ __global__ __launch_bounds__(256) void k_sgd_multi(SgdTable tb, float lr, float 
   }
 }
 
-void launch_sgd_multi(const SgdTable& tb, int count, size_t max_n, float lr, float momentum, float wd, float gscale, hipStream_t s) {
+void launch_sgd_multi(const SgdTable& tb, int count, size_t max_n, float lr, float momentum, float wd, float gscale,
+                      const float* skip, hipStream_t s) {
   size_t bx = (max_n / 4 + 255) / 256;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(k_sgd_multi, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, s, tb, lr, momentum, wd, gscale);
+  hipLaunchKernelGGL(k_sgd_multi, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, s, tb, lr, momentum, wd, gscale, skip);
 }
 
 }  // namespace node

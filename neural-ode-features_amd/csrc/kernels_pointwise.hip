@@ -727,6 +727,21 @@ void launch_commit(const CommitArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_commit, dim3((unsigned)blocks), dim3(256), 0, s, a);
 }
 
+__global__ void k_set_target(double* targets, double t_end) { targets[0] = t_end; }
+void launch_set_target(double* targets, double t_end, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_target, dim3(1), dim3(1), 0, s, targets, t_end);
+}
+// Deferred completion: what the host would have read back, left in the caller's device record; a miss (the steps
+// enqueued were not exactly the steps needed) also bumps the caller's flag, on which the optimizer step is predicated.
+__global__ void k_export_record(const Ctrl* c, node_step_record* r, float* miss_flag, int expect) {
+  const int miss = !(c->done && c->status == 0 && c->step_idx == expect);
+  r->done = c->done; r->status = c->status; r->steps = c->step_idx; r->accepted = c->n_acc; r->rejected = c->n_rej;
+  r->miss = miss; r->t = c->t; r->dt = c->dt; r->first_dt = c->first_dt;
+  if (miss && miss_flag != nullptr) *miss_flag += 1.f;
+}
+void launch_export_record(const Ctrl* ctrl, node_step_record* rec, float* miss_flag, int expect_steps, hipStream_t s) {
+  hipLaunchKernelGGL(k_export_record, dim3(1), dim3(1), 0, s, ctrl, rec, miss_flag, expect_steps);
+}
 __global__ void k_set_interval(Ctrl* c, double t, double dt) {
   c->t = t; c->dt = dt; c->t_prev = t; c->dt_used = 0.0;
   c->done = 0; c->step_idx = 0; c->j = 0; c->j0 = 0; c->j1 = 0; c->first_dt = 0.0; c->accept = 0;

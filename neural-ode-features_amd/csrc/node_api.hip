@@ -847,11 +847,26 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   io.n_forced = forced ? opts->n_forced_dt : 0;
   io.log_cap = (opts && opts->record_dt > 0 && opts->dt_log) ? (opts->record_dt < STEP_LIST_CAP ? opts->record_dt : STEP_LIST_CAP) : 0;
   io.y_out = y_out + numel;
-  TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
+  // deferred completion: exactly `blind_steps` steps, no read-back, no host staging (nothing of this call may be
+  // touched by the host after it returns); the outcome goes to the caller's device record
+  const int blind = (opts && opts->blind_steps > 0 && opts->record && n_t == 2 && !forced && io.log_cap == 0)
+                        ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
+  if (blind) launch_set_target(S.p.targets, ts[1], S.st);
+  else TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
   if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
   if (!forced) TRY(S.initial_step());
+  if (blind) {
+    for (int i = 0; i < blind; ++i) TRY(S.enqueue_step(io));
+    launch_export_record(S.p.ctrl, opts->record, opts->miss_flag, blind, S.st);
+    stt.status = NODE_PENDING;
+    stt.accepted = blind; stt.rejected = 0;            // predicted: true iff the record says no miss
+    stt.nfe = S.nfe + 6 * blind;
+    stt.t_final = ts[1];
+    if (stats) *stats = stt;
+    return S.check_launch("node_solve_fwd(dopri5, deferred)");
+  }
   StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 0, forced ? 1 : 0, rtol, atol, ts[0], ts[n_t - 1], 0};
   int status = 0;
   TRY(S.run_steps(io, max_steps, guess_steps(key), &status));
@@ -901,6 +916,9 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   io.n_forced = forced ? opts->n_forced_dt : 0;
   io.log_cap = (opts && opts->record_dt > 0 && opts->dt_log) ? (opts->record_dt < STEP_LIST_CAP ? opts->record_dt : STEP_LIST_CAP) : 0;
 
+  const int blind = (opts && opts->blind_steps > 0 && opts->record && n_t == 2 && !forced && io.log_cap == 0 &&
+                     method == NODE_METHOD_DOPRI5)
+                        ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
@@ -934,10 +952,21 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     } else {
       // replay list restarts per interval (one odeint call each upstream)
       launch_set_interval(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, S.st);
-      TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
+      if (blind) launch_set_target(S.p.targets, s1, S.st);
+      else TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
       launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], S.p.G, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
+      if (blind) {   // deferred completion (one interval): the record says later whether these were the steps needed
+        for (int q = 0; q < blind; ++q) TRY(S.enqueue_step(io));
+        launch_export_record(S.p.ctrl, opts->record, opts->miss_flag, blind, S.st);
+        steps_total += blind;
+        stt.accepted = blind; stt.rejected = 0; stt.status = 0;
+        cur_t = s1; cur_dt = 0.0;
+        launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+        launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+        continue;
+      }
       StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 1, forced ? 1 : 0, rtol, atol, s0, s1, 0};
       int status = 0;
       // the dense output of the adjoint, parameter and time segments at s1 happens on the device with the last step
@@ -970,6 +999,13 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     // time_vjps = [adj_time, dLd_t1, ..., dLd_t_{T-1}]
     launch_copy_scalar_out(S.p.ctrl, S.p.dots, S.st);
     HIP_TRY(hipMemcpyAsync(grad_t, S.p.dots, (size_t)n_t * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  }
+  if (blind) {
+    stt.status = NODE_PENDING;
+    stt.nfe = S.nfe + 6 * steps_total;
+    stt.t_final = cur_t;
+    if (stats) *stats = stt;
+    return S.check_launch("node_solve_adjoint(deferred)");
   }
   HIP_TRY(hipStreamSynchronize(S.st));
   stt.nfe = S.nfe + 6 * steps_total;
@@ -1243,7 +1279,7 @@ int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, c
 }
 
 int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float momentum, float weight_decay, float grad_scale,
-                  void* stream) {
+                  const float* skip_if_nonzero, void* stream) {
   if (count < 0) return fail(NODE_ERR_ARG, "count < 0");
   if (count == 0) return NODE_OK;
   if (!tensors) return fail(NODE_ERR_NULL, "tensors is NULL");
@@ -1263,7 +1299,7 @@ int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float mom
       tb.e[i].n = tensors[base + i].n;
       if (tb.e[i].n > max_n) max_n = tb.e[i].n;
     }
-    launch_sgd_multi(tb, m, max_n, lr, momentum, weight_decay, grad_scale, (hipStream_t)stream);
+    launch_sgd_multi(tb, m, max_n, lr, momentum, weight_decay, grad_scale, skip_if_nonzero, (hipStream_t)stream);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_sgd_step failed: %s", hipGetErrorString(e));

@@ -272,6 +272,11 @@ struct CommitArgs {
 };
 void launch_commit(const CommitArgs& a, hipStream_t s);
 void launch_set_interval(Ctrl* ctrl, double t, double dt, hipStream_t s);   // new interval: t, dt, done = 0, counters of the interval
+void launch_set_target(double* targets, double t_end, hipStream_t s);       // targets[0] = t_end without host staging
+}  // namespace node
+struct node_step_record;
+namespace node {
+void launch_export_record(const Ctrl* ctrl, node_step_record* rec, float* miss_flag, int expect_steps, hipStream_t s);
 
 // initial step (Hairer)
 struct InitSeg { const float* y0; const float* f0; const float* f1; size_t n; };
@@ -384,7 +389,8 @@ void launch_gn_relu_bwd(const node_shape& sh, const float* z, const float* gamma
 constexpr int SGD_TABLE = 64;
 struct SgdEntry { float* p; const float* g; float* m; size_t n; };
 struct SgdTable { SgdEntry e[SGD_TABLE]; };
-void launch_sgd_multi(const SgdTable& tb, int count, size_t max_n, float lr, float momentum, float wd, float gscale, hipStream_t s);
+void launch_sgd_multi(const SgdTable& tb, int count, size_t max_n, float lr, float momentum, float wd, float gscale,
+                      const float* skip, hipStream_t s);
 void launch_head_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      const float* stats, const float* gpool, float* dz, float* gpart, hipStream_t s);
 

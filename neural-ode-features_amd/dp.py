@@ -57,13 +57,16 @@ class _Bucket:
         self.fired = 0            # hooks seen since the last finish() (outside accumulate())
         self.work = None
         self.launched = False
+        self.extra = 0            # trailing slots behind the gradients (the deferred-completion miss flag)
+        self.payload: Optional[torch.Tensor] = None   # flat[:sum numel]
 
     def ensure_flat(self):
         if self.flat is not None and self.flat.device == self.params[0].device:
             return
         p0 = self.params[0]
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        self.flat = torch.zeros(total + self.extra, dtype=p0.dtype, device=p0.device)
+        self.payload = self.flat[:total]
         self.views = []
         off = 0
         for p in self.params:
@@ -116,6 +119,18 @@ class GradientReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.launch_order: List[int] = []   # bucket indices in the order their all-reduce was issued
         self._accumulating = False
+        self._flag: Optional[torch.Tensor] = None
+
+    def carry_flag(self, flag: torch.Tensor) -> torch.Tensor:
+        """Append a one-float slot to the LAST bucket (the one launched last in a backward pass), filled with `flag`
+        (a device float, e.g. `integrate.Deferred.miss_flag`) right before that bucket's all-reduce.  Returns the
+        slot: after `finish()` it holds the SUM of the ranks' flags -- non-zero on every rank if any rank's was."""
+        b = self.buckets[-1]
+        b.extra = 1
+        b.flat = None
+        b.ensure_flat()
+        self._flag = flag
+        return b.flat[-1:]
 
     def zero_grad(self):
         """`optimizer.zero_grad()` (set to None) for the reducer's parameters: no kernel; the next backward's
@@ -155,7 +170,7 @@ class GradientReducer:
         # stay; the rest go in with ONE launch when none is in place, one copy each otherwise
         loose = [(p, v) for p, v in zip(b.params, b.views) if p.grad is None or p.grad.data_ptr() != v.data_ptr()]
         if len(loose) == len(b.params) and all(p.grad is not None for p in b.params):
-            torch.cat([p.grad.reshape(-1) for p in b.params], out=b.flat)
+            torch.cat([p.grad.reshape(-1) for p in b.params], out=b.payload)
         else:
             for p, v in loose:
                 if p.grad is None:
@@ -164,6 +179,8 @@ class GradientReducer:
                     v.copy_(p.grad)
         for p, v in zip(b.params, b.views):
             p.grad = v                   # host only: the reduced gradient is read where the all-reduce leaves it
+        if b.extra and self._flag is not None:
+            b.flat[-1:].copy_(self._flag)    # this rank's miss flag rides behind the last bucket's gradients
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.launch_order.append(b.index)
 
@@ -178,7 +195,7 @@ class GradientReducer:
             for b in self.buckets:
                 b.work.wait()
                 if self.average:
-                    b.flat.div_(self.world)
+                    b.payload.div_(self.world)
         for b in self.buckets:
             b.reset()
         self.launch_order = []

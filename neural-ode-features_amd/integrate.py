@@ -172,17 +172,22 @@ def _params_struct(params: List[torch.Tensor], device) -> Tuple[_lib.NodeParams,
     return _lib.NodeParams(*ptrs), keep
 
 
-def _opts_struct(options: Optional[dict], key: str):
-    """(struct-or-None, keepalive)"""
+def _opts_struct(options: Optional[dict], key: str, blind: Optional[tuple] = None):
+    """(struct-or-None, keepalive).  blind = (steps, record device tensor, miss flag device tensor) for a solve
+    with deferred completion."""
     options = options or {}
     forced = options.get(key)
     max_steps = int(options.get('max_num_steps', 0) or 0)
     record = int(options.get('record_dt', 0) or 0)
-    if forced is None and max_steps == 0 and record == 0:
+    if forced is None and max_steps == 0 and record == 0 and blind is None:
         return None, None
     o = _lib.NodeSolveOpts()
     keep = {}
     o.max_num_steps = max_steps
+    if blind is not None:
+        o.blind_steps = int(blind[0])
+        o.record = blind[1].data_ptr()
+        o.miss_flag = blind[2].data_ptr() if blind[2] is not None else None
     if forced is not None:
         arr = (C.c_double * len(forced))(*[float(v) for v in forced])
         keep['forced'] = arr
@@ -210,7 +215,7 @@ def _stats_dict(stats: _lib.NodeStats, keep) -> dict:
 
 
 def solve_forward(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor, times: List[float],
-                  rtol: float, atol: float, method_id: int, options: Optional[dict]):
+                  rtol: float, atol: float, method_id: int, options: Optional[dict], blind: Optional[tuple] = None):
     lib = _lib.load()
     y0c = y0.detach().contiguous()
     shape = _shape_struct(y0c, rec)
@@ -224,7 +229,7 @@ def solve_forward(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor,
         out = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float32, device=y0c.device)
         tarr = (C.c_float * n_t)(*times)
         stats = _lib.NodeStats()
-        opts, keep_o = _opts_struct(options, 'forced_dts')
+        opts, keep_o = _opts_struct(options, 'forced_dts', blind)
         rc = lib.node_solve_fwd(C.byref(shape), C.byref(pstruct), y0c.data_ptr(), tarr, n_t,
                                 float(rtol), float(atol), method_id,
                                 C.byref(opts) if opts is not None else None,
@@ -237,7 +242,7 @@ def solve_forward(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor,
 
 def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Tensor, grad_out: torch.Tensor,
                   times: List[float], rtol: float, atol: float, method_id: int, options: Optional[dict],
-                  want_grad_t: bool = False):
+                  want_grad_t: bool = False, blind: Optional[tuple] = None):
     lib = _lib.load()
     y_traj = y_traj.detach().contiguous()
     grad_out = grad_out.detach().contiguous()
@@ -256,7 +261,7 @@ def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Ten
         grad_t = torch.empty(n_t, dtype=torch.float32, device=dev) if want_grad_t else None
         tarr = (C.c_float * n_t)(*times)
         stats = _lib.NodeStats()
-        opts, keep_o = _opts_struct(options, 'forced_dts_bwd')
+        opts, keep_o = _opts_struct(options, 'forced_dts_bwd', blind)
         rc = lib.node_solve_adjoint(C.byref(shape), C.byref(pstruct), y_traj.data_ptr(), grad_out.data_ptr(),
                                     tarr, n_t, float(rtol), float(atol), method_id,
                                     C.byref(opts) if opts is not None else None,
@@ -297,6 +302,95 @@ def solve_backprop(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor
     return grad_y0, grad_p
 
 
+class Deferred:
+    """Deferred completion of the solves of a training step: keep the queue fed across the solver.
+
+    A dopri5 solve normally ends with one read-back of the device controller (did the steps enqueued finish the
+    interval?), and the host dispatches everything behind it only afterwards -- the GPU idles while PyTorch launches
+    the head, and again while it launches the stem's backward.  With deferred completion enabled, a solve whose step
+    count is known from the previous iteration enqueues exactly that many steps and returns at once; whether they
+    were the steps needed is written by the device into a record, and a MISS (unfinished, finished early, or an
+    error status) bumps the device flag `miss_flag`.  Nothing that commits results may run unconditionally:
+    `optim.FusedSGD.skip_flag = deferred.miss_flag` predicates the parameter update on the device, so a step with a
+    miss changes nothing (under data parallelism the flag rides in the reducer's last bucket, so every rank skips
+    together).  The host looks at a record one iteration later, when it is long complete: a miss makes the next
+    solve of that kind run with a read-back again and re-learn its step count.
+
+        deferred = integrate.Deferred(device)        # opt-in; the drop-in API is unaffected while none is active
+        opt.skip_flag = deferred.miss_flag
+        with deferred:
+            for x, y in loader:
+                deferred.begin_step()                # zero the flag (one 4-byte memset)
+                loss = F.cross_entropy(model(x), y); loss.backward(); opt.step(); opt.zero_grad()
+        deferred.misses                              # steps whose update was skipped
+
+    Counts reported through `func.nfe` / `last_*_stats` are the predicted ones (exact unless the step was a miss)."""
+
+    active = None      # the instance whose `with` block is open
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.miss_flag = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.guess: Dict[tuple, Optional[int]] = {}
+        self.pending: Dict[tuple, tuple] = {}
+        self.records: Dict[tuple, tuple] = {}
+        self.misses = 0
+        self.blind_solves = 0
+
+    def __enter__(self):
+        Deferred.active = self
+        return self
+
+    def __exit__(self, *exc):
+        Deferred.active = None
+        return False
+
+    def begin_step(self):
+        self.miss_flag.zero_()
+
+    def _buffers(self, key):
+        b = self.records.get(key)
+        if b is None:
+            n = C.sizeof(_lib.NodeStepRecord)
+            b = (torch.zeros(n, dtype=torch.uint8, device=self.device), torch.zeros(n, dtype=torch.uint8).pin_memory(),
+                 torch.cuda.Event())
+            self.records[key] = b
+        return b
+
+    def plan(self, key):
+        """Steps to enqueue blind for `key`, or None for a solve with a read-back.  Looks at the record the previous
+        blind solve of this key left (one iteration old: complete)."""
+        pend = self.pending.pop(key, None)
+        if pend is not None:
+            dev, host, event = self._buffers(key)
+            event.synchronize()
+            r = _lib.NodeStepRecord.from_buffer_copy(bytes(host.numpy().tobytes()))
+            if r.miss:
+                self.misses += 1
+                self.guess[key] = None
+        return self.guess.get(key)
+
+    def blind_args(self, key, steps):
+        dev, _, _ = self._buffers(key)
+        return (steps, dev, self.miss_flag)
+
+    def launched(self, key, steps):
+        dev, host, event = self._buffers(key)
+        host.copy_(dev, non_blocking=True)
+        event.record(torch.cuda.current_stream(self.device))
+        self.pending[key] = (steps,)
+        self.blind_solves += 1
+
+    def learned(self, key, steps):
+        self.guess[key] = int(steps)
+
+    def resolve(self):
+        """Wait for every outstanding record (a synchronisation point) and count the misses."""
+        for key in list(self.pending):
+            self.plan(key)
+        return self.misses
+
+
 BACKPROP_LOG = 4096      # step sizes the forward solve can record for the non-adjoint backward (csrc: STEP_LIST_CAP)
 
 
@@ -309,7 +403,18 @@ class _HipOdeint(torch.autograd.Function):
         if not adjoint and (y0.requires_grad or any(p.requires_grad for p in params)):
             options = dict(options or {})          # the backward replays the accepted steps: log their sizes
             options['record_dt'] = max(int(options.get('record_dt', 0) or 0), BACKPROP_LOG)
-        out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
+        d = Deferred.active if (adjoint and method_id == _lib.METHOD_DOPRI5 and len(times) == 2 and not options) else None
+        if d is not None and d.device != y0.device:
+            d = None
+        dkey = ('fwd', id(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None
+        steps = d.plan(dkey) if d is not None else None
+        if steps:
+            out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options, blind=d.blind_args(dkey, steps))
+            d.launched(dkey, steps)
+        else:
+            out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
+            if d is not None:
+                d.learned(dkey, st['accepted'] + st['rejected'])
         func.nfe = getattr(func, 'nfe', 0) + st['nfe']          # model.py:340 convention
         func.last_forward_stats = st
         ctx.func, ctx.rec, ctx.times = func, rec, times
@@ -328,8 +433,20 @@ class _HipOdeint(torch.autograd.Function):
     def backward(ctx, grad_out):
         out, *params = ctx.saved_tensors
         if ctx.adjoint:
-            gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
-                                           ctx.method_id, ctx.options)
+            d = Deferred.active if (ctx.method_id == _lib.METHOD_DOPRI5 and len(ctx.times) == 2 and not ctx.options) else None
+            if d is not None and d.device != out.device:
+                d = None
+            dkey = ('bwd', id(ctx.func), tuple(out.shape[1:]), ctx.rtol, ctx.atol, tuple(ctx.times)) if d is not None else None
+            steps = d.plan(dkey) if d is not None else None
+            if steps:
+                gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
+                                               ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps))
+                d.launched(dkey, steps)
+            else:
+                gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
+                                               ctx.method_id, ctx.options)
+                if d is not None:
+                    d.learned(dkey, st['accepted'] + st['rejected'])
             ctx.func.nfe = getattr(ctx.func, 'nfe', 0) + st['nfe']
             ctx.func.last_backward_stats = st
         else:

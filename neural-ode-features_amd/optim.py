@@ -35,6 +35,11 @@ class FusedSGD(torch.optim.Optimizer):
                         maximize=False, foreach=None, differentiable=False, fused=None)
         super().__init__(params, defaults)
         self.grad_scale = 1.0        # dp.GradientReducer(average=False) leaves a SUM: set 1/world here
+        # device float (1 element) or None: the step leaves everything untouched when it holds a non-zero value --
+        # the commit point of a training step whose solves ran with deferred completion (integrate.Deferred)
+        self.skip_flag = None
+        self.flags_to_reset = []     # device tensors zeroed behind the step (the per-step miss flags): a step that forgot
+                                     # to reset them could otherwise skip every later update silently
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -74,6 +79,18 @@ class FusedSGD(torch.optim.Optimizer):
             with torch.cuda.device(dev):
                 _lib.check(lib.node_sgd_step(table, len(rows), float(group['lr']), float(group['momentum']),
                                              float(group['weight_decay']), float(self.grad_scale),
+                                             self.skip_flag.data_ptr() if self.skip_flag is not None else None,
                                              torch.cuda.current_stream(dev).cuda_stream))
             del keep
+        for f in self.flags_to_reset:
+            f.zero_()
         return loss
+
+    def use_deferred(self, deferred, reducer=None):
+        """Predicate the update on `deferred`'s miss flag (see integrate.Deferred).  Under data parallelism the flag
+        travels in the reducer's last bucket, so that every rank skips an update any rank missed."""
+        if reducer is not None and reducer.world > 1:
+            self.skip_flag = reducer.carry_flag(deferred.miss_flag)
+        else:
+            self.skip_flag = deferred.miss_flag
+        self.flags_to_reset = [deferred.miss_flag]

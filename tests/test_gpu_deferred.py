@@ -1,0 +1,113 @@
+"""GPU: deferred completion of the solves (integrate.Deferred): blind step counts, the device-side miss flag, and the
+optimizer step predicated on it."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _block(seed=7, tol=1e-4):
+    import neural_ode_features_amd as nof
+    from tests.helpers import make_func
+    f, _ = make_func(32, seed=seed, device='cuda', kink_free=True)
+    blk = nof.ODEBlock(n_filters=32, tol=tol, method='dopri5', adjoint=True, t1=1)
+    blk.odefunc.load_state_dict(f.state_dict())
+    return blk.cuda()
+
+
+def test_deferred_steps_equal_synchronous_steps():
+    """Same block, same data: four optimizer steps with deferred completion give the parameters four steps with a
+    read-back per solve give, bit for bit (same kernels, same step sequence; the solver's arithmetic is deterministic),
+    and after the first (learning) iteration every solve runs blind."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    a = _block()
+    b = copy.deepcopy(a)
+    oa = nof.FusedSGD(a.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    ob = nof.FusedSGD(b.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    x = torch.randn(4, 32, 8, 8, generator=torch.Generator().manual_seed(1)).cuda()
+    d = integrate.Deferred(x.device)
+    oa.use_deferred(d)
+    losses_a, losses_b = [], []
+    with d:
+        for _ in range(4):
+            la = a(x).square().mean()
+            la.backward()
+            oa.step()
+            oa.zero_grad()
+            losses_a.append(la)
+    assert integrate.Deferred.active is None
+    for _ in range(4):
+        lb = b(x).square().mean()
+        lb.backward()
+        ob.step()
+        ob.zero_grad()
+        losses_b.append(lb)
+    assert d.resolve() == 0 and d.blind_solves == 6          # iterations 2..4: forward + adjoint each
+    for la, lb in zip(losses_a, losses_b):
+        assert float(la) == float(lb)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    assert a.nfe == b.nfe                                     # the predicted counts were the true ones
+
+
+def test_deferred_miss_commits_nothing_and_relearns():
+    """A solve that needs more (or fewer) steps than the previous iteration took is a MISS: the device flag goes up,
+    the optimizer step of that iteration leaves parameters and momentum untouched, and the next solve of that kind
+    runs with a read-back again and re-learns its step count."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    blk = _block()
+    opt = nof.FusedSGD(blk.parameters(), lr=1e-3, momentum=0.9)
+    base = torch.randn(4, 32, 8, 8, generator=torch.Generator().manual_seed(2)).cuda()
+    easy, hard = base * 0.05, base * 30.0
+    d = integrate.Deferred(base.device)
+    opt.use_deferred(d)
+
+    def step(x):
+        loss = blk(x).square().mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in blk.parameters()]
+
+    with d:
+        step(easy)                       # learns the step counts (read-back)
+        p1 = step(easy)                  # blind, exact
+        assert d.blind_solves == 2 and d.resolve() == 0
+        blk.nfe = 0
+        p2 = step(easy)                  # blind again (records consumed by resolve(): still known good)
+        steps_easy = (blk.odefunc.last_forward_stats['accepted'], blk.odefunc.last_backward_stats['accepted'])
+        assert any(not torch.equal(a, b) for a, b in zip(p1, p2))
+        p3 = step(hard)                  # blind with the easy problem's counts -> miss -> nothing committed
+        for a, b in zip(p2, p3):
+            assert torch.equal(a, b)
+        assert float(d.miss_flag) == 0.0             # the optimizer reset the flag behind its (skipped) launch
+        p4 = step(hard)                  # finds the miss, solves with a read-back, learns the new counts, commits
+        assert d.misses >= 1
+        assert any(not torch.equal(a, b) for a, b in zip(p3, p4))
+        steps_hard = (blk.odefunc.last_forward_stats['accepted'] + blk.odefunc.last_forward_stats['rejected'],
+                      blk.odefunc.last_backward_stats['accepted'] + blk.odefunc.last_backward_stats['rejected'])
+        assert steps_hard != steps_easy
+        before = d.blind_solves
+        p5 = step(hard)                  # blind with the new counts, exact
+        assert d.blind_solves == before + 2 and d.resolve() == d.misses
+        assert any(not torch.equal(a, b) for a, b in zip(p4, p5))
+    for p in p5:
+        assert bool(torch.isfinite(p).all())
+
+
+def test_drop_in_api_is_unaffected_without_an_active_deferred():
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    blk = _block()
+    x = torch.randn(2, 32, 8, 8).cuda()
+    assert integrate.Deferred.active is None
+    with torch.no_grad():
+        blk(x)
+    st = blk.odefunc.last_forward_stats
+    assert st['status'] == 0 and st['nfe'] == 2 + 6 * (st['accepted'] + st['rejected'])

@@ -83,11 +83,11 @@ def test_sgd_step_argument_checks():
     lib = _lib.load()
     t = torch.zeros(64, device='cuda')
     row = _lib.NodeSgdTensor(t.data_ptr(), t.data_ptr(), t.data_ptr(), 64)
-    assert lib.node_sgd_step(None, 1, 0.1, 0.9, 0.0, 1.0, None) == -1
-    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr(), None, t.data_ptr(), 64)), 1, 0.1, 0.9, 0.0, 1.0, None) == -1
-    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr() + 2, t.data_ptr(), t.data_ptr(), 8)), 1, 0.1, 0.9, 0.0, 1.0, None) == -9
-    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 1, -0.1, 0.9, 0.0, 1.0, None) == -9
-    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 0, 0.1, 0.9, 0.0, 1.0, None) == 0
+    assert lib.node_sgd_step(None, 1, 0.1, 0.9, 0.0, 1.0, None, None) == -1
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr(), None, t.data_ptr(), 64)), 1, 0.1, 0.9, 0.0, 1.0, None, None) == -1
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(_lib.NodeSgdTensor(t.data_ptr() + 2, t.data_ptr(), t.data_ptr(), 8)), 1, 0.1, 0.9, 0.0, 1.0, None, None) == -9
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 1, -0.1, 0.9, 0.0, 1.0, None, None) == -9
+    assert lib.node_sgd_step((_lib.NodeSgdTensor * 1)(row), 0, 0.1, 0.9, 0.0, 1.0, None, None) == 0
 
 
 @pytest.mark.timeout(900)
