@@ -231,7 +231,8 @@ def main():
     ap.add_argument('--method', default='dopri5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-graphs', action='store_true', help='eager stem / head instead of the captured hipGraphs')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay the classifier head from hipGraphs (pays off only with --no-deferred: see graphs.py)')
     ap.add_argument('--no-deferred', action='store_true',
                     help='every solve ends with a read-back of the device controller (the drop-in default) instead of '
                          'deferred completion with a device-predicated optimizer step (integrate.Deferred)')
@@ -272,11 +273,12 @@ def main():
     x = torch.randn(cfg['batch'], 3, cfg['image'], cfg['image'], generator=gen).to(device)   # normalised CIFAR-shaped
     y = torch.randint(0, 10, (cfg['batch'],), generator=gen).to(device)
     model.train()
-    if not args.no_graphs:
+    if args.graphs:
         # the classifier head (forward and backward) as hipGraphs, captured before RCCL's watchdog thread exists.
-        # Same-process A/B at cfg 2 (tools/ab_step.py, medians of 60 steps): eager 8.93 ms, head graphed 8.80 ms,
-        # stem graphed 9.16 ms (its backward replays on the capture's side stream and pays cross-stream
-        # synchronisation with the eager optimizer), both 8.98 ms -> only the head is captured.
+        # Same-process A/B at cfg 2 with a read-back per solve (tools/ab_step.py, medians of 60 steps): eager 8.93 ms,
+        # head graphed 8.80 ms, stem graphed 9.16 ms, both 8.98 ms.  With deferred completion the host runs ahead of
+        # the GPU anyway and the capture's side-stream synchronisation only costs: 8.42 ms eager vs 8.61 ms graphed
+        # (profiles/r02_deferred_ab.txt) -- so the default is eager.
         nof.graphs.capture_static_parts(model, x, stem=False, head=True)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -402,7 +404,7 @@ def main():
                 'solver_completion': 'read-back per solve' if deferred is None else
                                      'deferred (device-predicated optimizer step; %d blind solves, %d misses in the timed region)'
                                      % (deferred.blind_solves, timed_misses),
-                'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'eager' if args.no_graphs else 'hipGraph', 'stem': 'eager (MIOpen)',
+                'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'hipGraph' if args.graphs else 'eager',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
                 'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],

@@ -11,7 +11,9 @@ total = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 conv = [i for i, r in enumerate(rows) if 'k_conv3x3' in r['Kernel_Name']]
-per_step = len(conv) // total
+# one k_sgd_multi launch per training step (older traces: fall back to the step count given)
+nsgd = sum(1 for r in rows if 'k_sgd_multi' in r['Kernel_Name'])
+per_step = len(conv) // (nsgd if nsgd else total)
 win = rows[conv[len(conv) - tail * per_step]:]
 short = lambda r: r['Kernel_Name'].split('(')[0].replace('void ', '')[:44]
 gaps = collections.defaultdict(lambda: [0, 0])
