@@ -333,6 +333,10 @@ __global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl
     r = e.y / (atol + rtol * fmaxf(fabsf(y0.y), fabsf(y1.y))); acc += r * r;
     r = e.z / (atol + rtol * fmaxf(fabsf(y0.z), fabsf(y1.z))); acc += r * r;
     r = e.w / (atol + rtol * fmaxf(fabsf(y0.w), fabsf(y1.w))); acc += r * r;
+    // upstream asserts the state is finite at every step ('non-finite values in state `y`'); fmaxf above drops a
+    // NaN operand and ReLU turns a NaN pre-activation into 0, so an infinite / NaN state would otherwise pass
+    // unnoticed: 0 * (inf or NaN) = NaN poisons the sum, and the controller reports NODE_ERR_NONFINITE
+    acc += 0.f * (((y0.x + y0.y) + (y0.z + y0.w)) + ((y1.x + y1.y) + (y1.z + y1.w)));
   }
   // scalar tail (n % 4), handled by block 0
   if (blockIdx.x == 0) {
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl
       for (int j = 2; j < 7; ++j) e += ce[j] * kk[j];
       const float r = e / (atol + rtol * fmaxf(fabsf(y0), fabsf(y1)));
       acc += r * r;
+      acc += 0.f * (y0 + y1);
     }
   }
   const float tot = block_sum_256(acc, red);
@@ -617,33 +622,6 @@ __device__ inline float interp_one(float y0, float y1, const float* k, float dt,
   const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
   return ca * x4 + cb * x3 + cc * x2 + cd * x + y0;
 }
-__global__ __launch_bounds__(256) void k_interp(InterpArgs a) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
-    float kk[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) kk[j] = (j == 1) ? 0.f : a.k[j][i];
-    a.out[i] = interp_one(a.y0[i], a.y1[i], kk, a.dt, a.x);
-  }
-}
-void launch_interp(const InterpArgs& a, hipStream_t s) {
-  size_t blocks = (a.n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_interp, dim3((unsigned)blocks), dim3(256), 0, s, a);
-}
-// scalar segment: called right after an ACCEPTED step: ts_cur already holds y1, ts_k[0] holds f1 (FSAL
-// copy), so the controller's pre-accept values are reconstructed from ts_new/ts_k[6].
-__global__ void k_interp_scalar(Ctrl* c, float dt, float x) {
-  // y1 = ts_new, f1 = ts_k[6]; (y0, f0) of the step were saved by the controller before FSAL
-  float kk[7];
-  for (int j = 0; j < 7; ++j) kk[j] = c->ts_k[j];
-  kk[0] = c->ts_f0_prev;
-  c->ts_cur = interp_one(c->ts_y0_prev, c->ts_new, kk, dt, x);
-}
-void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s) {
-  hipLaunchKernelGGL(k_interp_scalar, dim3(1), dim3(1), 0, s, ctrl, dt, x);
-}
-
 // ----------------------------------------------------------------------------
 // Device-resident stepping: what the host used to do between two steps after reading `Ctrl` back.
 // ----------------------------------------------------------------------------

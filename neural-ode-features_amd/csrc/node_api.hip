@@ -214,11 +214,11 @@ struct Plan {
   float* wd[2];             // packed dgrad weights (adjoint)
   float* tmap[2];
   float *Y, *Y1, *KY[7];
-  float *act1, *act2, *TMP;
+  float *act1, *act2;
   float* RAW;               // split-conv mode (Dims::csplit): the conv's raw output, consumed by the GroupNorm pass
   // adjoint
   float *A, *A1, *KA[7];
-  float *TH, *TH1, *THTMP, *KT[7];
+  float *TH, *TH1, *KT[7];
   float *xh1, *xh2, *xh3, *r1, *r2, *r3;
   float *dz1, *dz2, *G;
   float *wpart[2], *spart[2], *gpart[3], *sred, *wtime[2];
@@ -262,7 +262,6 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   // conv inputs carry a tail of C zeros: the 2-D Winograd kernel reads its zero halo there
   p.act1 = b.take<float>(d.numel + d.C);
   p.act2 = b.take<float>(d.numel + d.C);
-  p.TMP = b.take<float>(d.numel);
   if (d.csplit) p.RAW = b.take<float>(d.numel);
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
@@ -271,7 +270,6 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     for (int i = 0; i < 7; ++i) p.KA[i] = b.take<float>(d.numel);
     p.TH = b.take<float>(d.P);
     p.TH1 = b.take<float>(d.P);
-    p.THTMP = b.take<float>(d.P);
     for (int i = 0; i < 7; ++i) p.KT[i] = b.take<float>(d.P);
     p.xh1 = b.take<float>(d.numel);
     p.xh2 = b.take<float>(d.numel);

@@ -292,12 +292,6 @@ void launch_init_controller(const InitCtlArgs& a, hipStream_t s);
 void launch_set_ctrl(Ctrl* ctrl, double t, double dt, int reset_counters, hipStream_t s);
 void launch_set_scalar_state(Ctrl* ctrl, float v, int which, hipStream_t s);
 
-struct InterpArgs {
-  const float* y0; const float* y1; const float* k[7];
-  float* out; size_t n; float dt; float x;
-};
-void launch_interp(const InterpArgs& a, hipStream_t s);
-void launch_interp_scalar(Ctrl* ctrl, float dt, float x, hipStream_t s);   // ts_cur <- interp
 void launch_axpy(float* y, const float* x, float alpha, size_t n, hipStream_t s);  // y += alpha*x
 // ctrl->ts_cur -= sign * <a, b>;  *out_dot = sign * <a, b>
 void launch_dot_sub_scalar(Ctrl* ctrl, const float* a, const float* b, size_t n, float sign, float* partial, float* out_dot, hipStream_t s);
