@@ -17,7 +17,13 @@ than N devices, or the launcher's WORLD_SIZE disagrees, it exits non-zero.
 A "step" is the loop body of the reference's train.py:40-58 on device-resident
 synthetic tensors: p = model(x); loss = CE(p, y); loss.backward(); optimizer.step();
 optimizer.zero_grad().  The ODE block(s) -- the hot path -- run in libnode_hip.so
-through the C ABI.
+through the C ABI; the optimizer step is one fused launch (node_sgd_step).  By default
+the solves run with DEFERRED COMPLETION (integrate.Deferred): they enqueue the step
+count of the previous iteration and return without a host read-back, the device
+records whether that was exact, and the optimizer step is predicated on it on the
+device -- a step with a miss commits nothing, and a timed region that contains one is
+measured again (never reported).  `--no-deferred` gives the drop-in behaviour: one
+read-back per solve.
 
 Prints ONE JSON line (rank 0).  `value` = images of all ranks / wall time of exactly
 K steps (barrier + synchronize on both sides, max over ranks); `step_ms` holds the

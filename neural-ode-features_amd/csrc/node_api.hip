@@ -2,11 +2,12 @@
 //
 // The host code below is the *driver* of the integrator: it owns no numerics.
 // Every number (stage values, error norms, accept decisions, step sizes) is
-// produced by device kernels and stays in device memory; the host only
-//   * enqueues the kernels of one step on the caller's stream,
-//   * reads back one small `Ctrl` record per adaptive step (accept, t, dt) to
-//     know whether the requested output time has been passed, and
-//   * swaps buffer pointers on accept (FSAL, y <- y1).
+// produced by device kernels and stays in device memory -- including the decisions of the adaptive step loop
+// (accept / reject, which output times a step passed, dense output, FSAL commit, end of the interval).  The host
+//   * enqueues whole steps on the caller's stream, as many as the previous solve of the same problem needed,
+//   * reads one small `Ctrl` record back per solve to learn whether that was enough (and tops up if not), or --
+//     deferred completion, node_solve_opts.blind_steps -- reads nothing back at all and leaves the verdict in a
+//     device record on which the caller predicates whatever commits results.
 //
 // Algorithm: restated torchdiffeq dopri5 / rk4(3/8) / continuous adjoint, see
 // SURVEY.md 8c and oracle/torchdiffeq_restated.py (the CPU checker).
