@@ -1451,4 +1451,99 @@ void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
   else launch_conv_t<4, 2>(d, a, s);
 }
 
+
+// ============================================================================
+// k_conv3x3_small -- the LATENCY regime (evaluate.py:97-142: bs = 1, NFE per image; small inference batches).
+// The tiles above are sized for throughput: whole samples x 64 columns per workgroup, so that GroupNorm fuses into
+// the epilogue -- at [1, 256, 8, 8] that is a grid of FOUR workgroups and 75 MFLOP on four CUs (>= 36 us per conv
+// from the MFMA rate alone; measured 88 us per function evaluation).  Here the work is cut for parallelism
+// instead: a workgroup owns 32 pixels x 32 output channels (pixels are the flattened (sample, pixel) index, a
+// tile may straddle samples), its four waves split K (a quarter of the input channels x all nine taps each) and
+// meet through LDS once; GroupNorm runs as the pointwise pass behind it (k_combine_gn with an empty Butcher row,
+// as for split images).  Direct convolution: each lane loads ONE float4 of activations (four consecutive input
+// channels of its pixel, taken through a per-tap byte offset that points at the tensor's zero row outside the
+// image -- branch-free) and ONE float4 of filter taps (packed [tap][ci/4][co][4] by k_pack_weights_small), and
+// both feed four v_mfma_f32_32x32x2_f32 (lane half hi supplies channels +4..7).  No LDS in the loop, no barrier.
+// Forward only (inference solves); grids of 64+ workgroups keep the throughput kernels.
+// ============================================================================
+__global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs a, Dims d) {
+  if (a.et.ctrl != nullptr && a.et.ctrl->done) return;
+  __shared__ float red[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int P = d.N * d.HW;
+  const int pix = blockIdx.x * 32 + l31;
+  const int c0 = blockIdx.y * 32;
+  const unsigned zoff = (unsigned)((size_t)P * d.C * sizeof(float));   // the row of C zeros behind the tensor
+  unsigned off[9];
+  {
+    const int pp = pix < P ? pix : 0;
+    const int n = pp / d.HW, q = pp - n * d.HW;
+    const int h = q / d.W, x = q - h * d.W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = h + t / 3 - 1, xx = x + t % 3 - 1;
+      const bool in = pix < P && yy >= 0 && yy < d.H && xx >= 0 && xx < d.W;
+      off[t] = in ? (unsigned)(((size_t)(n * d.HW + yy * d.W + xx) * d.C) * sizeof(float)) : zoff;
+    }
+  }
+  const int C4 = d.C >> 2;
+  const int groups = d.C >> 5;                 // 8-channel groups per wave (a quarter of C / 8)
+  const int g0 = wave * groups;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const char* abase = reinterpret_cast<const char*>(a.in);
+  const float* wbase = a.wpacked + ((size_t)hi * d.C + c0 + l31) * 4;   // + ((tap * C4 + c8 / 4) * C) * 4
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {   // (fully unrolled: off[] stays in registers)
+    const char* ap = abase + off[t] + (size_t)(4 * hi) * sizeof(float);
+    const float* wp = wbase + (size_t)t * C4 * d.C * 4;
+#pragma unroll 4
+    for (int g = 0; g < groups; ++g) {
+      const int c8 = (g0 + g) * 8;
+      const float4 av = *reinterpret_cast<const float4*>(ap + (size_t)c8 * sizeof(float));
+      const float4 bv = *reinterpret_cast<const float4*>(wp + (size_t)(c8 >> 2) * d.C * 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * hi][l31] = acc[r];
+  __syncthreads();
+  const float tval = eval_time(a.et);
+  for (int e = tid; e < 1024; e += 256) {
+    const int r = e >> 5, c = e & 31;
+    const int p = blockIdx.x * 32 + r;
+    if (p >= P || c0 + c >= d.C) continue;
+    const int q = p % d.HW;
+    const float v = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+    a.raw_out[(size_t)p * d.C + c0 + c] = v + a.bias[c0 + c] + tval * a.tmap[(size_t)q * d.C + c0 + c];
+  }
+}
+
+// packed[tap][ci / 4][co][ci % 4] = W[co][1 + ci][kh][kw]   (input channel 0 of the reference's layout is time)
+__global__ __launch_bounds__(256) void k_pack_weights_small(const float* __restrict__ w, float* __restrict__ packed, int C) {
+  const size_t total = (size_t)9 * C * C;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int kk = (int)(idx & 3);
+    size_t r = idx >> 2;
+    const int co = (int)(r % C); r /= C;
+    const int cq = (int)(r % (C >> 2));
+    const int tap = (int)(r / (C >> 2));
+    packed[idx] = w[(((size_t)co * (C + 1) + 1 + cq * 4 + kk) * 3 + tap / 3) * 3 + tap % 3];
+  }
+}
+void launch_pack_weights_small(const Dims& d, const float* w, float* packed, hipStream_t s) {
+  size_t blocks = ((size_t)9 * d.C * d.C + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_pack_weights_small, dim3((unsigned)blocks), dim3(256), 0, s, w, packed, d.C);
+}
+void launch_conv_small(const Dims& d, const ConvArgs& a, hipStream_t s) {
+  const int P = d.N * d.HW;
+  hipLaunchKernelGGL(k_conv3x3_small, dim3((P + 31) / 32, d.C / 32), dim3(256), 0, s, a, d);
+}
+
 }  // namespace node

@@ -149,6 +149,13 @@ static int make_dims(const node_shape* sh, Dims* out) {
   while (d.wino != 2 && d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
   if (conv_lds_bytes(d, 0) > 160 * 1024) return fail(NODE_ERR_UNSUPPORTED, "conv tile does not fit LDS");
   d.mtiles = d.csplit ? d.N * d.csplit : (d.N + d.S - 1) / d.S;
+  {
+    // latency regime: the throughput tiles leave most of the chip idle (bs = 1 at C = 256: four workgroups)
+    static int small_env = -2;   // NODE_TUNE_SMALL = 0 / 1 forces the choice (A/B measurements)
+    if (small_env == -2) { const char* e = getenv("NODE_TUNE_SMALL"); small_env = e ? atoi(e) : -1; }
+    const bool fits = d.C % 32 == 0 && d.C >= 128 && ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32);
+    d.small = fits && (small_env >= 0 ? small_env != 0 : (long)d.mtiles * d.ntile < 32);
+  }
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
   static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels
   if (slab_elems < 0) { const char* e = getenv("NODE_TUNE_SLAB"); slab_elems = e ? atoi(e) : 2048; }
@@ -216,7 +223,8 @@ struct Plan {
   float* tmap[2];
   float *Y, *Y1, *KY[7];
   float *act1, *act2;
-  float* RAW;               // split-conv mode (Dims::csplit): the conv's raw output, consumed by the GroupNorm pass
+  float* RAW;               // split-conv / small mode: the conv's raw output, consumed by the GroupNorm pass
+  float* wsmall[2];         // small mode: filters packed for k_conv3x3_small
   // adjoint
   float *A, *A1, *KA[7];
   float *TH, *TH1, *KT[7];
@@ -263,7 +271,9 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   // conv inputs carry a tail of C zeros: the 2-D Winograd kernel reads its zero halo there
   p.act1 = b.take<float>(d.numel + d.C);
   p.act2 = b.take<float>(d.numel + d.C);
-  if (d.csplit) p.RAW = b.take<float>(d.numel);
+  if (d.csplit || d.small) p.RAW = b.take<float>(d.numel);
+  if (d.small && !adjoint)
+    for (int i = 0; i < 2; ++i) p.wsmall[i] = b.take<float>((size_t)9 * d.C * d.C);
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
     p.A = b.take<float>(d.numel);
@@ -374,6 +384,9 @@ struct Solver {
     return NODE_OK;
   }
 
+  // inference solves on grids the throughput tiles cannot spread over the chip (Dims::small)
+  bool small_mode() const { return d.small && !aug && p.wsmall[0] != nullptr; }
+
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
     if (aug)   // stage-2 parameter derivative: read with weight zero by the error norm / dense output, never written
@@ -381,7 +394,11 @@ struct Solver {
       HIP_TRY(hipMemsetAsync(p.KT[1], 0, d.P * sizeof(float), st));
     if (aug)   // arrival counter of k_theta_finalize
       HIP_TRY(hipMemsetAsync(p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64), 0, sizeof(unsigned), st));
-    if (d.wino == 2 || d.wgrad_wino == 2) {   // zero tails of the conv inputs (see make_plan)
+    if (small_mode()) {
+      launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
+      launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
+    }
+    if (d.wino == 2 || d.wgrad_wino == 2 || small_mode()) {   // zero tails of the conv inputs (see make_plan)
       HIP_TRY(hipMemsetAsync(p.act1 + d.numel, 0, d.C * sizeof(float), st));
       HIP_TRY(hipMemsetAsync(p.act2 + d.numel, 0, d.C * sizeof(float), st));
       if (aug) {
@@ -453,17 +470,19 @@ struct Solver {
     c1.bias = prm.conv1_b; c1.tmap = p.tmap[0]; c1.et = et;
     c1.gamma = prm.norm2_w; c1.beta = prm.norm2_b; c1.osign = 1.f;
     c1.out = p.act2; c1.xhat_out = train ? p.xh2 : nullptr; c1.rstd_out = train ? p.r2 : nullptr;
-    c1.raw_out = d.csplit ? p.RAW : nullptr;
-    { ProfScope ps(0, conv_flops(), st); launch_conv(d, c1, st); }
-    if (d.csplit) gn_pass_fwd(prm.norm2_w, prm.norm2_b, 1, 1.f, p.act2, train ? p.xh2 : nullptr, train ? p.r2 : nullptr);
+    const bool small = small_mode() && !train;
+    c1.raw_out = (d.csplit || small) ? p.RAW : nullptr;
+    if (small) c1.wpacked = p.wsmall[0];
+    { ProfScope ps(0, conv_flops(), st); if (small) launch_conv_small(d, c1, st); else launch_conv(d, c1, st); }
+    if (d.csplit || small) gn_pass_fwd(prm.norm2_w, prm.norm2_b, 1, 1.f, p.act2, train ? p.xh2 : nullptr, train ? p.r2 : nullptr);
 
     ConvArgs c2 = c1;
-    c2.in = p.act2; c2.wpacked = p.wf[1]; c2.mode = CM_FWD_GN;
+    c2.in = p.act2; c2.wpacked = small ? p.wsmall[1] : p.wf[1]; c2.mode = CM_FWD_GN;
     c2.bias = prm.conv2_b; c2.tmap = p.tmap[1];
     c2.gamma = prm.norm3_w; c2.beta = prm.norm3_b; c2.osign = et.tsign;
     c2.out = k_out; c2.xhat_out = train ? p.xh3 : nullptr; c2.rstd_out = train ? p.r3 : nullptr;
-    { ProfScope ps(0, conv_flops(), st); launch_conv(d, c2, st); }
-    if (d.csplit) gn_pass_fwd(prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr, train ? p.r3 : nullptr);
+    { ProfScope ps(0, conv_flops(), st); if (small) launch_conv_small(d, c2, st); else launch_conv(d, c2, st); }
+    if (d.csplit || small) gn_pass_fwd(prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr, train ? p.r3 : nullptr);
     if (count_nfe) nfe += 1;
     return check_launch("odefunc forward");
   }

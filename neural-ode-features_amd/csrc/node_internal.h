@@ -27,6 +27,8 @@ struct Dims {
   int wino;            // conv kernel: 0 direct, 1 Winograd F(2,3) along the rows (even W), 2 Winograd F(2x2,3x3) (even H, W; 128-pixel tiles)
   int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
+  int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
+                    // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
   int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
                     // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)
   int mtiles;          // ceil(N / S)
@@ -338,6 +340,8 @@ size_t conv_lds_bytes(const Dims& d, int mode);
 size_t conv_packed_elems(const Dims& d);
 void launch_pack_weights_w(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
 void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
+void launch_pack_weights_small(const Dims& d, const float* w, float* packed /*[9][C/4][C][4]*/, hipStream_t s);
+void launch_conv_small(const Dims& d, const ConvArgs& a, hipStream_t s);   // forward only; a.raw_out, a.wpacked = small packing
 
 struct WgradArgs {
   const float* act;       // [N,HW,C] conv input activation

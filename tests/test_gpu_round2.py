@@ -431,3 +431,29 @@ def test_device_loop_reports_non_finite_and_underflow():
             nof.odeint(f, y, t, rtol=1e-9, atol=1e-9, options={'max_num_steps': 3})
     out2 = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('shape', [(1, 256, 8, 8), (3, 128, 7, 7), (1, 256, 16, 16), (5, 160, 6, 6), (2, 1024, 4, 4)])
+def test_latency_regime_small_grid_kernel(shape):
+    """Inference on grids the throughput tiles cannot spread over the chip (bs = 1 census, evaluate.py:97-142) runs
+    k_conv3x3_small (32 pixels x 32 columns per workgroup, four-way split K, GroupNorm as a pass): one evaluation and a
+    whole forward solve against the oracle; the adjoint of the same shapes keeps the throughput kernels and must
+    agree with the same forward values."""
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=131, device='cuda')
+    gen = torch.Generator().manual_seed(132)
+    y = torch.randn(N, C, H, W, generator=gen)
+    got = nof.odefunc_forward(f, 0.7, y.cuda())
+    from oracle.dynamics import odefunc_forward as oracle_f
+    want = oracle_f(torch.tensor(0.7), y, dict(twin.named_parameters()))
+    print(shape, 'f rel err', rel_err(got, want))
+    assert rel_err(got, want) < 2e-5
+    t = torch.tensor([0.0, 0.4, 1.0])
+    with torch.no_grad():
+        out = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5')
+        ref = tdq.odeint(twin, y, t, rtol=1e-3, atol=1e-3, method='dopri5')
+    assert float((out.cpu() - ref).abs().max()) <= 1e-2 and rel_err(out, ref) < 1e-3
+    # the VJP entry point evaluates f with the throughput kernels (training path): same function
+    fo, _, _, _ = nof.odefunc_vjp(f, 0.7, y.cuda(), torch.ones_like(y).cuda())
+    assert rel_err(fo, got) < 2e-5
