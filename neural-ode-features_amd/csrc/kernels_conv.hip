@@ -1464,7 +1464,7 @@ void launch_conv(const Dims& d, const ConvArgs& a, hipStream_t s) {
 // channels of its pixel, taken through a per-tap byte offset that points at the tensor's zero row outside the
 // image -- branch-free) and ONE float4 of filter taps (packed [tap][ci/4][co][4] by k_pack_weights_small), and
 // both feed four v_mfma_f32_32x32x2_f32 (lane half hi supplies channels +4..7).  No LDS in the loop, no barrier.
-// Forward only (inference solves); grids of 64+ workgroups keep the throughput kernels.
+// Forward only (inference solves); used for single-digit grids only (Dims::small: measured crossover).
 // ============================================================================
 __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs a, Dims d) {
   if (a.et.ctrl != nullptr && a.et.ctrl->done) return;

@@ -154,7 +154,10 @@ static int make_dims(const node_shape* sh, Dims* out) {
     static int small_env = -2;   // NODE_TUNE_SMALL = 0 / 1 forces the choice (A/B measurements)
     if (small_env == -2) { const char* e = getenv("NODE_TUNE_SMALL"); small_env = e ? atoi(e) : -1; }
     const bool fits = d.C % 32 == 0 && d.C >= 128 && ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32);
-    d.small = fits && (small_env >= 0 ? small_env != 0 : (long)d.mtiles * d.ntile < 32);
+    // measured at C = 256, 8x8 (tools/latency_bs1.py, us per function evaluation, small / throughput tiles): bs 1: 74.7 /
+    // 87.6, bs 4: 99.3 / 90.8, bs 16: 99.3 / 93.0 -- the extra GroupNorm launches cost more than the parallelism
+    // buys as soon as the throughput grid has eight workgroups, so only single-digit grids take the small kernel
+    d.small = fits && (small_env >= 0 ? small_env != 0 : (long)d.mtiles * d.ntile < 8);
   }
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
   static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels

@@ -438,7 +438,8 @@ def test_latency_regime_small_grid_kernel(shape):
     """Inference on grids the throughput tiles cannot spread over the chip (bs = 1 census, evaluate.py:97-142) runs
     k_conv3x3_small (32 pixels x 32 columns per workgroup, four-way split K, GroupNorm as a pass): one evaluation and a
     whole forward solve against the oracle; the adjoint of the same shapes keeps the throughput kernels and must
-    agree with the same forward values."""
+    agree with the same forward values.  (The library picks the small kernel for grids under eight workgroups; the
+    larger shapes here run whatever it picks -- the assertion is the same.)"""
     import neural_ode_features_amd as nof
     N, C, H, W = shape
     f, twin = make_func(C, seed=131, device='cuda')
