@@ -172,3 +172,52 @@ def test_reference_model_py_runs_on_top_of_the_package_unchanged():
             sys.modules['torchdiffeq'] = saved
         else:
             sys.modules.pop('torchdiffeq', None)
+
+
+def test_header_is_plain_c_and_ctypes_layouts_match(tmp_path):
+    """include/node_hip.h must compile as C (it is the drop-in boundary: no C++ / torch types), and every struct the
+    ctypes binding mirrors must have the size and field offsets the C compiler gives it."""
+    import ctypes as C
+    import subprocess
+    from neural_ode_features_amd import _lib
+    structs = {
+        'node_shape': (_lib.NodeShape, ['n', 'c', 'h', 'w', 'groups', 'eps']),
+        'node_params': (_lib.NodeParams, ['norm1_w', 'conv1_w', 'norm3_b']),
+        'node_stats': (_lib.NodeStats, ['nfe', 'status', 'last_dt', 't_final', 'first_dt']),
+        'node_solve_opts': (_lib.NodeSolveOpts, ['max_num_steps', 'n_forced_dt', 'forced_dt', 'record_dt', 'dt_log', 'n_dt_log',
+                                                 'blind_steps', 'record', 'miss_flag']),
+        'node_step_record': (_lib.NodeStepRecord, ['done', 'status', 'steps', 'accepted', 'rejected', 'miss', 't', 'dt', 'first_dt']),
+        'node_sgd_tensor': (_lib.NodeSgdTensor, ['param', 'grad', 'momentum_buf', 'n']),
+        'node_profile': (_lib.NodeProfile, ['launches', 'total_ms', 'flops']),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "node_hip.h"', 'int main(void) {']
+    for name, (_, fields) in structs.items():
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'abi.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'abi'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, (ct, fields) in structs.items():
+        assert int(got[name]) == C.sizeof(ct), name
+        for f in fields:
+            assert int(got['%s.%s' % (name, f)]) == getattr(ct, f).offset, (name, f)
+
+
+def test_optimizer_and_training_loop_refuse_the_cpu():
+    import neural_ode_features_amd as nof
+    lin = torch.nn.Linear(3, 2)
+    opt = nof.FusedSGD(lin.parameters(), lr=0.1, momentum=0.9)
+    lin(torch.ones(1, 3)).sum().backward()
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        opt.step()
+    # torch.optim.SGD's state layout / scheduler surface without touching a device
+    assert opt.state_dict()['param_groups'][0]['momentum'] == 0.9
+    torch.optim.lr_scheduler.CosineAnnealingLR(opt, 4)
+    if not torch.cuda.is_available():
+        from neural_ode_features_amd import train as T
+        with pytest.raises(SystemExit):
+            T.main(['--dataset', 'mnist', '-e', '1', '--run-dir', '/tmp/never_created_run_dir_node'])
