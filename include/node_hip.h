@@ -102,8 +102,9 @@ typedef struct node_stats {
 } node_stats;
 
 /* What a solve that was enqueued WITHOUT a final synchronisation (node_solve_opts.blind_steps) leaves in device
- * memory, written on the stream behind its last step.  `miss` != 0: the steps enqueued were not exactly the steps
- * the solve needed (unfinished, finished early, or stopped with `status`), i.e. its outputs must not be used. */
+ * memory, written on the stream behind its last step.  `steps` = steps actually tried (steps enqueued past the end
+ * of the interval return at once).  `miss` != 0: the steps enqueued did not finish the interval, or it stopped with
+ * `status` -- its outputs must not be used. */
 typedef struct node_step_record {
   int32_t done, status, steps, accepted, rejected, miss;
   double t, dt, first_dt;
@@ -121,7 +122,8 @@ typedef struct node_solve_opts {
    * WITHOUT SYNCHRONISING.  The caller keeps its queue fed across the solve and learns the outcome later from
    * `record` (device memory, filled on the stream); `miss_flag` (device float, nullable) is incremented when the
    * record says miss, so that work which commits results (node_sgd_step's skip flag) can be predicated on the
-   * device.  stats then hold the PREDICTED counts (nfe = 2 + 6 blind_steps ...), status NODE_PENDING. */
+   * device.  stats then hold the counts as if all `blind_steps` had been needed (nfe = 2 + 6 blind_steps ...),
+   * status NODE_PENDING; the true step count is in `record` (steps past the end of the interval return at once). */
   int32_t blind_steps;
   node_step_record* record; /* device */
   float* miss_flag;         /* device, nullable */

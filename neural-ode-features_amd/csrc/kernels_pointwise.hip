@@ -710,9 +710,10 @@ void launch_set_target(double* targets, double t_end, hipStream_t s) {
   hipLaunchKernelGGL(k_set_target, dim3(1), dim3(1), 0, s, targets, t_end);
 }
 // Deferred completion: what the host would have read back, left in the caller's device record; a miss (the steps
-// enqueued were not exactly the steps needed) also bumps the caller's flag, on which the optimizer step is predicated.
+// enqueued did not finish the interval, or it stopped with a status) also bumps the caller's flag, on which the
+// optimizer step is predicated.
 __global__ void k_export_record(const Ctrl* c, node_step_record* r, float* miss_flag, int expect) {
-  const int miss = !(c->done && c->status == 0 && c->step_idx == expect);
+  const int miss = !(c->done && c->status == 0 && c->step_idx <= expect);   // (steps past the end did nothing)
   r->done = c->done; r->status = c->status; r->steps = c->step_idx; r->accepted = c->n_acc; r->rejected = c->n_rej;
   r->miss = miss; r->t = c->t; r->dt = c->dt; r->first_dt = c->first_dt;
   if (miss && miss_flag != nullptr) *miss_flag += 1.f;

@@ -313,8 +313,9 @@ class Deferred:
     error status) bumps the device flag `miss_flag`.  Nothing that commits results may run unconditionally:
     `optim.FusedSGD.skip_flag = deferred.miss_flag` predicates the parameter update on the device, so a step with a
     miss changes nothing (under data parallelism the flag rides in the reducer's last bucket, so every rank skips
-    together).  The host looks at a record one iteration later, when it is long complete: a miss makes the next
-    solve of that kind run with a read-back again and re-learn its step count.
+    together).  The host looks at a record one iteration later, when it is long complete: the true step count in it
+    becomes the next guess; a miss makes the next solve of that kind run with a read-back again.  While a solve's
+    count is still moving one spare step is enqueued, so only a count that jumps by two or more is a miss.
 
         deferred = integrate.Deferred(device)        # opt-in; the drop-in API is unaffected while none is active
         opt.skip_flag = deferred.miss_flag
@@ -324,14 +325,17 @@ class Deferred:
                 loss = F.cross_entropy(model(x), y); loss.backward(); opt.step(); opt.zero_grad()
         deferred.misses                              # steps whose update was skipped
 
-    Counts reported through `func.nfe` / `last_*_stats` are the predicted ones (exact unless the step was a miss)."""
+    `func.nfe` advances by the predicted count at once and is corrected when the record is read (sums over an
+    epoch are exact); `last_*_stats` of a deferred solve hold the prediction."""
 
     active = None      # the instance whose `with` block is open
+    CALM = 20          # exact predictions in a row after which no spare step is enqueued any more
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.miss_flag = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.guess: Dict[tuple, Optional[int]] = {}
+        self.calm: Dict[tuple, int] = {}          # consecutive solves of a key whose step count equalled the guess
         self.pending: Dict[tuple, tuple] = {}
         self.records: Dict[tuple, tuple] = {}
         self.misses = 0
@@ -357,32 +361,46 @@ class Deferred:
             self.records[key] = b
         return b
 
-    def plan(self, key):
-        """Steps to enqueue blind for `key`, or None for a solve with a read-back.  Looks at the record the previous
-        blind solve of this key left (one iteration old: complete)."""
+    def plan(self, key, func=None):
+        """Steps to enqueue blind for `key`, or None for a solve with a read-back.  Looks first at the record the
+        previous blind solve of this key left (one iteration old: complete): its true step count becomes the new
+        guess (and corrects `func.nfe`, which was advanced by the guess), a miss sends the next solve back to a
+        read-back.  While a key's count is still moving, ONE spare step is enqueued (a step past the end of the
+        interval returns at once on the device: ~0.1 ms of launches) so that a count that grows by one is no miss."""
         pend = self.pending.pop(key, None)
         if pend is not None:
+            guessed, = pend
             dev, host, event = self._buffers(key)
             event.synchronize()
             r = _lib.NodeStepRecord.from_buffer_copy(bytes(host.numpy().tobytes()))
             if r.miss:
                 self.misses += 1
                 self.guess[key] = None
-        return self.guess.get(key)
+                self.calm[key] = 0
+            else:
+                if func is not None and r.steps != guessed:
+                    func.nfe = getattr(func, 'nfe', 0) + 6 * (r.steps - guessed)    # late, but sums stay exact
+                self.calm[key] = self.calm.get(key, 0) + 1 if r.steps == guessed else 0
+                self.guess[key] = int(r.steps)
+        g = self.guess.get(key)
+        if not g:
+            return None
+        return g, g + (0 if self.calm.get(key, 0) >= self.CALM else 1)
 
-    def blind_args(self, key, steps):
+    def blind_args(self, key, enqueue):
         dev, _, _ = self._buffers(key)
-        return (steps, dev, self.miss_flag)
+        return (enqueue, dev, self.miss_flag)
 
-    def launched(self, key, steps):
+    def launched(self, key, guessed):
         dev, host, event = self._buffers(key)
         host.copy_(dev, non_blocking=True)
         event.record(torch.cuda.current_stream(self.device))
-        self.pending[key] = (steps,)
+        self.pending[key] = (guessed,)
         self.blind_solves += 1
 
     def learned(self, key, steps):
         self.guess[key] = int(steps)
+        self.calm[key] = 0
 
     def resolve(self):
         """Wait for every outstanding record (a synchronisation point) and count the misses."""
@@ -407,10 +425,12 @@ class _HipOdeint(torch.autograd.Function):
         if d is not None and d.device != y0.device:
             d = None
         dkey = ('fwd', id(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None
-        steps = d.plan(dkey) if d is not None else None
+        steps = d.plan(dkey, func) if d is not None else None
         if steps:
-            out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options, blind=d.blind_args(dkey, steps))
-            d.launched(dkey, steps)
+            out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options, blind=d.blind_args(dkey, steps[1]))
+            st['nfe'] -= 6 * (steps[1] - steps[0])      # advance the counter by the guess; the record corrects it
+            st['accepted'] = steps[0]
+            d.launched(dkey, steps[0])
         else:
             out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
             if d is not None:
@@ -437,11 +457,13 @@ class _HipOdeint(torch.autograd.Function):
             if d is not None and d.device != out.device:
                 d = None
             dkey = ('bwd', id(ctx.func), tuple(out.shape[1:]), ctx.rtol, ctx.atol, tuple(ctx.times)) if d is not None else None
-            steps = d.plan(dkey) if d is not None else None
+            steps = d.plan(dkey, ctx.func) if d is not None else None
             if steps:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
-                                               ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps))
-                d.launched(dkey, steps)
+                                               ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps[1]))
+                st['nfe'] -= 6 * (steps[1] - steps[0])
+                st['accepted'] = steps[0]
+                d.launched(dkey, steps[0])
             else:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
                                                ctx.method_id, ctx.options)

@@ -46,7 +46,8 @@ def test_deferred_steps_equal_synchronous_steps():
         ob.step()
         ob.zero_grad()
         losses_b.append(lb)
-    assert d.resolve() == 0 and d.blind_solves == 6          # iterations 2..4: forward + adjoint each
+    assert d.resolve() == 0 and d.blind_solves == 6          # iterations 2..4: forward + adjoint each (one spare
+                                                             # step enqueued each time: the counts are still young)
     for la, lb in zip(losses_a, losses_b):
         assert float(la) == float(lb)
     for p, q in zip(a.parameters(), b.parameters()):
@@ -55,9 +56,10 @@ def test_deferred_steps_equal_synchronous_steps():
 
 
 def test_deferred_miss_commits_nothing_and_relearns():
-    """A solve that needs more (or fewer) steps than the previous iteration took is a MISS: the device flag goes up,
-    the optimizer step of that iteration leaves parameters and momentum untouched, and the next solve of that kind
-    runs with a read-back again and re-learns its step count."""
+    """A solve that does not finish within the steps enqueued (the previous count + one spare while counts are young)
+    is a MISS: the device flag goes up, the optimizer step of that iteration leaves parameters and momentum untouched,
+    and the next solve of that kind runs with a read-back again and re-learns its step count.  Fewer steps than
+    guessed is no miss: the surplus steps do nothing, the record carries the true count and corrects `nfe`."""
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
     blk = _block()
@@ -97,6 +99,16 @@ def test_deferred_miss_commits_nothing_and_relearns():
         p5 = step(hard)                  # blind with the new counts, exact
         assert d.blind_solves == before + 2 and d.resolve() == d.misses
         assert any(not torch.equal(a, b) for a, b in zip(p4, p5))
+        # back to the easy input: FEWER steps than guessed -> no miss, the update is committed, and nfe is
+        # corrected by the record to what a synchronous solve counts
+        misses = d.misses
+        blk.nfe = 0
+        p6 = step(easy)
+        d.resolve()
+        assert d.misses == misses and any(not torch.equal(a, b) for a, b in zip(p5, p6))
+        true_counts = {k[0]: v for k, v in d.guess.items()}          # from the records: steps actually tried
+        assert blk.nfe == (2 + 6 * true_counts['fwd']) + (3 + 6 * true_counts['bwd'])
+        assert true_counts['fwd'] < steps_hard[0] or true_counts['bwd'] < steps_hard[1]
     for p in p5:
         assert bool(torch.isfinite(p).all())
 
