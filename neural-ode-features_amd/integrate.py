@@ -329,7 +329,7 @@ class Deferred:
     epoch are exact); `last_*_stats` of a deferred solve hold the prediction."""
 
     active = None      # the instance whose `with` block is open
-    CALM = 20          # exact predictions in a row after which no spare step is enqueued any more
+    CALM = 8           # exact predictions in a row after which no spare step is enqueued any more
 
     def __init__(self, device):
         self.device = torch.device(device)
