@@ -85,6 +85,7 @@ def test_deferred_miss_commits_nothing_and_relearns():
         p2 = step(easy)                  # blind again (records consumed by resolve(): still known good)
         steps_easy = (blk.odefunc.last_forward_stats['accepted'], blk.odefunc.last_backward_stats['accepted'])
         assert any(not torch.equal(a, b) for a, b in zip(p1, p2))
+        d.resolve()                      # consume the records of the step above (they would refresh the guesses)
         for k in d.guess:                # make the miss certain whatever the two inputs need: one step, no spare
             d.guess[k] = 1
             d.calm[k] = d.CALM
