@@ -103,15 +103,20 @@ def test_deferred_miss_commits_nothing_and_relearns():
         p5 = step(hard)                  # blind with the new counts, exact
         assert d.blind_solves == before + 2 and d.resolve() == d.misses
         assert any(not torch.equal(a, b) for a, b in zip(p4, p5))
-        # back to the easy input: FEWER steps than guessed -> no miss, the update is committed, and nfe is
-        # corrected by the record to what a synchronous solve counts
+        # MORE steps enqueued than needed is no miss: the surplus does nothing on the device, the update is committed,
+        # and nfe is corrected by the record to what a synchronous solve counts
+        d.resolve()
+        truth = {k: v for k, v in d.guess.items()}
+        for k in d.guess:
+            d.guess[k] = truth[k] + 3
         misses = d.misses
         blk.nfe = 0
-        p6 = step(easy)
+        p6 = step(hard)
         d.resolve()
         assert d.misses == misses and any(not torch.equal(a, b) for a, b in zip(p5, p6))
-        true_counts = {k[0]: v for k, v in d.guess.items()}          # from the records: steps actually tried
-        assert blk.nfe == (2 + 6 * true_counts['fwd']) + (3 + 6 * true_counts['bwd'])
+        counts = {k[0]: v for k, v in d.guess.items()}               # from the records: steps actually tried
+        assert blk.nfe == (2 + 6 * counts['fwd']) + (3 + 6 * counts['bwd'])
+        assert all(abs(d.guess[k] - truth[k]) <= 1 for k in truth)    # the guesses came back down
     for p in p5:
         assert bool(torch.isfinite(p).all())
 
