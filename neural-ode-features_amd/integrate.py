@@ -369,7 +369,9 @@ class Deferred:
         interval returns at once on the device: ~0.1 ms of launches) so that a count that grows by one is no miss."""
         pend = self.pending.pop(key, None)
         if pend is not None:
-            guessed, = pend
+            guessed, fref = pend
+            if func is None and fref is not None:
+                func = fref()
             dev, host, event = self._buffers(key)
             event.synchronize()
             r = _lib.NodeStepRecord.from_buffer_copy(bytes(host.numpy().tobytes()))
@@ -391,11 +393,11 @@ class Deferred:
         dev, _, _ = self._buffers(key)
         return (enqueue, dev, self.miss_flag)
 
-    def launched(self, key, guessed):
+    def launched(self, key, guessed, func=None):
         dev, host, event = self._buffers(key)
         host.copy_(dev, non_blocking=True)
         event.record(torch.cuda.current_stream(self.device))
-        self.pending[key] = (guessed,)
+        self.pending[key] = (guessed, weakref.ref(func) if func is not None else None)
         self.blind_solves += 1
 
     def learned(self, key, steps):
@@ -430,7 +432,7 @@ class _HipOdeint(torch.autograd.Function):
             out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options, blind=d.blind_args(dkey, steps[1]))
             st['nfe'] -= 6 * (steps[1] - steps[0])      # advance the counter by the guess; the record corrects it
             st['accepted'] = steps[0]
-            d.launched(dkey, steps[0])
+            d.launched(dkey, steps[0], func)
         else:
             out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options)
             if d is not None:
@@ -463,7 +465,7 @@ class _HipOdeint(torch.autograd.Function):
                                                ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps[1]))
                 st['nfe'] -= 6 * (steps[1] - steps[0])
                 st['accepted'] = steps[0]
-                d.launched(dkey, steps[0])
+                d.launched(dkey, steps[0], ctx.func)
             else:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
                                                ctx.method_id, ctx.options)
