@@ -340,6 +340,7 @@ class Deferred:
         self.records: Dict[tuple, tuple] = {}
         self.misses = 0
         self.blind_solves = 0
+        self.armed = False         # set by FusedSGD.use_deferred: without a predicated commit point nothing runs blind
 
     def __enter__(self):
         Deferred.active = self
@@ -385,7 +386,7 @@ class Deferred:
                 self.calm[key] = self.calm.get(key, 0) + 1 if r.steps == guessed else 0
                 self.guess[key] = int(r.steps)
         g = self.guess.get(key)
-        if not g:
+        if not g or not self.armed:
             return None
         return g, g + (0 if self.calm.get(key, 0) >= self.CALM else 1)
 
@@ -423,7 +424,11 @@ class _HipOdeint(torch.autograd.Function):
         if not adjoint and (y0.requires_grad or any(p.requires_grad for p in params)):
             options = dict(options or {})          # the backward replays the accepted steps: log their sizes
             options['record_dt'] = max(int(options.get('record_dt', 0) or 0), BACKPROP_LOG)
-        d = Deferred.active if (adjoint and method_id == _lib.METHOD_DOPRI5 and len(times) == 2 and not options) else None
+        # deferred completion only where a predicated commit point follows: training solves (a gradient is wanted)
+        # inside an armed `Deferred` scope; inference, sweeps and the drop-in API always return finished solves
+        wants_grad = y0.requires_grad or any(p.requires_grad for p in params)
+        d = Deferred.active if (adjoint and wants_grad and method_id == _lib.METHOD_DOPRI5 and len(times) == 2
+                                and not options) else None
         if d is not None and d.device != y0.device:
             d = None
         dkey = ('fwd', id(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None

@@ -94,3 +94,4 @@ class FusedSGD(torch.optim.Optimizer):
         else:
             self.skip_flag = deferred.miss_flag
         self.flags_to_reset = [deferred.miss_flag]
+        deferred.armed = True

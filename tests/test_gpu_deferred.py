@@ -121,13 +121,32 @@ def test_deferred_miss_commits_nothing_and_relearns():
         assert bool(torch.isfinite(p).all())
 
 
-def test_drop_in_api_is_unaffected_without_an_active_deferred():
+def test_nothing_runs_blind_without_a_predicated_commit_point():
+    """Inference inside a deferred scope, a scope no optimizer was armed with, and the plain drop-in API all return
+    finished solves with measured statistics."""
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
     blk = _block()
     x = torch.randn(2, 32, 8, 8).cuda()
     assert integrate.Deferred.active is None
+
+    def finished():
+        st = blk.odefunc.last_forward_stats
+        return st['status'] == 0 and st['nfe'] == 2 + 6 * (st['accepted'] + st['rejected'])
+
     with torch.no_grad():
         blk(x)
-    st = blk.odefunc.last_forward_stats
-    assert st['status'] == 0 and st['nfe'] == 2 + 6 * (st['accepted'] + st['rejected'])
+    assert finished()
+    d = integrate.Deferred(x.device)
+    with d:                                   # not armed: no optimizer predicates its step on the flag
+        for _ in range(3):
+            blk(x.clone().requires_grad_(True)).sum().backward()
+            assert finished() and blk.odefunc.last_backward_stats['status'] == 0
+    opt = nof.FusedSGD(blk.parameters(), lr=1e-3)
+    opt.use_deferred(d)
+    with d:
+        for _ in range(3):                    # armed, but inference: nothing commits, so nothing is deferred
+            with torch.no_grad():
+                blk(x)
+            assert finished()
+    assert d.blind_solves == 0
