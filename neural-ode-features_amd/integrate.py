@@ -420,13 +420,12 @@ class _HipOdeint(torch.autograd.Function):
     (continuous adjoint, what `odeint_adjoint` does upstream)."""
 
     @staticmethod
-    def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, y0, *params):
-        if not adjoint and (y0.requires_grad or any(p.requires_grad for p in params)):
+    def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, wants_grad, y0, *params):
+        if not adjoint and wants_grad:
             options = dict(options or {})          # the backward replays the accepted steps: log their sizes
             options['record_dt'] = max(int(options.get('record_dt', 0) or 0), BACKPROP_LOG)
         # deferred completion only where a predicated commit point follows: training solves (a gradient is wanted)
         # inside an armed `Deferred` scope; inference, sweeps and the drop-in API always return finished solves
-        wants_grad = y0.requires_grad or any(p.requires_grad for p in params)
         d = Deferred.active if (adjoint and wants_grad and method_id == _lib.METHOD_DOPRI5 and len(times) == 2
                                 and not options) else None
         if d is not None and d.device != y0.device:
@@ -489,7 +488,7 @@ class _HipOdeint(torch.autograd.Function):
             n = p.numel()
             grads.append(gp[off:off + n].view_as(p))
             off += n
-        return (None, None, None, None, None, None, None, None, gy0, *grads)
+        return (None, None, None, None, None, None, None, None, None, gy0, *grads)
 
 
 def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
@@ -503,7 +502,9 @@ def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
     dec = all(b < a for a, b in zip(times[:-1], times[1:]))
     if not (inc or dec):
         raise ValueError('t must be strictly increasing or strictly decreasing')
-    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, y0, *rec.params)
+    # (grad mode is off inside autograd.Function.forward: whether a gradient will be wanted is decided here)
+    wants_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in rec.params))
+    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, wants_grad, y0, *rec.params)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
