@@ -1499,7 +1499,6 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs a, Dims d) {
   for (int t = 0; t < 9; ++t) {   // (fully unrolled: off[] stays in registers)
     const char* ap = abase + off[t] + (size_t)(4 * hi) * sizeof(float);
     const float* wp = wbase + (size_t)t * C4 * d.C * 4;
-#pragma unroll 4
     for (int g = 0; g < groups; ++g) {
       const int c8 = (g0 + g) * 8;
       const float4 av = *reinterpret_cast<const float4*>(ap + (size_t)c8 * sizeof(float));

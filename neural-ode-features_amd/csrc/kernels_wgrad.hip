@@ -404,6 +404,7 @@ constexpr int WG2_THREADS = 512;
 template <int UT>
 __global__ __launch_bounds__(WG2_THREADS) void k_wgrad_w2(WgradArgs a, Dims d) {
   if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  if (blockIdx.z != 0) { a.act = a.act2; a.dz = a.dz2; a.wpart = a.wpart2; }   // second layer of a paired launch
 
   WSTAMP(a.stamps, 0, "s_memrealtime");
   WSTAMP(a.stamps, 1, "s_memtime");
@@ -977,8 +978,9 @@ void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s) {
   const dim3 grid(ntc * ntc, d.nsplit);
   const size_t lds = wgrad_lds_bytes(d);
   if (d.wgrad_wino == 2) {   // 2-D Winograd domain (make_dims sets wut)
-    if (d.wut == 8) { launch_wgrad_w2<8>(d, a, grid, s); return; }
-    if (d.wut == 4) { launch_wgrad_w2<4>(d, a, grid, s); return; }
+    const dim3 grid2(ntc * ntc, d.nsplit, a.act2 != nullptr ? 2 : 1);
+    if (d.wut == 8) { launch_wgrad_w2<8>(d, a, grid2, s); return; }
+    if (d.wut == 4) { launch_wgrad_w2<4>(d, a, grid2, s); return; }
   }
   if (d.wgrad_wino == 1) {   // 1-D Winograd-domain accumulation, ordinary nine-tap slabs (make_dims sets RB)
     if (d.W == 8 && d.RB == 8) { launch_wgrad_w<8, 8>(d, a, grid, s); return; }

@@ -196,7 +196,12 @@ static int make_dims(const node_shape* sh, Dims* out) {
   {
     const int U = d.wgrad_wino == 2 ? d.N * ((d.H / 2) * (d.W / 2) / d.wut) : d.N * d.nbands;
     const int ntc = (d.C + 63) / 64;
-    int ns = 256 / (ntc * ntc);   // one workgroup per CU (307 VGPR+AGPR: one wave per SIMD)
+    // both conv layers' weight gradients go out in ONE launch where the 2-D Winograd kernel serves them
+    // (NODE_TUNE_WGRAD_PAIR=0: two launches with twice the splits each, the round-1 arrangement)
+    static int pair_env = -2;
+    if (pair_env == -2) { const char* e = getenv("NODE_TUNE_WGRAD_PAIR"); pair_env = e ? atoi(e) : 1; }
+    d.wgrad_pair = (d.wgrad_wino == 2 && pair_env != 0) ? 1 : 0;
+    int ns = (d.wgrad_pair ? 128 : 256) / (ntc * ntc);   // one workgroup per CU (307 VGPR+AGPR: one wave per SIMD)
     if (ns < 1) ns = 1;
     if (ns > 32) ns = 32;
     if (ns > U) ns = U;
@@ -511,7 +516,7 @@ struct Solver {
     launch_gn_bwd(d, g, st);
     if (!fuse_colsum) launch_colsum(d, p.dz2, p.spart[1], st);
 
-    if (need_theta) {
+    if (need_theta && !d.wgrad_pair) {
       WgradArgs w2;
       memset(&w2, 0, sizeof(w2));
       w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1]; w2.ctrl = p.ctrl;
@@ -529,11 +534,12 @@ struct Solver {
     if (d.csplit) gn_pass_bwd(p.act2, p.xh2, p.r2, prm.norm2_w, 1.f, p.dz1, p.gpart[1], fuse_colsum ? p.spart[0] : nullptr);
     if (!fuse_colsum) launch_colsum(d, p.dz1, p.spart[0], st);
 
-    if (need_theta) {
+    if (need_theta) {   // dz1 exists now: with pairing, conv2's weight gradient rides in the same launch (grid.z = 1)
       WgradArgs w1;
       memset(&w1, 0, sizeof(w1));
       w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.ctrl = p.ctrl;
-      { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w1, st); }
+      if (d.wgrad_pair) { w1.act2 = p.act2; w1.dz2 = p.dz2; w1.wpart2 = p.wpart[1]; }
+      { ProfScope ps(1, (d.wgrad_pair ? 2.0 : 1.0) * conv_flops(), st); launch_wgrad(d, w1, st); }
     }
 
     ConvArgs b1 = b2;

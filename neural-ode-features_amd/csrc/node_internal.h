@@ -39,6 +39,7 @@ struct Dims {
   int RB;              // image rows per staging band
   int nbands;          // bands per sample
   int nsplit;          // K-split factor
+  int wgrad_pair;      // both layers' weight gradients in one k_wgrad_w2 launch (nsplit then fills the chip with two problems)
   size_t P;            // flat parameter count
   size_t numel;        // N*C*H*W
 };
@@ -349,6 +350,12 @@ struct WgradArgs {
   const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done (see Ctrl)
   float* wpart;           // [nsplit][9][C][C]
   unsigned long long* stamps;  // diagnostics only (NODE_STAMPS builds)
+  // second problem of the same geometry served by the same launch (grid.z = 1): the two conv layers of an augmented
+  // evaluation go out together, each with HALF the K splits (Dims::wgrad_pair) -- twice the K loop per workgroup,
+  // half the slab bytes, one launch boundary less.  nullptr: single problem.  k_wgrad_w2 only.
+  const float* act2;
+  const float* dz2;
+  float* wpart2;
 };
 void launch_wgrad(const Dims& d, const WgradArgs& a, hipStream_t s);
 // masked column sums of dz per sample: spart[N][9][C] (conv-bias / time-channel-weight / d-dt terms)
