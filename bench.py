@@ -363,10 +363,13 @@ def main():
     roofline = None
     if not args.no_roofline:
         # repeat of the timed steps with per-launch HIP events on the launch stream
+        # ... with a read-back per solve: under deferred completion a spare step may be enqueued whose kernels return
+        # at once, and those empty launches would be averaged into the per-launch duration
+        if deferred is not None:
+            deferred.resolve()
         integrate.profile_begin()
-        with scope:
-            for _ in range(min(args.steps, 5)):
-                train_step(model, opt, x, y, reducer)
+        for _ in range(min(args.steps, 5)):
+            train_step(model, opt, x, y, reducer)
         torch.cuda.synchronize(device)
         prof = integrate.profile_end()
         k = prof['conv3x3_implicit_gemm']
