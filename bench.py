@@ -367,6 +367,7 @@ def main():
         # at once, and those empty launches would be averaged into the per-launch duration
         if deferred is not None:
             deferred.resolve()
+        train_step(model, opt, x, y, reducer)     # unprofiled: refreshes the library's own step-count guesses
         integrate.profile_begin()
         for _ in range(min(args.steps, 5)):
             train_step(model, opt, x, y, reducer)
