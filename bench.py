@@ -270,6 +270,10 @@ def main():
         raise SystemExit('bench.py: LOCAL_RANK %d but only %d HIP device(s)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
+    # the stem's convolutions are MIOpen's: let it time its algorithms once per geometry (during the warm-up steps)
+    # instead of taking its heuristic pick -- stem forward 0.48 -> 0.46 ms, backward 0.93 -> 0.86 ms per step
+    # (tools/phase_times.py, BENCHMARK=1)
+    torch.backends.cudnn.benchmark = True
 
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
