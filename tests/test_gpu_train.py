@@ -53,3 +53,26 @@ def test_train_resume_and_checkpoint_layout(tmp_path):
         CosineAnnealingLR(o2, 4, last_epoch=3 - 2)
     assert abs(ck3['optim']['param_groups'][0]['lr'] - o2.param_groups[0]['lr']) < 1e-12
     assert abs(ck['optim']['param_groups'][0]['lr'] - saved['param_groups'][0]['lr']) < 1e-12
+
+
+def test_features_and_nfe_evaluations_on_a_trained_run(tmp_path):
+    """evaluate.py:24-142 on the HIP backend: dense-output feature extraction over a tolerance sweep, and the bs=1
+    NFE census, from a run directory written by the training loop."""
+    import numpy as np
+    import pandas as pd
+    from neural_ode_features_amd import evaluate as E
+    from neural_ode_features_amd import train as T
+    run = str(tmp_path / 'run')
+    assert T.main(['--dataset', 'mnist', '-f', '16', '-b', '32', '--synthetic-size', '64', '-a', '--lr', '0.05', '-e', '1',
+                   '--run-dir', run]) == 0
+    out = E.main(['features', run, '--t1', '0', '0.25', '0.5', '1', '--tol', '1e-3', '1e-1', '--limit', '40'])
+    z = np.load(out)
+    assert z['features'].shape == (2, 4, 40, 16) and z['y_true'].shape == (40,)          # [tols, T, N, C] (evaluate.py:84-88)
+    assert np.array_equal(z['features'][0, 0], z['features'][1, 0])                      # t = 0: the stem's output, no solve
+    assert not np.allclose(z['features'][0, -1], z['features'][0, 0])
+    assert np.abs(z['features'][0] - z['features'][1]).max() < 0.5                       # the two tolerances agree roughly
+    out = E.main(['nfe', run, '--t1', '0.5', '1', '--tol', '1e-3', '1e-1', '--limit', '6'])
+    df = pd.read_csv(out)
+    assert list(df.columns) == ['y_true', 'y_pred', 'nfe', 't1', 'tol'] and len(df) == 2 * 2 * 6   # evaluate.py:121-140
+    assert ((df.nfe - 2) % 6 == 0).all() and (df.nfe >= 8).all()                         # show.py:199: NFE = 2 + 6 steps
+    assert df[df.tol == 1e-1].nfe.mean() <= df[df.tol == 1e-3].nfe.mean()
