@@ -65,9 +65,9 @@ def test_features_and_nfe_evaluations_on_a_trained_run(tmp_path):
     run = str(tmp_path / 'run')
     assert T.main(['--dataset', 'mnist', '-f', '16', '-b', '32', '--synthetic-size', '64', '-a', '--lr', '0.05', '-e', '1',
                    '--run-dir', run]) == 0
-    out = E.main(['features', run, '--t1', '0', '0.25', '0.5', '1', '--tol', '1e-3', '1e-1', '--limit', '40'])
+    out = E.main(['features', run, '--t1', '0', '0.25', '0.5', '1', '--tol', '1e-3', '1e-1', '--limit', '24'])
     z = np.load(out)
-    assert z['features'].shape == (2, 4, 40, 16) and z['y_true'].shape == (40,)          # [tols, T, N, C] (evaluate.py:84-88)
+    assert z['features'].shape == (2, 4, 24, 16) and z['y_true'].shape == (24,)          # [tols, T, N, C] (evaluate.py:84-88)
     assert np.array_equal(z['features'][0, 0], z['features'][1, 0])                      # t = 0: the stem's output, no solve
     assert not np.allclose(z['features'][0, -1], z['features'][0, 0])
     assert np.abs(z['features'][0] - z['features'][1]).max() < 0.5                       # the two tolerances agree roughly
