@@ -50,46 +50,54 @@ def batches(x, y, bs, shuffle, gen):
         yield x[j], y[j]
 
 
+class Tally:
+    """Running sums of one pass over the data (the reference keeps them as locals, train.py:30-37, 78-84)."""
+
+    def __init__(self):
+        self.loss_sum = 0.0
+        self.hits = self.seen = self.batches = 0
+        self.nfe = [0, 0]                      # forward, backward
+
+    def count(self, logits, target, loss_value):
+        self.loss_sum += loss_value
+        self.hits += int((logits.argmax(dim=1) == target).sum())
+        self.seen += target.shape[0]
+
+
 def train(data, model, optimizer, args, gen):
-    """train.py:26-72."""
+    """One epoch; semantics of train.py:26-72 (loss read per batch, NFE counter read and reset after the forward and
+    after the backward, optimizer stepped every `batch_accumulation` batches)."""
     model.train()
     optimizer.zero_grad()
-    nfe_forward = nfe_backward = 0
-    n_correct = n_processed = n_batch = 0
-    total_loss = 0.0
-    for x, y in batches(data[0], data[1], args.batch_size, True, gen):
-        x, y = x.to(args.device), y.to(args.device)
-        p = model(x)
-        loss = F.cross_entropy(p, y)
-        total_loss += loss.item()
-        n_correct += (y == p.argmax(dim=1)).sum().item()
-        n_processed += y.shape[0]
-        nfe_forward += model.nfe(reset=True)
+    tally = Tally()
+    for images, target in batches(data[0], data[1], args.batch_size, True, gen):
+        images, target = images.to(args.device), target.to(args.device)
+        logits = model(images)
+        loss = F.cross_entropy(logits, target)
+        tally.count(logits, target, loss.item())
+        tally.nfe[0] += model.nfe(reset=True)
         loss.backward()
-        nfe_backward += model.nfe(reset=True)
-        n_batch += 1
-        if n_batch % args.batch_accumulation == 0:
+        tally.nfe[1] += model.nfe(reset=True)
+        tally.batches += 1
+        if tally.batches % args.batch_accumulation == 0:
             optimizer.step()
             optimizer.zero_grad()
-    return {'loss': total_loss / n_batch, 'acc': n_correct / n_processed, 'nfe-f': nfe_forward / n_batch,
-            'nfe-b': nfe_backward / n_batch}
+    nb = tally.batches
+    return {'loss': tally.loss_sum / nb, 'acc': tally.hits / tally.seen, 'nfe-f': tally.nfe[0] / nb, 'nfe-b': tally.nfe[1] / nb}
 
 
 def evaluate(data, model, args):
-    """train.py:75-108 (like the reference: no `no_grad`, the solver does not record a graph anyway)."""
+    """Test pass; semantics of train.py:75-108 (summed loss per image, NFE per batch)."""
     model.eval()
-    nfe_forward = n_correct = n_batches = n_processed = 0
-    total_loss = 0.0
+    tally = Tally()
     with torch.no_grad():
-        for x, y in batches(data[0], data[1], args.batch_size, False, None):
-            x, y = x.to(args.device), y.to(args.device)
-            p = model(x)
-            nfe_forward += model.nfe(reset=True)
-            total_loss += F.cross_entropy(p, y, reduction='sum').item()
-            n_correct += (y == p.argmax(dim=1)).sum().item()
-            n_processed += y.shape[0]
-            n_batches += 1
-    return {'test_loss': total_loss / n_processed, 'test_acc': n_correct / n_processed, 'test_nfe': nfe_forward / n_batches}
+        for images, target in batches(data[0], data[1], args.batch_size, False, None):
+            images, target = images.to(args.device), target.to(args.device)
+            logits = model(images)
+            tally.nfe[0] += model.nfe(reset=True)
+            tally.count(logits, target, F.cross_entropy(logits, target, reduction='sum').item())
+            tally.batches += 1
+    return {'test_loss': tally.loss_sum / tally.seen, 'test_acc': tally.hits / tally.seen, 'test_nfe': tally.nfe[0] / tally.batches}
 
 
 def read_log(path):
@@ -115,30 +123,34 @@ def push_log(path, metrics):
 
 def main(argv=None):
     parser = argparse.ArgumentParser(description='ODENet training on the HIP backend (flags of the reference train.py:196-225)')
-    parser.add_argument('--dataset', type=str, choices=tuple(SHAPES), default='mnist')
-    parser.add_argument('-d', '--downsample', type=str, choices=('ode2', 'ode', 'residual', 'convolution', 'minimal', 'one-shot'),
-                        default='residual')
-    parser.add_argument('-n', '--norm', type=str, choices=('group',), default='group')
-    parser.add_argument('-f', '--filters', type=int, default=64)
-    parser.add_argument('--dropout', type=float, default=0)
-    parser.add_argument('-e', '--epochs', type=int, default=100)
-    parser.add_argument('-b', '--batch-size', type=int, default=128)
-    parser.add_argument('--batch-accumulation', type=int, default=1)
-    parser.add_argument('-o', '--optim', type=str, choices=('sgd', 'adam'), default='sgd')
-    parser.add_argument('--lr', type=float, default=0.1)
-    parser.add_argument('--lrschedule', type=str, choices=('fixed', 'plateau', 'cosine'), default='plateau')
-    parser.add_argument('--lrcycle', type=int, default=0)
-    parser.add_argument('-p', '--patience', type=int, default=10)
-    parser.add_argument('--wd', type=float, default=0, help='weight decay')
-    parser.add_argument('--method', default='dopri5', choices=('dopri5', 'rk4'))
-    parser.add_argument('-t', '--tol', type=float, default=1e-3)
-    parser.add_argument('-a', '--adjoint', default=False, action='store_true')
-    parser.add_argument('-r', '--resume', action='store_true', default=False)
-    parser.add_argument('-s', '--seed', type=int, default=23)
-    # stand-ins for the reference's torchvision datasets / expman run directory
-    parser.add_argument('--data', type=str, default=None, help='.pt file with x_train, y_train, x_test, y_test')
-    parser.add_argument('--synthetic-size', type=int, default=512)
-    parser.add_argument('--run-dir', type=str, default=None)
+    stems = ('ode2', 'ode', 'residual', 'convolution', 'minimal', 'one-shot')
+    flags = [   # (names, keyword arguments) -- names, defaults and choices are the reference's
+        (('--dataset',), dict(type=str, choices=tuple(SHAPES), default='mnist')),
+        (('-d', '--downsample'), dict(type=str, choices=stems, default='residual')),
+        (('-n', '--norm'), dict(type=str, choices=('group',), default='group')),
+        (('-f', '--filters'), dict(type=int, default=64)),
+        (('--dropout',), dict(type=float, default=0)),
+        (('-e', '--epochs'), dict(type=int, default=100)),
+        (('-b', '--batch-size'), dict(type=int, default=128)),
+        (('--batch-accumulation',), dict(type=int, default=1)),
+        (('-o', '--optim'), dict(type=str, choices=('sgd', 'adam'), default='sgd')),
+        (('--lr',), dict(type=float, default=0.1)),
+        (('--lrschedule',), dict(type=str, choices=('fixed', 'plateau', 'cosine'), default='plateau')),
+        (('--lrcycle',), dict(type=int, default=0)),
+        (('-p', '--patience'), dict(type=int, default=10)),
+        (('--wd',), dict(type=float, default=0, help='weight decay')),
+        (('--method',), dict(default='dopri5', choices=('dopri5', 'rk4'))),
+        (('-t', '--tol'), dict(type=float, default=1e-3)),
+        (('-a', '--adjoint'), dict(default=False, action='store_true')),
+        (('-r', '--resume'), dict(action='store_true', default=False)),
+        (('-s', '--seed'), dict(type=int, default=23)),
+        # stand-ins for the reference's torchvision datasets / expman run directory
+        (('--data',), dict(type=str, default=None, help='.pt file with x_train, y_train, x_test, y_test')),
+        (('--synthetic-size',), dict(type=int, default=512)),
+        (('--run-dir',), dict(type=str, default=None)),
+    ]
+    for names, kw in flags:
+        parser.add_argument(*names, **kw)
     args = parser.parse_args(argv)
 
     torch.manual_seed(args.seed)
