@@ -1,4 +1,4 @@
-"""GPU: the fused SGD step (`node_sgd_step` through the C ABI, optim.FlatSGD) against torch.optim.SGD -- the
+"""GPU: the fused SGD step (`node_sgd_step` through the C ABI, optim.FusedSGD) against torch.optim.SGD -- the
 reference's optimizer (train.py:136), stepped and zeroed per iteration (train.py:56-58)."""
 import copy
 
@@ -9,7 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def test_flat_sgd_matches_torch_sgd_on_random_gradients():
+def test_fused_sgd_matches_torch_sgd_on_random_gradients():
     import neural_ode_features_amd as nof
     torch.manual_seed(3)
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 7, 3), torch.nn.GroupNorm(7, 7), torch.nn.Flatten(), torch.nn.Linear(7 * 36, 5)).cuda()
