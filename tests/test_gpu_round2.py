@@ -458,3 +458,53 @@ def test_latency_regime_small_grid_kernel(shape):
     # the VJP entry point evaluates f with the throughput kernels (training path): same function
     fo, _, _, _ = nof.odefunc_vjp(f, 0.7, y.cuda(), torch.ones_like(y).cuda())
     assert rel_err(fo, got) < 2e-5
+
+
+@pytest.mark.parametrize('shape', [(6, 64, 8, 8), (128, 256, 8, 8), (3, 64, 7, 7), (2, 128, 16, 16)])
+@pytest.mark.parametrize('fill', [0xFF, 0x7F, 0x00])
+def test_results_do_not_depend_on_workspace_contents(fill, shape):
+    """The caller-owned workspace is scratch: whatever it holds when a call starts (NaN patterns, huge finite values,
+    zeros -- a fresh allocation, another solve's leftovers) must not reach any result.  Forward solve (read-back and
+    blind), adjoint solve and the single-evaluation VJP, bit for bit."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    f, _ = make_func(shape[1], seed=141, device='cuda')
+    gen = torch.Generator().manual_seed(142)
+    y = torch.randn(*shape, generator=gen).cuda()
+    cot = torch.randn(*shape, generator=gen).cuda()
+    t = torch.tensor([0.0, 0.3, 1.0]).cuda()
+
+    def poison():
+        torch.cuda.synchronize()
+        for buf in integrate._WS.values():
+            buf.fill_(fill)
+        torch.cuda.synchronize()
+
+    def run():
+        yy = y.clone().requires_grad_(True)
+        out = nof.odeint_adjoint(f, yy, t, rtol=1e-4, atol=1e-4, method='dopri5')
+        (out * cot).sum().backward()
+        gp = torch.cat([p.grad.reshape(-1) for p in f.parameters()])
+        for p in f.parameters():
+            p.grad = None
+        fo, vy, vt, vp = nof.odefunc_vjp(f, 0.2, y, cot)
+        rec = integrate.Recognised(f)
+        steps = f.last_forward_stats['accepted'] + f.last_forward_stats['rejected']
+        return [out.detach().clone(), yy.grad.clone(), gp, fo, vy, vt.clone(), vp], rec, steps
+
+    base, rec, _ = run()                  # sizes the workspace
+    poison()
+    again, _, _ = run()
+    for a, b in zip(base, again):
+        assert torch.equal(a, b)
+    # blind (deferred-completion) forward solve on a poisoned workspace
+    t2 = [0.0, 1.0]
+    ref, st = integrate.solve_forward(rec, rec.params, y, t2, 1e-4, 1e-4, 0, None)
+    steps = st['accepted'] + st['rejected']
+    record = torch.zeros(64, dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, device='cuda')
+    for _ in range(3):
+        poison()
+        got, _ = integrate.solve_forward(rec, rec.params, y, t2, 1e-4, 1e-4, 0, None, blind=(steps, record, flag))
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and float(flag) == 0.0
