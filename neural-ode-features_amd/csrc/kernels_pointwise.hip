@@ -7,6 +7,7 @@
 // Algorithm follows the restated torchdiffeq spec; the CPU
 // statement of the same arithmetic is oracle/torchdiffeq_restated.py.
 #include "node_internal.h"
+#include <cstring>
 #include "../../include/node_hip.h"
 
 namespace node {
@@ -297,8 +298,15 @@ void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
 // For segments whose intermediate stages are never consumed (adj_params) the same
 // pass also forms y1 = y0 + dt * sum_j b_j k_j.
 // ============================================================================
-__global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl, float rtol, float atol, float* partial) {
+// One launch for up to three state segments (grid.y = segment): the augmented state's y, a and theta segments used to
+// be three launches per step.
+struct ErrSegs { ErrSeg seg[3]; float* partial[3]; };
+__device__ void error_norm_body(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial);
+__global__ __launch_bounds__(256) void k_error_norm(ErrSegs a, const Ctrl* ctrl, float rtol, float atol) {
   if (ctrl->done) return;
+  error_norm_body(a.seg[blockIdx.y], ctrl, rtol, atol, a.partial[blockIdx.y]);
+}
+__device__ void error_norm_body(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial) {
   __shared__ float red[4];
   const float dtf = (float)ctrl->dt;
   float ce[7], cb[7];
@@ -367,8 +375,11 @@ __global__ __launch_bounds__(256) void k_error_norm(ErrSeg seg, const Ctrl* ctrl
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-void launch_error_norm(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(k_error_norm, dim3(ERR_BLOCKS), dim3(256), 0, s, seg, ctrl, rtol, atol, partial);
+void launch_error_norm(const ErrSeg* segs, float* const* partial, int nseg, const Ctrl* ctrl, float rtol, float atol, hipStream_t s) {
+  ErrSegs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < nseg; ++i) { a.seg[i] = segs[i]; a.partial[i] = partial[i]; }
+  hipLaunchKernelGGL(k_error_norm, dim3(ERR_BLOCKS, nseg), dim3(256), 0, s, a, ctrl, rtol, atol);
 }
 
 // ============================================================================
@@ -496,7 +507,10 @@ void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
 //   phase 0: sum (y0/scale)^2, sum (f0/scale)^2      scale = atol + |y0| rtol
 //   phase 1: sum ((f1-f0)/scale)^2
 // ============================================================================
-__global__ __launch_bounds__(256) void k_init_norms(InitSeg seg, float rtol, float atol, int phase, float* partial) {
+struct InitSegs { InitSeg seg[3]; float* partial[3]; };
+__global__ __launch_bounds__(256) void k_init_norms(InitSegs a, float rtol, float atol, int phase) {
+  const InitSeg& seg = a.seg[blockIdx.y];
+  float* partial = a.partial[blockIdx.y];
   __shared__ float red[4];
   float a0 = 0.f, a1 = 0.f;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -516,8 +530,11 @@ __global__ __launch_bounds__(256) void k_init_norms(InitSeg seg, float rtol, flo
   const float t1 = block_sum_256(a1, red);
   if (threadIdx.x == 0) { partial[blockIdx.x * 2] = t0; partial[blockIdx.x * 2 + 1] = t1; }
 }
-void launch_init_norms(const InitSeg& seg, float rtol, float atol, int phase, float* partial, const Ctrl*, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_norms, dim3(ERR_BLOCKS), dim3(256), 0, s, seg, rtol, atol, phase, partial);
+void launch_init_norms(const InitSeg* segs, float* const* partial, int nseg, float rtol, float atol, int phase, hipStream_t s) {
+  InitSegs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < nseg; ++i) { a.seg[i] = segs[i]; a.partial[i] = partial[i]; }
+  hipLaunchKernelGGL(k_init_norms, dim3(ERR_BLOCKS, nseg), dim3(256), 0, s, a, rtol, atol, phase);
 }
 
 __global__ __launch_bounds__(256) void k_init_controller(InitCtlArgs a) {

@@ -588,7 +588,7 @@ struct Solver {
   int initial_step() {
     const int nseg = aug ? 3 : 1;
     InitSeg segs[3] = {{p.Y, p.KY[0], p.KY[1], d.numel}, {p.A, p.KA[0], p.KA[1], d.numel}, {p.TH, p.KT[0], p.KT[1], d.P}};
-    for (int i = 0; i < nseg; ++i) launch_init_norms(segs[i], rtol, atol, 0, p.partial[i], p.ctrl, st);
+    launch_init_norms(segs, p.partial, nseg, rtol, atol, 0, st);
     InitCtlArgs ic;
     memset(&ic, 0, sizeof(ic));
     ic.ctrl = p.ctrl;
@@ -597,7 +597,7 @@ struct Solver {
     launch_init_controller(ic, st);
     const double one[1] = {1.0};
     TRY(eval_sys(1, one, 1, SC_H0, et_probe(), false));
-    for (int i = 0; i < nseg; ++i) launch_init_norms(segs[i], rtol, atol, 1, p.partial[i], p.ctrl, st);
+    launch_init_norms(segs, p.partial, nseg, rtol, atol, 1, st);
     ic.phase = 1;
     launch_init_controller(ic, st);
     return check_launch("initial step");
@@ -626,20 +626,17 @@ struct Solver {
     }
     count_nfe = was_counting;
     const int nseg = aug ? 3 : 1;
-    ErrSeg e0;
-    e0.y0 = p.Y; e0.y1 = p.Y1; e0.n = d.numel; e0.compute_y1 = 0;
-    for (int j = 0; j < 7; ++j) e0.k[j] = p.KY[j];
-    launch_error_norm(e0, p.ctrl, rtol, atol, p.partial[0], st);
+    ErrSeg es[3];
+    es[0].y0 = p.Y; es[0].y1 = p.Y1; es[0].n = d.numel; es[0].compute_y1 = 0;
+    for (int j = 0; j < 7; ++j) es[0].k[j] = p.KY[j];
     if (aug) {
-      ErrSeg e1 = e0;
-      e1.y0 = p.A; e1.y1 = p.A1;
-      for (int j = 0; j < 7; ++j) e1.k[j] = p.KA[j];
-      launch_error_norm(e1, p.ctrl, rtol, atol, p.partial[1], st);
-      ErrSeg e2;
-      e2.y0 = p.TH; e2.y1 = p.TH1; e2.n = d.P; e2.compute_y1 = 1;
-      for (int j = 0; j < 7; ++j) e2.k[j] = p.KT[j];
-      launch_error_norm(e2, p.ctrl, rtol, atol, p.partial[2], st);
+      es[1] = es[0];
+      es[1].y0 = p.A; es[1].y1 = p.A1;
+      for (int j = 0; j < 7; ++j) es[1].k[j] = p.KA[j];
+      es[2].y0 = p.TH; es[2].y1 = p.TH1; es[2].n = d.P; es[2].compute_y1 = 1;
+      for (int j = 0; j < 7; ++j) es[2].k[j] = p.KT[j];
     }
+    launch_error_norm(es, p.partial, nseg, p.ctrl, rtol, atol, st);
     StepCtlArgs sc;
     memset(&sc, 0, sizeof(sc));
     sc.ctrl = p.ctrl;

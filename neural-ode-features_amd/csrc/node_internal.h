@@ -235,7 +235,8 @@ struct ErrSeg {
   int compute_y1;
 };
 constexpr int ERR_BLOCKS = 512;
-void launch_error_norm(const ErrSeg& seg, const Ctrl* ctrl, float rtol, float atol, float* partial /*[ERR_BLOCKS]*/, hipStream_t s);
+// all segments of the state in one launch (grid.y = segment)
+void launch_error_norm(const ErrSeg* segs, float* const* partial /*[ERR_BLOCKS] each*/, int nseg, const Ctrl* ctrl, float rtol, float atol, hipStream_t s);
 
 struct StepCtlArgs {
   Ctrl* ctrl;
@@ -283,7 +284,7 @@ void launch_export_record(const Ctrl* ctrl, node_step_record* rec, float* miss_f
 
 // initial step (Hairer)
 struct InitSeg { const float* y0; const float* f0; const float* f1; size_t n; };
-void launch_init_norms(const InitSeg& seg, float rtol, float atol, int phase, float* partial /*[ERR_BLOCKS][2]*/, const Ctrl* ctrl, hipStream_t s);
+void launch_init_norms(const InitSeg* segs, float* const* partial /*[ERR_BLOCKS][2] each*/, int nseg, float rtol, float atol, int phase, hipStream_t s);
 struct InitCtlArgs {
   Ctrl* ctrl;
   const float* partial[3];
