@@ -301,7 +301,9 @@ def main():
     opt = nof.FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
     if world > 1:
         nof.dp.broadcast_parameters(model, 0)
-        reducer = nof.dp.GradientReducer(model, average=False)   # all-reduce SUM in the bucket buffers ...
+        # 2 MB buckets: the stem's gradients leave in several all-reduces while its backward is still running, so only
+        # the last, small one (first conv + first block) is exposed behind it; the ODE block's 4.75 MB stay one bucket
+        reducer = nof.dp.GradientReducer(model, limits={model.downsample: 2 << 20}, average=False)   # all-reduce SUM in the bucket buffers ...
         opt.grad_scale = 1.0 / world                             # ... its 1/world folded into the optimizer step
 
     def sync():

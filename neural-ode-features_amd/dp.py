@@ -84,9 +84,11 @@ class GradientReducer:
     """Bucketed, overlapped gradient reduction without a copy-back (see the module docstring)."""
 
     def __init__(self, model: nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
-                 boundaries: Optional[Iterable[nn.Module]] = None, average: bool = True):
+                 boundaries: Optional[Iterable[nn.Module]] = None, average: bool = True, limits=None):
         """`average=False` leaves the SUM in the buckets for an optimizer that folds 1/world into its step
-        (`optim.FusedSGD.grad_scale`)."""
+        (`optim.FusedSGD.grad_scale`).  `limits`: {sub-module: bucket bytes} overriding `bucket_bytes` for the
+        parameters of that sub-module (the stem's gradients arrive one layer at a time and are worth sending in
+        pieces while its backward runs; the ODE block's arrive all at once and travel best as one bucket)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
@@ -95,15 +97,20 @@ class GradientReducer:
         owner = {}
         if boundaries is None:
             boundaries = [m for _, m in model.named_children()]
+        boundaries = list(boundaries)
+        limit_of = {}
         for bi, m in enumerate(boundaries):
             for p in m.parameters():
                 owner[id(p)] = bi
+            for lm, nbytes_limit in (limits or {}).items():
+                if lm is m:
+                    limit_of[bi] = int(nbytes_limit)
         self.buckets: List[_Bucket] = []
         cur, cur_bytes, cur_key = [], 0, None
         for p in reversed(params):
             key = (owner.get(id(p), -1), p.dtype, p.device)
             nbytes = p.numel() * p.element_size()
-            if cur and (key != cur_key or cur_bytes + nbytes > bucket_bytes):
+            if cur and (key != cur_key or cur_bytes + nbytes > limit_of.get(key[0], bucket_bytes)):
                 self.buckets.append(_Bucket(len(self.buckets), cur))
                 cur, cur_bytes = [], 0
             cur.append(p)
