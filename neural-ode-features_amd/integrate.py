@@ -318,12 +318,11 @@ class Deferred:
     count is still moving one spare step is enqueued, so only a count that jumps by two or more is a miss.
 
         deferred = integrate.Deferred(device)        # opt-in; the drop-in API is unaffected while none is active
-        opt.skip_flag = deferred.miss_flag
-        with deferred:
+        opt.use_deferred(deferred)                   # FusedSGD: the update is predicated on the flag and zeroes it
+        with deferred:                               # (nothing runs blind in a scope no optimizer was armed with)
             for x, y in loader:
-                deferred.begin_step()                # zero the flag (one 4-byte memset)
                 loss = F.cross_entropy(model(x), y); loss.backward(); opt.step(); opt.zero_grad()
-        deferred.misses                              # steps whose update was skipped
+        deferred.resolve()                           # -> number of steps whose update was skipped
 
     `func.nfe` advances by the predicted count at once and is corrected when the record is read (sums over an
     epoch are exact); `last_*_stats` of a deferred solve hold the prediction."""
@@ -349,9 +348,6 @@ class Deferred:
     def __exit__(self, *exc):
         Deferred.active = None
         return False
-
-    def begin_step(self):
-        self.miss_flag.zero_()
 
     def _buffers(self, key):
         b = self.records.get(key)
