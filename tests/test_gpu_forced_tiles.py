@@ -78,3 +78,43 @@ def test_skipping_the_zero_weight_stage_derivative_is_bit_identical(tmp_path):
             assert torch.equal(outs[0][k], outs[1][k]), k
         else:
             assert float((outs[0][k] - outs[1][k]).abs().max()) <= 1e-5 * float(outs[0][k].abs().max()) + 1e-9, k
+
+
+SMALL_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests.helpers import make_func, rel_err
+import neural_ode_features_amd as nof
+from oracle.dynamics import odefunc_forward as oracle_f
+from oracle import torchdiffeq_restated as tdq
+bad = 0
+for shape in [(1, 128, 8, 8), (3, 256, 4, 4), (5, 160, 6, 6), (2, 1024, 4, 4), (1, 256, 16, 16), (9, 128, 7, 7), (4, 512, 8, 8),
+              (40, 256, 8, 8)]:
+    N, C, H, W = shape
+    f, twin = make_func(C, seed=C + H, device='cuda')
+    gen = torch.Generator().manual_seed(7)
+    y = torch.randn(N, C, H, W, generator=gen)
+    got = nof.odefunc_forward(f, 0.3, y.cuda())
+    want = oracle_f(torch.tensor(0.3), y, dict(twin.named_parameters()))
+    e = rel_err(got, want)
+    t = torch.tensor([0.0, 1.0])
+    with torch.no_grad():
+        out = nof.odeint(f, y.cuda(), t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5')
+        ref = tdq.odeint(twin, y, t, rtol=1e-3, atol=1e-3, method='dopri5')
+    e2 = float((out.cpu() - ref).abs().max())
+    print(shape, e, e2)
+    if not (e < 2e-5 and e2 <= 1e-2):
+        bad += 1
+sys.exit(bad)
+'''
+
+
+def test_small_grid_kernel_forced_on_many_shapes():
+    """k_conv3x3_small is picked only for grids under eight workgroups; forced on (NODE_TUNE_SMALL=1, read once per
+    process, hence the child) it must serve any C % 32 == 0, C >= 128 geometry: ragged last pixel tile (N*HW not a
+    multiple of 32), tiles that straddle samples, 16x16 and odd images, 4 to 32 channel groups per wave, and a
+    batch large enough for 80 pixel tiles."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NODE_TUNE_SMALL='1')
+    r = subprocess.run([sys.executable, '-c', SMALL_CHILD, root], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
