@@ -1330,40 +1330,45 @@ static size_t conv_w2_lds_bytes(const Dims& d) {
 // 2-D filter transform + packing: packed[nt][chunk16][comp = xi*4 + nu][col 64][k 16],  U = G g G^T
 __global__ __launch_bounds__(256) void k_pack_weights_w2(const float* __restrict__ w, float* __restrict__ packed,
                                                          int C, int BNE, int ntile, int nchunk, int dgrad) {
-  const size_t total = (size_t)ntile * nchunk * 16 * BN * KCW;
+  // thread = (nt, chunk, col, k): reads the nine taps of its (co, ci) pair ONCE and writes all sixteen components
+  // (consecutive threads -> consecutive k, col: every component's store is contiguous across the wave)
+  const size_t total = (size_t)ntile * nchunk * BN * KCW;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int kk = idx % KCW;
     size_t r = idx / KCW;
     const int col = r % BN; r /= BN;
-    const int comp = r % 16; r /= 16;
     const int ch = r % nchunk;
     const int nt = r / nchunk;
     const int kidx = ch * KCW + kk, nidx = nt * BNE + col;
-    float v = 0.f;
-    if (col < BNE && kidx < C && nidx < C) {
-      float g[3][3];
+    float g[3][3];
+    const bool on = col < BNE && kidx < C && nidx < C;
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-          g[kh][kw] = dgrad ? w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
-                            : w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+      for (int kw = 0; kw < 3; ++kw)
+        g[kh][kw] = !on ? 0.f
+                        : dgrad ? w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                                : w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+    auto G = [](int a, int b) -> float {   // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+      return a == 0 ? (b == 0 ? 1.f : 0.f) : a == 1 ? 0.5f : a == 2 ? (b == 1 ? -0.5f : 0.5f) : (b == 2 ? 1.f : 0.f);
+    };
+    float* dst = packed + (((size_t)(nt * nchunk + ch) * 16) * BN + col) * KCW + kk;   // + comp * BN * KCW
+#pragma unroll
+    for (int comp = 0; comp < 16; ++comp) {
       const int xi = comp >> 2, nu = comp & 3;
-      auto G = [](int a, int b) -> float {   // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
-        return a == 0 ? (b == 0 ? 1.f : 0.f) : a == 1 ? 0.5f : a == 2 ? (b == 1 ? -0.5f : 0.5f) : (b == 2 ? 1.f : 0.f);
-      };
+      float v = 0.f;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) v += G(xi, kh) * g[kh][kw] * G(nu, kw);
       if (xi == 3) v = -v;   // the kernel's input transform uses the negated row xi = 3 (see AWRITE1)
+      dst[(size_t)comp * BN * KCW] = v;
     }
-    packed[idx] = v;
   }
 }
 void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
   const int nchunk = (d.C + KCW - 1) / KCW;
-  const size_t total = (size_t)d.ntile * nchunk * 16 * BN * KCW;
+  const size_t total = (size_t)d.ntile * nchunk * BN * KCW;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_pack_weights_w2, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, nchunk, dgrad);
