@@ -29,6 +29,7 @@
 //  * Epilogue: accumulators -> LDS tile once; statistics with a lane<->pixel mapping
 //    (conflict-free, no integer division in any loop); normalise + 16-B stores.
 #include "node_internal.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace node {
@@ -1328,8 +1329,12 @@ static size_t conv_w2_lds_bytes(const Dims& d) {
 }
 
 // 2-D filter transform + packing: packed[nt][chunk16][comp = xi*4 + nu][col 64][k 16],  U = G g G^T
-__global__ __launch_bounds__(256) void k_pack_weights_w2(const float* __restrict__ w, float* __restrict__ packed,
-                                                         int C, int BNE, int ntile, int nchunk, int dgrad) {
+struct PackJobs { const float* w[4]; float* packed[4]; int dgrad[4]; };
+__global__ __launch_bounds__(256) void k_pack_weights_w2(PackJobs jobs, int C, int BNE, int ntile, int nchunk) {
+  // blockIdx.y = job: the forward / data-gradient packings of both conv layers leave in one launch per solve
+  const float* __restrict__ w = jobs.w[blockIdx.y];
+  float* __restrict__ packed = jobs.packed[blockIdx.y];
+  const int dgrad = jobs.dgrad[blockIdx.y];
   // thread = (nt, chunk, col, k): reads the nine taps of its (co, ci) pair ONCE and writes all sixteen components
   // (consecutive threads -> consecutive k, col: every component's store is contiguous across the wave)
   const size_t total = (size_t)ntile * nchunk * BN * KCW;
@@ -1366,12 +1371,19 @@ __global__ __launch_bounds__(256) void k_pack_weights_w2(const float* __restrict
     }
   }
 }
-void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
+void launch_pack_weights_w2_multi(const Dims& d, const float* const* w, float* const* packed, const int* dgrad, int count,
+                                 hipStream_t s) {
+  PackJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  for (int i = 0; i < count; ++i) { jobs.w[i] = w[i]; jobs.packed[i] = packed[i]; jobs.dgrad[i] = dgrad[i]; }
   const int nchunk = (d.C + KCW - 1) / KCW;
   const size_t total = (size_t)d.ntile * nchunk * BN * KCW;
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_pack_weights_w2, dim3(blocks), dim3(256), 0, s, w, packed, d.C, d.BNE, d.ntile, nchunk, dgrad);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_pack_weights_w2, dim3(blocks, count), dim3(256), 0, s, jobs, d.C, d.BNE, d.ntile, nchunk);
+}
+void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s) {
+  launch_pack_weights_w2_multi(d, &w, &packed, &dgrad, 1, s);
 }
 
 static size_t conv_d_lds_bytes(const Dims& d) {

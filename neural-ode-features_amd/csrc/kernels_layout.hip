@@ -109,6 +109,44 @@ void launch_wtime(const Dims& d, const float* w, float* wtime, hipStream_t s) {
   hipLaunchKernelGGL(k_wtime, dim3((9 * d.C + 255) / 256), dim3(256), 0, s, w, wtime, d.C);
 }
 
+// Both layers' border maps (and, for an augmented solve, their gathered time-channel taps) in ONE launch per solve:
+// blockIdx.y = job.  Four to six launches of ~4.5 us each (their floor on this box) per training step otherwise.
+struct TimePrepArgs { const float* w[2]; float* tmap[2]; float* wtime[2]; };
+__global__ __launch_bounds__(256) void k_time_prep(TimePrepArgs a, int C, int H, int W) {
+  const int job = blockIdx.y, layer = job & 1;
+  const float* w = a.w[layer];
+  if (job < 2) {
+    float* tmap = a.tmap[layer];
+    const int HW = H * W;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW * C; idx += gridDim.x * blockDim.x) {
+      const int co = idx % C, p = idx / C;
+      const int h = p / W, x = p % W;
+      float sum = 0.f;
+      for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+          const int hh = h + kh - 1, ww = x + kw - 1;
+          if (hh >= 0 && hh < H && ww >= 0 && ww < W) sum += w[(((size_t)co * (C + 1)) * 3 + kh) * 3 + kw];
+        }
+      tmap[idx] = sum;
+    }
+  } else {
+    float* wt = a.wtime[layer];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 9 * C; i += gridDim.x * blockDim.x) {
+      const int tap = i / C, co = i - tap * C;
+      wt[i] = w[((size_t)co * (C + 1)) * 9 + tap];
+    }
+  }
+}
+void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tmap1, float* tmap2, float* wtime1, float* wtime2,
+                      hipStream_t s) {
+  TimePrepArgs a;
+  a.w[0] = w1; a.w[1] = w2; a.tmap[0] = tmap1; a.tmap[1] = tmap2; a.wtime[0] = wtime1; a.wtime[1] = wtime2;
+  const int total = d.HW * d.C;
+  int bx = (total + 255) / 256;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(k_time_prep, dim3(bx, wtime1 != nullptr ? 4 : 2), dim3(256), 0, s, a, d.C, d.H, d.W);
+}
+
 // ---------------------------------------------- theta internal -> PyTorch flat
 // flat (parameters() order): norm1.w, norm1.b, conv1.w [C][C+1][3][3], conv1.b, norm2.w, ...
 __global__ __launch_bounds__(256) void k_theta_to_torch(const float* __restrict__ th, float* __restrict__ flat, int C) {

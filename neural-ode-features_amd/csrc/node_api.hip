@@ -414,16 +414,20 @@ struct Solver {
         HIP_TRY(hipMemsetAsync(p.dz2 + d.numel, 0, d.C * sizeof(float), st));
       }
     }
-    pack(d, prm.conv1_w, p.wf[0], 0, st);
-    pack(d, prm.conv2_w, p.wf[1], 0, st);
-    launch_tmap(d, prm.conv1_w, p.tmap[0], st);
-    launch_tmap(d, prm.conv2_w, p.tmap[1], st);
-    if (aug) {
-      pack(d, prm.conv1_w, p.wd[0], 1, st);
-      pack(d, prm.conv2_w, p.wd[1], 1, st);
-      launch_wtime(d, prm.conv1_w, p.wtime[0], st);
-      launch_wtime(d, prm.conv2_w, p.wtime[1], st);
+    if (d.wino == 2) {   // every packing of the solve in one launch
+      const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
+      float* dst_[4] = {p.wf[0], p.wf[1], p.wd[0], p.wd[1]};
+      const int dg_[4] = {0, 0, 1, 1};
+      launch_pack_weights_w2_multi(d, ws_, dst_, dg_, aug ? 4 : 2, st);
+    } else {
+      pack(d, prm.conv1_w, p.wf[0], 0, st);
+      pack(d, prm.conv2_w, p.wf[1], 0, st);
+      if (aug) {
+        pack(d, prm.conv1_w, p.wd[0], 1, st);
+        pack(d, prm.conv2_w, p.wd[1], 1, st);
+      }
     }
+    launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, st);
     return check_launch("prepare");
   }
 

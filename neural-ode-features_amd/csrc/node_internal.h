@@ -141,6 +141,9 @@ void launch_nhwc_to_nchw(const Dims& d, const float* src, float* dst, hipStream_
 void launch_pack_weights(const Dims& d, const float* w /*[C][C+1][3][3]*/, float* packed, int dgrad, hipStream_t s);
 void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStream_t s);
 void launch_wtime(const Dims& d, const float* w, float* wtime /*[9][C]*/, hipStream_t s);
+// tmap of both layers (+ wtime of both when wtime1 != nullptr) in one launch
+void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tmap1, float* tmap2, float* wtime1, float* wtime2,
+                      hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
 
 // pointwise / reductions
@@ -342,6 +345,8 @@ size_t conv_lds_bytes(const Dims& d, int mode);
 size_t conv_packed_elems(const Dims& d);
 void launch_pack_weights_w(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
 void launch_pack_weights_w2(const Dims& d, const float* w, float* packed, int dgrad, hipStream_t s);
+void launch_pack_weights_w2_multi(const Dims& d, const float* const* w, float* const* packed, const int* dgrad, int count /*<= 4*/,
+                                 hipStream_t s);
 void launch_pack_weights_small(const Dims& d, const float* w, float* packed /*[9][C/4][C][4]*/, hipStream_t s);
 void launch_conv_small(const Dims& d, const ConvArgs& a, hipStream_t s);   // forward only; a.raw_out, a.wpacked = small packing
 
