@@ -3,6 +3,7 @@
 // -> PyTorch flat parameter layout conversion.  All HBM-bound and tiny next to
 // the convolutions (run once per solve, not per stage).
 #include "node_internal.h"
+#include <cstring>
 
 namespace node {
 
@@ -111,9 +112,16 @@ void launch_wtime(const Dims& d, const float* w, float* wtime, hipStream_t s) {
 
 // Both layers' border maps (and, for an augmented solve, their gathered time-channel taps) in ONE launch per solve:
 // blockIdx.y = job.  Four to six launches of ~4.5 us each (their floor on this box) per training step otherwise.
-struct TimePrepArgs { const float* w[2]; float* tmap[2]; float* wtime[2]; };
+struct TimePrepArgs { const float* w[2]; float* tmap[2]; float* wtime[2]; float* zero[6]; size_t zero_n[6]; int nzero; int njobs; };
 __global__ __launch_bounds__(256) void k_time_prep(TimePrepArgs a, int C, int H, int W) {
   const int job = blockIdx.y, layer = job & 1;
+  if (job >= a.njobs) {   // the solve's zero fills (zero rows behind the conv inputs, the never-written stage derivative,
+                          // the finalize kernel's arrival counter): they used to be one hipMemsetAsync each
+    const int z = job - a.njobs;
+    float* p = a.zero[z];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.zero_n[z]; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+    return;
+  }
   const float* w = a.w[layer];
   if (job < 2) {
     float* tmap = a.tmap[layer];
@@ -138,13 +146,17 @@ __global__ __launch_bounds__(256) void k_time_prep(TimePrepArgs a, int C, int H,
   }
 }
 void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tmap1, float* tmap2, float* wtime1, float* wtime2,
-                      hipStream_t s) {
+                      float* const* zero, const size_t* zero_n, int nzero, hipStream_t s) {
   TimePrepArgs a;
+  memset(&a, 0, sizeof(a));
   a.w[0] = w1; a.w[1] = w2; a.tmap[0] = tmap1; a.tmap[1] = tmap2; a.wtime[0] = wtime1; a.wtime[1] = wtime2;
+  a.njobs = wtime1 != nullptr ? 4 : 2;
+  a.nzero = nzero > 6 ? 6 : nzero;
+  for (int i = 0; i < a.nzero; ++i) { a.zero[i] = zero[i]; a.zero_n[i] = zero_n[i]; }
   const int total = d.HW * d.C;
   int bx = (total + 255) / 256;
   if (bx > 256) bx = 256;
-  hipLaunchKernelGGL(k_time_prep, dim3(bx, wtime1 != nullptr ? 4 : 2), dim3(256), 0, s, a, d.C, d.H, d.W);
+  hipLaunchKernelGGL(k_time_prep, dim3(bx, a.njobs + a.nzero), dim3(256), 0, s, a, d.C, d.H, d.W);
 }
 
 // ---------------------------------------------- theta internal -> PyTorch flat

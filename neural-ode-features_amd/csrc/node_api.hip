@@ -397,22 +397,28 @@ struct Solver {
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
-    if (aug)   // stage-2 parameter derivative: read with weight zero by the error norm / dense output, never written
-               // by dopri5 steps (the initial-step probe does write it) -- must hold finite values
-      HIP_TRY(hipMemsetAsync(p.KT[1], 0, d.P * sizeof(float), st));
-    if (aug)   // arrival counter of k_theta_finalize
-      HIP_TRY(hipMemsetAsync(p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64), 0, sizeof(unsigned), st));
+    // zero fills of the solve, folded into the preparation launch below: the stage-2 parameter derivative (read with
+    // weight zero by the error norm / dense output, never written by dopri5 steps -- the initial-step probe does
+    // write it -- so it must hold finite values), the arrival counter of k_theta_finalize, and the zero rows behind
+    // the conv inputs (see make_plan)
+    float* zr[6];
+    size_t zn[6];
+    int nz = 0;
+    if (aug) {
+      zr[nz] = p.KT[1]; zn[nz++] = d.P;
+      zr[nz] = p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64); zn[nz++] = 1;
+    }
+    if (d.wino == 2 || d.wgrad_wino == 2 || small_mode()) {
+      zr[nz] = p.act1 + d.numel; zn[nz++] = d.C;
+      zr[nz] = p.act2 + d.numel; zn[nz++] = d.C;
+      if (aug) {
+        zr[nz] = p.dz1 + d.numel; zn[nz++] = d.C;
+        zr[nz] = p.dz2 + d.numel; zn[nz++] = d.C;
+      }
+    }
     if (small_mode()) {
       launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
       launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
-    }
-    if (d.wino == 2 || d.wgrad_wino == 2 || small_mode()) {   // zero tails of the conv inputs (see make_plan)
-      HIP_TRY(hipMemsetAsync(p.act1 + d.numel, 0, d.C * sizeof(float), st));
-      HIP_TRY(hipMemsetAsync(p.act2 + d.numel, 0, d.C * sizeof(float), st));
-      if (aug) {
-        HIP_TRY(hipMemsetAsync(p.dz1 + d.numel, 0, d.C * sizeof(float), st));
-        HIP_TRY(hipMemsetAsync(p.dz2 + d.numel, 0, d.C * sizeof(float), st));
-      }
     }
     if (d.wino == 2) {   // every packing of the solve in one launch
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
@@ -427,7 +433,8 @@ struct Solver {
         pack(d, prm.conv2_w, p.wd[1], 1, st);
       }
     }
-    launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, st);
+    launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
+                     nz, st);
     return check_launch("prepare");
   }
 

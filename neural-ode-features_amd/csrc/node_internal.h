@@ -143,7 +143,7 @@ void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStre
 void launch_wtime(const Dims& d, const float* w, float* wtime /*[9][C]*/, hipStream_t s);
 // tmap of both layers (+ wtime of both when wtime1 != nullptr) in one launch
 void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tmap1, float* tmap2, float* wtime1, float* wtime2,
-                      hipStream_t s);
+                      float* const* zero, const size_t* zero_n, int nzero /*<= 6: regions to zero-fill*/, hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
 
 // pointwise / reductions
