@@ -184,43 +184,7 @@ __device__ inline void conv_epilogue_tail(const ConvArgs& a, const Dims& d, floa
 #pragma unroll
     for (int i = 0; i < 4; ++i) gm[i] = okq[i] ? a.gamma[c0 + colq + i] : 0.f;
     float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
-    constexpr int ITER = BM / RL;   // tile rows per thread
-    const bool flat = vec_ok && (d.HW % RL) == 0;
-    if (flat) {
-      // All of this thread's xhat / activation rows are requested up front (the accumulators are dead by now, so the
-      // registers are there): the row-by-row version below waits out one global-memory latency per row.  Same rows in
-      // the same order (RL divides HW), same arithmetic.
-      float4 xq[ITER], aq[ITER];
-      const int rows = nsamp * d.HW;
-#pragma unroll
-      for (int k = 0; k < ITER; ++k) {
-        const int row = rr + k * RL;
-        xq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        aq[k] = xq[k];
-        if (row < rows && okq[0]) {
-          const size_t off = ((size_t)n0 * d.HW + row) * d.C + c0 + colq;
-          xq[k] = *reinterpret_cast<const float4*>(a.xhat + off);
-          aq[k] = *reinterpret_cast<const float4*>(a.act + off);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < ITER; ++k) {
-        const int row = rr + k * RL;
-        if (row < rows) {
-          const float x[4] = {xq[k].x, xq[k].y, xq[k].z, xq[k].w};
-          const float ac[4] = {aq[k].x, aq[k].y, aq[k].z, aq[k].w};
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float du = (okq[i] && ac[i] > 0.f) ? Ct[row * CT2 + colq + i] : 0.f;
-            dg[i] += du * x[i];
-            db[i] += du;
-            Ct[row * CT2 + colq + i] = du * gm[i];
-            Xt[row * CT2 + colq + i] = x[i];
-          }
-        }
-      }
-    }
-    for (int s = 0; s < (flat ? 0 : nsamp); ++s) {
+    for (int s = 0; s < nsamp; ++s) {
       for (int p = rr; p < d.HW; p += RL) {
         const int row = s * d.HW + p;
         const size_t off = ((size_t)(n0 + s) * d.HW + p) * d.C + c0 + colq;
