@@ -193,7 +193,59 @@ __global__ __launch_bounds__(256) void k_theta_to_torch(const float* __restrict_
     flat[idx] = v;
   }
 }
+// The same conversion through LDS tiles for C % 32 == 0: the conv weights are [tap][ci][co] inside and
+// [co][1 + ci][tap] in PyTorch's layout, so the element-wise kernel above reads with a stride of C*C floats (26 us at
+// C = 256).  A workgroup moves a (32 co x 16 ci x 9 taps) tile: reads 128-byte runs along co, writes 576-byte runs
+// along (ci, tap).  The last workgroups copy the small vectors and scatter the time-channel taps.
+__global__ __launch_bounds__(256) void k_theta_to_torch_tiled(const float* __restrict__ th, float* __restrict__ flat, int C) {
+  __shared__ float tile[9 * 16 * 33];
+  const ThetaLayout L = theta_layout(C);
+  const size_t cw = (size_t)C * (C + 1) * 9;
+  const size_t per_layer = 3 * (size_t)C + cw;          // g, b, conv.w, conv.b
+  const int nco = C / 32, nci = C / 16;
+  const int nblk = 2 * nco * nci;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b < nblk) {
+    const int layer = b / (nco * nci), rem = b - layer * nco * nci;
+    const int co0 = (rem / nci) * 32, ci0 = (rem % nci) * 16;
+    for (int e = tid; e < 9 * 16 * 32; e += 256) {
+      const int co = e & 31, ci = (e >> 5) & 15, tap = e >> 9;
+      tile[(tap * 16 + ci) * 33 + co] = th[L.wc[layer] + ((size_t)tap * C + ci0 + ci) * C + co0 + co];
+    }
+    __syncthreads();
+    const size_t wbase = layer * per_layer + 2 * (size_t)C;
+    for (int e = tid; e < 32 * 144; e += 256) {
+      const int co = e / 144, r = e - co * 144;
+      const int ci = r / 9, tap = r - ci * 9;
+      flat[wbase + ((size_t)(co0 + co) * (C + 1) + 1 + ci0 + ci) * 9 + tap] = tile[(tap * 16 + ci) * 33 + co];
+    }
+    return;
+  }
+  // small parts: 3 x (g, b), 2 x conv bias, 2 x time-channel taps
+  const int nsmall = 26 * C;
+  for (int q = (b - nblk) * 256 + tid; q < nsmall; q += (gridDim.x - nblk) * 256) {
+    if (q < 6 * C) {
+      const int layer = q / (2 * C), r = q - layer * 2 * C;
+      const int which = r / C, c = r - which * C;
+      flat[layer * per_layer + (size_t)which * C + c] = th[(which ? L.b[layer] : L.g[layer]) + c];
+    } else if (q < 8 * C) {
+      const int r = q - 6 * C, layer = r / C, c = r - layer * C;
+      flat[layer * per_layer + 2 * (size_t)C + cw + c] = th[L.cb[layer] + c];
+    } else {
+      const int r = q - 8 * C, layer = r / (9 * C), rr = r - layer * 9 * C;
+      const int tap = rr / C, co = rr - tap * C;
+      flat[layer * per_layer + 2 * (size_t)C + ((size_t)co * (C + 1)) * 9 + tap] = th[L.wt[layer] + (size_t)tap * C + co];
+    }
+  }
+}
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s) {
+  if (d.C % 32 == 0) {
+    const int nblk = 2 * (d.C / 32) * (d.C / 16);
+    int extra = (26 * d.C + 255) / 256;
+    if (extra > 64) extra = 64;
+    hipLaunchKernelGGL(k_theta_to_torch_tiled, dim3(nblk + extra), dim3(256), 0, s, theta_int, flat, d.C);
+    return;
+  }
   int blocks = (int)((d.P + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_theta_to_torch, dim3(blocks), dim3(256), 0, s, theta_int, flat, d.C);
