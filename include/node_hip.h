@@ -127,6 +127,10 @@ typedef struct node_solve_opts {
   int32_t blind_steps;
   node_step_record* record; /* device */
   float* miss_flag;         /* device, nullable */
+  /* node_solve_adjoint only: the caller keeps just the last state of the trajectory (`out[-1]`, what ODEBlock returns
+   * with return_last_only, model.py:368-369), so dL/dy_out is zero in every other slice: `grad_out` then points to
+   * that ONE slice [n, c, h, w] and the zero slices are neither materialised by the caller nor read here. */
+  int32_t grad_last_only;
 } node_solve_opts;
 
 /* Per-kernel-class timing collected with HIP events on the caller's stream

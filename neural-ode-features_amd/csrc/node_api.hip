@@ -957,7 +957,10 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
-  launch_nchw_to_nhwc(S.d, grad_out + (size_t)(n_t - 1) * numel, S.p.A, S.st);  // adj_y = grad_output[-1]
+  // grad_last_only: `grad_out` is the last slice alone, every other slice of dL/dy_out is zero (node_solve_opts)
+  const bool last_only = opts && opts->grad_last_only;
+  const float* g_last = last_only ? grad_out : grad_out + (size_t)(n_t - 1) * numel;
+  launch_nchw_to_nhwc(S.d, g_last, S.p.A, S.st);  // adj_y = grad_output[-1]
   if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   double cur_t = 0.0, cur_dt = 0.0;
   bool first = true;
@@ -971,16 +974,20 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     const double s1 = (double)(decreasing ? -t_pts[i - 1] : t_pts[i - 1]);
 
     launch_nchw_to_nhwc(S.d, y_traj + (size_t)i * numel, S.p.Y, S.st);
-    launch_nchw_to_nhwc(S.d, grad_out + (size_t)i * numel, S.p.G, S.st);
+    // grad_output_i in NHWC for the dot product below: in the first interval the adjoint state still IS it; a zero
+    // slice (grad_last_only) contributes nothing
+    const float* gdot = i == n_t - 1 ? S.p.A : (last_only ? nullptr : S.p.G);
+    if (i != n_t - 1 && !last_only) launch_nchw_to_nhwc(S.d, grad_out + (size_t)i * numel, S.p.G, S.st);
     // func_i = f(t_i, y_i); adj_time -= <func_i, grad_output_i>.  Upstream evaluates f here and again as
     // the first stage of the augmented solve at the same (t_i, y_i); the stage-0 evaluation below
     // produces tsign * f bit-identically, so the dot product is taken from it (times tsign) and the
     // separate evaluation is only COUNTED (the reference's nfe counter, model.py:340, would have seen it).
     S.nfe += 1;
     float* dots_i = grad_t ? S.p.dots + i : nullptr;
+    if (gdot == nullptr && dots_i) launch_fill(dots_i, 0.f, 1, S.st);
 
     if (method == NODE_METHOD_RK4) {
-      TRY(S.rk4_interval(s0, s1, S.p.G, dots_i));
+      TRY(S.rk4_interval(s0, s1, gdot, gdot ? dots_i : nullptr));
       stt.accepted += 1;
       dlog.add(s1 - s0, true);
       cur_t = s1; cur_dt = s1 - s0;
@@ -990,7 +997,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       if (blind) launch_set_target(S.p.targets, s1, S.st);
       else TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
-      launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], S.p.G, numel, S.tsign, S.p.partial[0], dots_i, S.st);
+      if (gdot) launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], gdot, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
       if (blind) {   // deferred completion (one interval): the record says later whether these were the steps needed
         for (int q = 0; q < blind; ++q) TRY(S.enqueue_step(io));
@@ -998,8 +1005,10 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
         steps_total += blind;
         stt.accepted = blind; stt.rejected = 0; stt.status = 0;
         cur_t = s1; cur_dt = 0.0;
-        launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
-        launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+        if (!last_only) {
+          launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+          launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+        }
         continue;
       }
       StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 1, forced ? 1 : 0, rtol, atol, s0, s1, 0};
@@ -1024,8 +1033,10 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       if (stt.status != 0) break;
     }
     // adj_y += grad_output[i-1]
-    launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
-    launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+    if (!last_only) {
+      launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+      launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
+    }
   }
 
   launch_nhwc_to_nchw(S.d, S.p.A, grad_y0, S.st);

@@ -172,18 +172,19 @@ def _params_struct(params: List[torch.Tensor], device) -> Tuple[_lib.NodeParams,
     return _lib.NodeParams(*ptrs), keep
 
 
-def _opts_struct(options: Optional[dict], key: str, blind: Optional[tuple] = None):
+def _opts_struct(options: Optional[dict], key: str, blind: Optional[tuple] = None, grad_last_only: bool = False):
     """(struct-or-None, keepalive).  blind = (steps, record device tensor, miss flag device tensor) for a solve
     with deferred completion."""
     options = options or {}
     forced = options.get(key)
     max_steps = int(options.get('max_num_steps', 0) or 0)
     record = int(options.get('record_dt', 0) or 0)
-    if forced is None and max_steps == 0 and record == 0 and blind is None:
+    if forced is None and max_steps == 0 and record == 0 and blind is None and not grad_last_only:
         return None, None
     o = _lib.NodeSolveOpts()
     keep = {}
     o.max_num_steps = max_steps
+    o.grad_last_only = 1 if grad_last_only else 0
     if blind is not None:
         o.blind_steps = int(blind[0])
         o.record = blind[1].data_ptr()
@@ -242,7 +243,8 @@ def solve_forward(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor,
 
 def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Tensor, grad_out: torch.Tensor,
                   times: List[float], rtol: float, atol: float, method_id: int, options: Optional[dict],
-                  want_grad_t: bool = False, blind: Optional[tuple] = None):
+                  want_grad_t: bool = False, blind: Optional[tuple] = None, grad_last_only: bool = False):
+    """`grad_last_only`: `grad_out` is dL/d(y_traj[-1]) alone, shape [N, C, H, W]; all other slices are zero."""
     lib = _lib.load()
     y_traj = y_traj.detach().contiguous()
     grad_out = grad_out.detach().contiguous()
@@ -261,7 +263,7 @@ def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Ten
         grad_t = torch.empty(n_t, dtype=torch.float32, device=dev) if want_grad_t else None
         tarr = (C.c_float * n_t)(*times)
         stats = _lib.NodeStats()
-        opts, keep_o = _opts_struct(options, 'forced_dts_bwd', blind)
+        opts, keep_o = _opts_struct(options, 'forced_dts_bwd', blind, grad_last_only)
         rc = lib.node_solve_adjoint(C.byref(shape), C.byref(pstruct), y_traj.data_ptr(), grad_out.data_ptr(),
                                     tarr, n_t, float(rtol), float(atol), method_id,
                                     C.byref(opts) if opts is not None else None,
@@ -416,7 +418,7 @@ class _HipOdeint(torch.autograd.Function):
     (continuous adjoint, what `odeint_adjoint` does upstream)."""
 
     @staticmethod
-    def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, wants_grad, y0, *params):
+    def forward(ctx, func, rec, times, rtol, atol, method_id, options, adjoint, wants_grad, last_only, y0, *params):
         if not adjoint and wants_grad:
             options = dict(options or {})          # the backward replays the accepted steps: log their sizes
             options['record_dt'] = max(int(options.get('record_dt', 0) or 0), BACKPROP_LOG)
@@ -449,7 +451,10 @@ class _HipOdeint(torch.autograd.Function):
                                    'use odeint_adjoint' % BACKPROP_LOG)
             ctx.step_dts = [d for d, a in zip(st['dts'], st['accepts']) if a]
         ctx.save_for_backward(out, *params)
-        return out
+        ctx.last_only = bool(last_only)
+        # last_only: the caller keeps y(t[-1]) alone (ODEBlock.return_last_only); its gradient then arrives as one
+        # slice -- no [T, N, C, H, W] tensor of zeros is built by autograd, none is read by the adjoint
+        return out[-1] if last_only else out
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -462,13 +467,14 @@ class _HipOdeint(torch.autograd.Function):
             steps = d.plan(dkey, ctx.func) if d is not None else None
             if steps:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
-                                               ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps[1]))
+                                               ctx.method_id, ctx.options, blind=d.blind_args(dkey, steps[1]),
+                                               grad_last_only=ctx.last_only)
                 st['nfe'] -= 6 * (steps[1] - steps[0])
                 st['accepted'] = steps[0]
                 d.launched(dkey, steps[0], ctx.func)
             else:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
-                                               ctx.method_id, ctx.options)
+                                               ctx.method_id, ctx.options, grad_last_only=ctx.last_only)
                 if d is not None:
                     d.learned(dkey, st['accepted'] + st['rejected'])
             ctx.func.nfe = getattr(ctx.func, 'nfe', 0) + st['nfe']
@@ -476,6 +482,10 @@ class _HipOdeint(torch.autograd.Function):
         else:
             # upstream's non-adjoint backward is plain autograd through the solver's operations: it never calls
             # func.forward, so the reference's NFE counter does not move (model.py:340)
+            if ctx.last_only:        # the tape walk wants the cotangent of every output slice
+                full = torch.zeros_like(out)
+                full[-1] = grad_out
+                grad_out = full
             gy0, gp = solve_backprop(ctx.rec, params, out[0], grad_out, ctx.times, ctx.step_dts or [], ctx.method_id)
             ctx.func.last_backward_stats = {'nfe': 0, 'accepted': len(ctx.step_dts or []), 'rejected': 0, 'status': 0}
         grads = []
@@ -484,10 +494,10 @@ class _HipOdeint(torch.autograd.Function):
             n = p.numel()
             grads.append(gp[off:off + n].view_as(p))
             off += n
-        return (None, None, None, None, None, None, None, None, None, gy0, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, gy0, *grads)
 
 
-def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
+def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True, last_only=False):
     _check_state(y0)
     if not isinstance(func, nn.Module):
         raise ValueError('func is required to be an instance of nn.Module.')
@@ -500,7 +510,14 @@ def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True):
         raise ValueError('t must be strictly increasing or strictly decreasing')
     # (grad mode is off inside autograd.Function.forward: whether a gradient will be wanted is decided here)
     wants_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in rec.params))
-    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, wants_grad, y0, *rec.params)
+    return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, wants_grad, last_only, y0,
+                            *rec.params)
+
+
+def solve_last(func, y0, t, rtol, atol, method, adjoint):
+    """y(t[-1]) alone, [N, C, H, W]: what `ODEBlock.forward` returns with `return_last_only` (model.py:368-369),
+    without materialising the gradient of the slices nobody keeps."""
+    return _odeint_impl(func, y0, t, rtol, atol, method, None, adjoint=adjoint, last_only=True)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):

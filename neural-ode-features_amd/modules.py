@@ -93,6 +93,10 @@ class ODEBlock(nn.Module):
             if tag is not None and tag[0] == t._version:
                 integrate.tag_host_times(moved, tag[1])
             self.integration_time = moved
+        if self.return_last_only and (self.odeint is integrate.odeint or self.odeint is integrate.odeint_adjoint):
+            # same solve, same `out[-1]`; the backward receives that slice's gradient alone (integrate.solve_last)
+            return integrate.solve_last(self.odefunc, x, self.integration_time, self.tol, self.tol, self.method,
+                                        adjoint=self.odeint is integrate.odeint_adjoint)
         out = self.odeint(self.odefunc, x, self.integration_time,
                           method=self.method, rtol=self.tol, atol=self.tol)
         return out[-1] if self.return_last_only else out

@@ -508,3 +508,50 @@ def test_results_do_not_depend_on_workspace_contents(fill, shape):
         got, _ = integrate.solve_forward(rec, rec.params, y, t2, 1e-4, 1e-4, 0, None, blind=(steps, record, flag))
         torch.cuda.synchronize()
         assert torch.equal(got, ref) and float(flag) == 0.0
+
+
+@pytest.mark.parametrize('t1', [1, [0.2, 0.5, 1.0]])
+@pytest.mark.parametrize('method', ['dopri5', 'rk4'])
+def test_last_slice_gradient_path_equals_the_full_one(t1, method):
+    """`ODEBlock` with `return_last_only` hands the adjoint the gradient of `out[-1]` alone (no tensor of zeros for
+    the slices nobody keeps); `odeint_adjoint(...)[-1]` hands it the whole [T, ...] gradient with zero slices.  Same
+    solve, same arithmetic: forward, input gradient and parameter gradients bit for bit, for one and for several
+    intervals (zero slices in the middle)."""
+    import contextlib
+    import io
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    f, _ = make_func(64, seed=151, device='cpu')
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = nof.ODEBlock(n_filters=64, tol=1e-3, method=method, adjoint=True, t1=t1)
+    blk.odefunc.load_state_dict(f.state_dict())
+    blk = blk.cuda()
+    x = torch.randn(5, 64, 8, 8, generator=torch.Generator().manual_seed(152)).cuda()
+    w = torch.randn(5, 64, 8, 8, generator=torch.Generator().manual_seed(153)).cuda()
+
+    xa = x.clone().requires_grad_(True)
+    ya = blk(xa)                                         # last-slice path
+    (ya * w).sum().backward()
+    ga = [p.grad.clone() for p in blk.parameters()]
+    for p in blk.parameters():
+        p.grad = None
+    xb = x.clone().requires_grad_(True)
+    yb = integrate.odeint_adjoint(blk.odefunc, xb, blk.integration_time, rtol=1e-3, atol=1e-3, method=method)[-1]
+    (yb * w).sum().backward()
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    for a, p in zip(ga, blk.parameters()):
+        assert torch.equal(a, p.grad)
+    # the non-adjoint block takes the same forward and a tape walk with zero cotangents for the other slices
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk2 = nof.ODEBlock(n_filters=64, tol=1e-3, method=method, adjoint=False, t1=t1)
+    blk2.odefunc.load_state_dict(f.state_dict())
+    blk2 = blk2.cuda()
+    xc = x.clone().requires_grad_(True)
+    yc = blk2(xc)
+    (yc * w).sum().backward()
+    xd = x.clone().requires_grad_(True)
+    yd = integrate.odeint(blk2.odefunc, xd, blk2.integration_time, rtol=1e-3, atol=1e-3, method=method)[-1]
+    for p in blk2.parameters():
+        p.grad = None
+    (yd * w).sum().backward()
+    assert torch.equal(yc, yd) and torch.equal(xc.grad, xd.grad) and torch.equal(ya, yc)

@@ -185,7 +185,7 @@ def test_header_is_plain_c_and_ctypes_layouts_match(tmp_path):
         'node_params': (_lib.NodeParams, ['norm1_w', 'conv1_w', 'norm3_b']),
         'node_stats': (_lib.NodeStats, ['nfe', 'status', 'last_dt', 't_final', 'first_dt']),
         'node_solve_opts': (_lib.NodeSolveOpts, ['max_num_steps', 'n_forced_dt', 'forced_dt', 'record_dt', 'dt_log', 'n_dt_log',
-                                                 'blind_steps', 'record', 'miss_flag']),
+                                                 'blind_steps', 'record', 'miss_flag', 'grad_last_only']),
         'node_step_record': (_lib.NodeStepRecord, ['done', 'status', 'steps', 'accepted', 'rejected', 'miss', 't', 'dt', 'first_dt']),
         'node_sgd_tensor': (_lib.NodeSgdTensor, ['param', 'grad', 'momentum_buf', 'n']),
         'node_profile': (_lib.NodeProfile, ['launches', 'total_ms', 'flops']),
