@@ -110,3 +110,38 @@ def test_bench_two_ranks_through_self_launcher_on_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
     assert 'SHARE' in d['config']['parallelism']
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_carries_the_contract_keys():
+    """`python bench.py` (N = 1): ONE JSON line with the driver's keys, the roofline object of the dominant kernel and
+    the CPU baseline; the roofline fraction is a utilisation (<= 1), the algorithmic figure lives under its own key."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '6', '--warmup', '3'],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'step_ms'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 6 and d['warmup'] == 3 and d['unit'] == 'images/sec' and d['dtype'] == 'f32'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic'):
+        assert k in rf, k
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and 0.3 < rf['frac'] < 1.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['algorithmic']['achieved'] > rf['achieved']
+    assert rf['traffic'] is None or rf['traffic'] > 1e7
+    cb = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in cb, k
+    assert cb['kind'] == 'port' and cb['value'] > 0 and d['value'] > 10 * cb['value']
+    assert abs(d['value'] - 128 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
