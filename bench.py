@@ -417,6 +417,7 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'step_ms': {'median': statistics.median(per_step), 'min': min(per_step), 'max': max(per_step),
+                        'all': [round(v, 3) for v in per_step],
                         'source': 'HIP events on the compute stream of rank 0, one per step'},
             'higher_is_better': True,
             'scaling': 'weak',
@@ -426,6 +427,7 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
+                'timed_region': attempt + 1,      # 1 unless an earlier region held a skipped update and was measured again
                 'solver_completion': 'read-back per solve' if deferred is None else
                                      'deferred (device-predicated optimizer step; %d blind solves, %d misses in the timed region)'
                                      % (deferred.blind_solves, timed_misses),

@@ -167,6 +167,13 @@ int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t
                      float* f, float* vjp_y, float* vjp_t, float* vjp_params,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Diagnostics (tests, tools): y = conv3x3(x, weight[:, 1:], padding = 1) for an [n, c, 8, 8] tensor through the
+ * Winograd F(4x4,3x3) pipeline the solver uses when its tolerance allows (csrc/wino4.h); dgrad != 0: the data
+ * gradient (transposed convolution) instead.  weight is a ConcatConv2d filter [c][c+1][3][3] (model.py:320-323). */
+size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape);
+int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y,
+                    void* ws, size_t ws_bytes, void* stream);
+
 /* torchdiffeq.odeint(ODEfunc, y0, t, rtol, atol, method)  -- model.py:367
  * t_pts: host array of n_t strictly monotonic times; y_out: [n_t, n, c, h, w]
  * with y_out[0] = y0. */

@@ -7,6 +7,7 @@
 // Algorithm follows the restated torchdiffeq spec; the CPU
 // statement of the same arithmetic is oracle/torchdiffeq_restated.py.
 #include "node_internal.h"
+#include "wino4.h"
 #include <cstring>
 #include "../../include/node_hip.h"
 
@@ -74,6 +75,11 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
 
+  float* w4s = srstd + d.cs;               // W4_SCRATCH floats when a w4 hook is on
+  const W4Geom w4g = w4_geom(d.N, d.C);
+  if (a.w4.m_in) {   // the conv in front of this pass ran as 36 component GEMMs: output transform + bias + t * tmap
+    w4_load_tile(a.w4.m_in, n, c0, w4g, tile, csl, w4s, a.w4.bias, a.w4.tmap, a.w4.bias ? eval_time(a.w4.et) : 0.f, tid);
+  } else
   for (int v = tid; v < nvec; v += 256) {
     const int p = v / cs4, q = v - p * cs4;
     const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
@@ -141,11 +147,16 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
     }
     st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
     if (a.xhat_out) st4(a.xhat_out + off, make_float4(xh[0], xh[1], xh[2], xh[3]));
+    if (a.w4.v_out) st4(tile + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // own elements only: in place
+  }
+  if (a.w4.v_out) {   // input transform of the activation just produced, for the component GEMMs of the next conv
+    __syncthreads();
+    w4_emit_v(tile, csl, n, c0, a.w4.v_out, w4g, w4s, tid);
   }
 }
 
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s) {
-  size_t lds = ((size_t)d.HW * d.cs + 2 * (size_t)d.cs) * sizeof(float);
+  size_t lds = ((size_t)d.HW * d.cs + 2 * (size_t)d.cs + ((a.w4.m_in || a.w4.v_out) ? W4_SCRATCH : 0)) * sizeof(float);
   hipLaunchKernelGGL(k_combine_gn, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
 }
 
@@ -168,9 +179,9 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
   float* xt = gt + d.HW * d.cs;               // [HW][csl]   xhat
   float* sm1 = xt + d.HW * d.cs;              // [cs]
   float* sm2 = sm1 + d.cs;                    // [cs]
-  float* cred = sm2 + d.cs;                   // [256][2] channel partials
+  unsigned char* flg = reinterpret_cast<unsigned char*>(sm2 + d.cs);   // [HW] border flags (rounded up to 16 B)
+  float* cred = sm2 + d.cs + ((d.HW + 15) / 16) * 4;   // [256][2] channel partials
   float* red9 = cred + 512;                   // [9 * 256] masked column sums across pixel groups
-  unsigned char* flg = reinterpret_cast<unsigned char*>(red9 + 9 * 256);   // [HW] border flags
   if (a.spart)
     for (int p = tid; p < d.HW; p += 256) {
       const int h = p / d.W, x = p - h * d.W;
@@ -182,6 +193,35 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
 
+  // W4_SCRATCH floats over the reduction scratch (cred, red9: live only between the transforms) and beyond: the
+  // workgroup stays under 40 KB of LDS, four per CU -- its 1024 workgroups run in ONE round
+  float* w4s = cred;
+  const W4Geom w4g = w4_geom(d.N, d.C);
+  if (a.w4.m_in) {   // raw data gradient = output transform of the component GEMMs in front of this pass
+    // (HW = 64, cs = 32: two float4 per thread) the other operands of the pass are requested first, so their
+    // latency runs under the component rows' load and transform instead of behind it
+    float4 pmk[2], pxh[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int v = tid + it * 256;
+      const int p = v / cs4, q = v - p * cs4;
+      const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
+      pmk[it] = a.mask_act ? ld4(a.mask_act + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+      pxh[it] = ld4(a.xhat + off);
+    }
+    w4_load_tile(a.w4.m_in, n, c0, w4g, gt, csl, w4s, nullptr, nullptr, 0.f, tid);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int v = tid + it * 256;
+      const int p = v / cs4, q = v - p * cs4;
+      float4 gq = ld4(gt + p * csl + 4 * q);
+      gq.x = pmk[it].x > 0.f ? gq.x : 0.f; gq.y = pmk[it].y > 0.f ? gq.y : 0.f;
+      gq.z = pmk[it].z > 0.f ? gq.z : 0.f; gq.w = pmk[it].w > 0.f ? gq.w : 0.f;
+      st4(gt + p * csl + 4 * q, gq);
+      st4(xt + p * csl + 4 * q, pxh[it]);
+    }
+  } else
   for (int v = tid; v < nvec; v += 256) {
     const int p = v / cs4, q = v - p * cs4;
     const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
       o[i] = a.osign * (r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]));
     }
     st4(a.dz_out + off, make_float4(o[0], o[1], o[2], o[3]));
-    if (a.spart) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums below
+    if (a.spart || a.w4.v_out) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums / input transform below
   }
   if (a.spart) {   // masked column sums of this sample's dz slab while it is still in LDS (replaces a k_colsum launch)
     __syncthreads();
@@ -285,10 +325,19 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
                          a.spart + (size_t)n * 9 * d.C + c0 + cbase, d.C);
     }
   }
+  if (a.w4.v_out) {   // input transform of dz for the component GEMMs of the data-gradient conv that follows
+    __syncthreads();
+    w4_emit_v(gt, csl, n, c0, a.w4.v_out, w4g, w4s, tid);
+  }
 }
 
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
   size_t lds = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs + 512 + 9 * 256) * sizeof(float) + (size_t)d.HW + 16;
+  if (a.w4.m_in || a.w4.v_out) {   // the transforms' scratch lies over cred / red9 and what it needs beyond them
+    const size_t base = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs) * sizeof(float) + (((size_t)d.HW + 15) / 16) * 16;
+    const size_t want = base + W4_SCRATCH * sizeof(float);
+    if (want > lds) lds = want;
+  }
   hipLaunchKernelGGL(k_gn_bwd, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
 }
 

@@ -1,0 +1,269 @@
+// Winograd F(4x4,3x3) pipeline, stage 2: the 36 component GEMMs, and the once-per-solve filter transform.
+// gfx950 (MI355X / CDNA4) only.  See wino4.h for the data layouts.
+#include "wino4.h"
+#include <cstdlib>
+
+namespace node {
+
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+// ----------------------------------------------------------------------------
+// U = G g G^T for every (co, ci) pair, written in MFMA-ready blocks (wino4.h).  dgrad: the data-gradient filter
+// g'[ci][co][kh][kw] = g[co][ci][2-kh][2-kw].  Weights are [C][C+1][3][3] (input channel 0 = time, model.py:320-323).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
+  const float* __restrict__ w = jobs.w[blockIdx.y];
+  float* __restrict__ U = jobs.u[blockIdx.y];
+  const int dgrad = jobs.dgrad[blockIdx.y];
+  const int G8 = C >> 3;
+  const size_t total = (size_t)C * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int e = idx & 3, col = (idx >> 2) & 31, hi = (idx >> 7) & 1;
+    const int g = (int)((idx >> 8) % G8), cb = (int)((idx >> 8) / G8);
+    const int nidx = cb * 32 + col, kidx = 8 * g + 4 * hi + e;   // output column / reduction index of the GEMM
+    double gg[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        gg[kh][kw] = dgrad ? (double)w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                           : (double)w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+    double gt[6][3];   // G g
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) gt[i][kw] = W4_G[i][0] * gg[0][kw] + W4_G[i][1] * gg[1][kw] + W4_G[i][2] * gg[2][kw];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int l = 0; l < 6; ++l) {
+        const double v = gt[i][0] * W4_G[l][0] + gt[i][1] * W4_G[l][1] + gt[i][2] * W4_G[l][2];
+        U[(size_t)(i * 6 + l) * total + idx] = (float)v;
+      }
+  }
+}
+void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s) {
+  int blocks = (int)(((size_t)C * C + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_w4_pack, dim3(blocks, count), dim3(256), 0, s, jobs, C);
+}
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm: M_c[rows, C] = V_c[rows, C] x U_c[C, C] for the 36 components.
+// Workgroup = one 32-row block x one pair of 32-column blocks x NINE components (grid = N/8 x C/64 x 4): eight
+// waves take one component each over the whole K range (two accumulators sharing the row operand), the ninth
+// component is cut into eight K slices, one per wave, and summed through LDS -- 288 MFMAs per wave, 576 per SIMD,
+// no wave idles.  No operand is shared between waves, so nothing is staged through LDS: every (component, block,
+// eight channels) operand is a contiguous 1 KB block and one 16-B load per lane feeds four MFMA k-steps; four
+// loads deep in registers.  Per eight MFMAs a wave issues three vector loads and nothing else.
+// ----------------------------------------------------------------------------
+constexpr int W4_DEPTH = 4;    // operand sets in flight in the main loop (C % 64 == 0: C / 8 is a multiple)
+constexpr int W4_SDEPTH = 4;   // ... in a K slice of the shared component
+
+__device__ __forceinline__ void w4_mac(float16_t& acc0, float16_t& acc1, const float4& a, const float4& b0, const float4& b1) {
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+  acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+  acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+}
+
+// acc += V[comp, rb, g0 .. g0+ng) x U[comp, cb0 / cb0+1, g0 .. g0+ng).  A ring of W4_DEPTH operand sets: each set is
+// refilled, right behind the MFMAs that consumed it, with the block W4_DEPTH ahead -- unconditionally, so the last
+// sets read up to W4_DEPTH blocks past the range (the buffers carry that much slack, see w4_v_elems / w4_u_elems).
+template <int D>
+struct W4Ring {
+  float4 a[D], b0[D], b1[D];
+  const float4 *qa, *q0, *q1;
+};
+// requests in the steady state's order, pinned: the compiler merges the wait state of the loop entry into every
+// iteration, so any other order here would make each iteration wait for its youngest request
+template <int D>
+__device__ __forceinline__ void w4_ring_fill(W4Ring<D>& r, const float* pa, const float* pb0, const float* pb1) {
+  r.qa = reinterpret_cast<const float4*>(pa);
+  r.q0 = reinterpret_cast<const float4*>(pb0);
+  r.q1 = reinterpret_cast<const float4*>(pb1);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    r.a[i] = r.qa[i * 64];
+    r.b0[i] = r.q0[i * 64];
+    r.b1[i] = r.q1[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  r.qa += D * 64; r.q0 += D * 64; r.q1 += D * 64;
+}
+// GUARD: ng need not be a multiple of D and nothing is refilled (the K slices of the shared component: ng <= D)
+template <int D, bool GUARD>
+__device__ __forceinline__ void w4_ring_run(W4Ring<D>& r, float16_t& acc0, float16_t& acc1, int ng) {
+  for (int g = 0; g < ng; g += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (!GUARD || g + i < ng) w4_mac(acc0, acc1, r.a[i], r.b0[i], r.b1[i]);
+      // the empty asm ties the refill behind the MFMAs that read the old contents and keeps the three requests whole
+      asm volatile("" : "+v"(acc0), "+v"(acc1) :: "memory");
+      if (!GUARD) {
+        r.a[i] = r.qa[i * 64];
+        r.b0[i] = r.q0[i * 64];
+        r.b1[i] = r.q1[i * 64];
+      }
+    }
+    r.qa += D * 64; r.q0 += D * 64; r.q1 += D * 64;
+  }
+}
+
+// AB: timing-only ablations (tools/w4_time.py, NODE_TUNE_W4_ABLATE): 1 no shared component, 2 no main loop, 4 no stores
+template <int AB>
+__global__ __launch_bounds__(512) void k_w4_gemm(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                 const Ctrl* ctrl, W4Geom gm, int xmap) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [8 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCP = gm.C >> 6, nRB = gm.RB;
+  // Workgroups b and b + 8 share an XCD (and its L2).  An XCD takes one component group and half of the column
+  // pairs for every row block: its filter operands (9 components x nCP/2 pairs) stay resident in its L2 while the
+  // row operands stream through, each fetched by two XCDs.
+  int cg, rb, cp;
+  {
+    const int L = blockIdx.x;
+    if (xmap == 1 && (nRB & 1) == 0) {   // (A/B) an XCD = one component group x HALF of the row blocks x every column pair
+      const int xcd = L & 7, slot = L >> 3;
+      cg = xcd >> 1;
+      rb = (xcd & 1) * (nRB >> 1) + slot / nCP;
+      cp = slot % nCP;
+    } else if ((nCP & 1) == 0 && ((nRB * nCP * 4) & 7) == 0) {
+      const int xcd = L & 7, slot = L >> 3, half = nCP >> 1;
+      cg = xcd >> 1;
+      rb = slot / half;
+      cp = (xcd & 1) * half + slot % half;
+    } else {
+      cg = L & 3;
+      const int r = L >> 2;
+      cp = r % nCP;
+      rb = r / nCP;
+    }
+  }
+  const int G8 = gm.G8, CB = gm.C >> 5;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  const int b_off = lane * 4;
+  auto vblk = [&](int comp) { return V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off; };
+  auto ublk = [&](int comp, int cb) { return U + (((size_t)comp * CB + cb) * G8) * 256 + b_off; };
+
+  // --- this wave's own component, whole K range
+  const int comp = cg * 9 + wave;
+  {
+    W4Ring<W4_DEPTH> ring;
+    w4_ring_fill(ring, vblk(comp), ublk(comp, 2 * cp), ublk(comp, 2 * cp + 1));
+    float16_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if (!(AB & 2)) w4_ring_run<W4_DEPTH, false>(ring, acc0, acc1, G8);
+    float* mrow = M + ((size_t)comp * gm.R + rb * 32) * gm.C + cp * 64 + l31;
+    if (!(AB & 4)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        mrow[(size_t)row * gm.C] = acc0[r];
+        mrow[(size_t)row * gm.C + 32] = acc1[r];
+      }
+    } else if (acc0[0] == 12345.f) mrow[0] = acc0[1] + acc1[2];
+  }
+  // --- the ninth component, shared: K slice [wave * G8/8, (wave+1) * G8/8) per wave, summed through LDS.
+  // (Measured: running it first on operands requested together with the main loop's, or first in four waves and
+  // last in the other four, with eight operand sets in flight, were both 1.3 - 2 us SLOWER than this order.)
+  const int scomp = cg * 9 + 8;
+  if (!(AB & 1)) {
+    const int ng = G8 >> 3, g0 = wave * ng;
+    W4Ring<W4_SDEPTH> sr;
+    float16_t s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    for (int gs = 0; gs < ng; gs += W4_SDEPTH) {   // (one round at C <= 256)
+      w4_ring_fill(sr, vblk(scomp) + (size_t)(g0 + gs) * 256, ublk(scomp, 2 * cp) + (size_t)(g0 + gs) * 256,
+                   ublk(scomp, 2 * cp + 1) + (size_t)(g0 + gs) * 256);
+      w4_ring_run<W4_SDEPTH, true>(sr, s0, s1, min(W4_SDEPTH, ng - gs));
+    }
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      *reinterpret_cast<float4*>(red + (r4 * 64 + lane) * 4) = make_float4(s0[4 * r4], s0[4 * r4 + 1], s0[4 * r4 + 2], s0[4 * r4 + 3]);
+      *reinterpret_cast<float4*>(red + 1024 + (r4 * 64 + lane) * 4) = make_float4(s1[4 * r4], s1[4 * r4 + 1], s1[4 * r4 + 2], s1[4 * r4 + 3]);
+    }
+  }
+  if (!(AB & 1)) {
+    __syncthreads();
+    const int blk = tid >> 8, r4 = (tid >> 6) & 3;
+    float4 s = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* mrow = M + ((size_t)scomp * gm.R + rb * 32 + 8 * r4 + 4 * hi) * gm.C + cp * 64 + blk * 32 + l31;
+    mrow[0] = s.x;
+    mrow[(size_t)gm.C] = s.y;
+    mrow[(size_t)2 * gm.C] = s.z;
+    mrow[(size_t)3 * gm.C] = s.w;
+  }
+}
+
+void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s) {
+  static bool attr[4][MAX_DEVICES] = {};
+  static int ab = -1;
+  if (ab < 0) { const char* e = getenv("NODE_TUNE_W4_ABLATE"); ab = e ? atoi(e) : 0; }
+  static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
+  if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
+  const W4Geom gm = w4_geom(N, C);
+  const int grid = gm.RB * (C >> 6) * 4;
+  const size_t lds = 8 * 2048 * sizeof(float);
+#define W4_LAUNCH(AB, SLOT)                                                               \
+  {                                                                                        \
+    allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm<AB>), attr[SLOT]);               \
+    hipLaunchKernelGGL(k_w4_gemm<AB>, dim3(grid), dim3(512), lds, s, V, U, M, ctrl, gm, xm); \
+  }
+  if (ab == 1) W4_LAUNCH(1, 1)
+  else if (ab == 2) W4_LAUNCH(2, 2)
+  else if (ab == 4) W4_LAUNCH(4, 3)
+  else W4_LAUNCH(0, 0)
+#undef W4_LAUNCH
+}
+
+// ----------------------------------------------------------------------------
+// Stand-alone transforms around the GEMM (diagnostics / tests; the solver fuses them into its pointwise passes)
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_w4_input(const float* __restrict__ x, float* __restrict__ V, W4Geom gm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;               // [64][32]
+  float* scratch = smem + 64 * 32;
+  const int tid = threadIdx.x, n = blockIdx.x, c0 = blockIdx.y * 32;
+  for (int v = tid; v < 64 * 8; v += 256) {
+    const int p = v >> 3, q = v & 7;
+    *reinterpret_cast<float4*>(tile + p * 32 + 4 * q) =
+        *reinterpret_cast<const float4*>(x + ((size_t)n * 64 + p) * gm.C + c0 + 4 * q);
+  }
+  __syncthreads();
+  w4_emit_v(tile, 32, n, c0, V, gm, scratch, tid);
+}
+__global__ __launch_bounds__(256) void k_w4_output(const float* __restrict__ M, float* __restrict__ y, W4Geom gm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;
+  float* scratch = smem + 64 * 32;
+  const int tid = threadIdx.x, n = blockIdx.x, c0 = blockIdx.y * 32;
+  w4_load_tile(M, n, c0, gm, tile, 32, scratch, nullptr, nullptr, 0.f, tid);
+  __syncthreads();
+  for (int v = tid; v < 64 * 8; v += 256) {
+    const int p = v >> 3, q = v & 7;
+    *reinterpret_cast<float4*>(y + ((size_t)n * 64 + p) * gm.C + c0 + 4 * q) = *reinterpret_cast<const float4*>(tile + p * 32 + 4 * q);
+  }
+}
+void launch_w4_input(const float* x, float* V, int N, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4_input, dim3(N, C / 32), dim3(256), (64 * 32 + W4_SCRATCH) * sizeof(float), s, x, V, w4_geom(N, C));
+}
+void launch_w4_output(const float* M, float* y, int N, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4_output, dim3(N, C / 32), dim3(256), (64 * 32 + W4_SCRATCH) * sizeof(float), s, M, y, w4_geom(N, C));
+}
+
+}  // namespace node

@@ -29,6 +29,8 @@ struct Dims {
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
   int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
                     // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
+  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, N % 8 == 0, 32-channel slabs.
+                    // Whether a solve USES it depends on its tolerance (Solver::w4)
   int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
                     // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)
   int mtiles;          // ceil(N / S)
@@ -146,6 +148,17 @@ void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tm
                       float* const* zero, const size_t* zero_n, int nzero /*<= 6: regions to zero-fill*/, hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
 
+// Winograd F(4x4,3x3) pipeline hooks of the GroupNorm passes (wino4.h): read the conv result as its 36 component rows
+// (output transform on the fly, + bias + t * tmap for a forward conv) and / or leave the input transform of the
+// tensor just produced for the GEMM that follows.  All-zero = off.
+struct W4Hook {
+  const float* m_in;    // [36][4 N][C] component products of the conv in front of this pass (replaces comb.y)
+  float* v_out;         // blocked input transform of act_out / dz_out (the next conv's row operand)
+  const float* bias;    // forward conv only: [C]
+  const float* tmap;    // forward conv only: [HW][C] border-aware time-channel map
+  EvalTime et;          // time of the evaluation (tmap multiplier)
+};
+
 // pointwise / reductions
 struct CombineGnArgs {
   Comb comb;
@@ -158,6 +171,7 @@ struct CombineGnArgs {
   const float* beta;
   int relu;            // 1: act = relu(GN(y_i)); 0: act = GN(y_i)   (split-conv GroupNorm pass)
   float osign;         // output multiplier (1 for the stage combine)
+  W4Hook w4;
 };
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s);
 
@@ -227,6 +241,7 @@ struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN
   float* spart;        // nullable: [N][9][C] masked column sums of dz_out (see masked_colsum_tile)
   const float* mask_act;   // nullable: g is zeroed where this activation is <= 0 (ReLU mask of a split-conv data gradient)
   float osign;         // output multiplier (1 for GroupNorm-3's backward)
+  W4Hook w4;
 };
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s);
 

@@ -1,0 +1,127 @@
+"""GPU parity of the Winograd F(4x4,3x3) pipeline (csrc/wino4.h): the convolution alone against an fp64 convolution,
+then whole ODEfunc evaluations / VJPs / solves with the pipeline forced on against the same calls with it off
+(NODE_TUNE_WINO4 is read per call) and against the oracle.  Bounds: the transform's own rounding is 3.2e-6 of max|y|
+per convolution (tools/wino_error.py); a solve must stay within 10 x atol of the oracle (BASELINE.json north_star)."""
+import contextlib
+import ctypes as C
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import make_func, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def wino4(mode):
+    old = os.environ.get('NODE_TUNE_WINO4')
+    os.environ['NODE_TUNE_WINO4'] = str(mode)
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ['NODE_TUNE_WINO4']
+        else:
+            os.environ['NODE_TUNE_WINO4'] = old
+
+
+def _conv_w4(x, w, dgrad):
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    N, Cc, H, W = x.shape
+    shape = _lib.NodeShape(N, Cc, H, W, min(32, Cc), 1e-5)
+    nbytes = lib.node_conv3x3_w4_workspace_bytes(C.byref(shape))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+    base = (ws.data_ptr() + 255) & ~255
+    y = torch.empty_like(x)
+    rc = lib.node_conv3x3_w4(C.byref(shape), w.data_ptr(), int(dgrad), x.data_ptr(), y.data_ptr(), base, nbytes,
+                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc)
+    torch.cuda.synchronize()
+    return y
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8)])
+@pytest.mark.parametrize('dgrad', [0, 1])
+def test_w4_convolution_matches_fp64(shape, dgrad):
+    N, Cc, H, W = shape
+    gen = torch.Generator().manual_seed(3 + dgrad)
+    x = torch.randn(N, Cc, H, W, generator=gen).relu().cuda()
+    w = ((torch.rand(Cc, Cc + 1, 3, 3, generator=gen) * 2 - 1) / (9 * Cc) ** 0.5).cuda()
+    got = _conv_w4(x, w, dgrad)
+    wd = w[:, 1:].double()
+    if dgrad:
+        ref = F.conv_transpose2d(x.double(), wd, padding=1)
+    else:
+        ref = F.conv2d(x.double(), wd, padding=1)
+    err = float((got.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
+
+
+def _engaged(N, Cc):
+    """The workspace grows by the pipeline's buffers exactly when the geometry takes it."""
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    shape = _lib.NodeShape(N, Cc, 8, 8, min(32, Cc), 1e-5)
+    with wino4(0):
+        a = lib.node_workspace_bytes(C.byref(shape), 0, 1, 2)
+    with wino4(2):
+        b = lib.node_workspace_bytes(C.byref(shape), 0, 1, 2)
+    return b > a
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (128, 256, 8, 8)])
+def test_w4_odefunc_forward_and_vjp_match_f2(shape):
+    from neural_ode_features_amd import integrate
+    N, Cc, H, W = shape
+    assert _engaged(N, Cc)
+    f, _ = make_func(Cc, seed=5, device='cuda')
+    gen = torch.Generator().manual_seed(11)
+    y = torch.randn(N, Cc, H, W, generator=gen).cuda()
+    cot = torch.randn(N, Cc, H, W, generator=gen).cuda()
+    with wino4(0):
+        ref = integrate.odefunc_vjp(f, 0.3, y, cot)
+        ref_f = integrate.odefunc_forward(f, 0.3, y)
+    with wino4(2):
+        got = integrate.odefunc_vjp(f, 0.3, y, cot)
+        got_f = integrate.odefunc_forward(f, 0.3, y)
+    assert rel_err(got_f, ref_f) < 5e-5
+    names = ('f', 'vjp_y', 'vjp_t', 'vjp_params')
+    for name, g, r in zip(names, got, ref):
+        e = rel_err(g, r)
+        # a ReLU mask that flips on a pre-activation within rounding of zero moves vjp entries by O(1) locally
+        # (tests/helpers.py: make_func); the L2 error stays tiny
+        l2 = float((g.double() - r.double()).norm() / r.double().norm())
+        assert l2 < 1e-4, (name, l2, e)
+
+
+def test_w4_solve_matches_f2_and_oracle_tolerance():
+    """dopri5 at tol 1e-3 takes the F(4x4,3x3) path by itself; with it off the same solve runs on F(2x2,3x3)."""
+    import neural_ode_features_amd as nof
+    N, Cc = 16, 64
+    assert _engaged(N, Cc)
+    f, _ = make_func(Cc, seed=2, device='cuda', kink_free=True)
+    gen = torch.Generator().manual_seed(21)
+    y0 = torch.randn(N, Cc, 8, 8, generator=gen).cuda()
+    t = torch.tensor([0.0, 1.0]).cuda()
+    outs, grads, nfes = [], [], []
+    for mode in (0, 1):
+        with wino4(mode):
+            for p in f.parameters():
+                p.grad = None
+            y = y0.clone().requires_grad_(True)
+            f.nfe = 0
+            out = nof.odeint_adjoint(f, y, t, rtol=1e-3, atol=1e-3, method='dopri5')[-1]
+            nf = f.nfe
+            out.square().sum().backward()
+            outs.append(out.detach())
+            grads.append((y.grad.detach().clone(), torch.cat([p.grad.reshape(-1) for p in f.parameters()])))
+            nfes.append((nf, f.nfe - nf))
+    assert nfes[0] == nfes[1], nfes
+    assert float((outs[0] - outs[1]).abs().max()) < 1e-3           # 10 x atol would be 1e-2
+    assert rel_err(outs[1], outs[0]) < 1e-4
+    assert rel_err(grads[1][0], grads[0][0]) < 1e-3
+    assert rel_err(grads[1][1], grads[0][1]) < 1e-3

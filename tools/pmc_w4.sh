@@ -1,0 +1,22 @@
+#!/bin/bash
+# PMC passes over tools/w4_time.py (the F(4x4,3x3) diagnostic convolution at the cfg-2 shape): MFMA duty and clock
+# of k_w4_gemm, its HBM / L2 traffic.  One counter group per run.   usage: tools/pmc_w4.sh <out.json>
+OUT=${1:-gpurun_out/pmc_w4.json}
+R=$(cd "$(dirname "$0")/.." && pwd)
+cd /tmp && export TMPDIR=/tmp
+i=0
+dirs=""
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD"; do
+  rm -rf /tmp/pw_$i
+  rocprofv3 --pmc $grp --output-format csv -d /tmp/pw_$i -- python3 $R/tools/w4_time.py 10 > /tmp/pw_$i.log 2>&1 || { echo "group '$grp' failed"; tail -3 /tmp/pw_$i.log; }
+  dirs="$dirs /tmp/pw_$i"
+  i=$((i + 1))
+done
+cd $R
+python3 tools/pmc_agg.py $OUT $dirs
+python3 -c "
+import json
+d = json.load(open('$OUT'))
+for k, v in d.items():
+    print(k, {a: round(b, 1) for a, b in v.items()})
+"

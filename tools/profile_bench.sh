@@ -5,7 +5,7 @@
 set -e
 OUT=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
-STEPS=12; WARM=3
+STEPS=${STEPS:-12}; WARM=${WARM:-3}
 mkdir -p "$(dirname "$OUT")"
 D=/tmp/prof_$$
 rm -rf $D
@@ -16,9 +16,7 @@ grep '"metric"' $D.log > ${OUT}_bench.json || true
 KS=$(find $D -name '*kernel_stats.csv' | head -1)
 KT=$(find $D -name '*kernel_trace.csv' | head -1)
 cp $KS ${OUT}_kernel_stats.csv
-# bench runs WARM + STEPS + min(STEPS,5) profiled-repeat steps
-TOTAL=$((STEPS + WARM + 5))
-python3 tools/steady_profile.py $KT 5 $TOTAL > ${OUT}_steady.txt
-python3 tools/gap_profile.py $KT 5 $TOTAL > ${OUT}_gaps.txt
-head -30 ${OUT}_steady.txt
-head -16 ${OUT}_gaps.txt
+# bench runs WARM + STEPS (x timed_region, if a region was measured again) + 1 + min(STEPS,5) roofline-repeat steps
+REGION=$(python3 -c "import json,sys; print(json.loads(open('${OUT}_bench.json').read().strip().splitlines()[-1])['config'].get('timed_region', 1))")
+python3 tools/step_profile.py $KT --warmup $((WARM + (REGION - 1) * STEPS)) --steps $STEPS --repeat 5 --gaps ${DUMP_WINDOW:+--dump ${OUT}_window.csv} > ${OUT}_steps.txt
+cat ${OUT}_steps.txt
