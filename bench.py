@@ -206,19 +206,22 @@ def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
                       % (done, bs, nf, nb, dt)}
 
 
-def pmc_traffic(config):
+def pmc_traffic(config, kernel='k_conv3x3'):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None where no pass is committed."""
     shape_of = {2: 2, 3: 2, 5: 5}.get(config, config)       # cfg 3 runs cfg 2's kernels at cfg 2's state shape
-    for name in ('r02_pmc_eval_cfg%d.json' % shape_of, 'r01_k_pmc_eval_cfg%d.json' % shape_of):
+    names = ('r02_pmc_eval_cfg%d.json' % shape_of, 'r01_k_pmc_eval_cfg%d.json' % shape_of)
+    if kernel.startswith('k_w4'):
+        names = ('r02_pmc_w4_cfg%d.json' % shape_of,)
+    for name in names:
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
         try:
             with open(path) as fh:
                 pmc = json.load(fh)
-            k = next(v for n, v in pmc.items() if 'k_conv3x3' in n)
+            k = next(v for n, v in pmc.items() if kernel in n)
             return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
         except Exception:
             continue
@@ -380,7 +383,26 @@ def main():
         torch.cuda.synchronize(device)
         prof = integrate.profile_end()
         k = prof['conv3x3_implicit_gemm']
-        if k['launches'] > 0:
+        k4 = prof['w4_component_gemm']
+        if k4['launches'] > k['launches']:
+            # the convs ran as the F(4x4,3x3) pipeline (dopri5 at rtol, atol >= 1e-4 on 8x8 states): the dominant kernel
+            # is the component GEMM; the transforms around it run inside the GroupNorm passes
+            avg_ms = k4['total_ms'] / k4['launches']
+            algo_per_launch = k4['flops'] / k4['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
+            issued = 36.0 / (16.0 * 9.0)
+            ach = algo_per_launch * issued / (avg_ms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'k_w4_gemm64 (fp32 MFMA, the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad)',
+                        'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args.config, 'k_w4_gemm64'),
+                        'avg_launch_us': avg_ms * 1e3, 'launches': k4['launches'],
+                        'flops_per_launch': algo_per_launch * issued,
+                        'algorithmic': {'flops_per_launch': algo_per_launch,
+                                        'note': 'direct-convolution FLOPs of the conv this launch belongs to (SURVEY.md 8d); its '
+                                                'input / output transforms run in the GroupNorm passes around it, so no rate is '
+                                                'quoted against this launch alone'},
+                        'note': 'achieved/frac = MFMA FLOPs issued (0.25 of the direct-convolution FLOPs) over the fp32 matrix '
+                                'peak, i.e. matrix-pipe utilisation of the dominant kernel'}
+        elif k['launches'] > 0:
             avg_ms = k['total_ms'] / k['launches']
             algo_per_launch = k['flops'] / k['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
             wino = os.environ.get('NODE_TUNE_CONV_WINO', '2')
@@ -399,12 +421,13 @@ def main():
                         'note': 'achieved/frac = MFMA FLOPs issued (%.3f of the direct-convolution FLOPs: Winograd) over the '
                                 'fp32 matrix peak, i.e. matrix-pipe utilisation; `algorithmic` counts direct-convolution '
                                 'FLOPs (SURVEY.md 8d) and is not a utilisation' % issued}
-            w = prof['wgrad_gemm']
-            if w['launches'] > 0:
-                wavg = w['total_ms'] / w['launches']
-                walgo = w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12
-                roofline['wgrad'] = {'achieved': walgo * issued, 'frac': walgo * issued / MFMA_F32_PEAK_TFLOPS,
-                                     'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
+        w = prof['wgrad_gemm']
+        if roofline is not None and w['launches'] > 0:      # (k_wgrad_w2: F(2x2,3x3) domain on either conv path)
+            wavg = w['total_ms'] / w['launches']
+            walgo = w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12
+            wissued = {'2': 16.0 / 36.0, '1': 2.0 / 3.0}.get(os.environ.get('NODE_TUNE_WGRAD_WINO', '2'), 1.0)
+            roofline['wgrad'] = {'achieved': walgo * wissued, 'frac': walgo * wissued / MFMA_F32_PEAK_TFLOPS,
+                                 'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
 
     if rank == 0:
         global_batch = cfg['batch'] * world

@@ -134,8 +134,9 @@ typedef struct node_solve_opts {
 } node_solve_opts;
 
 /* Per-kernel-class timing collected with HIP events on the caller's stream
- * (bench.py's roofline block).  Classes: 0 conv3x3 fwd/dgrad implicit GEMM,
- * 1 wgrad GEMM, 2 everything else. */
+ * (bench.py's roofline block).  Classes: 0 conv3x3 fwd/dgrad as one fused kernel,
+ * 1 wgrad GEMM, 2 the component GEMMs of a conv3x3 fwd/dgrad that runs as the
+ * F(4x4,3x3) pipeline (`flops` counts the convolution's, as for class 0). */
 #define NODE_PROFILE_CLASSES 3
 typedef struct node_profile {
   int64_t launches[NODE_PROFILE_CLASSES];

@@ -102,8 +102,7 @@ __device__ __forceinline__ void w4_ring_run(W4Ring<D>& r, float16_t& acc0, float
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       if (!GUARD || g + i < ng) w4_mac(acc0, acc1, r.a[i], r.b0[i], r.b1[i]);
-      // the empty asm ties the refill behind the MFMAs that read the old contents and keeps the three requests whole
-      asm volatile("" : "+v"(acc0), "+v"(acc1) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
       if (!GUARD) {
         r.a[i] = r.qa[i * 64];
         r.b0[i] = r.q0[i * 64];
@@ -210,6 +209,131 @@ __global__ __launch_bounds__(512) void k_w4_gemm(const float* __restrict__ V, co
   }
 }
 
+// ----------------------------------------------------------------------------
+// k_w4_gemm64: the same products on 64 x 64 tiles, FOUR waves per workgroup (one per SIMD, up to 512 registers).
+// A wave owns one whole component of its tile -- two row blocks x two column blocks, four accumulators -- so four
+// 1 KB requests feed sixteen MFMAs (256 B per MFMA; k_w4_gemm: 384): the operand stream of a CU, which is what
+// bounds these K = C products (L2-served: ~70 GB/s per CU, Infinity Cache ~33), shrinks from 864 to 608 KB.
+// Eight workgroups share a tile: workgroup j takes components 4j .. 4j+3, and half a tile (32 rows) of component
+// 32 + j/2, whose K range its four waves split and sum through LDS -- 512 + 64 MFMAs per wave, 576 per SIMD,
+// every SIMD of the chip the same.  Workgroup j of every tile runs on XCD j: that XCD's 4.5 components of V and U
+// (3.5 MB at N = 128, C = 256) stay in its L2, so each operand byte leaves HBM / Infinity Cache once per launch.
+// Needs N % 16 == 0 and C % 64 == 0.
+// ----------------------------------------------------------------------------
+constexpr int W4_DEPTH64 = 8;
+
+template <int D>
+struct W4Ring4 {
+  float4 a0[D], a1[D], b0[D], b1[D];
+  const float4 *qa0, *qa1, *qb0, *qb1;
+};
+
+template <int AB>
+__global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                   const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 6, nRB = gm.RB, G8 = gm.G8, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rt = tile / nCT, ct = tile - rt * nCT;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  const int b_off = lane * 4;
+  auto vblk = [&](int comp, int rb) { return V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off; };
+  auto ublk = [&](int comp, int cb) { return U + (((size_t)comp * CB + cb) * G8) * 256 + b_off; };
+
+  // --- this wave's own component: the whole 64 x 64 tile over the whole K range
+  {
+    const int comp = 4 * j + wave;
+    W4Ring4<W4_DEPTH64> r;
+    r.qa0 = reinterpret_cast<const float4*>(vblk(comp, 2 * rt));
+    r.qa1 = reinterpret_cast<const float4*>(vblk(comp, 2 * rt + 1));
+    r.qb0 = reinterpret_cast<const float4*>(ublk(comp, 2 * ct));
+    r.qb1 = reinterpret_cast<const float4*>(ublk(comp, 2 * ct + 1));
+    // requests in the steady state's order, pinned (see w4_ring_fill)
+#pragma unroll
+    for (int i = 0; i < W4_DEPTH64; ++i) {
+      r.a0[i] = r.qa0[i * 64]; r.a1[i] = r.qa1[i * 64]; r.b0[i] = r.qb0[i * 64]; r.b1[i] = r.qb1[i * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    r.qa0 += W4_DEPTH64 * 64; r.qa1 += W4_DEPTH64 * 64; r.qb0 += W4_DEPTH64 * 64; r.qb1 += W4_DEPTH64 * 64;
+    float16_t c00, c01, c10, c11;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { c00[q] = 0.f; c01[q] = 0.f; c10[q] = 0.f; c11[q] = 0.f; }
+    if (!(AB & 2))
+      for (int g = 0; g < G8; g += W4_DEPTH64) {
+#pragma unroll
+        for (int i = 0; i < W4_DEPTH64; ++i) {
+          const float4 a0 = r.a0[i], a1 = r.a1[i], b0 = r.b0[i], b1 = r.b1[i];
+#define W4_STEP(E)                                                          \
+  c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, c00, 0, 0, 0);     \
+  c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, c01, 0, 0, 0);     \
+  c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b0.E, c10, 0, 0, 0);     \
+  c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b1.E, c11, 0, 0, 0);
+          W4_STEP(x) W4_STEP(y) W4_STEP(z) W4_STEP(w)
+#undef W4_STEP
+          __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
+          r.a0[i] = r.qa0[i * 64]; r.a1[i] = r.qa1[i * 64]; r.b0[i] = r.qb0[i * 64]; r.b1[i] = r.qb1[i * 64];
+        }
+        r.qa0 += W4_DEPTH64 * 64; r.qa1 += W4_DEPTH64 * 64; r.qb0 += W4_DEPTH64 * 64; r.qb1 += W4_DEPTH64 * 64;
+      }
+    if (!(AB & 4)) {
+      float* m0 = M + ((size_t)comp * gm.R + rt * 64) * gm.C + ct * 64 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
+        m0[(size_t)row * gm.C] = c00[q];
+        m0[(size_t)row * gm.C + 32] = c01[q];
+        m0[(size_t)(row + 32) * gm.C] = c10[q];
+        m0[(size_t)(row + 32) * gm.C + 32] = c11[q];
+      }
+    } else if (c00[0] == 12345.f) M[0] = c00[1] + c01[2] + c10[3] + c11[4];
+  }
+  // --- half a tile of a shared component: rows [32 half, 32 half + 32), K slice [wave G8/4, (wave+1) G8/4) per wave
+  if (!(AB & 1)) {
+    const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
+    const int ng = G8 >> 2, g0 = wave * ng;
+    W4Ring<W4_SDEPTH> sr;
+    float16_t s0, s1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+    if (ng % W4_SDEPTH == 0) {
+      w4_ring_fill(sr, vblk(scomp, rb) + (size_t)g0 * 256, ublk(scomp, 2 * ct) + (size_t)g0 * 256, ublk(scomp, 2 * ct + 1) + (size_t)g0 * 256);
+      w4_ring_run<W4_SDEPTH, false>(sr, s0, s1, ng);
+    } else {
+      for (int gs = 0; gs < ng; gs += W4_SDEPTH) {
+        w4_ring_fill(sr, vblk(scomp, rb) + (size_t)(g0 + gs) * 256, ublk(scomp, 2 * ct) + (size_t)(g0 + gs) * 256,
+                     ublk(scomp, 2 * ct + 1) + (size_t)(g0 + gs) * 256);
+        w4_ring_run<W4_SDEPTH, true>(sr, s0, s1, min(W4_SDEPTH, ng - gs));
+      }
+    }
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      *reinterpret_cast<float4*>(red + (r4 * 64 + lane) * 4) = make_float4(s0[4 * r4], s0[4 * r4 + 1], s0[4 * r4 + 2], s0[4 * r4 + 3]);
+      *reinterpret_cast<float4*>(red + 1024 + (r4 * 64 + lane) * 4) = make_float4(s1[4 * r4], s1[4 * r4 + 1], s1[4 * r4 + 2], s1[4 * r4 + 3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk = u >> 8, r4 = (u >> 6) & 3;
+      float4 s = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* mrow = M + ((size_t)scomp * gm.R + rb * 32 + 8 * r4 + 4 * hi) * gm.C + ct * 64 + blk * 32 + l31;
+      mrow[0] = s.x;
+      mrow[(size_t)gm.C] = s.y;
+      mrow[(size_t)2 * gm.C] = s.z;
+      mrow[(size_t)3 * gm.C] = s.w;
+    }
+  }
+}
+
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s) {
   static bool attr[4][MAX_DEVICES] = {};
   static int ab = -1;
@@ -223,6 +347,17 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   {                                                                                        \
     allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm<AB>), attr[SLOT]);               \
     hipLaunchKernelGGL(k_w4_gemm<AB>, dim3(grid), dim3(512), lds, s, V, U, M, ctrl, gm, xm); \
+  }
+  static int g64 = -1;   // NODE_TUNE_W4_GEMM64 = 0: k_w4_gemm (eight waves, 32 x 64 tiles) everywhere
+  if (g64 < 0) { const char* e = getenv("NODE_TUNE_W4_GEMM64"); g64 = e ? atoi(e) : 1; }
+  if (g64 && N % 16 == 0) {
+    const int grid64 = (N / 16) * (C >> 6) * 8;
+    const size_t lds64 = 4 * 2048 * sizeof(float);
+    if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+    else if (ab == 2) hipLaunchKernelGGL(k_w4_gemm64<2>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+    else if (ab == 4) hipLaunchKernelGGL(k_w4_gemm64<4>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+    else hipLaunchKernelGGL(k_w4_gemm64<0>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+    return;
   }
   if (ab == 1) W4_LAUNCH(1, 1)
   else if (ab == 2) W4_LAUNCH(2, 2)

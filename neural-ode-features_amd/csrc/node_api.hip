@@ -509,7 +509,7 @@ struct Solver {
   // behind it reads the products (output transform, + bias + t * tmap for a forward conv) and, when another conv
   // follows, leaves that conv's row operand in W4V again
   void w4_gemm(int which) {
-    ProfScope ps(0, conv_flops(), st);
+    ProfScope ps(2, conv_flops(), st);
     launch_w4_gemm(p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N, d.C, st);
   }
   void w4_pass_fwd(const float* bias, const float* tmap, const EvalTime& et, const float* gamma, const float* beta, int relu,
@@ -996,7 +996,7 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   DtLog dlog(opts);
   const size_t numel = S.d.numel;
 
-  S.choose_w4(method == NODE_METHOD_DOPRI5 && !forced);
+  S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   TRY(S.prepare());
   launch_nchw_to_nhwc(S.d, y0, S.p.Y, S.st);
   HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
@@ -1094,7 +1094,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   const int blind = (opts && opts->blind_steps > 0 && opts->record && n_t == 2 && !forced && io.log_cap == 0 &&
                      method == NODE_METHOD_DOPRI5)
                         ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
-  S.choose_w4(method == NODE_METHOD_DOPRI5 && !forced);
+  S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0

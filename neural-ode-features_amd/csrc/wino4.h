@@ -111,10 +111,21 @@ __device__ inline void w4_emit_v(const float* tile, int ld, int n, int c0, float
 __device__ inline void w4_load_tile(const float* __restrict__ M, int n, int c0, const W4Geom gm, float* tile, int ld,
                                     float* scratch, const float* __restrict__ bias, const float* __restrict__ tmap,
                                     float tval, int tid) {
-  for (int u = tid; u < W4_COMPS * 32; u += 256) {
+  // all of a thread's requests first (4.5 x 16 B), then the LDS writes: written as one loop the compiler waits for
+  // every request before it issues the next -- five dependent round trips at the head of every pass
+  constexpr int NU = W4_COMPS * 32;
+  float4 mv[5];
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const int u = min(tid + it * 256, NU - 1);   // clamped, not predicated: a masked request makes the compiler wait
     const int comp = u >> 5, t = (u >> 3) & 3, q = u & 7;
-    const float4 v = *reinterpret_cast<const float4*>(M + ((size_t)comp * gm.R + 4 * n + t) * gm.C + c0 + 4 * q);
-    *reinterpret_cast<float4*>(scratch + (comp * 4 + t) * 32 + 4 * q) = v;
+    mv[it] = *reinterpret_cast<const float4*>(M + ((size_t)comp * gm.R + 4 * n + t) * gm.C + c0 + 4 * q);
+  }
+#pragma unroll
+  for (int it = 0; it < 5; ++it) {
+    const int u = min(tid + it * 256, NU - 1);   // (the clamped duplicates rewrite the last unit with its own value)
+    const int comp = u >> 5, t = (u >> 3) & 3, q = u & 7;
+    *reinterpret_cast<float4*>(scratch + (comp * 4 + t) * 32 + 4 * q) = mv[it];
   }
   __syncthreads();
   const int c = tid & 31, t = (tid >> 5) & 3, h = tid >> 7;

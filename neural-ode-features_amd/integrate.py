@@ -589,6 +589,6 @@ def profile_begin():
 def profile_end() -> dict:
     prof = _lib.NodeProfile()
     _lib.check(_lib.load().node_profile_end(C.byref(prof)))
-    names = ['conv3x3_implicit_gemm', 'wgrad_gemm', 'other']
+    names = ['conv3x3_implicit_gemm', 'wgrad_gemm', 'w4_component_gemm']
     return {names[i]: {'launches': int(prof.launches[i]), 'total_ms': float(prof.total_ms[i]),
                        'flops': float(prof.flops[i])} for i in range(3)}
