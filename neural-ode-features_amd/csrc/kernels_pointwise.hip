@@ -58,6 +58,44 @@ __device__ inline void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) =
 // in LDS between the statistics pass and the normalise pass, so y_i is never
 // written to HBM unless the caller asks for it (last stage -> y1).
 // ============================================================================
+// y + sum_j cf[j] * k[j] at TWO offsets of the same thread, every request issued before the first use.  Written as a
+// loop over a run-time term count the compiler waits for each tensor's load before it requests the next: (1 + nk) x 2
+// dependent round trips at the head of every combine (12 for the last dopri5 stage).  Same summation order as the
+// generic loops below.
+template <int NK>
+__device__ __forceinline__ void comb_pair(const Comb& c, const float* cf, size_t off0, size_t off1, float4& r0, float4& r1) {
+  float4 y0 = ld4(c.y + off0), y1 = ld4(c.y + off1);
+  float4 k0[NK > 0 ? NK : 1], k1[NK > 0 ? NK : 1];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) { k0[j] = ld4(c.k[j] + off0); k1[j] = ld4(c.k[j] + off1); }
+  if (NK > 0) {
+    float4 s0, s1;
+    s0.x = cf[0] * k0[0].x; s0.y = cf[0] * k0[0].y; s0.z = cf[0] * k0[0].z; s0.w = cf[0] * k0[0].w;
+    s1.x = cf[0] * k1[0].x; s1.y = cf[0] * k1[0].y; s1.z = cf[0] * k1[0].z; s1.w = cf[0] * k1[0].w;
+#pragma unroll
+    for (int j = 1; j < NK; ++j) {
+      s0.x += cf[j] * k0[j].x; s0.y += cf[j] * k0[j].y; s0.z += cf[j] * k0[j].z; s0.w += cf[j] * k0[j].w;
+      s1.x += cf[j] * k1[j].x; s1.y += cf[j] * k1[j].y; s1.z += cf[j] * k1[j].z; s1.w += cf[j] * k1[j].w;
+    }
+    y0.x += s0.x; y0.y += s0.y; y0.z += s0.z; y0.w += s0.w;
+    y1.x += s1.x; y1.y += s1.y; y1.z += s1.z; y1.w += s1.w;
+  }
+  r0 = y0;
+  r1 = y1;
+}
+__device__ __forceinline__ void comb_pair_any(const Comb& c, const float* cf, size_t off0, size_t off1, float4& r0, float4& r1) {
+  switch (c.nk) {
+    case 0: comb_pair<0>(c, cf, off0, off1, r0, r1); break;
+    case 1: comb_pair<1>(c, cf, off0, off1, r0, r1); break;
+    case 2: comb_pair<2>(c, cf, off0, off1, r0, r1); break;
+    case 3: comb_pair<3>(c, cf, off0, off1, r0, r1); break;
+    case 4: comb_pair<4>(c, cf, off0, off1, r0, r1); break;
+    case 5: comb_pair<5>(c, cf, off0, off1, r0, r1); break;
+    case 6: comb_pair<6>(c, cf, off0, off1, r0, r1); break;
+    default: comb_pair<7>(c, cf, off0, off1, r0, r1); break;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
   if (a.ctrl->done) return;   // a step enqueued past the end of the interval (see Ctrl)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -79,6 +117,16 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
   const W4Geom w4g = w4_geom(d.N, d.C);
   if (a.w4.m_in) {   // the conv in front of this pass ran as 36 component GEMMs: output transform + bias + t * tmap
     w4_load_tile(a.w4.m_in, n, c0, w4g, tile, csl, w4s, a.w4.bias, a.w4.tmap, a.w4.bias ? eval_time(a.w4.et) : 0.f, tid);
+  } else if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
+    for (int v = tid; v < nvec; v += 512) {
+      const int p0 = v / cs4, q0 = v - p0 * cs4, p1 = (v + 256) / cs4, q1 = (v + 256) - p1 * cs4;
+      const size_t off0 = ((size_t)(n * d.HW + p0)) * d.C + c0 + 4 * q0, off1 = ((size_t)(n * d.HW + p1)) * d.C + c0 + 4 * q1;
+      float4 y0, y1;
+      comb_pair_any(a.comb, cf, off0, off1, y0, y1);
+      st4(tile + p0 * csl + 4 * q0, y0);
+      st4(tile + p1 * csl + 4 * q1, y1);
+      if (a.y_out) { st4(a.y_out + off0, y0); st4(a.y_out + off1, y1); }
+    }
   } else
   for (int v = tid; v < nvec; v += 256) {
     const int p = v / cs4, q = v - p * cs4;
@@ -220,6 +268,25 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
       gq.z = pmk[it].z > 0.f ? gq.z : 0.f; gq.w = pmk[it].w > 0.f ? gq.w : 0.f;
       st4(gt + p * csl + 4 * q, gq);
       st4(xt + p * csl + 4 * q, pxh[it]);
+    }
+  } else if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
+    for (int v = tid; v < nvec; v += 512) {
+      const int p0 = v / cs4, q0 = v - p0 * cs4, p1 = (v + 256) / cs4, q1 = (v + 256) - p1 * cs4;
+      const size_t off0 = ((size_t)(n * d.HW + p0)) * d.C + c0 + 4 * q0, off1 = ((size_t)(n * d.HW + p1)) * d.C + c0 + 4 * q1;
+      const float4 x0 = ld4(a.xhat + off0), x1 = ld4(a.xhat + off1);
+      float4 m0 = make_float4(1.f, 1.f, 1.f, 1.f), m1 = m0;
+      if (a.mask_act) { m0 = ld4(a.mask_act + off0); m1 = ld4(a.mask_act + off1); }
+      float4 a0, a1;
+      comb_pair_any(a.comb, cf, off0, off1, a0, a1);
+      if (a.a_out) { st4(a.a_out + off0, a0); st4(a.a_out + off1, a1); }
+      float4 g0 = make_float4(a.csign * a0.x, a.csign * a0.y, a.csign * a0.z, a.csign * a0.w);
+      float4 g1 = make_float4(a.csign * a1.x, a.csign * a1.y, a.csign * a1.z, a.csign * a1.w);
+      g0.x = m0.x > 0.f ? g0.x : 0.f; g0.y = m0.y > 0.f ? g0.y : 0.f; g0.z = m0.z > 0.f ? g0.z : 0.f; g0.w = m0.w > 0.f ? g0.w : 0.f;
+      g1.x = m1.x > 0.f ? g1.x : 0.f; g1.y = m1.y > 0.f ? g1.y : 0.f; g1.z = m1.z > 0.f ? g1.z : 0.f; g1.w = m1.w > 0.f ? g1.w : 0.f;
+      st4(gt + p0 * csl + 4 * q0, g0);
+      st4(gt + p1 * csl + 4 * q1, g1);
+      st4(xt + p0 * csl + 4 * q0, x0);
+      st4(xt + p1 * csl + 4 * q1, x1);
     }
   } else
   for (int v = tid; v < nvec; v += 256) {

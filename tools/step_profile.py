@@ -7,7 +7,7 @@
     averages with HIP events (bench.py repeats the steps in that mode so that no launch is an early-exit one).
 
 Under deferred completion the host enqueues a guessed number of solver steps; launches behind the solve's end
-return at their first instruction (`if (ctrl->done) return;`, < 2 us).  They are counted apart ("dead") and left
+return at their first instruction (`if (ctrl->done) return;`: 1 - 5 us to dispatch and retire).  They are counted apart ("dead") and left
 out of the live average, which is the figure to hold against `roofline.avg_launch_us`.
 
     python tools/step_profile.py <kernel_trace.csv> --warmup 3 --steps 12 --repeat 5 [--gaps]
@@ -39,8 +39,9 @@ def cut_steps(rows):
 
 
 def dead_threshold(rows):
-    """name -> duration under which a launch of an early-exit kernel counts as dead (a quarter of the median of
-    the launches above 2 us; only for node:: kernels whose live launches are long enough to tell apart)."""
+    """name -> duration under which a launch of an early-exit kernel counts as dead: 0.35 x the median of the launches
+    above 2 us (a dead launch of a 256-workgroup kernel still takes 2 - 5 us to dispatch and retire); only for node::
+    kernels whose live launches are long enough to tell apart."""
     by = collections.defaultdict(list)
     for s, e, n in rows:
         if n.startswith('node::'):
@@ -49,7 +50,7 @@ def dead_threshold(rows):
     for n, d in by.items():
         live = [x for x in d if x > 2000]
         if live and statistics.median(live) > 8000:
-            thr[n] = 2000
+            thr[n] = max(2000, int(0.35 * statistics.median(live)))
     return thr
 
 
