@@ -243,6 +243,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
   auto vblk = [&](int comp, int rb) { return V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off; };
   auto ublk = [&](int comp, int cb) { return U + (((size_t)comp * CB + cb) * G8) * 256 + b_off; };
 
+  // The shared component's first operand sets are requested BEFORE the own component's loop (one wave per SIMD:
+  // nothing else would cover their latency behind it), and its MFMAs run while the own component's 18.9 MB of
+  // result stores drain.
+  const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
+  const int ng = G8 >> 2, g0 = wave * ng;
+  const bool early = !(AB & 1) && ng % W4_SDEPTH == 0;
+  W4Ring<W4_SDEPTH> sr;
+  if (early) {
+    w4_ring_fill(sr, vblk(scomp, rb) + (size_t)g0 * 256, ublk(scomp, 2 * ct) + (size_t)g0 * 256, ublk(scomp, 2 * ct + 1) + (size_t)g0 * 256);
+    asm volatile("" ::: "memory");   // the compiler may not sink these requests to their first use behind the loop
+  }
   // --- this wave's own component: the whole 64 x 64 tile over the whole K range
   {
     const int comp = 4 * j + wave;
@@ -292,14 +303,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
   }
   // --- half a tile of a shared component: rows [32 half, 32 half + 32), K slice [wave G8/4, (wave+1) G8/4) per wave
   if (!(AB & 1)) {
-    const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
-    const int ng = G8 >> 2, g0 = wave * ng;
-    W4Ring<W4_SDEPTH> sr;
     float16_t s0, s1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
-    if (ng % W4_SDEPTH == 0) {
-      w4_ring_fill(sr, vblk(scomp, rb) + (size_t)g0 * 256, ublk(scomp, 2 * ct) + (size_t)g0 * 256, ublk(scomp, 2 * ct + 1) + (size_t)g0 * 256);
+    if (early) {
       w4_ring_run<W4_SDEPTH, false>(sr, s0, s1, ng);
     } else {
       for (int gs = 0; gs < ng; gs += W4_SDEPTH) {
