@@ -330,7 +330,10 @@ class Deferred:
     epoch are exact); `last_*_stats` of a deferred solve hold the prediction."""
 
     active = None      # the instance whose `with` block is open
-    CALM = 8           # exact predictions in a row after which no spare step is enqueued any more
+    # Exact predictions in a row after which no spare step is enqueued any more.  A spare step costs ~0.5 ms of empty
+    # launches per training step at cfg 2, a miss one whole step (7.5 ms): the spare pays while a count changes more
+    # often than once in ~15 iterations, and four exact predictions in a row are taken as the sign that it does not.
+    CALM = 4
 
     def __init__(self, device):
         self.device = torch.device(device)

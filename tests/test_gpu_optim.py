@@ -138,7 +138,11 @@ def test_bench_line_carries_the_contract_keys():
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic'):
         assert k in rf, k
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and 0.3 < rf['frac'] < 1.0
-    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['algorithmic']['achieved'] > rf['achieved']
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    # the direct-convolution count behind the launch lives under its own key; a rate against it is quoted only where
+    # one launch IS the whole convolution (the fused kernels), not for the component GEMMs of the F(4x4,3x3) pipeline
+    assert rf['algorithmic']['flops_per_launch'] > rf['flops_per_launch']
+    assert 'achieved' not in rf['algorithmic'] or rf['algorithmic']['achieved'] > rf['achieved']
     assert rf['traffic'] is None or rf['traffic'] > 1e7
     cb = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
