@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
       if (a.relu) vv = fmaxf(vv, 0.f);
       o[i] = a.osign * vv;
     }
-    st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
+    if (a.act_out) st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
     if (a.xhat_out) st4(a.xhat_out + off, make_float4(xh[0], xh[1], xh[2], xh[3]));
     if (a.w4.v_out) st4(tile + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // own elements only: in place
   }

@@ -539,11 +539,14 @@ struct Solver {
     ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
     ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
     ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
-    if (w4) ca.w4.v_out = p.W4V;
+    if (w4) {
+      ca.w4.v_out = p.W4V;
+      if (!train) ca.act_out = nullptr;   // only the weight gradient and the ReLU mask of a VJP read the plain activation
+    }
     launch_combine_gn(d, ca, st);
     if (w4) {
       w4_gemm(0);
-      w4_pass_fwd(prm.conv1_b, p.tmap[0], et, prm.norm2_w, prm.norm2_b, 1, 1.f, p.act2, train ? p.xh2 : nullptr,
+      w4_pass_fwd(prm.conv1_b, p.tmap[0], et, prm.norm2_w, prm.norm2_b, 1, 1.f, train ? p.act2 : nullptr, train ? p.xh2 : nullptr,
                   train ? p.r2 : nullptr, true);
       w4_gemm(1);
       w4_pass_fwd(prm.conv2_b, p.tmap[1], et, prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr,

@@ -164,7 +164,7 @@ struct CombineGnArgs {
   Comb comb;
   const Ctrl* ctrl;
   float* y_out;        // nullable
-  float* act_out;      // relu(GN(y_i))
+  float* act_out;      // relu(GN(y_i)); nullable when w4.v_out carries it on (an inference evaluation never reads the plain tensor)
   float* xhat_out;     // nullable
   float* rstd_out;     // nullable [N][G]
   const float* gamma;
