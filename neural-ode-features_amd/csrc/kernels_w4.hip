@@ -49,7 +49,8 @@ void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s) {
 }
 
 // ----------------------------------------------------------------------------
-// k_w4_gemm: M_c[rows, C] = V_c[rows, C] x U_c[C, C] for the 36 components.
+// k_w4_gemm: M_c[rows, C] = V_c[rows, C] x U_c[C, C] for the 36 components -- the first version, kept for batches that
+// are a multiple of 8 but not of 16 (k_w4_gemm64 below is 2 - 4 us faster where it applies).
 // Workgroup = one 32-row block x one pair of 32-column blocks x NINE components (grid = N/8 x C/64 x 4): eight
 // waves take one component each over the whole K range (two accumulators sharing the row operand), the ninth
 // component is cut into eight K slices, one per wave, and summed through LDS -- 288 MFMAs per wave, 576 per SIMD,

@@ -1,15 +1,15 @@
 // Winograd F(4x4, 3x3) as a three-stage pipeline (gfx950 only): the 3x3 convolutions of an 8x8 state whose
-// solver tolerance leaves room for the transform's rounding (see Solver::use_w4, node_api.hip).
+// solver tolerance leaves room for the transform's rounding (see Solver::choose_w4, node_api.hip).
 //
 //   V = B^T d B   6x6 input transform of every 4x4 output tile's 6x6 patch -- written by the PRODUCER of the conv
 //                 input (k_combine_gn, k_gn_bwd: w4_emit_v below), not by the conv
-//   M_c = V_c U_c 36 independent [rows x C] x [C x C] products, rows = samples x 4 tiles: k_w4_gemm (fp32 MFMA,
+//   M_c = V_c U_c 36 independent [rows x C] x [C x C] products, rows = samples x 4 tiles: k_w4_gemm64 (fp32 MFMA,
 //                 operands straight from L2 into registers in MFMA-ready blocks, no LDS, no transform in the loop)
 //   Y = A^T M A   4x4 output transform -- done by the CONSUMER (the GroupNorm pass behind the conv: w4_load_tile)
 //
 // 36 multiplies per 16 outputs = 0.25 of the direct convolution's (F(2x2,3x3): 0.444).  Interpolation points
 // (0, 1, -1, 1/2, -2, inf): max error 3.2e-6 of max|y| at C = 256 against an fp64 direct convolution (the textbook
-// points (0, +-1, +-2, inf): 9.0e-6; F(2x2,3x3): 4.9e-7; tools/wino_error.py).
+// points (0, +-1, +-2, inf): 8.4e-6; F(2x2,3x3): 4.9e-7; tools/wino_error.py).
 //
 // Layouts (H = W = 8: T = 4 tiles per sample, R = 4 N rows, RB = N / 8 row blocks of 32; G8 = C / 8):
 //   V  [comp 36][rb][g G8][s 8][hi 2][t 4][e 4]   channel = 8 g + 4 hi + e, sample = 8 rb + s: one contiguous 1 KB
