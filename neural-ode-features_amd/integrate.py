@@ -331,9 +331,10 @@ class Deferred:
 
     active = None      # the instance whose `with` block is open
     # Exact predictions in a row after which no spare step is enqueued any more.  A spare step costs ~0.5 ms of empty
-    # launches per training step at cfg 2, a miss one whole step (7.5 ms): the spare pays while a count changes more
-    # often than once in ~15 iterations, and four exact predictions in a row are taken as the sign that it does not.
-    CALM = 4
+    # launches per training step at cfg 2, a miss one whole step (7.5 ms) AND a skipped update.  Measured on fresh
+    # batches with moving weights (tools/deferred_soak.py, 400 steps): 8 -> 0 misses in 818 blind solves, 4 -> 4 misses
+    # in 814; on bench.py's fixed batch 4 is ~1 % faster over the first 25 iterations.  Skipped updates weigh more.
+    CALM = 8
 
     def __init__(self, device):
         self.device = torch.device(device)
