@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define NODE_ABI_VERSION 1
+#define NODE_ABI_VERSION 2
 
 /* method -- the two solver names that reach model.py:367 on the graded configs
  * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
@@ -136,12 +136,17 @@ typedef struct node_solve_opts {
 /* Per-kernel-class timing collected with HIP events on the caller's stream
  * (bench.py's roofline block).  Classes: 0 conv3x3 fwd/dgrad as one fused kernel,
  * 1 wgrad GEMM, 2 the component GEMMs of a conv3x3 fwd/dgrad that runs as the
- * F(4x4,3x3) pipeline (`flops` counts the convolution's, as for class 0). */
-#define NODE_PROFILE_CLASSES 3
+ * F(4x4,3x3) pipeline (`flops` counts the convolution's, as for class 0);
+ * 3..8 the HBM-bound GroupNorm / transform passes of that pipeline, one class per
+ * kernel instance (3 combine, 4 forward pass, 5 forward pass + next combine,
+ * 6 forward pass + backward top, 7 backward pass, 8 backward pass + next combine):
+ * for these `flops` holds the ALGORITHMIC BYTES of the launches (every tensor the
+ * pass must read or write, once). */
+#define NODE_PROFILE_CLASSES 9
 typedef struct node_profile {
   int64_t launches[NODE_PROFILE_CLASSES];
   double total_ms[NODE_PROFILE_CLASSES];
-  double flops[NODE_PROFILE_CLASSES]; /* algorithmic FLOPs issued in those launches */
+  double flops[NODE_PROFILE_CLASSES]; /* algorithmic FLOPs (classes 0..2) / bytes (3..8) of those launches */
 } node_profile;
 
 int node_abi_version(void);

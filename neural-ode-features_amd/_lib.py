@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
 
-NODE_ABI_VERSION = 1
+NODE_ABI_VERSION = 2
 METHOD_DOPRI5, METHOD_RK4 = 0, 1
 METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
 
@@ -67,7 +67,7 @@ NODE_PENDING = 1
 
 
 class NodeProfile(C.Structure):
-    _fields_ = [('launches', C.c_int64 * 3), ('total_ms', C.c_double * 3), ('flops', C.c_double * 3)]
+    _fields_ = [('launches', C.c_int64 * 9), ('total_ms', C.c_double * 9), ('flops', C.c_double * 9)]
 
 
 class NodeSgdTensor(C.Structure):

@@ -7,7 +7,6 @@
 // Algorithm follows the restated torchdiffeq spec; the CPU
 // statement of the same arithmetic is oracle/torchdiffeq_restated.py.
 #include "node_internal.h"
-#include "wino4.h"
 #include <cstring>
 #include "../../include/node_hip.h"
 
@@ -22,10 +21,6 @@ __device__ __constant__ float c_CERR[7] = {
     (float)(35.0 / 384.0 - 1951.0 / 21600.0), 0.f, (float)(500.0 / 1113.0 - 22642.0 / 50085.0),
     (float)(125.0 / 192.0 - 451.0 / 720.0), (float)(-2187.0 / 6784.0 - -12231.0 / 42400.0),
     (float)(11.0 / 84.0 - 649.0 / 6300.0), (float)(-1.0 / 60.0)};
-__device__ __constant__ float c_CMID[7] = {
-    (float)(6025192743.0 / 30085553152.0 / 2.0), 0.f, (float)(51252292925.0 / 65400821598.0 / 2.0),
-    (float)(-2691868925.0 / 45128329728.0 / 2.0), (float)(187940372067.0 / 1594534317056.0 / 2.0),
-    (float)(-1776094331.0 / 19743644256.0 / 2.0), (float)(11237099.0 / 235043384.0 / 2.0)};
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -113,11 +108,7 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
 
-  float* w4s = srstd + d.cs;               // W4_SCRATCH floats when a w4 hook is on
-  const W4Geom w4g = w4_geom(d.N, d.C);
-  if (a.w4.m_in) {   // the conv in front of this pass ran as 36 component GEMMs: output transform + bias + t * tmap
-    w4_load_tile(a.w4.m_in, n, c0, w4g, tile, csl, w4s, a.w4.bias, a.w4.tmap, a.w4.bias ? eval_time(a.w4.et) : 0.f, tid);
-  } else if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
+  if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
     for (int v = tid; v < nvec; v += 512) {
       const int p0 = v / cs4, q0 = v - p0 * cs4, p1 = (v + 256) / cs4, q1 = (v + 256) - p1 * cs4;
       const size_t off0 = ((size_t)(n * d.HW + p0)) * d.C + c0 + 4 * q0, off1 = ((size_t)(n * d.HW + p1)) * d.C + c0 + 4 * q1;
@@ -195,16 +186,11 @@ __global__ __launch_bounds__(256) void k_combine_gn(CombineGnArgs a, Dims d) {
     }
     if (a.act_out) st4(a.act_out + off, make_float4(o[0], o[1], o[2], o[3]));
     if (a.xhat_out) st4(a.xhat_out + off, make_float4(xh[0], xh[1], xh[2], xh[3]));
-    if (a.w4.v_out) st4(tile + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // own elements only: in place
-  }
-  if (a.w4.v_out) {   // input transform of the activation just produced, for the component GEMMs of the next conv
-    __syncthreads();
-    w4_emit_v(tile, csl, n, c0, a.w4.v_out, w4g, w4s, tid);
   }
 }
 
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s) {
-  size_t lds = ((size_t)d.HW * d.cs + 2 * (size_t)d.cs + ((a.w4.m_in || a.w4.v_out) ? W4_SCRATCH : 0)) * sizeof(float);
+  size_t lds = ((size_t)d.HW * d.cs + 2 * (size_t)d.cs) * sizeof(float);
   hipLaunchKernelGGL(k_combine_gn, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
 }
 
@@ -241,35 +227,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
 #pragma unroll
   for (int j = 0; j < 7; ++j) cf[j] = scale * a.comb.coef[j];
 
-  // W4_SCRATCH floats over the reduction scratch (cred, red9: live only between the transforms) and beyond: the
-  // workgroup stays under 40 KB of LDS, four per CU -- its 1024 workgroups run in ONE round
-  float* w4s = cred;
-  const W4Geom w4g = w4_geom(d.N, d.C);
-  if (a.w4.m_in) {   // raw data gradient = output transform of the component GEMMs in front of this pass
-    // (HW = 64, cs = 32: two float4 per thread) the other operands of the pass are requested first, so their
-    // latency runs under the component rows' load and transform instead of behind it
-    float4 pmk[2], pxh[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int v = tid + it * 256;
-      const int p = v / cs4, q = v - p * cs4;
-      const size_t off = ((size_t)(n * d.HW + p)) * d.C + c0 + 4 * q;
-      pmk[it] = a.mask_act ? ld4(a.mask_act + off) : make_float4(1.f, 1.f, 1.f, 1.f);
-      pxh[it] = ld4(a.xhat + off);
-    }
-    w4_load_tile(a.w4.m_in, n, c0, w4g, gt, csl, w4s, nullptr, nullptr, 0.f, tid);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int v = tid + it * 256;
-      const int p = v / cs4, q = v - p * cs4;
-      float4 gq = ld4(gt + p * csl + 4 * q);
-      gq.x = pmk[it].x > 0.f ? gq.x : 0.f; gq.y = pmk[it].y > 0.f ? gq.y : 0.f;
-      gq.z = pmk[it].z > 0.f ? gq.z : 0.f; gq.w = pmk[it].w > 0.f ? gq.w : 0.f;
-      st4(gt + p * csl + 4 * q, gq);
-      st4(xt + p * csl + 4 * q, pxh[it]);
-    }
-  } else if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
+  if ((nvec & 511) == 0) {   // two units per thread and round, all their requests in flight together
     for (int v = tid; v < nvec; v += 512) {
       const int p0 = v / cs4, q0 = v - p0 * cs4, p1 = (v + 256) / cs4, q1 = (v + 256) - p1 * cs4;
       const size_t off0 = ((size_t)(n * d.HW + p0)) * d.C + c0 + 4 * q0, off1 = ((size_t)(n * d.HW + p1)) * d.C + c0 + 4 * q1;
@@ -382,7 +340,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
       o[i] = a.osign * (r * (g[i] * w[i] - sm1[gl] - x[i] * sm2[gl]));
     }
     st4(a.dz_out + off, make_float4(o[0], o[1], o[2], o[3]));
-    if (a.spart || a.w4.v_out) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums / input transform below
+    if (a.spart) st4(gt + p * csl + 4 * q, make_float4(o[0], o[1], o[2], o[3]));   // dz tile for the column sums below
   }
   if (a.spart) {   // masked column sums of this sample's dz slab while it is still in LDS (replaces a k_colsum launch)
     __syncthreads();
@@ -392,19 +350,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd(GnBwdArgs a, Dims d) {
                          a.spart + (size_t)n * 9 * d.C + c0 + cbase, d.C);
     }
   }
-  if (a.w4.v_out) {   // input transform of dz for the component GEMMs of the data-gradient conv that follows
-    __syncthreads();
-    w4_emit_v(gt, csl, n, c0, a.w4.v_out, w4g, w4s, tid);
-  }
 }
 
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s) {
   size_t lds = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs + 512 + 9 * 256) * sizeof(float) + (size_t)d.HW + 16;
-  if (a.w4.m_in || a.w4.v_out) {   // the transforms' scratch lies over cred / red9 and what it needs beyond them
-    const size_t base = (2 * (size_t)d.HW * d.cs + 2 * (size_t)d.cs) * sizeof(float) + (((size_t)d.HW + 15) / 16) * 16;
-    const size_t want = base + W4_SCRATCH * sizeof(float);
-    if (want > lds) lds = want;
-  }
   hipLaunchKernelGGL(k_gn_bwd, dim3(d.N, d.nslab), dim3(256), lds, s, a, d);
 }
 
@@ -504,7 +453,6 @@ void launch_error_norm(const ErrSeg* segs, float* const* partial, int nseg, cons
 // squared error ratio <= 1; dt <- dt / clamp(sqrt(max ratio)^(1/5)/0.9, 0.1, 1/dfactor).
 // t / dt are float64 like upstream's adaptive solvers.
 // ============================================================================
-__device__ inline float interp_one(float y0, float y1, const float* k, float dt, float x);
 __device__ inline float reduce_partials_512(const float* p, float* red) {
   float v = p[threadIdx.x] + p[threadIdx.x + 256];
   return block_sum_256(v, red);
@@ -742,19 +690,6 @@ void launch_set_scalar_state(Ctrl* ctrl, float v, int which, hipStream_t s) {
 // Dense output: quartic through (y0, y1, y_mid, f0, f1) of the last accepted step
 //   (`_interp_fit_dopri5` + `_interp_evaluate`, power form like upstream)
 // ============================================================================
-__device__ inline float interp_one(float y0, float y1, const float* k, float dt, float x) {
-  float s = (dt * c_CMID[0]) * k[0];
-#pragma unroll
-  for (int j = 2; j < 7; ++j) s += (dt * c_CMID[j]) * k[j];
-  const float ymid = y0 + s;
-  const float f0 = k[0], f1 = k[6];
-  const float ca = (-2.f * dt) * f0 + (2.f * dt) * f1 + -8.f * y0 + -8.f * y1 + 16.f * ymid;
-  const float cb = (5.f * dt) * f0 + (-3.f * dt) * f1 + 18.f * y0 + 14.f * y1 + -32.f * ymid;
-  const float cc = (-4.f * dt) * f0 + dt * f1 + -11.f * y0 + -5.f * y1 + 16.f * ymid;
-  const float cd = dt * f0;
-  const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-  return ca * x4 + cb * x3 + cc * x2 + cd * x + y0;
-}
 // ----------------------------------------------------------------------------
 // Device-resident stepping: what the host used to do between two steps after reading `Ctrl` back.
 // ----------------------------------------------------------------------------

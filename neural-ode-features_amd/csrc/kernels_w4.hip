@@ -161,13 +161,16 @@ __global__ __launch_bounds__(512) void k_w4_gemm(const float* __restrict__ V, co
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     if (!(AB & 2)) w4_ring_run<W4_DEPTH, false>(ring, acc0, acc1, G8);
-    float* mrow = M + ((size_t)comp * gm.R + rb * 32) * gm.C + cp * 64 + l31;
+    // M is [n][C/32][36][4 t][32 c] (wino4.h): accumulator register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 hi
+    // = tile r & 3 of sample 2 (r >> 2) + hi of this 8-sample row block
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample
+    float* mrow = M + ((size_t)(rb * 8 + hi) * (gm.C >> 5) + 2 * cp) * (36 * 128) + (size_t)comp * 128 + l31;
     if (!(AB & 4)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        mrow[(size_t)row * gm.C] = acc0[r];
-        mrow[(size_t)row * gm.C + 32] = acc1[r];
+        float* q = mrow + (size_t)(2 * (r >> 2)) * sstride + (r & 3) * 32;
+        q[0] = acc0[r];
+        q[36 * 128] = acc1[r];
       }
     } else if (acc0[0] == 12345.f) mrow[0] = acc0[1] + acc1[2];
   }
@@ -202,11 +205,12 @@ __global__ __launch_bounds__(512) void k_w4_gemm(const float* __restrict__ V, co
       const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    float* mrow = M + ((size_t)scomp * gm.R + rb * 32 + 8 * r4 + 4 * hi) * gm.C + cp * 64 + blk * 32 + l31;
+    // rows 8 r4 + 4 hi + (0..3) of the block = tiles 0..3 of sample 2 r4 + hi
+    float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * cp + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
     mrow[0] = s.x;
-    mrow[(size_t)gm.C] = s.y;
-    mrow[(size_t)2 * gm.C] = s.z;
-    mrow[(size_t)3 * gm.C] = s.w;
+    mrow[32] = s.y;
+    mrow[64] = s.z;
+    mrow[96] = s.w;
   }
 }
 
@@ -291,14 +295,16 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
         r.qa0 += W4_DEPTH64 * 64; r.qa1 += W4_DEPTH64 * 64; r.qb0 += W4_DEPTH64 * 64; r.qb1 += W4_DEPTH64 * 64;
       }
     if (!(AB & 4)) {
-      float* m0 = M + ((size_t)comp * gm.R + rt * 64) * gm.C + ct * 64 + l31;
+      // M is [n][C/32][36][4 t][32 c] (wino4.h): register q of a lane = tile q & 3 of sample 2 (q >> 2) + hi of its row block
+      const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample
+      float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hi;
-        m0[(size_t)row * gm.C] = c00[q];
-        m0[(size_t)row * gm.C + 32] = c01[q];
-        m0[(size_t)(row + 32) * gm.C] = c10[q];
-        m0[(size_t)(row + 32) * gm.C + 32] = c11[q];
+        float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+        o[0] = c00[q];
+        o[36 * 128] = c01[q];
+        o[8 * sstride] = c10[q];
+        o[8 * sstride + 36 * 128] = c11[q];
       }
     } else if (c00[0] == 12345.f) M[0] = c00[1] + c01[2] + c10[3] + c11[4];
   }
@@ -333,11 +339,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
         const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
-      float* mrow = M + ((size_t)scomp * gm.R + rb * 32 + 8 * r4 + 4 * hi) * gm.C + ct * 64 + blk * 32 + l31;
+      float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
       mrow[0] = s.x;
-      mrow[(size_t)gm.C] = s.y;
-      mrow[(size_t)2 * gm.C] = s.z;
-      mrow[(size_t)3 * gm.C] = s.w;
+      mrow[32] = s.y;
+      mrow[64] = s.z;
+      mrow[96] = s.w;
     }
   }
 }
@@ -372,41 +378,6 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   else if (ab == 4) W4_LAUNCH(4, 3)
   else W4_LAUNCH(0, 0)
 #undef W4_LAUNCH
-}
-
-// ----------------------------------------------------------------------------
-// Stand-alone transforms around the GEMM (diagnostics / tests; the solver fuses them into its pointwise passes)
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_w4_input(const float* __restrict__ x, float* __restrict__ V, W4Geom gm) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile = smem;               // [64][32]
-  float* scratch = smem + 64 * 32;
-  const int tid = threadIdx.x, n = blockIdx.x, c0 = blockIdx.y * 32;
-  for (int v = tid; v < 64 * 8; v += 256) {
-    const int p = v >> 3, q = v & 7;
-    *reinterpret_cast<float4*>(tile + p * 32 + 4 * q) =
-        *reinterpret_cast<const float4*>(x + ((size_t)n * 64 + p) * gm.C + c0 + 4 * q);
-  }
-  __syncthreads();
-  w4_emit_v(tile, 32, n, c0, V, gm, scratch, tid);
-}
-__global__ __launch_bounds__(256) void k_w4_output(const float* __restrict__ M, float* __restrict__ y, W4Geom gm) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tile = smem;
-  float* scratch = smem + 64 * 32;
-  const int tid = threadIdx.x, n = blockIdx.x, c0 = blockIdx.y * 32;
-  w4_load_tile(M, n, c0, gm, tile, 32, scratch, nullptr, nullptr, 0.f, tid);
-  __syncthreads();
-  for (int v = tid; v < 64 * 8; v += 256) {
-    const int p = v >> 3, q = v & 7;
-    *reinterpret_cast<float4*>(y + ((size_t)n * 64 + p) * gm.C + c0 + 4 * q) = *reinterpret_cast<const float4*>(tile + p * 32 + 4 * q);
-  }
-}
-void launch_w4_input(const float* x, float* V, int N, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4_input, dim3(N, C / 32), dim3(256), (64 * 32 + W4_SCRATCH) * sizeof(float), s, x, V, w4_geom(N, C));
-}
-void launch_w4_output(const float* M, float* y, int N, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4_output, dim3(N, C / 32), dim3(256), (64 * 32 + W4_SCRATCH) * sizeof(float), s, M, y, w4_geom(N, C));
 }
 
 }  // namespace node

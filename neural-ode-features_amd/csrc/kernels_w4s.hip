@@ -1,0 +1,562 @@
+// Winograd F(4x4,3x3) pipeline, stages 1 and 3: the GroupNorm passes around the component GEMMs (wino4.h), as
+// WAVE-INDEPENDENT kernels: no LDS, no barrier, every value of a (sample, channel) stays in registers from the
+// conv's component products to the next conv's row operand.  gfx950 (MI355X / CDNA4) only.
+//
+//   lane = (tile t of the 8x8 image, channel c15 of a 16-channel block): 64 lanes = 4 tiles x 16 channels.  A thread
+//   owns the 4x4 pixels of its tile for its channel:
+//     * output transform Y = A^T M A: 36 loads of its own (tile, channel) element, all arithmetic in registers;
+//     * GroupNorm statistics: a group (cpg <= 16 consecutive channels x 4 tiles) lies inside ONE wave -- DPP + two
+//       cross-row shuffles, no workgroup reduction;
+//     * the 6x6 patch of the input transform V = B^T d B needs one pixel ring around the tile: an 8x8 image is 2x2
+//       tiles, so the ring is nine values held by the lanes t^1, t^2, t^3 of the same wave -- nine shuffles;
+//     * Butcher combines, adjoint combines and every solver-state tensor are read / written as 16-B vectors in the
+//       tile-blocked state layout (W4S, below), so a wave instruction moves 1 KB of contiguous memory.
+//
+// The passes of one dynamics evaluation (model.py:339-348) and of its VJP, with what round 2 launched separately
+// merged where the data is local to a (sample, channel) anyway:
+//   C     combine (Butcher row) -> GroupNorm-1 -> ReLU -> V                                         <0,1>
+//   P2    M -> +bias + t*tmap -> GroupNorm-2 -> ReLU -> V                                           <1,0>
+//   P3    M -> +bias + t*tmap -> GroupNorm-3 -> k                                                   <1,0>
+//   P3C   P3, then the NEXT stage's C with k taken from registers (forward solves)                  <1,1>
+//   P3B3  P3, then the top of the backward chain: adjoint combine -> GroupNorm-3 backward -> V      <1,2>
+//         (xhat-3 and 1/sigma-3 never leave the registers)
+//   PB2   M (data gradient) -> ReLU mask -> GroupNorm-2 backward -> dz1 -> V                        <2,0>
+//   PB1   M (data gradient) -> ReLU mask -> GroupNorm-1 backward -> k_a                             <2,0>
+//   PB1C  PB1, then the NEXT stage's C (augmented solves)                                           <2,1>
+// The ReLU mask is recomputed from the saved xhat (fma(xhat, gamma, beta) > 0, the producer's own expression), so the
+// backward passes do not read the activations.
+//
+// State layout W4S (every solver-state tensor of an F(4x4,3x3) solve: Y, Y1, KY[], A, A1, KA[], the saved xhat):
+//   float4 index (((n * C/16 + cb) * 4 + i) * 64 + lane), components = the four pixels of tile row i
+//   (pixel (4 ty + i, 4 tx + j), t = 2 ty + tx, channel 16 cb + c15, lane = 16 t + c15).
+// Element-wise kernels (error norm, commit, axpy, ...) do not care; NCHW <-> W4S happens at the solve boundary.
+// M (component products) is [n][C/32][36][4 t][32 c]: what a wave pair reads is one contiguous 18 KB block.
+#include "wino4.h"
+#include <cstring>
+
+namespace node {
+
+constexpr int W4S_THREADS = 128;   // two waves = 32 channels of one sample: whole 128-B lines of M, V and the NHWC copies
+
+template <int CTRL>
+__device__ __forceinline__ float w4s_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the four tiles of a channel (lanes l, l^16, l^32, l^48); every lane gets the result
+__device__ __forceinline__ float w4s_tile_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+// sum over a GroupNorm group: cpg (1, 2, 4, 8, 16) consecutive channels x the four tiles; every lane gets the result
+__device__ __forceinline__ float w4s_group_sum(float v, int cpg) {
+  if (cpg >= 2) v += w4s_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (cpg >= 4) v += w4s_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (cpg >= 8) v += w4s_dpp<0x141>(v);   // row_half_mirror
+  if (cpg >= 16) v += w4s_dpp<0x140>(v);  // row_mirror
+  return w4s_tile_sum(v);
+}
+
+// A^T x for the points (0, 1, -1, 1/2, -2, inf)   (W4_AT)
+__device__ __forceinline__ void w4s_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& o0, float& o1,
+                                        float& o2, float& o3) {
+  const float a = m1 + m2, b = m1 - m2;
+  o0 = (m0 + a) + (m3 + m4);
+  o1 = b + (0.5f * m3 - 2.f * m4);
+  o2 = a + (0.25f * m3 + 4.f * m4);
+  o3 = (b + m5) + (0.125f * m3 - 8.f * m4);
+}
+// B^T x   (W4_BT)
+__device__ __forceinline__ void w4s_bt6(float d0, float d1, float d2, float d3, float d4, float d5, float& r0, float& r1,
+                                        float& r2, float& r3, float& r4, float& r5) {
+  const float p = d3 - d1, q = d4 - d2;
+  r0 = (d0 + (d4 - 2.f * d2)) + 1.5f * p;
+  r1 = (d4 - d1) + (0.5f * d2 + 2.5f * d3);
+  r2 = (d4 + d1) + (0.5f * d3 - 2.5f * d2);
+  r3 = q + 2.f * p;
+  r4 = q - 0.5f * p;
+  r5 = (d5 + (d1 - 2.f * d3)) + 1.5f * q;
+}
+
+// Y = A^T M A of the thread's (tile, channel): `mp` points at its element of component 0, components 128 floats apart
+__device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, float y[4][4]) {
+  float m[36];
+#pragma unroll
+  for (int q = 0; q < 36; ++q) m[q] = mp[q * 128];
+  float z[4][6];
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu)
+    w4s_at6(m[nu], m[6 + nu], m[12 + nu], m[18 + nu], m[24 + nu], m[30 + nu], z[0][nu], z[1][nu], z[2][nu], z[3][nu]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w4s_at6(z[i][0], z[i][1], z[i][2], z[i][3], z[i][4], z[i][5], y[i][0], y[i][1], y[i][2], y[i][3]);
+}
+
+// V = B^T d B of the thread's tile (+ one pixel ring from the three other tiles of the image, zero outside) -> the
+// blocked row operand of the component GEMMs.  `vp`: the thread's element of component 0; components `cstride` apart.
+__device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, float* __restrict__ vp, size_t cstride) {
+  float sh[4], sv[4], rh[4], rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sh[i] = tx ? a[i][0] : a[i][3];   // my edge column facing the horizontal neighbour
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sv[j] = ty ? a[0][j] : a[3][j];   // my edge row facing the vertical neighbour
+  const float sc = ty ? (tx ? a[0][0] : a[0][3]) : (tx ? a[3][0] : a[3][3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rh[i] = __shfl_xor(sh[i], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rv[j] = __shfl_xor(sv[j], 32, 64);
+  const float rc = __shfl_xor(sc, 48, 64);
+  float d[6][6];   // patch row r <-> image row 4 ty - 1 + r, column k <-> image column 4 tx - 1 + k
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[1 + i][1 + j] = a[i][j];
+    d[1 + i][0] = tx ? rh[i] : 0.f;
+    d[1 + i][5] = tx ? 0.f : rh[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d[0][1 + j] = ty ? rv[j] : 0.f;
+    d[5][1 + j] = ty ? 0.f : rv[j];
+  }
+  d[0][0] = (ty && tx) ? rc : 0.f;
+  d[0][5] = (ty && !tx) ? rc : 0.f;
+  d[5][0] = (!ty && tx) ? rc : 0.f;
+  d[5][5] = (!ty && !tx) ? rc : 0.f;
+  float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
+#pragma unroll
+  for (int j = 0; j < 6; ++j) w4s_bt6(d[j][0], d[j][1], d[j][2], d[j][3], d[j][4], d[j][5], w[j][0], w[j][1], w[j][2], w[j][3], w[j][4], w[j][5]);
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
+    w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
+    vp[(size_t)(0 * 6 + l) * cstride] = v0;
+    vp[(size_t)(1 * 6 + l) * cstride] = v1;
+    vp[(size_t)(2 * 6 + l) * cstride] = v2;
+    vp[(size_t)(3 * 6 + l) * cstride] = v3;
+    vp[(size_t)(4 * 6 + l) * cstride] = v4;
+    vp[(size_t)(5 * 6 + l) * cstride] = v5;
+  }
+}
+
+// masked column sums of the thread's channel (node_internal.h, masked_colsum_tile): out[tap * ld] for the nine taps
+__device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, int ty, int tx, float* __restrict__ out, int ld) {
+  float R[4], Cc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) R[i] = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) Cc[j] = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
+  float T = (R[0] + R[1]) + (R[2] + R[3]);
+  float rf = ty == 0 ? R[0] : 0.f, rl = ty == 1 ? R[3] : 0.f;
+  float cf = tx == 0 ? Cc[0] : 0.f, cl = tx == 1 ? Cc[3] : 0.f;
+  float k00 = t == 0 ? v[0][0] : 0.f, k01 = t == 1 ? v[0][3] : 0.f, k10 = t == 2 ? v[3][0] : 0.f, k11 = t == 3 ? v[3][3] : 0.f;
+  T = w4s_tile_sum(T); rf = w4s_tile_sum(rf); rl = w4s_tile_sum(rl); cf = w4s_tile_sum(cf); cl = w4s_tile_sum(cl);
+  k00 = w4s_tile_sum(k00); k01 = w4s_tile_sum(k01); k10 = w4s_tile_sum(k10); k11 = w4s_tile_sum(k11);
+  if (t == 0) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {   // tap (kh, kw) excludes the first (k == 0) / last (k == 2) row and column
+      const int kh = tap / 3, kw = tap % 3;
+      float o = T;
+      if (kh == 0) o -= rf;
+      if (kh == 2) o -= rl;
+      if (kw == 0) o -= cf;
+      if (kw == 2) o -= cl;
+      if (kh == 0 && kw == 0) o += k00;
+      if (kh == 0 && kw == 2) o += k01;
+      if (kh == 2 && kw == 0) o += k10;
+      if (kh == 2 && kw == 2) o += k11;
+      out[(size_t)tap * ld] = o;
+    }
+  }
+}
+
+__device__ __forceinline__ float4 w4s_ld4(const float* p, size_t f4) { return reinterpret_cast<const float4*>(p)[f4]; }
+__device__ __forceinline__ void w4s_st4(float* p, size_t f4, const float r[4]) {
+  reinterpret_cast<float4*>(p)[f4] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// y + sum_j cf[j] k[j] on the thread's 16 pixels, every request issued before the first use (NK is a compile-time
+// count: a loop over a run-time count makes the compiler wait for each tensor before it requests the next).
+// SELF: the last term is `self` (the stage derivative the head of this pass just produced), not a load.
+// Summation order as in k_combine_gn: s = cf0 k0; s += cfj kj; y += s.
+template <int NK, bool SELF>
+__device__ __forceinline__ void w4s_comb(const Comb& c, const float* cf, size_t f4, const float self[4][4], float y[4][4]) {
+  constexpr int NL = SELF ? NK - 1 : NK;
+  float4 yv[4], kv[NL > 0 ? NL : 1][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) yv[i] = w4s_ld4(c.y, f4 + i * 64);
+#pragma unroll
+  for (int j = 0; j < NL; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kv[j][i] = w4s_ld4(c.k[j], f4 + i * 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float yy[4] = {yv[i].x, yv[i].y, yv[i].z, yv[i].w};
+    if (NK > 0) {
+      float s[4];
+      if (NL > 0) {
+        s[0] = cf[0] * kv[0][i].x; s[1] = cf[0] * kv[0][i].y; s[2] = cf[0] * kv[0][i].z; s[3] = cf[0] * kv[0][i].w;
+#pragma unroll
+        for (int j = 1; j < NL; ++j) {
+          s[0] += cf[j] * kv[j][i].x; s[1] += cf[j] * kv[j][i].y; s[2] += cf[j] * kv[j][i].z; s[3] += cf[j] * kv[j][i].w;
+        }
+        if (SELF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += cf[NK - 1] * self[i][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = cf[0] * self[i][e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) yy[e] += s[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[i][e] = yy[e];
+  }
+}
+template <bool SELF>
+__device__ __forceinline__ void w4s_comb_any(const Comb& c, const float* cf, size_t f4, const float self[4][4], float y[4][4]) {
+  switch (c.nk) {
+    case 0: w4s_comb<0, false>(c, cf, f4, self, y); break;
+    case 1: w4s_comb<1, SELF>(c, cf, f4, self, y); break;
+    case 2: w4s_comb<2, SELF>(c, cf, f4, self, y); break;
+    case 3: w4s_comb<3, SELF>(c, cf, f4, self, y); break;
+    case 4: w4s_comb<4, SELF>(c, cf, f4, self, y); break;
+    case 5: w4s_comb<5, SELF>(c, cf, f4, self, y); break;
+    case 6: w4s_comb<6, SELF>(c, cf, f4, self, y); break;
+    default: w4s_comb<7, SELF>(c, cf, f4, self, y); break;
+  }
+}
+
+// the thread's 16 pixels -> an NHWC tensor (the weight-gradient kernel's operand layout)
+__device__ __forceinline__ void w4s_store_nhwc(float* __restrict__ dst, int n, int C, int c, int ty, int tx, const float v[4][4]) {
+  float* base = dst + ((size_t)n * 64 + (4 * ty) * 8 + 4 * tx) * C + c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) base[(size_t)(i * 8 + j) * C] = v[i][j];
+}
+
+// GroupNorm statistics of the thread's group (two passes over the registers, like the reference's kernels)
+__device__ __forceinline__ void w4s_gn_stats(const float z[4][4], int cpg, float inv_m, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += (z[i][0] + z[i][1]) + (z[i][2] + z[i][3]);
+  mean = w4s_group_sum(s, cpg) * inv_m;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float dv = z[i][j] - mean; s2 += dv * dv; }
+  const float var = w4s_group_sum(s2, cpg) * inv_m;
+  rstd = 1.0f / sqrtf(var + eps);
+}
+
+// GroupNorm backward on the thread's pixels: g = d L / d (affine output); returns dz = osign * rstd (g gamma - m1 - xhat m2)
+// and leaves the per-sample (dgamma, dbeta) partials of the channel in gpart ([N][2][C]).
+__device__ __forceinline__ void w4s_gn_bwd(const float g[4][4], const float xh[4][4], float gam, float rstd, int cpg, float inv_m,
+                                           float osign, int n, int C, int c, int t, float* __restrict__ gpart, float dz[4][4]) {
+  float dg = 0.f, db = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      dg += g[i][j] * xh[i][j];
+      db += g[i][j];
+      const float dxh = g[i][j] * gam;
+      s1 += dxh;
+      s2 += dxh * xh[i][j];
+    }
+  dg = w4s_tile_sum(dg);
+  db = w4s_tile_sum(db);
+  if (t == 0) {
+    gpart[((size_t)n * 2 + 0) * C + c] = dg;
+    gpart[((size_t)n * 2 + 1) * C + c] = db;
+  }
+  s1 = w4s_group_sum(s1, cpg) * inv_m;
+  s2 = w4s_group_sum(s2, cpg) * inv_m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dz[i][j] = osign * (rstd * (g[i][j] * gam - s1 - xh[i][j] * s2));
+}
+
+// HEAD: 0 none, 1 forward (conv result -> GroupNorm), 2 backward (data gradient -> ReLU mask -> GroupNorm backward)
+// TAIL: 0 none, 1 stage combine -> GroupNorm-1 -> ReLU, 2 adjoint combine -> GroupNorm-3 backward (needs HEAD 1)
+template <int HEAD, int TAIL>
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  const int lane = threadIdx.x & 63;
+  const int CB = a.C >> 4;
+  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
+  const int n = unit / CB, cb = unit - n * CB;
+  const int t = lane >> 4, c15 = lane & 15, ty = t >> 1, tx = t & 1;
+  const int c = cb * 16 + c15;
+  const int cpg = a.cpg, G = a.C / cpg, grp = c / cpg;
+  const float inv_m = 1.0f / (float)(64 * cpg);
+  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;   // float4 index of tile row 0 in a W4S tensor (rows 64 apart)
+
+  float v[4][4];     // the conv input whose transform leaves at the end
+  float hx[4][4];    // HEAD 1: xhat of the head's GroupNorm
+  float ho[4][4];    // the head's output (a stage derivative)
+  float hrstd = 0.f;
+
+  if (HEAD == 1) {
+    const W4sHead& h = a.h;
+    const float* mp = h.M + (((size_t)n * (a.C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
+    float z[4][4];
+    w4s_out_transform(mp, z);
+    const float tval = eval_time(h.et), bv = h.bias[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 tm = w4s_ld4(h.tmapS, (size_t)cb * 256 + i * 64 + lane);
+      z[i][0] += fmaf(tval, tm.x, bv); z[i][1] += fmaf(tval, tm.y, bv); z[i][2] += fmaf(tval, tm.z, bv); z[i][3] += fmaf(tval, tm.w, bv);
+    }
+    float mean;
+    w4s_gn_stats(z, cpg, inv_m, a.eps, mean, hrstd);
+    const float gam = h.gamma[c], bet = h.beta[c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hx[i][j] = (z[i][j] - mean) * hrstd;
+        float vv = fmaf(hx[i][j], gam, bet);
+        if (h.relu) vv = fmaxf(vv, 0.f);
+        ho[i][j] = h.osign * vv;
+      }
+    if (h.out_s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4s_st4(h.out_s, f4 + i * 64, ho[i]);
+    }
+    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
+    if (h.xhat_s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4s_st4(h.xhat_s, f4 + i * 64, hx[i]);
+    }
+    if (h.rstd && t == 0 && c % cpg == 0) h.rstd[(size_t)n * G + grp] = hrstd;
+    if (TAIL == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = ho[i][j];
+    }
+  }
+  if (HEAD == 2) {
+    const W4sHead& h = a.h;
+    const float* mp = h.M + (((size_t)n * (a.C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
+    float4 xq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xq[i] = w4s_ld4(h.xhat_s, f4 + i * 64);
+    const float gam = h.gamma[c], bet = h.beta[c], rs = h.rstd[(size_t)n * G + grp];
+    float g[4][4], xh[4][4];
+    w4s_out_transform(mp, g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xh[i][0] = xq[i].x; xh[i][1] = xq[i].y; xh[i][2] = xq[i].z; xh[i][3] = xq[i].w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[i][j] = fmaf(xh[i][j], gam, bet) > 0.f ? g[i][j] : 0.f;   // ReLU mask of this layer's output
+    }
+    w4s_gn_bwd(g, xh, gam, rs, cpg, inv_m, h.osign, n, a.C, c, t, h.gpart, ho);
+    if (h.out_s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4s_st4(h.out_s, f4 + i * 64, ho[i]);
+    }
+    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
+    if (h.spart) w4s_colsums(ho, t, ty, tx, h.spart + (size_t)n * 9 * a.C + c, a.C);
+    if (TAIL == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = ho[i][j];
+    }
+  }
+
+  if (TAIL != 0) {
+    const W4sTail& tl = a.t;
+    const float scale = comb_scale(tl.comb, a.ctrl);
+    float cf[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cf[j] = scale * tl.comb.coef[j];
+    float y[4][4];
+    if (HEAD == 1 && TAIL == 1) {
+      if (tl.self) w4s_comb_any<true>(tl.comb, cf, f4, ho, y);
+      else w4s_comb_any<false>(tl.comb, cf, f4, ho, y);
+    } else {
+      w4s_comb_any<false>(tl.comb, cf, f4, ho, y);
+    }
+    if (tl.y_out) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w4s_st4(tl.y_out, f4 + i * 64, y[i]);
+    }
+    if (TAIL == 1) {   // GroupNorm-1 -> ReLU (model.py:341-342)
+      float mean, rstd;
+      w4s_gn_stats(y, cpg, inv_m, a.eps, mean, rstd);
+      const float gam = tl.gamma[c], bet = tl.beta[c];
+      float xh[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (y[i][j] - mean) * rstd;
+          v[i][j] = fmaxf(fmaf(xh[i][j], gam, bet), 0.f);
+        }
+      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
+      if (tl.xhat_s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4s_st4(tl.xhat_s, f4 + i * 64, xh[i]);
+      }
+      if (tl.rstd && t == 0 && c % cpg == 0) tl.rstd[(size_t)n * G + grp] = rstd;
+    } else {   // cotangent g = csign * (adjoint combine) through GroupNorm-3's backward (xhat-3, 1/sigma-3 from the head)
+      float g[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[i][j] = tl.csign * y[i][j];
+      w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, n, a.C, c, t, tl.gpart, v);
+      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
+      if (tl.spart) w4s_colsums(v, t, ty, tx, tl.spart + (size_t)n * 9 * a.C + c, a.C);
+    }
+  }
+
+  if (a.V != nullptr) {
+    const int g8 = cb * 2 + (c15 >> 3), hi = (c15 >> 2) & 1, e = c15 & 3;
+    float* vp = a.V + ((size_t)((n >> 3) * (a.C >> 3) + g8) * 256 + (n & 7) * 32 + hi * 16 + t * 4 + e);
+    w4s_emit_v(v, ty, tx, vp, (size_t)4 * a.N * a.C);
+  }
+}
+
+void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s) {
+  const int units = a.N * (a.C >> 4);
+  const dim3 grid(units / (W4S_THREADS / 64)), block(W4S_THREADS);
+#define W4S_GO(H, T) hipLaunchKernelGGL((k_w4s_pass<H, T>), grid, block, 0, s, a)
+  if (head == 0 && tail == 1) W4S_GO(0, 1);
+  else if (head == 1 && tail == 0) W4S_GO(1, 0);
+  else if (head == 1 && tail == 1) W4S_GO(1, 1);
+  else if (head == 1 && tail == 2) W4S_GO(1, 2);
+  else if (head == 2 && tail == 0) W4S_GO(2, 0);
+  else if (head == 2 && tail == 1) W4S_GO(2, 1);
+#undef W4S_GO
+}
+
+// ----------------------------------------------------------------------------
+// NCHW <-> W4S at the solve boundary: both sides of a (sample, 16-channel block) are the same contiguous 4 KB, the
+// 16-B vectors (four pixels of an image row inside one tile) permuted.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ int w4s_of_nchw(int f) {   // float4 index inside the block: NCHW -> W4S
+  const int c15 = f >> 4, y = (f >> 1) & 7, tx = f & 1;
+  return (y & 3) * 64 + ((y >> 2) * 2 + tx) * 16 + c15;
+}
+__global__ __launch_bounds__(256) void k_w4s_layout(const float4* __restrict__ src, float4* __restrict__ dst, size_t total, int to_nchw) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t blk = idx >> 8;
+  const int f = (int)(idx & 255);           // NCHW position inside the block
+  const int g = w4s_of_nchw(f);
+  if (to_nchw) dst[idx] = src[(blk << 8) + g];      // coalesced writes
+  else dst[(blk << 8) + g] = src[idx];              // coalesced reads
+}
+void launch_w4s_from_nchw(const float* src, float* dst, int N, int C, hipStream_t s) {
+  const size_t total = (size_t)N * C * 16;
+  hipLaunchKernelGGL(k_w4s_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), total, 0);
+}
+void launch_w4s_to_nchw(const float* src, float* dst, int N, int C, hipStream_t s) {
+  const size_t total = (size_t)N * C * 16;
+  hipLaunchKernelGGL(k_w4s_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), total, 1);
+}
+
+// border-aware time-channel map [HW][C] -> the W4S blocking ([C/16][4 i][64 lanes][4 j]) the forward passes read
+__global__ __launch_bounds__(256) void k_w4s_tmap(const float* __restrict__ tmap0, const float* __restrict__ tmap1, float* __restrict__ out0,
+                                                  float* __restrict__ out1, int C) {
+  const float* tm = blockIdx.y ? tmap1 : tmap0;
+  float* out = blockIdx.y ? out1 : out0;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 64 * C) return;
+  const int j = idx & 3, lane = (idx >> 2) & 63, i = (idx >> 8) & 3, cb = idx >> 10;
+  const int t = lane >> 4, c = cb * 16 + (lane & 15);
+  const int p = (4 * (t >> 1) + i) * 8 + 4 * (t & 1) + j;
+  out[idx] = tm[(size_t)p * C + c];
+}
+void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4s_tmap, dim3((64 * C + 255) / 256, 2), dim3(256), 0, s, tmap0, tmap1, out0, out1, C);
+}
+
+// Dense output of the forward solve (k_emit_outputs) for W4S state: element-wise on the 16-B vectors, written at their
+// NCHW position.
+__global__ __launch_bounds__(256) void k_w4s_emit_outputs(EmitArgs a, size_t total /* float4s per tensor */) {
+  const Ctrl* c = a.ctrl;
+  const int j0 = c->j0, j1 = c->j1;
+  if (j1 <= j0) return;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // NCHW float4 position
+  if (idx >= total) return;
+  const size_t src = ((idx >> 8) << 8) + w4s_of_nchw((int)(idx & 255));
+  const float dt = (float)c->dt_used;
+  const float t0f = (float)c->t_prev, t1f = (float)c->t;
+  const float4 y0 = w4s_ld4(a.y0, src), y1 = w4s_ld4(a.y1, src);
+  float4 kq[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) kq[q] = (q == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : w4s_ld4(a.k[q], src);
+  for (int j = j0; j < j1; ++j) {
+    const float x = ((float)a.targets[j] - t0f) / (t1f - t0f);
+    float kk[7];
+    float4 o;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kk[q] = kq[q].x;
+    o.x = interp_one(y0.x, y1.x, kk, dt, x);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kk[q] = kq[q].y;
+    o.y = interp_one(y0.y, y1.y, kk, dt, x);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kk[q] = kq[q].z;
+    o.z = interp_one(y0.z, y1.z, kk, dt, x);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) kk[q] = kq[q].w;
+    o.w = interp_one(y0.w, y1.w, kk, dt, x);
+    reinterpret_cast<float4*>(a.y_out)[(size_t)j * total + idx] = o;
+  }
+}
+void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s) {
+  const size_t total = d.numel / 4;
+  hipLaunchKernelGGL(k_w4s_emit_outputs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+}
+
+// ----------------------------------------------------------------------------
+// Stand-alone transforms around the GEMM (diagnostics / tests: node_conv3x3_w4): W4S tensor -> V, M -> W4S tensor
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_input(const float* __restrict__ x, float* __restrict__ V, int N, int C) {
+  const int lane = threadIdx.x & 63, CB = C >> 4;
+  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
+  const int n = unit / CB, cb = unit - n * CB;
+  const int t = lane >> 4, c15 = lane & 15, ty = t >> 1, tx = t & 1;
+  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;
+  float v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 q = w4s_ld4(x, f4 + i * 64);
+    v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+  }
+  const int g8 = cb * 2 + (c15 >> 3), hi = (c15 >> 2) & 1, e = c15 & 3;
+  float* vp = V + ((size_t)((n >> 3) * (C >> 3) + g8) * 256 + (n & 7) * 32 + hi * 16 + t * 4 + e);
+  w4s_emit_v(v, ty, tx, vp, (size_t)4 * N * C);
+}
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_output(const float* __restrict__ M, float* __restrict__ y, int N, int C) {
+  const int lane = threadIdx.x & 63, CB = C >> 4;
+  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
+  const int n = unit / CB, cb = unit - n * CB;
+  const int t = lane >> 4, c15 = lane & 15;
+  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;
+  const float* mp = M + (((size_t)n * (C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
+  float z[4][4];
+  w4s_out_transform(mp, z);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w4s_st4(y, f4 + i * 64, z[i]);
+}
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4s_input, dim3(N * (C >> 4) / (W4S_THREADS / 64)), dim3(W4S_THREADS), 0, s, x_w4s, V, N, C);
+}
+void launch_w4_output(const float* M, float* y_w4s, int N, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4s_output, dim3(N * (C >> 4) / (W4S_THREADS / 64)), dim3(W4S_THREADS), 0, s, M, y_w4s, N, C);
+}
+
+}  // namespace node

@@ -175,7 +175,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // the other switches) so that one test process can run both conv paths on the same inputs.
     const char* w4e = getenv("NODE_TUNE_WINO4");
     const int w4_env = w4e ? atoi(w4e) : 1;
-    d.wino4 = (w4_env != 0 && d.H == 8 && d.W == 8 && d.C % 64 == 0 && d.N % 8 == 0 && d.cs == 32 && 32 % d.cpg == 0) ? w4_env : 0;
+    d.wino4 = (w4_env != 0 && d.H == 8 && d.W == 8 && d.C % 64 == 0 && d.N % 8 == 0 && 16 % d.cpg == 0) ? w4_env : 0;
   }
   d.RB = 64 / d.W;
   if (d.RB < 1) d.RB = 1;
@@ -244,6 +244,9 @@ struct Plan {
   float* wsmall[2];         // small mode: filters packed for k_conv3x3_small
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
+  float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
+  float *act1b, *xh1b, *r1b;   // second set of GroupNorm-1's saved tensors: the pass that ends evaluation s also forms
+                               // stage s + 1's conv input, while evaluation s's own set is still being read
   // adjoint
   float *A, *A1, *KA[7];
   float *TH, *TH1, *KT[7];
@@ -297,6 +300,12 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.W4V = b.take<float>(w4_v_elems(d.N, d.C));
     p.W4M = b.take<float>(w4_v_elems(d.N, d.C));
     for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4u[i] = b.take<float>(w4_u_elems(d.C));
+    for (int i = 0; i < 2; ++i) p.tmapS[i] = b.take<float>((size_t)d.HW * d.C);
+    if (adjoint) {
+      p.act1b = b.take<float>(d.numel + d.C);
+      p.xh1b = b.take<float>(d.numel);
+      p.r1b = b.take<float>((size_t)d.N * d.G);
+    }
   }
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
@@ -405,6 +414,22 @@ struct Solver {
   void choose_w4(bool adaptive) {
     w4 = d.wino4 == 2 || (d.wino4 == 1 && adaptive && rtol >= 1e-4f && atol >= 1e-4f);
   }
+  // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
+  // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
+  bool v_ready = false;    // the next evaluation's first pass has run
+  int cur = 0;             // which set of GroupNorm-1's saved tensors (act1, xhat-1, 1/sigma-1) the current evaluation owns
+  float* act1_of(int i) const { return i ? p.act1b : p.act1; }
+  float* xh1_of(int i) const { return i ? p.xh1b : p.xh1; }
+  float* r1_of(int i) const { return i ? p.r1b : p.r1; }
+  void to_state(const float* nchw, float* dst) {    // NCHW -> the solve's internal state layout
+    if (w4) launch_w4s_from_nchw(nchw, dst, d.N, d.C, st);
+    else launch_nchw_to_nhwc(d, nchw, dst, st);
+  }
+  void from_state(const float* src, float* nchw) {
+    if (w4) launch_w4s_to_nchw(src, nchw, d.N, d.C, st);
+    else launch_nhwc_to_nchw(d, src, nchw, st);
+  }
+  struct NextComb { Comb cy; float* y_out; };
   bool count_nfe = true;   // off while steps are enqueued blind: those evaluations are counted from the device's step counter
   Ctrl* hctrl = nullptr;
 
@@ -425,8 +450,8 @@ struct Solver {
     // weight zero by the error norm / dense output, never written by dopri5 steps -- the initial-step probe does
     // write it -- so it must hold finite values), the arrival counter of k_theta_finalize, and the zero rows behind
     // the conv inputs (see make_plan)
-    float* zr[6];
-    size_t zn[6];
+    float* zr[8];
+    size_t zn[8];
     int nz = 0;
     if (aug) {
       zr[nz] = p.KT[1]; zn[nz++] = d.P;
@@ -438,6 +463,7 @@ struct Solver {
       if (aug) {
         zr[nz] = p.dz1 + d.numel; zn[nz++] = d.C;
         zr[nz] = p.dz2 + d.numel; zn[nz++] = d.C;
+        if (p.act1b) { zr[nz] = p.act1b + d.numel; zn[nz++] = d.C; }
       }
     }
     if (small_mode()) {
@@ -465,6 +491,9 @@ struct Solver {
     }
     launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
                      nz, st);
+    if (w4) launch_w4s_tmap(p.tmap[0], p.tmap[1], p.tmapS[0], p.tmapS[1], d.C, st);
+    v_ready = false;
+    cur = 0;
     return check_launch("prepare");
   }
 
@@ -512,48 +541,141 @@ struct Solver {
     ProfScope ps(2, conv_flops(), st);
     launch_w4_gemm(p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N, d.C, st);
   }
-  void w4_pass_fwd(const float* bias, const float* tmap, const EvalTime& et, const float* gamma, const float* beta, int relu,
-                   float osign, float* out, float* xhat_out, float* rstd_out, bool emit_v) {
-    CombineGnArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.comb.y = p.W4M; ca.comb.nk = 0; ca.comb.scale_mode = SC_ABS; ca.ctrl = p.ctrl;
-    ca.act_out = out; ca.xhat_out = xhat_out; ca.rstd_out = rstd_out;
-    ca.gamma = gamma; ca.beta = beta; ca.relu = relu; ca.osign = osign;
-    ca.w4.m_in = p.W4M; ca.w4.bias = bias; ca.w4.tmap = tmap; ca.w4.et = et; ca.w4.v_out = emit_v ? p.W4V : nullptr;
-    launch_combine_gn(d, ca, st);
+  W4sArgs w4_args() const {
+    W4sArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ctrl = p.ctrl; a.N = d.N; a.C = d.C; a.cpg = d.cpg; a.eps = d.eps;
+    return a;
   }
-  void w4_pass_bwd(const float* act, const float* xhat, const float* rstd, const float* gamma, float osign, float* out,
-                   float* gpart, float* spart, bool emit_v) {
-    GnBwdArgs g;
-    memset(&g, 0, sizeof(g));
-    g.comb.y = p.W4M; g.comb.nk = 0; g.comb.scale_mode = SC_ABS; g.ctrl = p.ctrl; g.csign = 1.f;
-    g.xhat = xhat; g.rstd = rstd; g.gamma = gamma; g.dz_out = out; g.gpart = gpart; g.spart = spart;
-    g.mask_act = act; g.osign = osign;
-    g.w4.m_in = p.W4M; g.w4.v_out = emit_v ? p.W4V : nullptr;
-    launch_gn_bwd(d, g, st);
+  // tail 1 of a pass: stage combine -> GroupNorm-1 -> ReLU -> V (+ act1, xhat-1, 1/sigma-1 of set `set` when training)
+  void w4_tail_combine(W4sArgs& a, const Comb& cy, float* y_out, bool train, int set, int self) {
+    a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
+    if (train) { a.t.act_nhwc = act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
+    a.V = p.W4V;
+  }
+  // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
+  // must read or write, once) in the record
+  void w4_pass(int head, int tail, const W4sArgs& a) {
+    double bytes = 0.0;
+    if (g_prof.on) {
+      const double state = (double)d.numel * sizeof(float), comp = 36.0 * 4.0 * d.N * d.C * sizeof(float);
+      int tensors = 0;
+      if (head) {
+        tensors += (a.h.out_s != nullptr) + (a.h.out_nhwc != nullptr);
+        tensors += a.h.xhat_s != nullptr;      // written (forward) or read (backward)
+        bytes += comp;
+      }
+      if (tail) {
+        tensors += 1 + a.t.comb.nk - (a.t.self ? 1 : 0);
+        tensors += (a.t.y_out != nullptr) + (a.t.act_nhwc != nullptr) + (a.t.xhat_s != nullptr);
+      }
+      if (a.V) bytes += comp;
+      bytes += tensors * state;
+    }
+    const int cls = head == 0 ? 3 : head == 1 ? 4 + tail : 7 + tail;
+    ProfScope ps(cls, bytes, st);
+    launch_w4s_pass(head, tail, a, st);
+  }
+  // One dynamics evaluation (ca == nullptr) or one augmented evaluation on the F(4x4,3x3) pipeline.  `next`: the
+  // evaluation that follows takes its conv input from this one's last pass (v_ready).
+  int eval_w4(const Comb& cy, float* y_out, const EvalTime& et, float* kY_out, bool train, const Comb* ca, float* a_out,
+              float* kA_out, float* kT_out, int kidx, float csign, float* vjp_t_out, bool need_theta, const NextComb* next) {
+    const bool do_aug = ca != nullptr;
+    if (next != nullptr)   // a combine that reads this evaluation's own derivative anywhere but as its last term cannot merge
+      for (int j = 0; j + 1 < next->cy.nk; ++j)
+        if (next->cy.k[j] == kY_out || (do_aug && next->cy.k[j] == kA_out)) next = nullptr;
+    if (!v_ready) {
+      W4sArgs a = w4_args();
+      w4_tail_combine(a, cy, y_out, train, cur, 0);
+      w4_pass(0, 1, a);
+    }
+    v_ready = false;
+    w4_gemm(0);
+    {   // P2
+      W4sArgs a = w4_args();
+      a.h.M = p.W4M; a.h.bias = prm.conv1_b; a.h.tmapS = p.tmapS[0]; a.h.et = et; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b;
+      a.h.osign = 1.f; a.h.relu = 1;
+      if (train) { a.h.out_nhwc = p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
+      a.V = p.W4V;
+      w4_pass(1, 0, a);
+    }
+    w4_gemm(1);
+    W4sArgs a3 = w4_args();
+    a3.h.M = p.W4M; a3.h.bias = prm.conv2_b; a3.h.tmapS = p.tmapS[1]; a3.h.et = et; a3.h.gamma = prm.norm3_w; a3.h.beta = prm.norm3_b;
+    a3.h.osign = et.tsign; a3.h.relu = 0; a3.h.out_s = kY_out;
+    if (!do_aug) {
+      if (next != nullptr) {   // P3C
+        const int self = next->cy.nk > 0 && next->cy.k[next->cy.nk - 1] == kY_out;
+        w4_tail_combine(a3, next->cy, next->y_out, false, cur, self);
+        w4_pass(1, 1, a3);
+        v_ready = true;
+      } else {
+        w4_pass(1, 0, a3);
+      }
+      if (count_nfe) nfe += 1;
+      return check_launch("odefunc forward (F(4x4,3x3))");
+    }
+    // P3B3: GroupNorm-3, then the adjoint combine through its backward
+    a3.t.comb = *ca; a3.t.csign = csign; a3.t.y_out = a_out; a3.t.gpart = p.gpart[2]; a3.t.spart = p.spart[1]; a3.t.act_nhwc = p.dz2;
+    a3.V = p.W4V;
+    w4_pass(1, 2, a3);
+    if (count_nfe) nfe += 1;
+    w4_gemm(3);   // data gradient of conv2
+    {   // PB2
+      W4sArgs a = w4_args();
+      a.h.M = p.W4M; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; a.h.osign = 1.f;
+      a.h.out_nhwc = p.dz1; a.h.gpart = p.gpart[1]; a.h.spart = p.spart[0];
+      a.V = p.W4V;
+      w4_pass(2, 0, a);
+    }
+    if (need_theta) {
+      WgradArgs w1;
+      memset(&w1, 0, sizeof(w1));
+      w1.act = act1_of(cur); w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.ctrl = p.ctrl;
+      if (d.wgrad_pair) { w1.act2 = p.act2; w1.dz2 = p.dz2; w1.wpart2 = p.wpart[1]; }
+      { ProfScope ps(1, (d.wgrad_pair ? 2.0 : 1.0) * conv_flops(), st); launch_wgrad(d, w1, st); }
+      if (!d.wgrad_pair) {
+        WgradArgs w2 = w1;
+        w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
+        { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
+      }
+    }
+    w4_gemm(2);   // data gradient of conv1
+    {   // PB1 (+ the next evaluation's combine)
+      W4sArgs a = w4_args();
+      a.h.M = p.W4M; a.h.gamma = prm.norm1_w; a.h.beta = prm.norm1_b; a.h.xhat_s = xh1_of(cur); a.h.rstd = r1_of(cur);
+      a.h.osign = et.tsign; a.h.out_s = kA_out; a.h.gpart = p.gpart[0];
+      if (next != nullptr) {
+        w4_tail_combine(a, next->cy, next->y_out, true, cur ^ 1, 0);
+        w4_pass(2, 1, a);
+        cur ^= 1;
+        v_ready = true;
+      } else {
+        w4_pass(2, 0, a);
+      }
+    }
+    if (!need_theta) return check_launch("augmented dynamics (F(4x4,3x3))");
+    ThetaFinalizeArgs tf;
+    memset(&tf, 0, sizeof(tf));
+    tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
+    tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
+    tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
+    tf.gpart_rows[0] = tf.gpart_rows[1] = tf.gpart_rows[2] = d.N;   // per-sample partials from the GroupNorm passes
+    tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
+    tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
+    tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
+    launch_theta_finalize(d, tf, st);
+    return check_launch("augmented dynamics (F(4x4,3x3))");
   }
 
-  int eval_fwd(const Comb& cy, float* y_out, const EvalTime& et, float* k_out, bool train) {
+  int eval_fwd(const Comb& cy, float* y_out, const EvalTime& et, float* k_out, bool train, const NextComb* next = nullptr) {
+    if (w4) return eval_w4(cy, y_out, et, k_out, train, nullptr, nullptr, nullptr, nullptr, -1, 0.f, nullptr, false, next);
     CombineGnArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
     ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
     ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
-    if (w4) {
-      ca.w4.v_out = p.W4V;
-      if (!train) ca.act_out = nullptr;   // only the weight gradient and the ReLU mask of a VJP read the plain activation
-    }
     launch_combine_gn(d, ca, st);
-    if (w4) {
-      w4_gemm(0);
-      w4_pass_fwd(prm.conv1_b, p.tmap[0], et, prm.norm2_w, prm.norm2_b, 1, 1.f, train ? p.act2 : nullptr, train ? p.xh2 : nullptr,
-                  train ? p.r2 : nullptr, true);
-      w4_gemm(1);
-      w4_pass_fwd(prm.conv2_b, p.tmap[1], et, prm.norm3_w, prm.norm3_b, 0, et.tsign, k_out, train ? p.xh3 : nullptr,
-                  train ? p.r3 : nullptr, false);
-      if (count_nfe) nfe += 1;
-      return check_launch("odefunc forward (F(4x4,3x3))");
-    }
 
     ConvArgs c1;
     memset(&c1, 0, sizeof(c1));
@@ -586,7 +708,8 @@ struct Solver {
   // (finite, zero-weighted) contents.
   int eval_aug(const Comb& cy, const Comb& ca, float* y_out, float* a_out, const EvalTime& et,
                float* kY_out, float* kA_out, float* kT_out, int kidx, float csign, float* vjp_t_out,
-               bool need_theta = true) {
+               bool need_theta = true, const NextComb* next = nullptr) {
+    if (w4) return eval_w4(cy, y_out, et, kY_out, true, &ca, a_out, kA_out, kT_out, kidx, csign, vjp_t_out, need_theta, next);
     TRY(eval_fwd(cy, y_out, et, kY_out, true));
 
     GnBwdArgs g;
@@ -595,39 +718,8 @@ struct Solver {
     g.xhat = p.xh3; g.rstd = p.r3; g.gamma = prm.norm3_w; g.dz_out = p.dz2; g.gpart = p.gpart[2]; g.osign = 1.f;
     static int fuse_colsum = -1;   // NODE_TUNE_FUSE_COLSUM=0: separate k_colsum launches (A/B measurements)
     if (fuse_colsum < 0) { const char* e = getenv("NODE_TUNE_FUSE_COLSUM"); fuse_colsum = e ? atoi(e) : 1; }
-    g.spart = (fuse_colsum || w4) ? p.spart[1] : nullptr;   // masked column sums of dz2, fused (k_colsum otherwise)
-    if (w4) g.w4.v_out = p.W4V;
+    g.spart = fuse_colsum ? p.spart[1] : nullptr;   // masked column sums of dz2, fused (k_colsum otherwise)
     launch_gn_bwd(d, g, st);
-    if (w4) {
-      w4_gemm(3);   // data gradient of conv2
-      w4_pass_bwd(p.act2, p.xh2, p.r2, prm.norm2_w, 1.f, p.dz1, p.gpart[1], p.spart[0], true);
-      if (need_theta) {
-        WgradArgs w1;
-        memset(&w1, 0, sizeof(w1));
-        w1.act = p.act1; w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.ctrl = p.ctrl;
-        if (d.wgrad_pair) { w1.act2 = p.act2; w1.dz2 = p.dz2; w1.wpart2 = p.wpart[1]; }
-        { ProfScope ps(1, (d.wgrad_pair ? 2.0 : 1.0) * conv_flops(), st); launch_wgrad(d, w1, st); }
-        if (!d.wgrad_pair) {
-          WgradArgs w2 = w1;
-          w2.act = p.act2; w2.dz = p.dz2; w2.wpart = p.wpart[1];
-          { ProfScope ps(1, conv_flops(), st); launch_wgrad(d, w2, st); }
-        }
-      }
-      w4_gemm(2);   // data gradient of conv1
-      w4_pass_bwd(p.act1, p.xh1, p.r1, prm.norm1_w, et.tsign, kA_out, p.gpart[0], nullptr, false);
-      if (!need_theta) return check_launch("augmented dynamics (F(4x4,3x3))");
-      ThetaFinalizeArgs tf;
-      memset(&tf, 0, sizeof(tf));
-      tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
-      tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
-      tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
-      tf.gpart_rows[0] = tf.gpart_rows[1] = tf.gpart_rows[2] = d.N;   // per-sample partials from the GroupNorm passes
-      tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
-      tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
-      tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
-      launch_theta_finalize(d, tf, st);
-      return check_launch("augmented dynamics (F(4x4,3x3))");
-    }
     if (!fuse_colsum) launch_colsum(d, p.dz2, p.spart[1], st);
 
     if (need_theta && !d.wgrad_pair) {
@@ -683,13 +775,21 @@ struct Solver {
   EvalTime et_probe() const { EvalTime e; e.ctrl = p.ctrl; e.alpha = 0.f; e.tsign = tsign; e.mode = TM_PROBE; return e; }
 
   // evaluate the system at (state + scale * sum coef_j k_j) into k[kout]
+  // next_coef (F(4x4,3x3) solves): the Butcher row of the evaluation that follows -- its combine rides in this one's last pass
   int eval_sys(int kout, const double* coef, int ncoef, int scale_mode, const EvalTime& et, bool write_new,
-               bool need_theta = true) {
+               bool need_theta = true, const double* next_coef = nullptr, int next_ncoef = 0, bool next_write_new = false) {
     Comb cy = make_comb(p.Y, p.KY, coef, ncoef, scale_mode);
-    if (!aug) return eval_fwd(cy, write_new ? p.Y1 : nullptr, et, p.KY[kout], false);
+    NextComb nc;
+    const NextComb* next = nullptr;
+    if (w4 && next_coef != nullptr) {
+      nc.cy = make_comb(p.Y, p.KY, next_coef, next_ncoef, scale_mode);
+      nc.y_out = next_write_new ? p.Y1 : nullptr;
+      next = &nc;
+    }
+    if (!aug) return eval_fwd(cy, write_new ? p.Y1 : nullptr, et, p.KY[kout], false, next);
     Comb ca = make_comb(p.A, p.KA, coef, ncoef, scale_mode);
     return eval_aug(cy, ca, write_new ? p.Y1 : nullptr, write_new ? p.A1 : nullptr, et,
-                    p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr, need_theta);
+                    p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr, need_theta, next);
   }
 
   int readback() {
@@ -735,7 +835,8 @@ struct Solver {
     const bool was_counting = count_nfe;
     count_nfe = false;
     for (int s = 0; s < 6; ++s) {
-      const int rc = eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5, !(skip_k2 && s == 0));
+      const int rc = eval_sys(s + 1, DP_BETA[s], s + 1, SC_DT, et_stage(DP_ALPHA[s]), s == 5, !(skip_k2 && s == 0),
+                              s < 5 ? DP_BETA[s + 1] : nullptr, s + 2, s + 1 == 5);
       if (rc != NODE_OK) { count_nfe = was_counting; return rc; }
     }
     count_nfe = was_counting;
@@ -767,7 +868,8 @@ struct Solver {
       ea.ctrl = p.ctrl; ea.targets = p.targets; ea.y0 = p.Y; ea.y1 = p.Y1;
       for (int j = 0; j < 7; ++j) ea.k[j] = p.KY[j];
       ea.y_out = io.y_out;
-      launch_emit_outputs(d, ea, st);
+      if (w4) launch_w4s_emit_outputs(d, ea, st);
+      else launch_emit_outputs(d, ea, st);
     }
     CommitArgs cm;
     memset(&cm, 0, sizeof(cm));
@@ -913,9 +1015,9 @@ int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t
   S.choose_w4(false);
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, (double)t, 0.0, 1, S.st);
-  launch_nchw_to_nhwc(S.d, y, S.p.Y, S.st);
+  S.to_state(y, S.p.Y);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
-  launch_nhwc_to_nchw(S.d, S.p.KY[0], f, S.st);
+  S.from_state(S.p.KY[0], f);
   return S.check_launch("node_odefunc_fwd");
 }
 
@@ -946,11 +1048,11 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   memset(&jobs, 0, sizeof(jobs));
   jobs.w[0] = weight; jobs.u[0] = U; jobs.dgrad[0] = dgrad ? 1 : 0;
   launch_w4_pack(jobs, 1, d.C, st);
-  launch_nchw_to_nhwc(d, x, xn, st);
+  launch_w4s_from_nchw(x, xn, d.N, d.C, st);
   launch_w4_input(xn, V, d.N, d.C, st);
   launch_w4_gemm(V, U, M, nullptr, d.N, d.C, st);
   launch_w4_output(M, yn, d.N, d.C, st);
-  launch_nhwc_to_nchw(d, yn, y, st);
+  launch_w4s_to_nchw(yn, y, d.N, d.C, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
   return NODE_OK;
@@ -965,13 +1067,13 @@ int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t
   S.choose_w4(false);
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, (double)t, 0.0, 1, S.st);
-  launch_nchw_to_nhwc(S.d, y, S.p.Y, S.st);
-  launch_nchw_to_nhwc(S.d, cot, S.p.A, S.st);
+  S.to_state(y, S.p.Y);
+  S.to_state(cot, S.p.A);
   Comb cy = Solver::make_comb(S.p.Y, S.p.KY, nullptr, 0, SC_ABS);
   Comb ca = Solver::make_comb(S.p.A, S.p.KA, nullptr, 0, SC_ABS);
   TRY(S.eval_aug(cy, ca, nullptr, nullptr, S.et_stage(0.0), S.p.KY[0], S.p.KA[0], S.p.KT[0], -1, +1.f, vjp_t));
-  launch_nhwc_to_nchw(S.d, S.p.KY[0], f, S.st);
-  launch_nhwc_to_nchw(S.d, S.p.KA[0], vjp_y, S.st);
+  S.from_state(S.p.KY[0], f);
+  S.from_state(S.p.KA[0], vjp_y);
   launch_theta_to_torch(S.d, S.p.KT[0], vjp_params, S.st);
   return S.check_launch("node_odefunc_vjp");
 }
@@ -1001,14 +1103,14 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
 
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   TRY(S.prepare());
-  launch_nchw_to_nhwc(S.d, y0, S.p.Y, S.st);
+  S.to_state(y0, S.p.Y);
   HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
 
   if (method == NODE_METHOD_RK4) {
     launch_set_ctrl(S.p.ctrl, ts[0], 0.0, 1, S.st);
     for (int j = 1; j < n_t; ++j) {
       TRY(S.rk4_interval(ts[j - 1], ts[j]));
-      launch_nhwc_to_nchw(S.d, S.p.Y, y_out + (size_t)j * numel, S.st);
+      S.from_state(S.p.Y, y_out + (size_t)j * numel);
       stt.accepted += 1;
       dlog.add(ts[j] - ts[j - 1], true);
     }
@@ -1104,7 +1206,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   // grad_last_only: `grad_out` is the last slice alone, every other slice of dL/dy_out is zero (node_solve_opts)
   const bool last_only = opts && opts->grad_last_only;
   const float* g_last = last_only ? grad_out : grad_out + (size_t)(n_t - 1) * numel;
-  launch_nchw_to_nhwc(S.d, g_last, S.p.A, S.st);  // adj_y = grad_output[-1]
+  S.to_state(g_last, S.p.A);  // adj_y = grad_output[-1]
   if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   double cur_t = 0.0, cur_dt = 0.0;
   bool first = true;
@@ -1117,11 +1219,11 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     const double s0 = (double)(decreasing ? -t_pts[i] : t_pts[i]);
     const double s1 = (double)(decreasing ? -t_pts[i - 1] : t_pts[i - 1]);
 
-    launch_nchw_to_nhwc(S.d, y_traj + (size_t)i * numel, S.p.Y, S.st);
+    S.to_state(y_traj + (size_t)i * numel, S.p.Y);
     // grad_output_i in NHWC for the dot product below: in the first interval the adjoint state still IS it; a zero
     // slice (grad_last_only) contributes nothing
     const float* gdot = i == n_t - 1 ? S.p.A : (last_only ? nullptr : S.p.G);
-    if (i != n_t - 1 && !last_only) launch_nchw_to_nhwc(S.d, grad_out + (size_t)i * numel, S.p.G, S.st);
+    if (i != n_t - 1 && !last_only) S.to_state(grad_out + (size_t)i * numel, S.p.G);
     // func_i = f(t_i, y_i); adj_time -= <func_i, grad_output_i>.  Upstream evaluates f here and again as
     // the first stage of the augmented solve at the same (t_i, y_i); the stage-0 evaluation below
     // produces tsign * f bit-identically, so the dot product is taken from it (times tsign) and the
@@ -1150,7 +1252,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
         stt.accepted = blind; stt.rejected = 0; stt.status = 0;
         cur_t = s1; cur_dt = 0.0;
         if (!last_only) {
-          launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+          S.to_state(grad_out + (size_t)(i - 1) * numel, S.p.G);
           launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
         }
         continue;
@@ -1178,12 +1280,12 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     }
     // adj_y += grad_output[i-1]
     if (!last_only) {
-      launch_nchw_to_nhwc(S.d, grad_out + (size_t)(i - 1) * numel, S.p.G, S.st);
+      S.to_state(grad_out + (size_t)(i - 1) * numel, S.p.G);
       launch_axpy(S.p.A, S.p.G, 1.f, numel, S.st);
     }
   }
 
-  launch_nhwc_to_nchw(S.d, S.p.A, grad_y0, S.st);
+  S.from_state(S.p.A, grad_y0);
   launch_theta_to_torch(S.d, S.p.TH, grad_params, S.st);
   if (grad_t) {
     // time_vjps = [adj_time, dLd_t1, ..., dLd_t_{T-1}]
@@ -1276,7 +1378,7 @@ extern "C" int node_solve_backprop(const node_shape* shape, const node_params* p
   std::vector<double> tn(n_steps + 1), dtn(n_steps);
   std::vector<int> out_step(n_t, -1);          // which step's dense output produced y_out[j]
   std::vector<float> out_x(n_t, 0.f);
-  launch_nchw_to_nhwc(d, y0, tp.Y[0], S.st);
+  S.to_state(y0, tp.Y[0]);
   const double c2[1] = {1.0 / 3}, c3[2] = {-1.0 / 3, 1.0}, c4[3] = {1.0, -1.0, 1.0};
   const double* rk4_rows[3] = {c2, c3, c4};
   const double rk4_alpha[3] = {1.0 / 3, 2.0 / 3, 1.0};
@@ -1340,7 +1442,7 @@ extern "C" int node_solve_backprop(const node_shape* shape, const node_params* p
     // dense-output contributions of the outputs this step produced (transposed quartic)
     for (int j = n_t - 1; j >= 1; --j) {
       if (out_step[j] != n) continue;
-      launch_nchw_to_nhwc(d, grad_out + (size_t)j * numel, tp.G, S.st);
+      S.to_state(grad_out + (size_t)j * numel, tp.G);
       ScatterArgs sa;
       memset(&sa, 0, sizeof(sa));
       sa.src = tp.G; sa.n = numel;
@@ -1412,9 +1514,9 @@ extern "C" int node_solve_backprop(const node_shape* shape, const node_params* p
     for (int i = 0; i < (dopri ? 6 : 4); ++i) launch_fill(tp.KB[i], 0.f, numel, S.st);
   }
   // out[0] = y0
-  launch_nchw_to_nhwc(d, grad_out, tp.G, S.st);
+  S.to_state(grad_out, tp.G);
   launch_axpy(tp.YB, tp.G, 1.f, numel, S.st);
-  launch_nhwc_to_nchw(d, tp.YB, grad_y0, S.st);
+  S.from_state(tp.YB, grad_y0);
   launch_theta_to_torch(d, S.p.TH, grad_params, S.st);
   HIP_TRY(hipStreamSynchronize(S.st));
   return S.check_launch("node_solve_backprop");

@@ -29,7 +29,7 @@ struct Dims {
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
   int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
                     // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
-  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, N % 8 == 0, 32-channel slabs.
+  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, N % 8 == 0, cpg | 16.
                     // Whether a solve USES it depends on its tolerance (Solver::w4)
   int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
                     // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)
@@ -122,6 +122,26 @@ __device__ inline float comb_scale(const Comb& c, const Ctrl* ctrl) {
   return c.scale_mode == SC_ABS ? 1.0f : (c.scale_mode == SC_DT ? (float)ctrl->dt : ctrl->h0);
 }
 
+// Dense output: quartic through (y0, y1, y_mid, f0, f1) of the last accepted step (`_interp_fit_dopri5` +
+// `_interp_evaluate`, power form like upstream); k[1] has weight zero everywhere.
+__device__ constexpr float DP_CMID_F[7] = {
+    (float)(6025192743.0 / 30085553152.0 / 2.0), 0.f, (float)(51252292925.0 / 65400821598.0 / 2.0),
+    (float)(-2691868925.0 / 45128329728.0 / 2.0), (float)(187940372067.0 / 1594534317056.0 / 2.0),
+    (float)(-1776094331.0 / 19743644256.0 / 2.0), (float)(11237099.0 / 235043384.0 / 2.0)};
+__device__ inline float interp_one(float y0, float y1, const float* k, float dt, float x) {
+  float s = (dt * DP_CMID_F[0]) * k[0];
+#pragma unroll
+  for (int j = 2; j < 7; ++j) s += (dt * DP_CMID_F[j]) * k[j];
+  const float ymid = y0 + s;
+  const float f0 = k[0], f1 = k[6];
+  const float ca = (-2.f * dt) * f0 + (2.f * dt) * f1 + -8.f * y0 + -8.f * y1 + 16.f * ymid;
+  const float cb = (5.f * dt) * f0 + (-3.f * dt) * f1 + 18.f * y0 + 14.f * y1 + -32.f * ymid;
+  const float cc = (-4.f * dt) * f0 + dt * f1 + -11.f * y0 + -5.f * y1 + 16.f * ymid;
+  const float cd = dt * f0;
+  const float x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+  return ca * x4 + cb * x3 + cc * x2 + cd * x + y0;
+}
+
 // Kernels that stage more than 64 KB of LDS need the opt-in attribute, and the attribute is PER DEVICE: a process
 // that drives several GPUs must set it on each (one flag per device ordinal; benign if two threads race to set it).
 constexpr int MAX_DEVICES = 64;
@@ -145,33 +165,21 @@ void launch_tmap(const Dims& d, const float* w, float* tmap /*[HW][C]*/, hipStre
 void launch_wtime(const Dims& d, const float* w, float* wtime /*[9][C]*/, hipStream_t s);
 // tmap of both layers (+ wtime of both when wtime1 != nullptr) in one launch
 void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tmap1, float* tmap2, float* wtime1, float* wtime2,
-                      float* const* zero, const size_t* zero_n, int nzero /*<= 6: regions to zero-fill*/, hipStream_t s);
+                      float* const* zero, const size_t* zero_n, int nzero /*<= 8: regions to zero-fill*/, hipStream_t s);
 void launch_theta_to_torch(const Dims& d, const float* theta_int, float* flat, hipStream_t s);
-
-// Winograd F(4x4,3x3) pipeline hooks of the GroupNorm passes (wino4.h): read the conv result as its 36 component rows
-// (output transform on the fly, + bias + t * tmap for a forward conv) and / or leave the input transform of the
-// tensor just produced for the GEMM that follows.  All-zero = off.
-struct W4Hook {
-  const float* m_in;    // [36][4 N][C] component products of the conv in front of this pass (replaces comb.y)
-  float* v_out;         // blocked input transform of act_out / dz_out (the next conv's row operand)
-  const float* bias;    // forward conv only: [C]
-  const float* tmap;    // forward conv only: [HW][C] border-aware time-channel map
-  EvalTime et;          // time of the evaluation (tmap multiplier)
-};
 
 // pointwise / reductions
 struct CombineGnArgs {
   Comb comb;
   const Ctrl* ctrl;
   float* y_out;        // nullable
-  float* act_out;      // relu(GN(y_i)); nullable when w4.v_out carries it on (an inference evaluation never reads the plain tensor)
+  float* act_out;      // relu(GN(y_i))
   float* xhat_out;     // nullable
   float* rstd_out;     // nullable [N][G]
   const float* gamma;
   const float* beta;
   int relu;            // 1: act = relu(GN(y_i)); 0: act = GN(y_i)   (split-conv GroupNorm pass)
   float osign;         // output multiplier (1 for the stage combine)
-  W4Hook w4;
 };
 void launch_combine_gn(const Dims& d, const CombineGnArgs& a, hipStream_t s);
 
@@ -241,7 +249,6 @@ struct GnBwdArgs {     // cotangent g = csign * (a + scale*sum coef*k);  dz = GN
   float* spart;        // nullable: [N][9][C] masked column sums of dz_out (see masked_colsum_tile)
   const float* mask_act;   // nullable: g is zeroed where this activation is <= 0 (ReLU mask of a split-conv data gradient)
   float osign;         // output multiplier (1 for GroupNorm-3's backward)
-  W4Hook w4;
 };
 void launch_gn_bwd(const Dims& d, const GnBwdArgs& a, hipStream_t s);
 

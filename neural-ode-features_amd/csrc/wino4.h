@@ -2,10 +2,10 @@
 // solver tolerance leaves room for the transform's rounding (see Solver::choose_w4, node_api.hip).
 //
 //   V = B^T d B   6x6 input transform of every 4x4 output tile's 6x6 patch -- written by the PRODUCER of the conv
-//                 input (k_combine_gn, k_gn_bwd: w4_emit_v below), not by the conv
+//                 input (the GroupNorm passes, kernels_w4s.hip), not by the conv
 //   M_c = V_c U_c 36 independent [rows x C] x [C x C] products, rows = samples x 4 tiles: k_w4_gemm64 (fp32 MFMA,
 //                 operands straight from L2 into registers in MFMA-ready blocks, no LDS, no transform in the loop)
-//   Y = A^T M A   4x4 output transform -- done by the CONSUMER (the GroupNorm pass behind the conv: w4_load_tile)
+//   Y = A^T M A   4x4 output transform -- done by the CONSUMER (the GroupNorm pass behind the conv, kernels_w4s.hip)
 //
 // 36 multiplies per 16 outputs = 0.25 of the direct convolution's (F(2x2,3x3): 0.444).  Interpolation points
 // (0, 1, -1, 1/2, -2, inf): max error 3.2e-6 of max|y| at C = 256 against an fp64 direct convolution (the textbook
@@ -13,17 +13,17 @@
 //
 // Layouts (H = W = 8: T = 4 tiles per sample, R = 4 N rows, RB = N / 8 row blocks of 32; G8 = C / 8):
 //   V  [comp 36][rb][g G8][s 8][hi 2][t 4][e 4]   channel = 8 g + 4 hi + e, sample = 8 rb + s: one contiguous 1 KB
-//      block per (comp, rb, g) = ONE 16-B load per lane for four MFMA k-steps; a producer workgroup (one sample,
-//      32 channels) writes whole 128-B lines
+//      block per (comp, rb, g) = ONE 16-B load per lane for four MFMA k-steps; a producer wave (one sample,
+//      16 channels) writes whole 128-B lines
 //   U  [comp 36][cb C/32][g G8][hi 2][col 32][e 4]   the same for the filter operand (k_w4_pack, once per solve)
-//   M  [comp 36][row R][C]
+//   M  [n][C/32][comp 36][t 4][c 32]   what one pass workgroup (sample, 32 channels) reads is ONE contiguous 18 KB
+//      block; a GEMM store instruction (32 columns x rows r, r + 4 of an accumulator) writes two whole 128-B lines
 #pragma once
 #include "node_internal.h"
 
 namespace node {
 
 constexpr int W4_COMPS = 36;
-constexpr int W4_SCRATCH = 36 * 4 * 36;   // floats of LDS scratch the two helpers below need (they may share it)
 
 // B^T (6x6), A^T (4x6), G (6x3) for the points (0, 1, -1, 1/2, -2, inf)
 __device__ constexpr float W4_BT[6][6] = {{1.f, -1.5f, -2.f, 1.5f, 1.f, 0.f}, {0.f, -1.f, 0.5f, 2.5f, 1.f, 0.f},
@@ -52,123 +52,59 @@ constexpr int W4_SLACK = 16 * 256;         // floats behind V and U that k_w4_ge
 __host__ __device__ inline size_t w4_v_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C + W4_SLACK; }
 __host__ __device__ inline size_t w4_u_elems(int C) { return (size_t)W4_COMPS * C * C + W4_SLACK; }
 
-// Input transform of one sample's [64 px][32 ch] slab held in LDS (`tile`, row stride `ld` floats) into the blocked
-// V layout.  256 threads; `scratch` = W4_SCRATCH floats of LDS.  The caller has synchronised after writing `tile`;
-// the function ends without a barrier (it only reads `tile`).
-__device__ inline void w4_emit_v(const float* tile, int ld, int n, int c0, float* __restrict__ V, const W4Geom gm,
-                                 float* scratch, int tid) {
-  const int c = tid & 31, t = (tid >> 5) & 3, h = tid >> 7;
-  const int y0 = 4 * (t >> 1) - 1, x0 = 4 * (t & 1) - 1;
-  float w[6][6];   // W = d B:  W[j][l] = sum_k d[j][k] B^T[l][k]
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    float dr[6];
-    const int y = y0 + j;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int x = x0 + k;
-      const bool in = y >= 0 && y < 8 && x >= 0 && x < 8;
-      dr[k] = in ? tile[(y * 8 + x) * ld + c] : 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < 6; ++l) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (W4_BT[l][k] != 0.f) s += W4_BT[l][k] * dr[k];
-      w[j][l] = s;
-    }
-  }
-  const int gq = c >> 3, hi = (c >> 2) & 1, e = c & 3;
-#pragma unroll
-  for (int ii = 0; ii < 3; ++ii) {
-    // rows 3h .. 3h+2 of V = B^T W (h is uniform per half of the workgroup; both variants are unrolled)
-#pragma unroll
-    for (int l = 0; l < 6; ++l) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (W4_BT[ii][j] != 0.f) s0 += W4_BT[ii][j] * w[j][l];
-        if (W4_BT[ii + 3][j] != 0.f) s1 += W4_BT[ii + 3][j] * w[j][l];
-      }
-      const int i = ii + 3 * h;
-      scratch[((i * 6 + l) * 4 + gq) * 36 + hi * 16 + t * 4 + e] = h ? s1 : s0;
-    }
-  }
-  __syncthreads();
-  const int rb = n >> 3, s = n & 7;
-  for (int u = tid; u < W4_COMPS * 32; u += 256) {
-    const int comp = u >> 5, g4 = (u >> 3) & 3, q = u & 7;   // q = hi * 4 + t
-    const float4 v = *reinterpret_cast<const float4*>(scratch + (comp * 4 + g4) * 36 + q * 4);
-    const size_t dst = (((((size_t)comp * gm.RB + rb) * gm.G8 + (c0 >> 3) + g4) * 8 + s) * 8 + q) * 4;
-    *reinterpret_cast<float4*>(V + dst) = v;
-  }
-}
-
-// Output transform: the 36 component rows of one sample's four tiles, channels [c0, c0 + 32), -> `tile`
-// [64 px][ld] (+ bias[c] + tval * tmap[p][c] when bias != nullptr).  256 threads; `scratch` = W4_SCRATCH floats.
-// Ends WITHOUT a barrier: the caller synchronises before reading `tile`.
-__device__ inline void w4_load_tile(const float* __restrict__ M, int n, int c0, const W4Geom gm, float* tile, int ld,
-                                    float* scratch, const float* __restrict__ bias, const float* __restrict__ tmap,
-                                    float tval, int tid) {
-  // all of a thread's requests first (4.5 x 16 B), then the LDS writes: written as one loop the compiler waits for
-  // every request before it issues the next -- five dependent round trips at the head of every pass
-  constexpr int NU = W4_COMPS * 32;
-  float4 mv[5];
-#pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int u = min(tid + it * 256, NU - 1);   // clamped, not predicated: a masked request makes the compiler wait
-    const int comp = u >> 5, t = (u >> 3) & 3, q = u & 7;
-    mv[it] = *reinterpret_cast<const float4*>(M + ((size_t)comp * gm.R + 4 * n + t) * gm.C + c0 + 4 * q);
-  }
-#pragma unroll
-  for (int it = 0; it < 5; ++it) {
-    const int u = min(tid + it * 256, NU - 1);   // (the clamped duplicates rewrite the last unit with its own value)
-    const int comp = u >> 5, t = (u >> 3) & 3, q = u & 7;
-    *reinterpret_cast<float4*>(scratch + (comp * 4 + t) * 32 + 4 * q) = mv[it];
-  }
-  __syncthreads();
-  const int c = tid & 31, t = (tid >> 5) & 3, h = tid >> 7;
-  float z[2][6];   // rows 2h, 2h+1 of A^T M
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float m[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) m[j] = scratch[((j * 6 + k) * 4 + t) * 32 + c];
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (W4_AT[ii][j] != 0.f) s0 += W4_AT[ii][j] * m[j];
-        if (W4_AT[ii + 2][j] != 0.f) s1 += W4_AT[ii + 2][j] * m[j];
-      }
-      z[ii][k] = h ? s1 : s0;
-    }
-  }
-  const float bv = bias ? bias[c0 + c] : 0.f;
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii) {
-    const int y = 4 * (t >> 1) + ii + 2 * h;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < 6; ++k)
-        if (W4_AT[l][k] != 0.f) s += z[ii][k] * W4_AT[l][k];
-      const int p = y * 8 + 4 * (t & 1) + l;
-      if (bias) s += bv + tval * tmap[(size_t)p * gm.C + c0 + c];
-      tile[p * ld + c] = s;
-    }
-  }
-}
+// ----------------------------------------------------------------------------
+// The GroupNorm passes around the component GEMMs (kernels_w4s.hip): wave-independent, register-resident.
+// ----------------------------------------------------------------------------
+struct W4sHead {          // the conv result in front of this pass
+  const float* M;         // component products [N][C/32][36][4][32]
+  const float* bias;      // forward: conv bias [C]
+  const float* tmapS;     // forward: border-aware time-channel map in the W4S blocking (launch_w4s_tmap)
+  EvalTime et;            // forward: time of the evaluation (tmap multiplier)
+  const float* gamma;     // GroupNorm weight of this pass [C]
+  const float* beta;      // forward: GroupNorm bias; backward: bias of the layer's ReLU mask fma(xhat, gamma, beta) > 0
+  float osign;            // output multiplier
+  int relu;               // forward: ReLU behind the affine
+  float* out_s;           // W4S output, nullable (forward GroupNorm-3: k; backward GroupNorm-1: k_a)
+  float* out_nhwc;        // NHWC output, nullable (forward GroupNorm-2: act2; backward GroupNorm-2: dz1): the weight gradient's operand
+  float* xhat_s;          // forward: xhat out (W4S, nullable); backward: xhat in
+  float* rstd;            // forward: 1/sigma out [N][G] (nullable); backward: in
+  float* gpart;           // backward: [N][2][C] per-sample (dgamma, dbeta) partials
+  float* spart;           // backward, nullable: [N][9][C] masked column sums of the output (masked_colsum_tile)
+};
+struct W4sTail {          // what follows the head inside the same launch
+  Comb comb;              // stage combine (tail 1) / adjoint combine (tail 2), W4S tensors
+  int self;               // tail 1 behind a forward head: comb.k[comb.nk - 1] IS the head's output (taken from registers)
+  float csign;            // tail 2: cotangent = csign * combine
+  float* y_out;           // the combined state, nullable (W4S: y1 / a1)
+  const float* gamma;     // tail 1: GroupNorm-1 weight, bias
+  const float* beta;
+  float* act_nhwc;        // tail 1: act1 (nullable); tail 2: dz2 -- NHWC, the weight gradient's operands
+  float* xhat_s;          // tail 1: xhat-1 out (W4S, nullable)
+  float* rstd;            // tail 1: 1/sigma-1 out (nullable)
+  float* gpart;           // tail 2: GroupNorm-3's (dgamma, dbeta) partials
+  float* spart;           // tail 2: masked column sums of dz2
+};
+struct W4sArgs {
+  const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done
+  int N, C, cpg;
+  float eps;
+  W4sHead h;
+  W4sTail t;
+  float* V;               // nullable: blocked input transform of the tensor this pass hands to the next conv
+};
+// head: 0 none / 1 forward / 2 backward; tail: 0 none / 1 stage combine + GroupNorm-1 + ReLU / 2 adjoint combine + GroupNorm-3 backward
+void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s);
+void launch_w4s_from_nchw(const float* src_nchw, float* dst_w4s, int N, int C, hipStream_t s);
+void launch_w4s_to_nchw(const float* src_w4s, float* dst_nchw, int N, int C, hipStream_t s);
+void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, hipStream_t s);
+void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
 
 // launchers (kernels_w4.hip)
 struct W4PackJobs { const float* w[4]; float* u[4]; int dgrad[4]; };
 void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s);
-// stand-alone transforms (diagnostics: node_conv3x3_w4)
-void launch_w4_input(const float* x_nhwc, float* V, int N, int C, hipStream_t s);
-void launch_w4_output(const float* M, float* y_nhwc, int N, int C, hipStream_t s);
+// stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, hipStream_t s);
+void launch_w4_output(const float* M, float* y_w4s, int N, int C, hipStream_t s);
 
 }  // namespace node

@@ -407,6 +407,11 @@ class Deferred:
         self.guess[key] = int(steps)
         self.calm[key] = 0
 
+    def settled(self):
+        """True once every kind of solve seen so far runs blind WITHOUT a spare step (CALM exact predictions in a row):
+        from then on a training step enqueues no launch that returns at once."""
+        return bool(self.guess) and all(g and self.calm.get(k, 0) >= self.CALM for k, g in self.guess.items())
+
     def resolve(self):
         """Wait for every outstanding record (a synchronisation point) and count the misses."""
         for key in list(self.pending):
@@ -593,6 +598,9 @@ def profile_begin():
 def profile_end() -> dict:
     prof = _lib.NodeProfile()
     _lib.check(_lib.load().node_profile_end(C.byref(prof)))
-    names = ['conv3x3_implicit_gemm', 'wgrad_gemm', 'w4_component_gemm']
+    # classes 3..8: the GroupNorm / transform passes of the F(4x4,3x3) pipeline, `flops` = algorithmic BYTES there
+    names = ['conv3x3_implicit_gemm', 'wgrad_gemm', 'w4_component_gemm', 'w4s_pass<0,1> combine', 'w4s_pass<1,0> forward',
+             'w4s_pass<1,1> forward + next combine', 'w4s_pass<1,2> forward + backward top', 'w4s_pass<2,0> backward',
+             'w4s_pass<2,1> backward + next combine']
     return {names[i]: {'launches': int(prof.launches[i]), 'total_ms': float(prof.total_ms[i]),
-                       'flops': float(prof.flops[i])} for i in range(3)}
+                       'flops': float(prof.flops[i])} for i in range(len(names))}

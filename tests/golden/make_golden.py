@@ -13,6 +13,8 @@ name first.  What the fixtures pin:
 
   odefunc_c{8,16,64}.pt   reference ``ODEfunc`` (model.py:326-348): inputs, parameters,
                           f(t, y) and autograd VJPs (d/dy, d/dt, d/dtheta) for a fixed cotangent
+  odefunc_c64_n8.pt,      the same at N = 8, 8x8: the smallest shape the Winograd F(4x4,3x3) pipeline takes (round 3:
+  odefunc_c64_n8_kf.pt    ``python tests/golden/make_golden.py w4``); _kf = GroupNorm biases in front of the ReLUs at +8
   odenet_t0.pt            reference ``ODENet(..., t1=0)`` logits (stem + head, no solver; model.py:27-46,363-364)
   odeblock_t1_cases.json  reference ``ODEBlock.t1`` setter semantics (model.py:380-403)
   odenet_rk4.pt /         reference ``ODENet`` driven end-to-end (forward, CE loss, backward) with the
@@ -64,11 +66,16 @@ def randomize_(module, gen):
                 p.copy_(0.1 * torch.randn(p.shape, generator=gen))
 
 
-def make_odefunc(ref, C, N, H, W, seed):
+def make_odefunc(ref, C, N, H, W, seed, name=None, kink_free=False):
     torch.manual_seed(seed)
     gen = torch.Generator().manual_seed(seed + 1)
     func = ref.ODEfunc(C)
     randomize_(func, gen)
+    if kink_free:   # GroupNorm biases in front of the two ReLUs at +8: no pre-activation anywhere near a kink
+        with torch.no_grad():
+            for pname, p in func.named_parameters():
+                if pname.startswith(('norm1', 'norm2')) and pname.endswith('bias'):
+                    p.add_(8.0)
     y = torch.randn(N, C, H, W, generator=gen)
     cot = torch.randn(N, C, H, W, generator=gen)
     t = torch.tensor(0.37)
@@ -84,7 +91,7 @@ def make_odefunc(ref, C, N, H, W, seed):
         'f': f.detach(), 'vjp_t': grads[0], 'vjp_y': grads[1],
         'vjp_params': torch.cat([g.reshape(-1) for g in grads[2:]]),
     }
-    torch.save(out, os.path.join(HERE, 'odefunc_c%d.pt' % C))
+    torch.save(out, os.path.join(HERE, name or 'odefunc_c%d.pt' % C))
     print('odefunc C=%d: |f|=%.4f |vjp_y|=%.4f vjp_t=%.5f P=%d' % (
         C, f.norm(), grads[1].norm(), grads[0], out['vjp_params'].numel()))
 
@@ -193,6 +200,10 @@ def make_ode2_train(ref):
 
 def main():
     ref = import_reference_model()
+    if 'w4' in sys.argv[1:]:           # only the fixtures added in round 3
+        make_odefunc(ref, 64, 8, 8, 8, seed=41, name='odefunc_c64_n8.pt')
+        make_odefunc(ref, 64, 8, 8, 8, seed=42, name='odefunc_c64_n8_kf.pt', kink_free=True)
+        return
     if 'stems' in sys.argv[1:]:        # only the fixtures added in round 2
         make_ode_stem_features(ref)
         make_ode2_train(ref)
@@ -200,6 +211,8 @@ def main():
     make_odefunc(ref, 8, 2, 7, 7, seed=23)
     make_odefunc(ref, 16, 3, 5, 6, seed=24)
     make_odefunc(ref, 64, 2, 8, 8, seed=25)
+    make_odefunc(ref, 64, 8, 8, 8, seed=41, name='odefunc_c64_n8.pt')
+    make_odefunc(ref, 64, 8, 8, 8, seed=42, name='odefunc_c64_n8_kf.pt', kink_free=True)
     make_odenet_t0(ref)
     make_t1_cases(ref)
     # config-1-like plumbing case (MNIST-shaped, rk4, one 3/8 step) and a small dopri5 case

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.helpers import make_func, rel_err
+from tests.helpers import make_func, rel_err, oracle_vjp
 
 pytestmark = pytest.mark.gpu
 
@@ -96,6 +96,53 @@ def test_w4_odefunc_forward_and_vjp_match_f2(shape):
         # (tests/helpers.py: make_func); the L2 error stays tiny
         l2 = float((g.double() - r.double()).norm() / r.double().norm())
         assert l2 < 1e-4, (name, l2, e)
+
+
+@pytest.mark.parametrize('name', ['odefunc_c64_n8.pt', 'odefunc_c64_n8_kf.pt'])
+def test_w4_pipeline_matches_reference_odefunc_fixture(golden_dir, name):
+    """The F(4x4,3x3) pipeline (forced on for a single evaluation) against the REFERENCE's own ODEfunc outputs and
+    autograd VJPs (tests/golden/make_golden.py, N = 8: the smallest batch the pipeline takes).  _kf: GroupNorm biases
+    in front of the ReLUs at +8, no mask can flip, so every VJP is held in max-norm; the ordinary fixture holds f in
+    max-norm and the VJPs in relative L2 (a flipped mask moves single entries by O(1), tests/helpers.py)."""
+    import neural_ode_features_amd as nof
+    g = torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
+    assert _engaged(g['N'], g['C'])
+    f = nof.ODEfunc(g['C'])
+    f.load_state_dict(g['state_dict'])
+    f = f.cuda()
+    with wino4(2):
+        fo, vy, vt, vp = nof.odefunc_vjp(f, float(g['t']), g['y'].cuda(), g['cotangent'].cuda())
+        f_only = nof.odefunc_forward(f, float(g['t']), g['y'].cuda())
+    # two F(4x4,3x3) convolutions at 3.2e-6 of max|y| each (tools/wino_error.py), GroupNorm in between
+    assert rel_err(fo, g['f']) < 3e-5 and rel_err(f_only, g['f']) < 3e-5
+    kf = name.endswith('_kf.pt')
+    for label, got, ref in (('vjp_y', vy, g['vjp_y']), ('vjp_params', vp, g['vjp_params'])):
+        l2 = float((got.cpu().double() - ref.double()).norm() / ref.double().norm())
+        assert l2 < 5e-5, (label, l2)
+        if kf:
+            assert rel_err(got, ref) < 1e-4, (label, rel_err(got, ref))
+    scale = max(1.0, abs(float(g['vjp_t'])))
+    assert abs(float(vt) - float(g['vjp_t'])) < (1e-4 if kf else 2e-3) * scale
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (128, 256, 8, 8)])
+def test_w4_odefunc_forward_and_vjp_match_oracle(shape):
+    """The pipeline's single evaluation and VJP against the CPU oracle (oracle/dynamics.py, pinned by the reference's
+    fixtures), kink-free parameters, at the smallest and at the configs[1] shape: max-norm bounds."""
+    from neural_ode_features_amd import integrate
+    N, Cc, H, W = shape
+    assert _engaged(N, Cc)
+    f, twin = make_func(Cc, seed=7, device='cuda', kink_free=True)
+    gen = torch.Generator().manual_seed(13)
+    y = torch.randn(N, Cc, H, W, generator=gen)
+    cot = torch.randn(N, Cc, H, W, generator=gen)
+    ref_f, ref_vy, ref_vt, ref_vp = oracle_vjp(torch.tensor(0.3), y, dict(twin.named_parameters()), cot)
+    with wino4(2):
+        fo, vy, vt, vp = integrate.odefunc_vjp(f, 0.3, y.cuda(), cot.cuda())
+    errs = dict(f=rel_err(fo, ref_f), vjp_y=rel_err(vy, ref_vy), vjp_params=rel_err(vp, ref_vp),
+                vjp_t=abs(float(vt) - float(ref_vt)) / max(1.0, abs(float(ref_vt))))
+    print('F(4x4,3x3) vs oracle at', shape, {k: '%.2e' % v for k, v in errs.items()})
+    assert errs['f'] < 3e-5 and errs['vjp_y'] < 1e-4 and errs['vjp_params'] < 1e-4 and errs['vjp_t'] < 1e-4, errs
 
 
 def test_w4_solve_matches_f2_and_oracle_tolerance():

@@ -17,7 +17,7 @@ def _load(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
 
 
-@pytest.mark.parametrize('name', ['odefunc_c8.pt', 'odefunc_c16.pt', 'odefunc_c64.pt'])
+@pytest.mark.parametrize('name', ['odefunc_c8.pt', 'odefunc_c16.pt', 'odefunc_c64.pt', 'odefunc_c64_n8.pt', 'odefunc_c64_n8_kf.pt'])
 def test_oracle_dynamics_match_reference_odefunc(golden_dir, name):
     g = _load(golden_dir, name)
     assert g['param_names'] == PARAM_ORDER                       # flat-gradient layout
