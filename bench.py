@@ -475,7 +475,11 @@ def main():
             wavg = w['total_ms'] / w['launches']
             walgo = w['flops'] / w['launches'] / (wavg * 1e-3) / 1e12
             wissued = {'2': 16.0 / 36.0, '1': 2.0 / 3.0}.get(os.environ.get('NODE_TUNE_WGRAD_WINO', '2'), 1.0)
-            roofline['wgrad'] = {'achieved': walgo * wissued, 'frac': walgo * wissued / MFMA_F32_PEAK_TFLOPS,
+            wname = 'k_wgrad_w2 (F(2x2,3x3) domain, split-K slabs)'
+            if k4['launches'] > k['launches'] and cfg['filters'] % 128 == 0:
+                # behind the F(4x4,3x3) pipeline the weight gradient runs in that domain too (k_w4_wgrad, both layers per launch)
+                wissued, wname = 36.0 / 144.0, 'k_w4_wgrad (F(4x4,3x3) domain, both conv layers per launch, no split-K slabs)'
+            roofline['wgrad'] = {'kernel': wname, 'achieved': walgo * wissued, 'frac': walgo * wissued / MFMA_F32_PEAK_TFLOPS,
                                  'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
         # the HBM-bound side ("report both fractions separately"): the GroupNorm / transform passes of the
         # F(4x4,3x3) pipeline, per kernel instance, ALGORITHMIC bytes (every tensor a pass must read or write, once)

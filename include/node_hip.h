@@ -206,12 +206,14 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params,
  * from y0 (`step_dt`: their sizes as node_solve_fwd logged them through node_solve_opts.dt_log, accepted ones only,
  * `n_steps` of them; ignored for rk4, whose grid is t_pts), all stage derivatives are kept, and the cotangent
  * grad_out [n_t, n, c, h, w] is carried back through every step: grad_y0 [n, c, h, w], grad_params flat in
- * parameters() order.  Step sizes are constants of the differentiation.  Workspace: node_backprop_workspace_bytes
- * (it holds the tape: 7 state-sized tensors per step). */
+ * parameters() order.  Step sizes are constants of the differentiation.  `rtol`, `atol`: the forward solve's -- they
+ * select the convolution kernels exactly as node_solve_fwd did (the F(4x4,3x3) pipeline for dopri5 at rtol, atol >=
+ * 1e-4 on 8x8 states), so the replayed stage values are the ones the forward output was computed from.  Workspace:
+ * node_backprop_workspace_bytes (it holds the tape: 7 state-sized tensors per step). */
 size_t node_backprop_workspace_bytes(const node_shape* shape, int method, int n_t, int n_steps);
 int node_solve_backprop(const node_shape* shape, const node_params* params,
                         const float* y0, const float* t_pts, int n_t,
-                        const double* step_dt, int n_steps, int method,
+                        const double* step_dt, int n_steps, float rtol, float atol, int method,
                         const float* grad_out, float* grad_y0, float* grad_params,
                         void* ws, size_t ws_bytes, void* stream);
 
@@ -247,7 +249,7 @@ int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma
  * (dampening 0, no Nesterov: the reference's settings).  `tensors` is a HOST array of `count` records of device
  * pointers; gradients are read where autograd / the data-parallel reducer left them.  grad_scale folds the
  * 1/world of a data-parallel gradient SUM into the step.  momentum_buf must start at zero (the first step then
- * equals PyTorch's buf = g).  `skip_if_nonzero` (device float, nullable): the launch leaves everything untouched
+ * equals PyTorch's buf = g); it may be NULL when momentum == 0 (torch.optim.SGD keeps no buffer then).  `skip_if_nonzero` (device float, nullable): the launch leaves everything untouched
  * when it reads a non-zero value there -- the commit point of a step whose solves ran with deferred completion. */
 typedef struct node_sgd_tensor {
   float* param;

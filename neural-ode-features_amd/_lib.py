@@ -116,7 +116,7 @@ def load():
     lib.node_backprop_workspace_bytes.restype = sz
     lib.node_backprop_workspace_bytes.argtypes = [P(NodeShape), i32, i32, i32]
     lib.node_solve_backprop.restype = i32
-    lib.node_solve_backprop.argtypes = [P(NodeShape), P(NodeParams), vp, P(C.c_float), i32, P(C.c_double), i32, i32,
+    lib.node_solve_backprop.argtypes = [P(NodeShape), P(NodeParams), vp, P(C.c_float), i32, P(C.c_double), i32, f32, f32, i32,
                                         vp, vp, vp, vp, sz, vp]
     lib.node_head_fwd.restype = i32
     lib.node_head_fwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp]

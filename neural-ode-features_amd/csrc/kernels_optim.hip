@@ -21,6 +21,10 @@ __global__ __launch_bounds__(256) void k_sgd_multi(SgdTable tb, float lr, float 
   const size_t start = (size_t)blockIdx.x * 256 + threadIdx.x;
   const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) == 0;
   size_t done = 0;
+  if (m == nullptr) {   // momentum == 0: torch.optim.SGD keeps no buffer then, p = p - lr (grad_scale grad + wd p)
+    for (size_t i = start; i < n; i += stride) p[i] -= lr * (gscale * g[i] + wd * p[i]);
+    return;
+  }
   if (vec) {
     const size_t n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);

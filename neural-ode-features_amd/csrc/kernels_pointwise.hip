@@ -7,6 +7,7 @@
 // Algorithm follows the restated torchdiffeq spec; the CPU
 // statement of the same arithmetic is oracle/torchdiffeq_restated.py.
 #include "node_internal.h"
+#include "wino4.h"
 #include <cstring>
 #include "../../include/node_hip.h"
 
@@ -899,6 +900,42 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
     const float4* wp = reinterpret_cast<const float4*>(a.wpart[layer]);
     float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
     const size_t stride = (size_t)wb * 256;
+    if (a.dU != nullptr) {   // F(4x4,3x3)-domain gradients, every element written once by k_w4_wgrad: dW = G^T dU G
+      const size_t cc4 = CC / 4;
+      const float4* du = reinterpret_cast<const float4*>(a.dU + (size_t)layer * W4_COMPS * CC);
+      for (size_t i = (size_t)bx * 256 + threadIdx.x; i < cc4; i += stride) {
+        float4 tq[6][3];   // t[xi][kw] = sum_nu dU[xi][nu] G[nu][kw]
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+          float4 u[6];
+#pragma unroll
+          for (int nu = 0; nu < 6; ++nu) u[nu] = du[(size_t)(xi * 6 + nu) * cc4 + i];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+              const float gq = (float)W4_G[nu][kw];
+              if (gq != 0.f) { s.x += gq * u[nu].x; s.y += gq * u[nu].y; s.z += gq * u[nu].z; s.w += gq * u[nu].w; }
+            }
+            tq[xi][kw] = s;
+          }
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int xi = 0; xi < 6; ++xi) {
+              const float gq = (float)W4_G[xi][kh];
+              if (gq != 0.f) { s.x += gq * tq[xi][kw].x; s.y += gq * tq[xi][kw].y; s.z += gq * tq[xi][kw].z; s.w += gq * tq[xi][kw].w; }
+            }
+            out[(size_t)(kh * 3 + kw) * cc4 + i] = make_float4(a.osign * s.x, a.osign * s.y, a.osign * s.z, a.osign * s.w);
+          }
+      }
+      return;
+    }
     for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n4; i += stride) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       int sp = 0;

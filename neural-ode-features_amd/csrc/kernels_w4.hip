@@ -380,4 +380,156 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
 #undef W4_LAUNCH
 }
 
+
+// ----------------------------------------------------------------------------
+// k_w4_wgrad: the weight gradients of BOTH conv layers of an augmented evaluation in the F(4x4,3x3) domain,
+//   dU_c[ci][co] = sum_rows V_c[row][ci] Z_c[row][co]        c = 0..35, rows = samples x 4 tiles
+// with V = B^T d B the forward conv's own row operand (as its GroupNorm pass left it for k_w4_gemm64 -- no second copy)
+// and Z = A dz A^T of the conv output's cotangent (written by the pass that produces dz, wino4.h).  dW = G^T dU G
+// happens in k_theta_finalize.  2.4 GFLOP per layer instead of the F(2x2,3x3) domain's 4.3, and NO split-K slabs:
+// the decomposition mirrors k_w4_gemm64 -- a wave owns one whole component of a (128 ci x 32 co) tile over the WHOLE
+// reduction (four 32x32 accumulators), eight workgroups share a tile, workgroup j takes components 4j .. 4j+3 and two of
+// the four accumulator blocks of component 32 + j/2, whose reduction range its four waves split and sum through LDS:
+// 1024 + 128 MFMAs per wave, every SIMD of the chip the same; every result element is written once.
+// Operands: a lane's 16 B of V hold FOUR ci of one row -- they feed four MFMAs with four different accumulator blocks
+// (block e = channels 8 g + 4 hi + e: any assignment of channels to MFMA rows is as good as another), so V is read in
+// the layout the conv wants; a lane's 16 B of Z hold four ROWS of one co ([comp][co/32][sample][co%32][tile]: one
+// contiguous 1 KB per wave request).  Workgroup j of every tile runs on XCD j: its 4.5 components of V and Z stream
+// through that XCD's L2 once.  Needs N % 8 == 0, C % 128 == 0.
+// ----------------------------------------------------------------------------
+struct W4WgOps { float4 a0, a1, a2, a3, z; };
+template <int NSUB>
+__device__ __forceinline__ void w4_wg_mac(float16_t (&acc)[4], const W4WgOps& o, int sub0) {
+#define W4WG_STEP(A, ZC)                                                                    \
+  if (NSUB == 4) {                                                                           \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, ZC, acc[0], 0, 0, 0);                  \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, ZC, acc[1], 0, 0, 0);                  \
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, ZC, acc[2], 0, 0, 0);                  \
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, ZC, acc[3], 0, 0, 0);                  \
+  } else {                                                                                   \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sub0 ? A.z : A.x, ZC, acc[0], 0, 0, 0);     \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sub0 ? A.w : A.y, ZC, acc[1], 0, 0, 0);     \
+  }
+  W4WG_STEP(o.a0, o.z.x) W4WG_STEP(o.a1, o.z.y) W4WG_STEP(o.a2, o.z.z) W4WG_STEP(o.a3, o.z.w)
+#undef W4WG_STEP
+}
+// operands of reduction unit q (eight rows = samples 2q, 2q+1): pa / pz point at unit 0 of this lane
+__device__ __forceinline__ void w4_wg_load(W4WgOps& o, const float* pa, const float4* pz, int q, size_t rbs) {
+  const float4* a = reinterpret_cast<const float4*>(pa + (size_t)(q >> 2) * rbs + (q & 3) * 64);
+  o.a0 = a[0]; o.a1 = a[1]; o.a2 = a[2]; o.a3 = a[3];
+  o.z = pz[(size_t)q * 64];
+}
+// acc += sum over units [q0, q0 + nq): a ring of R units in registers, each refilled right behind the MFMAs that
+// consumed it.  nq must be a multiple of R.
+template <int R, int NSUB>
+__device__ __forceinline__ void w4_wg_run(float16_t (&acc)[4], const float* pa, const float4* pz, int q0, int nq, size_t rbs, int sub0) {
+  W4WgOps ring[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    w4_wg_load(ring[i], pa, pz, q0 + i, rbs);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int q = q0;
+  for (; q + R < q0 + nq; q += R) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      w4_wg_mac<NSUB>(acc, ring[i], sub0);
+      __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
+      w4_wg_load(ring[i], pa, pz, q + R + i, rbs);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    w4_wg_mac<NSUB>(acc, ring[i], sub0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int C = a.C, N = a.N;
+  const int nCO = C >> 5, per_layer = (C >> 7) * nCO;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int layer = tile / per_layer, tl = tile - layer * per_layer;
+  const int cit = tl / nCO, cot = tl - cit * nCO;
+  const float* __restrict__ V = layer ? a.V2 : a.V1;
+  const float4* __restrict__ Z = reinterpret_cast<const float4*>(layer ? a.Z2 : a.Z1);
+  float* __restrict__ dU = a.dU + (size_t)layer * 36 * C * C;
+  const int g = l31 >> 1, hic = l31 & 1;                       // accumulator row j <-> channels 8 g + 4 hic + e (block e)
+  const size_t cs = (size_t)4 * N * C, rbs = (size_t)(C >> 3) * 256;   // floats per component / per 8-sample row block of V
+  const int Q = N >> 1;                                        // reduction units of eight rows
+  const float* pa0 = V + (size_t)(cit * 16 + g) * 256 + h * 32 + hic * 16;
+  const float4* pz0 = Z + (size_t)cot * N * 32 + h * 32 + l31;
+  const size_t zcs = (size_t)nCO * N * 32;                     // float4s per component of Z
+
+  // --- this wave's own component over the whole reduction
+  {
+    const int comp = 4 * j + wave;
+    float16_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    w4_wg_run<R, 4>(acc, pa0 + (size_t)comp * cs, pz0 + (size_t)comp * zcs, 0, Q, rbs, 0);
+    float* o = dU + ((size_t)comp * C + cit * 128) * C + cot * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;          // accumulator row -> ci = 8 (m >> 1) + 4 (m & 1) + e
+        o[(size_t)(8 * (m >> 1) + 4 * (m & 1) + e) * C] = acc[e][r];
+      }
+  }
+  // --- two accumulator blocks of a shared component: reduction range [wave Q/4, (wave+1) Q/4) per wave
+  {
+    const int scomp = 32 + (j >> 1), sub0 = j & 1;             // blocks e = 2 sub0, 2 sub0 + 1
+    const int nq = Q >> 2, q0 = wave * nq;
+    float16_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+    if (nq % 4 == 0) w4_wg_run<4, 2>(acc, pa0 + (size_t)scomp * cs, pz0 + (size_t)scomp * zcs, q0, nq, rbs, sub0);
+    else for (int q = q0; q < q0 + nq; ++q) w4_wg_run<1, 2>(acc, pa0 + (size_t)scomp * cs, pz0 + (size_t)scomp * zcs, q, 1, rbs, sub0);
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + e * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(acc[e][4 * r4], acc[e][4 * r4 + 1], acc[e][4 * r4 + 2], acc[e][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int e = u >> 8, r4 = (u >> 6) & 3;
+      float4 s = *reinterpret_cast<const float4*>(smem + e * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + e * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int ee = 2 * sub0 + e;
+      float* o = dU + ((size_t)scomp * C + cit * 128) * C + cot * 32 + l31;
+      const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = i + 8 * r4 + 4 * h;                       // register 4 r4 + i of the block
+        o[(size_t)(8 * (m >> 1) + 4 * (m & 1) + ee) * C] = sv[i];
+      }
+    }
+  }
+}
+
+void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s) {
+  const int grid = 2 * (a.C >> 7) * (a.C >> 5) * 8;
+  const size_t lds = 4 * 2048 * sizeof(float);
+  if (a.N % 16 == 0) hipLaunchKernelGGL(k_w4_wgrad<8>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(k_w4_wgrad<4>, dim3(grid), dim3(256), lds, s, a);
+}
+
 }  // namespace node

@@ -138,6 +138,37 @@ __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, 
   }
 }
 
+// Z = A dz A^T of the thread's tile (no halo: the transform of a conv OUTPUT's cotangent) for the F(4x4,3x3)-domain
+// weight gradient (k_w4_wgrad): [comp][co/32][sample][co%32][tile], i.e. 256 contiguous bytes per wave and component.
+__device__ __forceinline__ void w4s_a6(float d0, float d1, float d2, float d3, float& o0, float& o1, float& o2, float& o3,
+                                       float& o4, float& o5) {
+  const float s02 = d0 + d2, s13 = d1 + d3;
+  o0 = d0;
+  o1 = s02 + s13;
+  o2 = s02 - s13;
+  o3 = (d0 + 0.25f * d2) + (0.5f * d1 + 0.125f * d3);
+  o4 = (d0 + 4.f * d2) - (2.f * d1 + 8.f * d3);
+  o5 = d3;
+}
+__device__ __forceinline__ void w4s_emit_z(const float a[4][4], int n, int N, int C, int c, int t, float* __restrict__ Z) {
+  float w[4][6];   // w[i][nu] = sum_j a[i][j] A^T[j][nu]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w4s_a6(a[i][0], a[i][1], a[i][2], a[i][3], w[i][0], w[i][1], w[i][2], w[i][3], w[i][4], w[i][5]);
+  float* zp = Z + ((size_t)(c >> 5) * N + n) * 128 + (c & 31) * 4 + t;
+  const size_t cs = (size_t)4 * N * C;
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    float z0, z1, z2, z3, z4, z5;   // Z[xi][nu] = sum_i A^T[i][xi] w[i][nu]
+    w4s_a6(w[0][nu], w[1][nu], w[2][nu], w[3][nu], z0, z1, z2, z3, z4, z5);
+    zp[(size_t)(0 * 6 + nu) * cs] = z0;
+    zp[(size_t)(1 * 6 + nu) * cs] = z1;
+    zp[(size_t)(2 * 6 + nu) * cs] = z2;
+    zp[(size_t)(3 * 6 + nu) * cs] = z3;
+    zp[(size_t)(4 * 6 + nu) * cs] = z4;
+    zp[(size_t)(5 * 6 + nu) * cs] = z5;
+  }
+}
+
 // masked column sums of the thread's channel (node_internal.h, masked_colsum_tile): out[tap * ld] for the nine taps
 __device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, int ty, int tx, float* __restrict__ out, int ld) {
   float R[4], Cc[4];
@@ -363,6 +394,7 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
     }
     if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
     if (h.spart) w4s_colsums(ho, t, ty, tx, h.spart + (size_t)n * 9 * a.C + c, a.C);
+    if (h.z_out) w4s_emit_z(ho, n, a.N, a.C, c, t, h.z_out);
     if (TAIL == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -415,6 +447,7 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
       w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, n, a.C, c, t, tl.gpart, v);
       if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
       if (tl.spart) w4s_colsums(v, t, ty, tx, tl.spart + (size_t)n * 9 * a.C + c, a.C);
+      if (tl.z_out) w4s_emit_z(v, n, a.N, a.C, c, t, tl.z_out);
     }
   }
 

@@ -245,6 +245,8 @@ struct Plan {
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
   float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
+  float *W4Va[2], *W4Z[2], *W4dU;   // F(4x4,3x3)-domain weight gradient (C % 128 == 0): the forward convs' row operands
+                                    // kept until it runs, Z = A dz A^T of both conv outputs' cotangents, the gradients
   float *act1b, *xh1b, *r1b;   // second set of GroupNorm-1's saved tensors: the pass that ends evaluation s also forms
                                // stage s + 1's conv input, while evaluation s's own set is still being read
   // adjoint
@@ -301,6 +303,11 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.W4M = b.take<float>(w4_v_elems(d.N, d.C));
     for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4u[i] = b.take<float>(w4_u_elems(d.C));
     for (int i = 0; i < 2; ++i) p.tmapS[i] = b.take<float>((size_t)d.HW * d.C);
+    if (adjoint && d.C % 128 == 0) {
+      for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N, d.C));
+      for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N, d.C));
+      p.W4dU = b.take<float>(w4_du_elems(d.C));
+    }
     if (adjoint) {
       p.act1b = b.take<float>(d.numel + d.C);
       p.xh1b = b.take<float>(d.numel);
@@ -537,10 +544,13 @@ struct Solver {
   // F(4x4,3x3) pipeline: one conv = component GEMMs on the row operand its producer left in W4V; the GroupNorm pass
   // behind it reads the products (output transform, + bias + t * tmap for a forward conv) and, when another conv
   // follows, leaves that conv's row operand in W4V again
-  void w4_gemm(int which) {
+  void w4_gemm(int which, const float* V = nullptr) {
     ProfScope ps(2, conv_flops(), st);
-    launch_w4_gemm(p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N, d.C, st);
+    launch_w4_gemm(V ? V : p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N, d.C, st);
   }
+  // the weight gradients of an augmented evaluation in the F(4x4,3x3) domain (k_w4_wgrad): needs the forward convs'
+  // row operands alive behind the data-gradient convs, so they get buffers of their own
+  bool w4_wgrad_on() const { return w4 && aug && p.W4dU != nullptr; }
   W4sArgs w4_args() const {
     W4sArgs a;
     memset(&a, 0, sizeof(a));
@@ -550,8 +560,8 @@ struct Solver {
   // tail 1 of a pass: stage combine -> GroupNorm-1 -> ReLU -> V (+ act1, xhat-1, 1/sigma-1 of set `set` when training)
   void w4_tail_combine(W4sArgs& a, const Comb& cy, float* y_out, bool train, int set, int self) {
     a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
-    if (train) { a.t.act_nhwc = act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
-    a.V = p.W4V;
+    if (train) { a.t.act_nhwc = w4_wgrad_on() ? nullptr : act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
+    a.V = (train && w4_wgrad_on()) ? p.W4Va[0] : p.W4V;
   }
   // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
   // must read or write, once) in the record
@@ -590,16 +600,17 @@ struct Solver {
       w4_pass(0, 1, a);
     }
     v_ready = false;
-    w4_gemm(0);
+    const bool wg4 = do_aug && w4_wgrad_on();
+    w4_gemm(0, wg4 ? p.W4Va[0] : nullptr);
     {   // P2
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.bias = prm.conv1_b; a.h.tmapS = p.tmapS[0]; a.h.et = et; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b;
       a.h.osign = 1.f; a.h.relu = 1;
-      if (train) { a.h.out_nhwc = p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
-      a.V = p.W4V;
+      if (train) { a.h.out_nhwc = wg4 ? nullptr : p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
+      a.V = wg4 ? p.W4Va[1] : p.W4V;
       w4_pass(1, 0, a);
     }
-    w4_gemm(1);
+    w4_gemm(1, wg4 ? p.W4Va[1] : nullptr);
     W4sArgs a3 = w4_args();
     a3.h.M = p.W4M; a3.h.bias = prm.conv2_b; a3.h.tmapS = p.tmapS[1]; a3.h.et = et; a3.h.gamma = prm.norm3_w; a3.h.beta = prm.norm3_b;
     a3.h.osign = et.tsign; a3.h.relu = 0; a3.h.out_s = kY_out;
@@ -616,7 +627,9 @@ struct Solver {
       return check_launch("odefunc forward (F(4x4,3x3))");
     }
     // P3B3: GroupNorm-3, then the adjoint combine through its backward
-    a3.t.comb = *ca; a3.t.csign = csign; a3.t.y_out = a_out; a3.t.gpart = p.gpart[2]; a3.t.spart = p.spart[1]; a3.t.act_nhwc = p.dz2;
+    a3.t.comb = *ca; a3.t.csign = csign; a3.t.y_out = a_out; a3.t.gpart = p.gpart[2]; a3.t.spart = p.spart[1];
+    if (wg4) a3.t.z_out = need_theta ? p.W4Z[1] : nullptr;
+    else a3.t.act_nhwc = p.dz2;
     a3.V = p.W4V;
     w4_pass(1, 2, a3);
     if (count_nfe) nfe += 1;
@@ -624,11 +637,19 @@ struct Solver {
     {   // PB2
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; a.h.osign = 1.f;
-      a.h.out_nhwc = p.dz1; a.h.gpart = p.gpart[1]; a.h.spart = p.spart[0];
+      a.h.gpart = p.gpart[1]; a.h.spart = p.spart[0];
+      if (wg4) a.h.z_out = need_theta ? p.W4Z[0] : nullptr;
+      else a.h.out_nhwc = p.dz1;
       a.V = p.W4V;
       w4_pass(2, 0, a);
     }
-    if (need_theta) {
+    if (need_theta && wg4) {
+      W4WgradArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N; wa.C = d.C;
+      ProfScope ps(1, 2.0 * conv_flops(), st);
+      launch_w4_wgrad(wa, st);
+    } else if (need_theta) {
       WgradArgs w1;
       memset(&w1, 0, sizeof(w1));
       w1.act = act1_of(cur); w1.dz = p.dz1; w1.wpart = p.wpart[0]; w1.ctrl = p.ctrl;
@@ -657,6 +678,7 @@ struct Solver {
     if (!need_theta) return check_launch("augmented dynamics (F(4x4,3x3))");
     ThetaFinalizeArgs tf;
     memset(&tf, 0, sizeof(tf));
+    tf.dU = wg4 ? p.W4dU : nullptr;
     tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
     tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
     tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
@@ -1131,8 +1153,14 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   // touched by the host after it returns); the outcome goes to the caller's device record
   const int blind = (opts && opts->blind_steps > 0 && opts->record && n_t == 2 && !forced && io.log_cap == 0)
                         ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
-  if (blind) launch_set_target(S.p.targets, ts[1], S.st);
-  else TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
+  if (blind) {
+    launch_set_target(S.p.targets, ts[1], S.st);
+    // a MISSED blind solve never emits its output: leave y0 there, not uninitialised memory (the caller's loss of
+    // such a step is then a finite number of a step whose update is skipped anyway)
+    HIP_TRY(hipMemcpyAsync(y_out + numel, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  } else {
+    TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
+  }
   if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
   launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
@@ -1312,7 +1340,8 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
 // ----------------------------------------------------------------------------
 // Backward of the NON-adjoint `odeint` (model.py:359 with adjoint=False, the constructor default model.py:7):
 // upstream differentiates through the solver's own operations.  Here: the accepted steps are replayed from y0 with
-// the recorded step sizes (same kernels, bit-identical stage values), every stage derivative is kept on a tape, and
+// the recorded step sizes (the kernels the forward solve ran -- Solver::choose_w4 on its tolerances -- so the stage
+// values are the ones its output was computed from), every stage derivative is kept on a tape, and
 // the cotangents walk the steps backwards -- one VJP of the dynamics per stage evaluation, the Butcher rows and the
 // dense-output polynomial transposed.  Step sizes are treated as constants (upstream's 2019 controller is itself
 // differentiable; that sensitivity is O(local error) and is not reproduced -- DESIGN.md).
@@ -1339,7 +1368,7 @@ extern "C" size_t node_backprop_workspace_bytes(const node_shape* shape, int met
 }
 
 extern "C" int node_solve_backprop(const node_shape* shape, const node_params* params, const float* y0, const float* t_pts,
-                                   int n_t, const double* step_dt, int n_steps, int method, const float* grad_out,
+                                   int n_t, const double* step_dt, int n_steps, float rtol, float atol, int method, const float* grad_out,
                                    float* grad_y0, float* grad_params, void* ws, size_t ws_bytes, void* stream) {
   if (!y0 || !grad_out || !grad_y0 || !grad_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
@@ -1351,7 +1380,8 @@ extern "C" int node_solve_backprop(const node_shape* shape, const node_params* p
   TRY(check_common(shape, params, ws, ws_bytes, 1, n_t, &S.d, &S.p));
   const size_t need = node_backprop_workspace_bytes(shape, method, n_t, n_steps);
   if (ws_bytes < need) return fail(NODE_ERR_WORKSPACE, "workspace too small: %zu < %zu", ws_bytes, need);
-  S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.rtol = 0.f; S.atol = 0.f;
+  S.prm = *params; S.st = (hipStream_t)stream; S.aug = true; S.rtol = rtol; S.atol = atol;
+  S.choose_w4(dopri);   // the forward solve's decision (node_solve_fwd): the replay below runs the kernels it ran
   const Dims& d = S.d;
   const size_t numel = d.numel;
   const bool decreasing = t_pts[1] < t_pts[0];
@@ -1577,7 +1607,8 @@ int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float mom
   if (!tensors) return fail(NODE_ERR_NULL, "tensors is NULL");
   if (!(lr >= 0.f) || !(momentum >= 0.f) || !(weight_decay >= 0.f)) return fail(NODE_ERR_ARG, "lr / momentum / weight_decay must be >= 0");
   for (int i = 0; i < count; ++i) {
-    if (!tensors[i].param || !tensors[i].grad || !tensors[i].momentum_buf) return fail(NODE_ERR_NULL, "tensor %d: a pointer is NULL", i);
+    if (!tensors[i].param || !tensors[i].grad) return fail(NODE_ERR_NULL, "tensor %d: a pointer is NULL", i);
+    if (!tensors[i].momentum_buf && momentum != 0.f) return fail(NODE_ERR_NULL, "tensor %d: momentum buffer is NULL with momentum %g", i, momentum);
     if ((((uintptr_t)tensors[i].param) | ((uintptr_t)tensors[i].grad) | ((uintptr_t)tensors[i].momentum_buf)) & 3)
       return fail(NODE_ERR_ARG, "tensor %d: pointers must be 4-byte aligned", i);
   }

@@ -391,6 +391,7 @@ void launch_colsum(const Dims& d, const float* dz, float* spart, hipStream_t s);
 size_t wgrad_lds_bytes(const Dims& d);
 
 struct ThetaFinalizeArgs {
+  const float* dU;         // nullable: F(4x4,3x3)-domain weight gradients [2][36][C][C] (k_w4_wgrad) instead of wpart: dW = G^T dU G
   const float* wpart[2];   // conv1, conv2
   const float* spart[2];   // [N][9][C] each
   const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)

@@ -70,6 +70,7 @@ struct W4sHead {          // the conv result in front of this pass
   float* rstd;            // forward: 1/sigma out [N][G] (nullable); backward: in
   float* gpart;           // backward: [N][2][C] per-sample (dgamma, dbeta) partials
   float* spart;           // backward, nullable: [N][9][C] masked column sums of the output (masked_colsum_tile)
+  float* z_out;           // backward, nullable: Z = A out A^T for the F(4x4,3x3)-domain weight gradient (dz1)
 };
 struct W4sTail {          // what follows the head inside the same launch
   Comb comb;              // stage combine (tail 1) / adjoint combine (tail 2), W4S tensors
@@ -83,6 +84,7 @@ struct W4sTail {          // what follows the head inside the same launch
   float* rstd;            // tail 1: 1/sigma-1 out (nullable)
   float* gpart;           // tail 2: GroupNorm-3's (dgamma, dbeta) partials
   float* spart;           // tail 2: masked column sums of dz2
+  float* z_out;           // tail 2, nullable: Z = A dz2 A^T for the F(4x4,3x3)-domain weight gradient
 };
 struct W4sArgs {
   const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done
@@ -98,6 +100,23 @@ void launch_w4s_from_nchw(const float* src_nchw, float* dst_w4s, int N, int C, h
 void launch_w4s_to_nchw(const float* src_w4s, float* dst_nchw, int N, int C, hipStream_t s);
 void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, hipStream_t s);
 void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
+
+// F(4x4,3x3)-domain weight gradient of both conv layers (k_w4_wgrad, kernels_w4.hip).
+//   Z  [comp 36][co/32][sample N][co%32][tile 4]   Z = A dz A^T of the conv output's cotangent: a lane's 16 B are four
+//      rows of the reduction for one output channel; what a wave of the producing pass writes per component is 256
+//      contiguous bytes
+//   dU [layer 2][comp 36][ci][co]                  every element written once (no split-K slabs); dW = G^T dU G in
+//      k_theta_finalize
+struct W4WgradArgs {
+  const float* V1; const float* Z1;   // conv1: V of act1, Z of dz1
+  const float* V2; const float* Z2;   // conv2: V of act2, Z of dz2
+  float* dU;
+  const Ctrl* ctrl;                   // nullable: the launch returns at once when ctrl->done
+  int N, C;
+};
+void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s);
+__host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C; }
+__host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COMPS * C * C; }
 
 // launchers (kernels_w4.hip)
 struct W4PackJobs { const float* w[4]; float* u[4]; int dgrad[4]; };

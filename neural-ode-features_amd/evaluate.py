@@ -79,8 +79,7 @@ def nfe(args):
     rows = []
     with torch.no_grad():
         for tol, t1 in itertools.product(args.tol, args.t1):
-            if t1 == 0 and len(args.t1) > 1:
-                continue                                   # t1 = 0 is the identity block: no solve to count
+            # (t1 = 0 is the identity block, model.py:363-364: rows with nfe = 0, as the reference writes them)
             model.odeblock.t1 = t1
             model.odeblock.tol = tol
             model.nfe(reset=True)

@@ -10,6 +10,7 @@ that are not the reference's Conv-GroupNorm-ReLU `ODEfunc` raise.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -277,8 +278,9 @@ def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Ten
 
 
 def solve_backprop(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor, grad_out: torch.Tensor,
-                   times: List[float], step_dts: List[float], method_id: int):
-    """Backward of the non-adjoint `odeint`: backpropagation through the forward solve's accepted steps."""
+                   times: List[float], step_dts: List[float], method_id: int, rtol: float = 0.0, atol: float = 0.0):
+    """Backward of the non-adjoint `odeint`: backpropagation through the forward solve's accepted steps.  `rtol`,
+    `atol`: the forward solve's (they select the convolution kernels the replay runs, like the forward solve did)."""
     lib = _lib.load()
     y0 = y0.detach().contiguous()
     grad_out = grad_out.detach().contiguous()
@@ -296,7 +298,8 @@ def solve_backprop(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor
         grad_p = torch.empty(lib.node_param_count(C.byref(shape)), dtype=torch.float32, device=dev)
         tarr = (C.c_float * n_t)(*times)
         darr = (C.c_double * max(1, len(step_dts)))(*step_dts)
-        rc = lib.node_solve_backprop(C.byref(shape), C.byref(pstruct), y0.data_ptr(), tarr, n_t, darr, n_steps, method_id,
+        rc = lib.node_solve_backprop(C.byref(shape), C.byref(pstruct), y0.data_ptr(), tarr, n_t, darr, n_steps,
+                                     float(rtol), float(atol), method_id,
                                      grad_out.data_ptr(), grad_y0.data_ptr(), grad_p.data_ptr(), _aligned_ptr(ws), ws_bytes,
                                      torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(rc)
@@ -311,8 +314,10 @@ class Deferred:
     interval?), and the host dispatches everything behind it only afterwards -- the GPU idles while PyTorch launches
     the head, and again while it launches the stem's backward.  With deferred completion enabled, a solve whose step
     count is known from the previous iteration enqueues exactly that many steps and returns at once; whether they
-    were the steps needed is written by the device into a record, and a MISS (unfinished, finished early, or an
-    error status) bumps the device flag `miss_flag`.  Nothing that commits results may run unconditionally:
+    were the steps needed is written by the device into a record, and a MISS (the interval unfinished after them, or an
+    error status; finishing EARLY is no miss -- the steps past the end return at once) bumps the device flag
+    `miss_flag`.  The output of a missed solve is its y0 (the trajectory buffer is pre-filled), and every number
+    computed from it -- loss, accuracy -- belongs to a step whose update was skipped: `step_verdicts()` lists which.  Nothing that commits results may run unconditionally:
     `optim.FusedSGD.skip_flag = deferred.miss_flag` predicates the parameter update on the device, so a step with a
     miss changes nothing (under data parallelism the flag rides in the reducer's last bucket, so every rank skips
     together).  The host looks at a record one iteration later, when it is long complete: the true step count in it
@@ -342,9 +347,11 @@ class Deferred:
         self.guess: Dict[tuple, Optional[int]] = {}
         self.calm: Dict[tuple, int] = {}          # consecutive solves of a key whose step count equalled the guess
         self.pending: Dict[tuple, tuple] = {}
+        self._seq: Dict[tuple, int] = {}
         self.records: Dict[tuple, tuple] = {}
         self.misses = 0
         self.blind_solves = 0
+        self.verdicts: List[tuple] = []   # (blind solve index, key kind, missed?) in the order the records were read
         self.armed = False         # set by FusedSGD.use_deferred: without a predicated commit point nothing runs blind
 
     def __enter__(self):
@@ -378,6 +385,9 @@ class Deferred:
             dev, host, event = self._buffers(key)
             event.synchronize()
             r = _lib.NodeStepRecord.from_buffer_copy(bytes(host.numpy().tobytes()))
+            self.verdicts.append((self._seq.pop(key, -1), key[0], bool(r.miss)))
+            if len(self.verdicts) > 4096:
+                del self.verdicts[:2048]
             if r.miss:
                 self.misses += 1
                 self.guess[key] = None
@@ -401,11 +411,17 @@ class Deferred:
         host.copy_(dev, non_blocking=True)
         event.record(torch.cuda.current_stream(self.device))
         self.pending[key] = (guessed, weakref.ref(func) if func is not None else None)
+        self._seq[key] = self.blind_solves
         self.blind_solves += 1
 
     def learned(self, key, steps):
         self.guess[key] = int(steps)
         self.calm[key] = 0
+
+    def step_verdicts(self):
+        """[(blind solve index, 'fwd' | 'bwd', missed)] for the records read so far (one iteration late): a caller that
+        logs losses or drives an LR schedule from them drops the iterations whose solves missed."""
+        return list(self.verdicts)
 
     def settled(self):
         """True once every kind of solve seen so far runs blind WITHOUT a spare step (CALM exact predictions in a row):
@@ -417,6 +433,22 @@ class Deferred:
         for key in list(self.pending):
             self.plan(key)
         return self.misses
+
+
+_TOKENS = itertools.count(1)
+
+
+def _func_token(func):
+    """A key for `func` that is never reused: id() can be handed to a new object after the old one was collected,
+    and a new dynamics function would then inherit a stale step-count guess."""
+    tok = getattr(func, '_node_token', None)
+    if tok is None:
+        tok = next(_TOKENS)
+        try:
+            object.__setattr__(func, '_node_token', tok)
+        except Exception:
+            return id(func)
+    return tok
 
 
 BACKPROP_LOG = 4096      # step sizes the forward solve can record for the non-adjoint backward (csrc: STEP_LIST_CAP)
@@ -437,7 +469,7 @@ class _HipOdeint(torch.autograd.Function):
                                 and not options) else None
         if d is not None and d.device != y0.device:
             d = None
-        dkey = ('fwd', id(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None
+        dkey = ('fwd', _func_token(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None
         steps = d.plan(dkey, func) if d is not None else None
         if steps:
             out, st = solve_forward(rec, list(params), y0, times, rtol, atol, method_id, options, blind=d.blind_args(dkey, steps[1]))
@@ -472,7 +504,7 @@ class _HipOdeint(torch.autograd.Function):
             d = Deferred.active if (ctx.method_id == _lib.METHOD_DOPRI5 and len(ctx.times) == 2 and not ctx.options) else None
             if d is not None and d.device != out.device:
                 d = None
-            dkey = ('bwd', id(ctx.func), tuple(out.shape[1:]), ctx.rtol, ctx.atol, tuple(ctx.times)) if d is not None else None
+            dkey = ('bwd', _func_token(ctx.func), tuple(out.shape[1:]), ctx.rtol, ctx.atol, tuple(ctx.times)) if d is not None else None
             steps = d.plan(dkey, ctx.func) if d is not None else None
             if steps:
                 gy0, gp, _, st = solve_adjoint(ctx.rec, params, out, grad_out, ctx.times, ctx.rtol, ctx.atol,
@@ -495,7 +527,8 @@ class _HipOdeint(torch.autograd.Function):
                 full = torch.zeros_like(out)
                 full[-1] = grad_out
                 grad_out = full
-            gy0, gp = solve_backprop(ctx.rec, params, out[0], grad_out, ctx.times, ctx.step_dts or [], ctx.method_id)
+            gy0, gp = solve_backprop(ctx.rec, params, out[0], grad_out, ctx.times, ctx.step_dts or [], ctx.method_id,
+                                     ctx.rtol, ctx.atol)
             ctx.func.last_backward_stats = {'nfe': 0, 'accepted': len(ctx.step_dts or []), 'rejected': 0, 'status': 0}
         grads = []
         off = 0

@@ -49,6 +49,10 @@ class FusedSGD(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         for group in self.param_groups:
+            if group.get('nesterov') or group.get('dampening') or group.get('maximize'):
+                raise ValueError('FusedSGD implements plain SGD with momentum and weight decay (train.py:136): nesterov, '
+                                 'dampening and maximize are not supported (got %r)'
+                                 % {k: group.get(k) for k in ('nesterov', 'dampening', 'maximize')})
             rows = []
             keep = []
             dev = None
@@ -69,10 +73,12 @@ class FusedSGD(torch.optim.Optimizer):
                     g = g.contiguous()
                 st = self.state[p]
                 buf = st.get('momentum_buffer')
-                if buf is None:               # torch's first step sets buf = grad: zero + one fused step does the same
+                if group['momentum'] == 0:
+                    buf = None                # torch.optim.SGD keeps no buffer then: same state_dict, half the memory
+                elif buf is None:             # torch's first step sets buf = grad: zero + one fused step does the same
                     buf = st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 keep.append(g)
-                rows.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel()))
+                rows.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else None, p.numel()))
             if not rows:
                 continue
             table = (_lib.NodeSgdTensor * len(rows))(*[_lib.NodeSgdTensor(*r) for r in rows])

@@ -150,3 +150,24 @@ def test_nothing_runs_blind_without_a_predicated_commit_point():
                 blk(x)
             assert finished()
     assert d.blind_solves == 0
+
+
+@pytest.mark.timeout(900)
+def test_a_miss_on_one_rank_skips_the_update_on_every_rank():
+    """Two ranks sharing cuda:0 over gloo (tests/dp_miss_child.py): a miss forced on rank 1 ONLY must skip the optimizer
+    step on BOTH ranks (the flag travels in the reducer's last bucket, dp.GradientReducer.carry_flag), parameters
+    bit-identical across the ranks before, at and after the skipped step."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    env_clean = {k: None for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    old = {k: os.environ.pop(k, None) for k in env_clean}
+    try:
+        rc = bench.spawn_ranks(2, [sys.executable, os.path.join(root, 'tests', 'dp_miss_child.py')], timeout=800)
+    finally:
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
+    assert rc == 0

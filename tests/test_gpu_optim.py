@@ -78,6 +78,28 @@ def test_fused_sgd_on_a_real_model_matches_torch_sgd():
         assert torch.equal(p, q)
 
 
+def test_fused_sgd_without_momentum_keeps_no_buffer_and_rejects_unsupported_modes():
+    import neural_ode_features_amd as nof
+    torch.manual_seed(4)
+    ps = [torch.randn(257, device='cuda', requires_grad=True), torch.randn(8, 16, device='cuda', requires_grad=True)]
+    ref = [p.detach().clone().requires_grad_(True) for p in ps]
+    for p, r in zip(ps, ref):
+        g = torch.randn_like(p)
+        p.grad, r.grad = g.clone(), g.clone()
+    a = nof.FusedSGD(ps, lr=0.05, momentum=0.0, weight_decay=1e-3)
+    b = torch.optim.SGD(ref, lr=0.05, momentum=0.0, weight_decay=1e-3)
+    a.step(); b.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, rtol=1e-6, atol=1e-7)
+        assert torch.equal(p.grad, r.grad)                              # the gradients are left as autograd wrote them
+    assert all('momentum_buffer' not in a.state[p] for p in ps)         # torch.optim.SGD keeps none either
+    for bad in (dict(nesterov=True), dict(dampening=0.1), dict(maximize=True)):
+        a.param_groups[0].update(bad)
+        with pytest.raises(ValueError):
+            a.step()
+        a.param_groups[0].update(dict(nesterov=False, dampening=0, maximize=False))
+
+
 def test_sgd_step_argument_checks():
     from neural_ode_features_amd import _lib
     lib = _lib.load()

@@ -125,10 +125,12 @@ def test_w4_pipeline_matches_reference_odefunc_fixture(golden_dir, name):
     assert abs(float(vt) - float(g['vjp_t'])) < (1e-4 if kf else 2e-3) * scale
 
 
-@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (128, 256, 8, 8)])
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (8, 128, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8)])
 def test_w4_odefunc_forward_and_vjp_match_oracle(shape):
     """The pipeline's single evaluation and VJP against the CPU oracle (oracle/dynamics.py, pinned by the reference's
-    fixtures), kink-free parameters, at the smallest and at the configs[1] shape: max-norm bounds."""
+    fixtures), kink-free parameters, at the smallest and at the configs[1] shape: max-norm bounds.  C = 64 takes the
+    F(2x2,3x3)-domain weight gradient behind the pipeline, C % 128 == 0 the F(4x4,3x3)-domain one (k_w4_wgrad; N = 8:
+    its short operand ring)."""
     from neural_ode_features_amd import integrate
     N, Cc, H, W = shape
     assert _engaged(N, Cc)
