@@ -207,26 +207,62 @@ def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
                       % (done, bs, nf, nb, dt)}
 
 
-def pmc_traffic(config, kernel='k_conv3x3'):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
-    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of tools/prof_eval.py at this workload's state shape;
-    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None where no pass is committed."""
-    shape_of = {2: 2, 3: 2, 5: 5}.get(config, config)       # cfg 3 runs cfg 2's kernels at cfg 2's state shape
-    names = ('r02_pmc_eval_cfg%d.json' % shape_of, 'r01_k_pmc_eval_cfg%d.json' % shape_of)
-    if kernel.startswith('k_w4'):
-        names = ('r02_pmc_w4_cfg%d.json' % shape_of,)
-    for name in names:
-        path = os.path.join(ROOT, 'profiles', name)
-        if not os.path.exists(path):
-            continue
+def pmc_measure(state, conv_path_env, timeout=420):
+    """HBM bytes per launch of every library kernel of an augmented dynamics evaluation at this workload's state shape,
+    MEASURED in this run: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no
+    trace domain, the program itself behind `--`) over tools/prof_eval.py, started BEFORE this process touches the GPU.
+    FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (wide coalesced reads are tallied at half
+    their bytes); WRITE_SIZE also counts evictions of the previous kernel's dirty lines.  Returns {kernel name: bytes}
+    or None (no rocprofv3, a failed pass): `roofline.traffic` is then null -- never a stale committed number."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if rocprof is None:
+        return None
+    env = dict(os.environ)
+    env.update(conv_path_env)
+    env['TMPDIR'] = '/tmp'
+    got = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='node_pmc_', dir='/tmp')
+        cmd = [rocprof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
+               os.path.join(ROOT, 'tools', 'prof_eval.py'), '--shape', ','.join(str(v) for v in state), '--iters', '4']
         try:
-            with open(path) as fh:
-                pmc = json.load(fh)
-            k = next(v for n, v in pmc.items() if kernel in n)
-            return (2.0 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+            r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row['Kernel_Name'].split('(')[0].replace('void ', '')
+                    if 'node::' in k and row['Counter_Name'] == counter:
+                        a = acc.setdefault(k, [0.0, 0])
+                        a[0] += float(row['Counter_Value'])
+                        a[1] += 1
+            if not acc:
+                return None
+            for k, (tot, n) in acc.items():
+                got.setdefault(k, {})[counter] = tot / n
         except Exception:
-            continue
-    return None
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k, v in got.items():
+        if 'FETCH_SIZE' in v and 'WRITE_SIZE' in v:
+            out[k] = {'read': 2.0 * v['FETCH_SIZE'] * 1024.0, 'written': v['WRITE_SIZE'] * 1024.0,
+                      'bytes': (2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0}
+    return out or None
+
+
+def pmc_lookup(pmc, kernel):
+    """bytes per launch of the kernel whose name contains `kernel` (the instance with the most bytes), or None"""
+    if not pmc:
+        return None
+    hits = [v for k, v in pmc.items() if kernel in k]
+    return max(hits, key=lambda v: v['bytes']) if hits else None
 
 
 def main():
@@ -241,6 +277,7 @@ def main():
     ap.add_argument('--method', default='dopri5')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc child passes (roofline.traffic = null)')
     ap.add_argument('--graphs', action='store_true',
                     help='replay the classifier head from hipGraphs (pays off only with --no-deferred: see graphs.py)')
     ap.add_argument('--settle', type=int, default=24,
@@ -266,6 +303,17 @@ def main():
         cfg['tol'] = args.tol
 
     world, rank, local_rank = resolve_world(args)
+
+    side = cfg['image'] // 4
+    state = [cfg['batch'], cfg['filters'], side, side]
+    pmc = None
+    if world == 1 and not args.no_roofline and not args.no_pmc:
+        # HBM traffic of the kernels of this workload, counted in THIS run (child processes under rocprofv3 --pmc), before
+        # anything here initialises the GPU.  Single evaluations take the tolerance-gated F(4x4,3x3) pipeline only when
+        # forced, so the children run with the conv path the timed solves will take.
+        w4_default = os.environ.get('NODE_TUNE_WINO4', '1')
+        takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 1e-4 and side == 8 and w4_default != '0'
+        pmc = pmc_measure(state, {'NODE_TUNE_WINO4': '2' if takes_w4 else '0'})
 
     import torch
     import torch.distributed as dist
@@ -416,8 +464,6 @@ def main():
                           'timed in the same run right behind the headline region'}
         opt.use_deferred(deferred, reducer)        # (armed again for the roofline repeat's bookkeeping below)
 
-    side = cfg['image'] // 4
-    state = [cfg['batch'], cfg['filters'], side, side]
     roofline = None
     if not args.no_roofline:
         # repeat of the timed steps with per-launch HIP events on the launch stream
@@ -442,7 +488,8 @@ def main():
             ach = algo_per_launch * issued / (avg_ms * 1e-3) / 1e12
             roofline = {'bound': 'mfma', 'kernel': 'k_w4_gemm64 (fp32 MFMA, the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad)',
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args.config, 'k_w4_gemm64'),
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': (pmc_lookup(pmc, 'k_w4_gemm') or {}).get('bytes'),
+                        'traffic_detail': pmc_lookup(pmc, 'k_w4_gemm'),
                         'avg_launch_us': avg_ms * 1e3, 'launches': k4['launches'],
                         'flops_per_launch': algo_per_launch * issued,
                         'algorithmic': {'flops_per_launch': algo_per_launch,
@@ -451,6 +498,27 @@ def main():
                                                 'quoted against this launch alone'},
                         'note': 'achieved/frac = MFMA FLOPs issued (0.25 of the direct-convolution FLOPs) over the fp32 matrix '
                                 'peak, i.e. matrix-pipe utilisation of the dominant kernel'}
+            if os.environ.get('NODE_TUNE_W4_BF16X3', '1') != '0' and cfg['batch'] % 16 == 0 and os.environ.get('NODE_TUNE_W4_GEMM64', '1') != '0':
+                # k_w4_gemm64b: the same products on the bf16 matrix pipe at fp32 accuracy (every fp32 operand an exact sum
+                # of three bf16 parts, six of the nine part products).  Its arithmetic intensity -- 14.5 GFLOP issued over
+                # 52 MB (V fp32 + the filters' bf16 triples + M fp32) = 279 FLOP/B -- sits left of the bf16 ridge
+                # (2500 TFLOP/s / 8 TB/s = 312 FLOP/B): the HBM side bounds it.
+                C, Nn = cfg['filters'], cfg['batch']
+                bytes_algo = 36.0 * 4 * Nn * C * 4 * 2 + 36.0 * C * C * 6
+                tbs = bytes_algo / (avg_ms * 1e-3) / 1e12
+                issued_bf16 = algo_per_launch * issued * 6.0 / (avg_ms * 1e-3) / 1e12
+                roofline.update({
+                    'bound': 'hbm', 'kernel': 'k_w4_gemm64b (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
+                                              'at fp32 accuracy: exact three-way bf16 split of both operands, six products)',
+                    'achieved': tbs, 'peak': HBM_PEAK_TBS, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS,
+                    'bytes_per_launch': bytes_algo,
+                    'mfma': {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / 2500.0,
+                             'fp32_equivalent_tflops': ach, 'vs_fp32_matrix_peak': ach / MFMA_F32_PEAK_TFLOPS,
+                             'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
+                                     'launch time; against the fp32 matrix peak it may exceed 1 -- the products run at the '
+                                     'bf16 rate'},
+                    'note': 'achieved = algorithmic bytes per launch (row operand fp32 + filter bf16 triples + products fp32) '
+                            '/ mean launch duration (HIP events); `traffic` = the bytes counted by rocprofv3 PMC in this run'})
         elif k['launches'] > 0:
             avg_ms = k['total_ms'] / k['launches']
             algo_per_launch = k['flops'] / k['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
@@ -462,7 +530,8 @@ def main():
             ach = algo * issued
             roofline = {'bound': 'mfma', 'kernel': kname,
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': pmc_traffic(args.config),
+                        'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': (pmc_lookup(pmc, 'k_conv3x3') or {}).get('bytes'),
+                        'traffic_detail': pmc_lookup(pmc, 'k_conv3x3'),
                         'avg_launch_us': avg_ms * 1e3, 'launches': k['launches'],
                         'flops_per_launch': algo_per_launch * issued,
                         'algorithmic': {'flops_per_launch': algo_per_launch, 'achieved': algo,
@@ -494,7 +563,9 @@ def main():
             dom = max(passes, key=lambda n: passes[n]['total_ms'])
             tot = {'launches': sum(v['launches'] for v in passes.values()), 'total_ms': sum(v['total_ms'] for v in passes.values()),
                    'flops': sum(v['flops'] for v in passes.values())}
+            inst = dom[dom.index('<'):dom.index('>') + 1].replace(',', ', ')      # 'w4s_pass<1,2> ...' -> '<1, 2>' as rocprofv3 prints it
             roofline['hbm'] = dict(hb(passes[dom]), bound='hbm', kernel='k_' + dom, peak=HBM_PEAK_TBS, unit='TB/s',
+                                   traffic=(pmc_lookup(pmc, 'k_w4s_pass' + inst) or {}).get('bytes'),
                                    all_passes=dict(hb(tot), ms_per_step=tot['total_ms'] / min(args.steps, 5)),
                                    per_kernel={n: hb(v) for n, v in passes.items()},
                                    note='algorithmic bytes per launch / mean launch duration (HIP events on the launch stream); '

@@ -11,15 +11,34 @@ typedef float float16_t __attribute__((ext_vector_type(16)));
 // U = G g G^T for every (co, ci) pair, written in MFMA-ready blocks (wino4.h).  dgrad: the data-gradient filter
 // g'[ci][co][kh][kw] = g[co][ci][2-kh][2-kw].  Weights are [C][C+1][3][3] (input channel 0 = time, model.py:320-323).
 // ----------------------------------------------------------------------------
+// With jobs.ub: additionally the split-precision form k_w4_gemm64b reads -- every fp32 value u as three bf16 parts
+// h = bf16(u), m = bf16(u - h), l = bf16(u - h - m) (u = h + m + l exactly), laid out [comp][cb][g/2][part 3][hi 2][col 32]
+// [8 values: g even e 0..3, g odd e 0..3], i.e. one 16-B load per lane and part feeds one K = 16 bf16 MFMA.
+__device__ __forceinline__ unsigned short w4_bf16_rne(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);   // round to nearest even (finite inputs)
+}
+__device__ __forceinline__ float w4_bf16_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
 __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
   const float* __restrict__ w = jobs.w[blockIdx.y];
   float* __restrict__ U = jobs.u[blockIdx.y];
+  unsigned short* __restrict__ Ub = jobs.ub[blockIdx.y];
   const int dgrad = jobs.dgrad[blockIdx.y];
   const int G8 = C >> 3;
   const size_t total = (size_t)C * C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int e = idx & 3, col = (idx >> 2) & 31, hi = (idx >> 7) & 1;
-    const int g = (int)((idx >> 8) % G8), cb = (int)((idx >> 8) / G8);
+    // consecutive threads write consecutive elements of the layout this launch produces: fp32 [cb][g][hi][col][e], or
+    // the bf16 triples [cb][g/2][part][hi][col][g & 1][e] (eight values = one 16-B operand of a lane)
+    int e, col, hi, g, cb;
+    if (Ub == nullptr) {
+      e = idx & 3; col = (idx >> 2) & 31; hi = (idx >> 7) & 1;
+      g = (int)((idx >> 8) % G8); cb = (int)((idx >> 8) / G8);
+    } else {
+      e = idx & 3; col = (idx >> 3) & 31; hi = (idx >> 8) & 1;
+      const int g2 = (int)((idx >> 9) % (G8 >> 1));
+      g = 2 * g2 + (int)((idx >> 2) & 1); cb = (int)((idx >> 9) / (G8 >> 1));
+    }
     const int nidx = cb * 32 + col, kidx = 8 * g + 4 * hi + e;   // output column / reduction index of the GEMM
     double gg[3][3];
 #pragma unroll
@@ -33,12 +52,26 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) gt[i][kw] = W4_G[i][0] * gg[0][kw] + W4_G[i][1] * gg[1][kw] + W4_G[i][2] * gg[2][kw];
+    const size_t fidx = ((((size_t)cb * G8 + g) * 2 + hi) * 32 + col) * 4 + e;
+    const size_t bidx = ((((size_t)cb * (G8 >> 1) + (g >> 1)) * 3) * 64 + (size_t)(hi * 32 + col)) * 8 + (g & 1) * 4 + e;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int l = 0; l < 6; ++l) {
         const double v = gt[i][0] * W4_G[l][0] + gt[i][1] * W4_G[l][1] + gt[i][2] * W4_G[l][2];
-        U[(size_t)(i * 6 + l) * total + idx] = (float)v;
+        const float uf = (float)v;
+        if (Ub == nullptr) {
+          U[(size_t)(i * 6 + l) * total + fidx] = uf;
+        } else {
+          const unsigned short hb = w4_bf16_rne(uf);
+          const float r1 = uf - w4_bf16_f32(hb);
+          const unsigned short mb = w4_bf16_rne(r1);
+          const unsigned short lb = w4_bf16_rne(r1 - w4_bf16_f32(mb));
+          unsigned short* o = Ub + (size_t)(i * 6 + l) * total * 3 + bidx;
+          o[0] = hb;
+          o[512] = mb;
+          o[1024] = lb;
+        }
       }
   }
 }
@@ -348,7 +381,208 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
   }
 }
 
-void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s) {
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm64b: k_w4_gemm64's products on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand is split EXACTLY
+// into three bf16 parts (x = h + m + l: 3 x 8 mantissa bits; U once per solve by k_w4_pack, V in registers here with
+// v_cvt_pk_bf16_f32), and a K = 16 step of a 32 x 32 block is six v_mfma_f32_32x32x16_bf16 -- hh, hm, mh, mm, hl, lh,
+// fp32 accumulation; the dropped products ml, lm, ll are <= 2^-24 of the result -- instead of eight
+// v_mfma_f32_32x32x2_f32: 192 instead of 512 matrix-pipe cycles.  Measured against an fp64 product the error is that
+// of the fp32 MFMA chain (tools/bf16x3 check in tests/test_gpu_w4.py: same 3.2e-6-of-max|y| convolution error).
+// Same decomposition, layouts of V and M, and XCD placement as k_w4_gemm64; a lane's eight K values of a step are
+// channels {8 g + 4 hi + e} of TWO consecutive g blocks (two of the 16-B loads the fp32 kernel issues too).
+// ----------------------------------------------------------------------------
+typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 w4_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4)));
+
+struct W4Split { w4_bf16x8 h, m, l; };
+__device__ __forceinline__ W4Split w4_split8(const float4& p, const float4& q) {
+  const w4_f32x2 v[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
+  w4_u32x4 hh, mm, ll;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const w4_bf16x2 h = __builtin_convertvector(v[i], w4_bf16x2);
+    const w4_f32x2 r = v[i] - __builtin_convertvector(h, w4_f32x2);
+    const w4_bf16x2 m = __builtin_convertvector(r, w4_bf16x2);
+    const w4_f32x2 t = r - __builtin_convertvector(m, w4_f32x2);
+    const w4_bf16x2 l = __builtin_convertvector(t, w4_bf16x2);
+    hh[i] = __builtin_bit_cast(unsigned, h);
+    mm[i] = __builtin_bit_cast(unsigned, m);
+    ll[i] = __builtin_bit_cast(unsigned, l);
+  }
+  W4Split o;
+  o.h = __builtin_bit_cast(w4_bf16x8, hh);
+  o.m = __builtin_bit_cast(w4_bf16x8, mm);
+  o.l = __builtin_bit_cast(w4_bf16x8, ll);
+  return o;
+}
+// acc += a * b over one K = 16 step, smallest products first
+__device__ __forceinline__ void w4_mac6(float16_t& acc, const W4Split& a, const w4_u32x4& bh, const w4_u32x4& bm, const w4_u32x4& bl) {
+  const w4_bf16x8 Bh = __builtin_bit_cast(w4_bf16x8, bh), Bm = __builtin_bit_cast(w4_bf16x8, bm), Bl = __builtin_bit_cast(w4_bf16x8, bl);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, Bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, Bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, Bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, Bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, Bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, Bh, acc, 0, 0, 0);
+}
+
+constexpr int W4B_DEPTH = 4;   // K = 16 steps (two g blocks each) in flight
+
+struct W4BStage { float4 a[2][2]; w4_u32x4 b[2][3]; };   // [row block][g of the pair], [column block][part]
+struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; };
+template <int NRB>
+__device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2) {
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) {
+    s.a[r][0] = p.a[r][(size_t)(2 * g2) * 64];
+    s.a[r][1] = p.a[r][(size_t)(2 * g2 + 1) * 64];
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s.b[c][q] = p.b[c][(size_t)(g2 * 3 + q) * 64];
+}
+// the 6 * NRB * 2 MFMAs of one K = 16 step, the independent accumulators round-robin (no dependent back-to-back pair)
+template <int NRB>
+__device__ __forceinline__ void w4b_mac(float16_t (&acc)[2][2], const W4Split (&a)[2], const W4BStage& s) {
+  w4_bf16x8 B[2][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) B[c][q] = __builtin_bit_cast(w4_bf16x8, s.b[c][q]);
+#define W4B_P(AP, BQ)                                                                             \
+  _Pragma("unroll") for (int r = 0; r < NRB; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)   \
+      acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r].AP, B[c][BQ], acc[r][c], 0, 0, 0);
+  W4B_P(l, 0) W4B_P(h, 2) W4B_P(m, 1) W4B_P(m, 0) W4B_P(h, 1) W4B_P(h, 0)   // smallest products first
+#undef W4B_P
+}
+// acc += sum over K = 16 steps [g0, g0 + n) (n a multiple of D): a ring of D stages, each refilled right behind the
+// MFMAs that consumed it; the refills of the last D steps read up to D steps past the range (buffer slack).  The exact
+// bf16 split of the NEXT step's row operand (v_cvt_pk_bf16_f32 + subtracts: ~44 VALU instructions per row block) is
+// interleaved with the CURRENT step's MFMAs -- one matrix instruction, then a few vector ones -- so that a wave that
+// has its SIMD to itself keeps both pipes busy.
+template <int D, int NRB>
+__device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p, int g0, int n) {
+  W4BStage ring[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    w4b_load<NRB>(ring[i], p, g0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  W4Split cur[2], nxt[2];
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) cur[r] = w4_split8(ring[0].a[r][0], ring[0].a[r][1]);
+  for (int g = g0; g < g0 + n; g += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const W4BStage& ns = ring[(i + 1) % D];          // the step after this one (refilled D - 1 steps ago)
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) nxt[r] = w4_split8(ns.a[r][0], ns.a[r][1]);
+      w4b_mac<NRB>(acc, cur, ring[i]);
+#pragma unroll
+      for (int k = 0; k < 12 * NRB; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // ... then up to four VALU instructions of the split
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
+      w4b_load<NRB>(ring[i], p, g + D + i);
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) cur[r] = nxt[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
+                                                    const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 6, nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rt = tile / nCT, ct = tile - rt * nCT;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
+
+  // --- this wave's own component: the whole 64 x 64 tile over the whole K range
+  {
+    const int comp = 4 * j + wave;
+    W4BPtrs p;
+    p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
+    p.b[0] = ublk(comp, 2 * ct); p.b[1] = ublk(comp, 2 * ct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+    w4b_run<W4B_DEPTH, 2>(acc, p, 0, G2);
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      o[0] = acc[0][0][q];
+      o[36 * 128] = acc[0][1][q];
+      o[8 * sstride] = acc[1][0][q];
+      o[8 * sstride + 36 * 128] = acc[1][1][q];
+    }
+  }
+  // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
+  {
+    const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
+    const int ng = G2 >> 2, g0 = wave * ng;
+    W4BPtrs p;
+    p.a[0] = vblk(scomp, rb); p.a[1] = p.a[0];
+    p.b[0] = ublk(scomp, 2 * ct); p.b[1] = ublk(scomp, 2 * ct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
+    if (ng % 4 == 0) w4b_run<4, 1>(acc, p, g0, ng);
+    else if (ng % 2 == 0) w4b_run<2, 1>(acc, p, g0, ng);
+    else w4b_run<1, 1>(acc, p, g0, ng);
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + c * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(acc[0][c][4 * r4], acc[0][c][4 * r4 + 1], acc[0][c][4 * r4 + 2], acc[0][c][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk = u >> 8, r4 = (u >> 6) & 3;
+      float4 s = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
+      mrow[0] = s.x;
+      mrow[32] = s.y;
+      mrow[64] = s.z;
+      mrow[96] = s.w;
+    }
+  }
+}
+
+bool w4_uses_bf16(int N) {
+  const char* g64e = getenv("NODE_TUNE_W4_GEMM64");
+  const char* b16e = getenv("NODE_TUNE_W4_BF16X3");
+  const char* abe = getenv("NODE_TUNE_W4_ABLATE");
+  return N % 16 == 0 && (g64e ? atoi(g64e) : 1) != 0 && (b16e ? atoi(b16e) : 1) != 0 && (abe ? atoi(abe) : 0) == 0;
+}
+
+void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {
   static bool attr[4][MAX_DEVICES] = {};
   static int ab = -1;
   if (ab < 0) { const char* e = getenv("NODE_TUNE_W4_ABLATE"); ab = e ? atoi(e) : 0; }
@@ -364,9 +598,15 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   }
   static int g64 = -1;   // NODE_TUNE_W4_GEMM64 = 0: k_w4_gemm (eight waves, 32 x 64 tiles) everywhere
   if (g64 < 0) { const char* e = getenv("NODE_TUNE_W4_GEMM64"); g64 = e ? atoi(e) : 1; }
+  // NODE_TUNE_W4_BF16X3 = 0: the fp32 MFMA kernel (A/B measurements, tests; read on every call like NODE_TUNE_WINO4)
+  const bool b16 = w4_uses_bf16(N);
   if (g64 && N % 16 == 0) {
     const int grid64 = (N / 16) * (C >> 6) * 8;
     const size_t lds64 = 4 * 2048 * sizeof(float);
+    if (b16 && Ub != nullptr && ab == 0) {
+      hipLaunchKernelGGL(k_w4_gemm64b, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
+      return;
+    }
     if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
     else if (ab == 2) hipLaunchKernelGGL(k_w4_gemm64<2>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
     else if (ab == 4) hipLaunchKernelGGL(k_w4_gemm64<4>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
     }
     if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
     if (h.spart) w4s_colsums(ho, t, ty, tx, h.spart + (size_t)n * 9 * a.C + c, a.C);
-    if (h.z_out) w4s_emit_z(ho, n, a.N, a.C, c, t, h.z_out);
+    if (h.z_out) w4s_emit_z(ho, n, a.Nv, a.C, c, t, h.z_out);
     if (TAIL == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -447,14 +447,14 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
       w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, n, a.C, c, t, tl.gpart, v);
       if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
       if (tl.spart) w4s_colsums(v, t, ty, tx, tl.spart + (size_t)n * 9 * a.C + c, a.C);
-      if (tl.z_out) w4s_emit_z(v, n, a.N, a.C, c, t, tl.z_out);
+      if (tl.z_out) w4s_emit_z(v, n, a.Nv, a.C, c, t, tl.z_out);
     }
   }
 
   if (a.V != nullptr) {
     const int g8 = cb * 2 + (c15 >> 3), hi = (c15 >> 2) & 1, e = c15 & 3;
     float* vp = a.V + ((size_t)((n >> 3) * (a.C >> 3) + g8) * 256 + (n & 7) * 32 + hi * 16 + t * 4 + e);
-    w4s_emit_v(v, ty, tx, vp, (size_t)4 * a.N * a.C);
+    w4s_emit_v(v, ty, tx, vp, (size_t)4 * a.Nv * a.C);
   }
 }
 

@@ -175,7 +175,8 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // the other switches) so that one test process can run both conv paths on the same inputs.
     const char* w4e = getenv("NODE_TUNE_WINO4");
     const int w4_env = w4e ? atoi(w4e) : 1;
-    d.wino4 = (w4_env != 0 && d.H == 8 && d.W == 8 && d.C % 64 == 0 && d.N % 8 == 0 && 16 % d.cpg == 0) ? w4_env : 0;
+    d.wino4 = (w4_env != 0 && d.H == 8 && d.W == 8 && d.C % 64 == 0 && 16 % d.cpg == 0) ? w4_env : 0;
+    d.N8 = (d.N + 7) & ~7;
   }
   d.RB = 64 / d.W;
   if (d.RB < 1) d.RB = 1;
@@ -244,6 +245,7 @@ struct Plan {
   float* wsmall[2];         // small mode: filters packed for k_conv3x3_small
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
+  unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
   float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
   float *W4Va[2], *W4Z[2], *W4dU;   // F(4x4,3x3)-domain weight gradient (C % 128 == 0): the forward convs' row operands
                                     // kept until it runs, Z = A dz A^T of both conv outputs' cotangents, the gradients
@@ -299,13 +301,14 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   if (d.small && !adjoint)
     for (int i = 0; i < 2; ++i) p.wsmall[i] = b.take<float>((size_t)9 * d.C * d.C);
   if (d.wino4) {
-    p.W4V = b.take<float>(w4_v_elems(d.N, d.C));
-    p.W4M = b.take<float>(w4_v_elems(d.N, d.C));
+    p.W4V = b.take<float>(w4_v_elems(d.N8, d.C));
+    p.W4M = b.take<float>(w4_v_elems(d.N8, d.C));
     for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4u[i] = b.take<float>(w4_u_elems(d.C));
+    for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4ub[i] = b.take<unsigned short>(w4_ub_elems(d.C));
     for (int i = 0; i < 2; ++i) p.tmapS[i] = b.take<float>((size_t)d.HW * d.C);
     if (adjoint && d.C % 128 == 0) {
-      for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N, d.C));
-      for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N, d.C));
+      for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N8, d.C));
+      for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N8, d.C));
       p.W4dU = b.take<float>(w4_du_elems(d.C));
     }
     if (adjoint) {
@@ -423,6 +426,7 @@ struct Solver {
   }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
+  bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
   bool v_ready = false;    // the next evaluation's first pass has run
   int cur = 0;             // which set of GroupNorm-1's saved tensors (act1, xhat-1, 1/sigma-1) the current evaluation owns
   float* act1_of(int i) const { return i ? p.act1b : p.act1; }
@@ -481,7 +485,8 @@ struct Solver {
       W4PackJobs jobs;
       memset(&jobs, 0, sizeof(jobs));
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
-      for (int i = 0; i < (aug ? 4 : 2); ++i) { jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.dgrad[i] = i >= 2; }
+      w4_b16 = w4_uses_bf16(d.N8);
+      for (int i = 0; i < (aug ? 4 : 2); ++i) { jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr; jobs.dgrad[i] = i >= 2; }
       launch_w4_pack(jobs, aug ? 4 : 2, d.C, st);
     } else if (d.wino == 2) {   // every packing of the solve in one launch
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
@@ -499,6 +504,13 @@ struct Solver {
     launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
                      nz, st);
     if (w4) launch_w4s_tmap(p.tmap[0], p.tmap[1], p.tmapS[0], p.tmapS[1], d.C, st);
+    if (w4 && aug && d.N != d.N8 && p.W4dU != nullptr) {
+      // the weight gradient SUMS over the GEMM rows: the rows of the padding samples (never written by a pass) must be zero
+      for (int i = 0; i < 2; ++i) {
+        launch_fill(p.W4Va[i], 0.f, w4_v_elems(d.N8, d.C), st);
+        launch_fill(p.W4Z[i], 0.f, w4_z_elems(d.N8, d.C), st);
+      }
+    }
     v_ready = false;
     cur = 0;
     return check_launch("prepare");
@@ -546,7 +558,7 @@ struct Solver {
   // follows, leaves that conv's row operand in W4V again
   void w4_gemm(int which, const float* V = nullptr) {
     ProfScope ps(2, conv_flops(), st);
-    launch_w4_gemm(V ? V : p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N, d.C, st);
+    launch_w4_gemm(V ? V : p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N8, d.C, st, w4_b16 ? p.w4ub[which] : nullptr);
   }
   // the weight gradients of an augmented evaluation in the F(4x4,3x3) domain (k_w4_wgrad): needs the forward convs'
   // row operands alive behind the data-gradient convs, so they get buffers of their own
@@ -554,7 +566,7 @@ struct Solver {
   W4sArgs w4_args() const {
     W4sArgs a;
     memset(&a, 0, sizeof(a));
-    a.ctrl = p.ctrl; a.N = d.N; a.C = d.C; a.cpg = d.cpg; a.eps = d.eps;
+    a.ctrl = p.ctrl; a.N = d.N; a.Nv = d.N8; a.C = d.C; a.cpg = d.cpg; a.eps = d.eps;
     return a;
   }
   // tail 1 of a pass: stage combine -> GroupNorm-1 -> ReLU -> V (+ act1, xhat-1, 1/sigma-1 of set `set` when training)
@@ -646,7 +658,7 @@ struct Solver {
     if (need_theta && wg4) {
       W4WgradArgs wa;
       memset(&wa, 0, sizeof(wa));
-      wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N; wa.C = d.C;
+      wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
       ProfScope ps(1, 2.0 * conv_flops(), st);
       launch_w4_wgrad(wa, st);
     } else if (need_theta) {
@@ -1048,7 +1060,8 @@ int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t
 size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape) {
   if (!shape) return 0;
   const size_t numel = (size_t)shape->n * shape->c * shape->h * shape->w;
-  return (2 * numel + 2 * w4_v_elems(shape->n, shape->c) + w4_u_elems(shape->c)) * sizeof(float) + 5 * 256;
+  return (2 * numel + 2 * w4_v_elems(shape->n, shape->c) + w4_u_elems(shape->c)) * sizeof(float) +
+         w4_ub_elems(shape->c) * sizeof(unsigned short) + 6 * 256;
 }
 int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y, void* ws,
                     size_t ws_bytes, void* stream) {
@@ -1066,13 +1079,15 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   float* V = b.take<float>(w4_v_elems(d.N, d.C));
   float* M = b.take<float>(w4_v_elems(d.N, d.C));
   float* U = b.take<float>(w4_u_elems(d.C));
+  unsigned short* Ub = b.take<unsigned short>(w4_ub_elems(d.C));
   W4PackJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
-  jobs.w[0] = weight; jobs.u[0] = U; jobs.dgrad[0] = dgrad ? 1 : 0;
+  const bool b16 = w4_uses_bf16(d.N);
+  jobs.w[0] = weight; jobs.u[0] = U; jobs.ub[0] = b16 ? Ub : nullptr; jobs.dgrad[0] = dgrad ? 1 : 0;
   launch_w4_pack(jobs, 1, d.C, st);
   launch_w4s_from_nchw(x, xn, d.N, d.C, st);
   launch_w4_input(xn, V, d.N, d.C, st);
-  launch_w4_gemm(V, U, M, nullptr, d.N, d.C, st);
+  launch_w4_gemm(V, U, M, nullptr, d.N, d.C, st, b16 ? Ub : nullptr);
   launch_w4_output(M, yn, d.N, d.C, st);
   launch_w4s_to_nchw(yn, y, d.N, d.C, st);
   hipError_t e = hipGetLastError();

@@ -29,7 +29,10 @@ struct Dims {
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
   int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
                     // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
-  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, N % 8 == 0, cpg | 16.
+  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, cpg | 16.  Any batch: the
+                    // component GEMMs run on N8 = N rounded up to 8 samples (their rows are independent; the weight gradient,
+                    // which sums over rows, sees zero rows for the padding samples)
+  int N8;
                     // Whether a solve USES it depends on its tolerance (Solver::w4)
   int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
                     // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)

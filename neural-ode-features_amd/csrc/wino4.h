@@ -89,6 +89,8 @@ struct W4sTail {          // what follows the head inside the same launch
 struct W4sArgs {
   const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done
   int N, C, cpg;
+  int Nv;                 // N rounded up to the component GEMMs' row block (8 samples): strides of V, Z (rows of the padding
+                          // samples are never written and never read by anything that leaves the GEMM's own rows)
   float eps;
   W4sHead h;
   W4sTail t;
@@ -119,9 +121,14 @@ __host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_C
 __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COMPS * C * C; }
 
 // launchers (kernels_w4.hip)
-struct W4PackJobs { const float* w[4]; float* u[4]; int dgrad[4]; };
+// per job ONE of u (fp32, k_w4_gemm / k_w4_gemm64) and ub (exact bf16 triples, k_w4_gemm64b) is written: ub when non-null
+struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; };
+// which form launch_w4_gemm will read for this batch (NODE_TUNE_W4_BF16X3, read on every call)
+bool w4_uses_bf16(int N);
+__host__ __device__ inline size_t w4_ub_elems(int C) { return (size_t)W4_COMPS * C * C * 3 + 8 * 1536; }   // bf16 values (+ ring slack)
 void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
-void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s);
+void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s,
+                    const unsigned short* Ub = nullptr);
 // stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
 void launch_w4_input(const float* x_w4s, float* V, int N, int C, hipStream_t s);
 void launch_w4_output(const float* M, float* y_w4s, int N, int C, hipStream_t s);

@@ -16,7 +16,8 @@ grep '"metric"' $D.log > ${OUT}_bench.json || true
 KS=$(find $D -name '*kernel_stats.csv' | head -1)
 KT=$(find $D -name '*kernel_trace.csv' | head -1)
 cp $KS ${OUT}_kernel_stats.csv
-# bench runs WARM + STEPS (x timed_region, if a region was measured again) + 1 + min(STEPS,5) roofline-repeat steps
+# bench runs WARM + settle_steps + STEPS (x timed_region, if a region was measured again) + 2 + STEPS (drop-in region) + 1 + min(STEPS,5) roofline-repeat steps
 REGION=$(python3 -c "import json,sys; print(json.loads(open('${OUT}_bench.json').read().strip().splitlines()[-1])['config'].get('timed_region', 1))")
-python3 tools/step_profile.py $KT --warmup $((WARM + (REGION - 1) * STEPS)) --steps $STEPS --repeat 5 --gaps ${DUMP_WINDOW:+--dump ${OUT}_window.csv} > ${OUT}_steps.txt
+SETTLE=$(python3 -c "import json,sys; print(json.loads(open('${OUT}_bench.json').read().strip().splitlines()[-1])['config'].get('settle_steps', 0))")
+python3 tools/step_profile.py $KT --warmup $((WARM + SETTLE + (REGION - 1) * STEPS)) --steps $STEPS --repeat 5 --gaps --top ${TOP:-60} ${DUMP_WINDOW:+--dump ${OUT}_window.csv} > ${OUT}_steps.txt
 cat ${OUT}_steps.txt

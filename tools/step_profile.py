@@ -86,11 +86,11 @@ def report(title, steps, thr, show_gaps):
     print('%s: %d steps, %.1f dispatches/step, span %.3f ms/step, kernel time %.3f ms/step, idle %.3f ms/step (GPU busy %.1f%%)'
           % (title, k, len(flat) / k, span / 1e6 / k, tot / 1e6 / k, idle / 1e6 / k, 100.0 * (span - idle) / span))
     print('  %-64s %8s %8s %10s %9s %6s' % ('kernel', 'live/st', 'dead/st', 'live avg us', 'ms/step', '%'))
-    for n, (c, d, dead) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
+    for n, (c, d, dead) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:TOP]:
         if c:
             print('  %-64s %8.1f %8.1f %10.2f %9.3f %6.2f' % (n, c / k, dead / k, d / c / 1e3, d / 1e6 / k, 100.0 * d / tot))
     edges = [2, 5, 10, 20, 40, 60]
-    for name in ('node::k_conv3x3_w2', 'node::k_wgrad_w2<8>', 'node::k_combine_gn'):
+    for name in ('node::k_conv3x3_w2', 'node::k_w4_wgrad<8>', 'node::k_w4s_pass<1, 0>'):
         d = [(e - s) / 1e3 for s, e, n in flat if n == name]
         if d:
             hist = [sum(1 for x in d if lo <= x < hi) for lo, hi in zip([0] + edges, edges + [1e9])]
@@ -102,6 +102,9 @@ def report(title, steps, thr, show_gaps):
             print('    %-40s -> %-40s %7.1f/st %8.2f us %8.3f ms/step' % (a, b, c / k, g / c / 1e3, g / 1e6 / k))
 
 
+TOP = 22
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('trace')
@@ -109,8 +112,11 @@ def main():
     ap.add_argument('--steps', type=int, default=12)
     ap.add_argument('--repeat', type=int, default=5)
     ap.add_argument('--gaps', action='store_true')
+    ap.add_argument('--top', type=int, default=22, help='kernels listed per window')
     ap.add_argument('--dump', default=None, help='write the timed window as a compact CSV (start_ns,dur_ns,name)')
     a = ap.parse_args()
+    global TOP
+    TOP = a.top
     rows = load(a.trace)
     steps, rest = cut_steps(rows)
     thr = dead_threshold(rows)
