@@ -575,10 +575,71 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
   }
 }
 
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm_small: the component GEMMs of a batch of at most 16 samples (the bs = 1 census, evaluate.py:97-142).  The
+// throughput kernels give every wave a whole K range however few rows there are (23.9 us per launch at ONE sample);
+// here a workgroup owns ONE 32 x 32 block of one component, its four waves split K (all operand requests of a wave in
+// flight at once, 32 MFMAs at C = 256) and meet through LDS: 36 x C/32 x N8/8 workgroups, one memory round trip deep.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                       const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;
+  __shared__ __attribute__((aligned(16))) float red[4 * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int CB = gm.C >> 5, G8 = gm.G8;
+  const int cb = blockIdx.x % CB, comp = (blockIdx.x / CB) % W4_COMPS, rb = blockIdx.x / (CB * W4_COMPS);
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;
+  const int ng = G8 >> 2, g0 = wave * ng;          // this wave's K quarter (C % 64 == 0: ng is a multiple of 2)
+  const float4* pa = reinterpret_cast<const float4*>(V + (((size_t)comp * gm.RB + rb) * G8 + g0) * 256 + a_off);
+  const float4* pb = reinterpret_cast<const float4*>(U + (((size_t)comp * CB + cb) * G8 + g0) * 256 + lane * 4);
+  float16_t acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  for (int g = 0; g < ng; g += 8) {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // (clamped, not predicated: a masked request makes the compiler wait)
+      const int gi = g + i < ng ? g + i : ng - 1;
+      a[i] = pa[(size_t)gi * 64];
+      b[i] = pb[(size_t)gi * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (g + i < ng) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[i].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[i].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[i].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[i].w, acc, 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4)
+    *reinterpret_cast<float4*>(red + wave * 1024 + (r4 * 64 + lane) * 4) = make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+  __syncthreads();
+  {   // thread (r4 = wave, lane): registers 4 r4 .. 4 r4 + 3 of the block = tiles 0..3 of sample 2 r4 + hi
+    const int r4 = wave;
+    float4 s = *reinterpret_cast<const float4*>(red + (r4 * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(red + w * 1024 + (r4 * 64 + lane) * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * CB + cb) * (36 * 128) + (size_t)comp * 128 + l31;
+    mrow[0] = s.x;
+    mrow[32] = s.y;
+    mrow[64] = s.z;
+    mrow[96] = s.w;
+  }
+}
+
 bool w4_uses_bf16(int N) {
   const char* g64e = getenv("NODE_TUNE_W4_GEMM64");
   const char* b16e = getenv("NODE_TUNE_W4_BF16X3");
   const char* abe = getenv("NODE_TUNE_W4_ABLATE");
+  const char* sme = getenv("NODE_TUNE_W4_SMALL");
+  if (N <= 16 && (sme ? atoi(sme) : 1) != 0) return false;   // (k_w4_gemm_small reads the fp32 filters)
   return N % 16 == 0 && (g64e ? atoi(g64e) : 1) != 0 && (b16e ? atoi(b16e) : 1) != 0 && (abe ? atoi(abe) : 0) == 0;
 }
 
@@ -589,6 +650,12 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
+  static int smallg = -1;   // NODE_TUNE_W4_SMALL = 0: never the small-batch kernel (A/B measurements)
+  if (smallg < 0) { const char* e = getenv("NODE_TUNE_W4_SMALL"); smallg = e ? atoi(e) : 1; }
+  if (smallg && N <= 16 && ab == 0) {
+    hipLaunchKernelGGL(k_w4_gemm_small, dim3(gm.RB * W4_COMPS * (C >> 5)), dim3(256), 0, s, V, U, M, ctrl, gm);
+    return;
+  }
   const int grid = gm.RB * (C >> 6) * 4;
   const size_t lds = 8 * 2048 * sizeof(float);
 #define W4_LAUNCH(AB, SLOT)                                                               \
