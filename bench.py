@@ -290,6 +290,10 @@ def main():
                          'deferred completion with a device-predicated optimizer step (integrate.Deferred)')
     ap.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
                     help='collective backend (nccl = RCCL; gloo only for the shared-GPU smoke test)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='with --gpus 1: run the N-rank code path anyway -- process group on the chosen backend (nccl = RCCL), '
+                         'bucketed all-reduce of the gradients, the deferred-completion flag slot -- as a world of ONE rank; what '
+                         'a 1-GPU box can prove about the multi-GPU path')
     ap.add_argument('--share-gpu', action='store_true',
                     help='TESTING ONLY: ranks share the devices that exist (rank %% device_count); exercises the N-rank code '
                          'path on a 1-GPU box, the number it prints is not a measurement')
@@ -347,8 +351,10 @@ def main():
         # the GPU anyway and the capture's side-stream synchronisation only costs: 8.42 ms eager vs 8.61 ms graphed
         # (profiles/r02_deferred_ab.txt) -- so the default is eager.
         nof.graphs.capture_static_parts(model, x, stem=False, head=True)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
@@ -356,16 +362,21 @@ def main():
     reducer = None
     # SGD lr .1 momentum .9 wd 1e-4 (reproduce.sh:3-6, train.py:136): one fused launch for all parameter tensors
     opt = nof.FusedSGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-    if world > 1:
-        nof.dp.broadcast_parameters(model, 0)
+    if dist_on:
+        if world > 1:
+            nof.dp.broadcast_parameters(model, 0)
+        else:
+            for p in model.parameters():
+                dist.broadcast(p.data, src=0)
         # 2 MB buckets: the stem's gradients leave in several all-reduces while its backward is still running, so only
         # the last, small one (first conv + first block) is exposed behind it; the ODE block's 4.75 MB stay one bucket
-        reducer = nof.dp.GradientReducer(model, limits={model.downsample: 2 << 20}, average=False)   # all-reduce SUM in the bucket buffers ...
+        reducer = nof.dp.GradientReducer(model, limits={model.downsample: 2 << 20}, average=False,
+                                         collectives_at_world_1=args.force_dist)   # all-reduce SUM in the bucket buffers ...
         opt.grad_scale = 1.0 / world                             # ... its 1/world folded into the optimizer step
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -597,6 +608,7 @@ def main():
                 'solver_completion': 'read-back per solve' if deferred is None else
                                      'deferred (device-predicated optimizer step; %d blind solves, %d misses in the timed region)'
                                      % (deferred.blind_solves, timed_misses),
+                'collectives': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if dist_on else 'none (one rank)',
                 'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'hipGraph' if args.graphs else 'eager',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
@@ -610,7 +622,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(init_state, cfg, args.method)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -84,13 +84,17 @@ class GradientReducer:
     """Bucketed, overlapped gradient reduction without a copy-back (see the module docstring)."""
 
     def __init__(self, model: nn.Module, bucket_bytes: int = 32 << 20, process_group=None,
-                 boundaries: Optional[Iterable[nn.Module]] = None, average: bool = True, limits=None):
+                 boundaries: Optional[Iterable[nn.Module]] = None, average: bool = True, limits=None,
+                 collectives_at_world_1: bool = False):
         """`average=False` leaves the SUM in the buckets for an optimizer that folds 1/world into its step
         (`optim.FusedSGD.grad_scale`).  `limits`: {sub-module: bucket bytes} overriding `bucket_bytes` for the
         parameters of that sub-module (the stem's gradients arrive one layer at a time and are worth sending in
         pieces while its backward runs; the ODE block's arrive all at once and travel best as one bucket)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # run the packing + all-reduce machinery even with ONE rank (a sum over one rank): lets a 1-GPU box execute the
+        # N-rank code path on the real RCCL backend (bench.py --force-dist, tests/test_gpu_optim.py)
+        self.always = bool(collectives_at_world_1) and dist.is_initialized()
         self.average = average
         params = [p for p in model.parameters() if p.requires_grad]
         # cut buckets at sub-module boundaries (head | ode block | stem) first, then by size and dtype/device
@@ -170,7 +174,7 @@ class GradientReducer:
 
     def _launch(self, b: _Bucket):
         b.launched = True
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         b.ensure_flat()
         # pack: gradients that already live in their slice (a caller that zeroes in place instead of dropping them)
@@ -195,7 +199,7 @@ class GradientReducer:
         """Wait for every in-flight all-reduce (and average in place unless `average=False`).  Buckets whose hooks
         did not all fire (parameters unused this step) are launched here, in bucket order -- the same order on
         every rank."""
-        if self.world > 1:
+        if self.world > 1 or self.always:
             for b in self.buckets:
                 if not b.launched:
                     self._launch(b)

@@ -95,7 +95,7 @@ class FusedSGD(torch.optim.Optimizer):
     def use_deferred(self, deferred, reducer=None):
         """Predicate the update on `deferred`'s miss flag (see integrate.Deferred).  Under data parallelism the flag
         travels in the reducer's last bucket, so that every rank skips an update any rank missed."""
-        if reducer is not None and reducer.world > 1:
+        if reducer is not None and (reducer.world > 1 or getattr(reducer, 'always', False)):
             self.skip_flag = reducer.carry_flag(deferred.miss_flag)
         else:
             self.skip_flag = deferred.miss_flag

@@ -135,6 +135,29 @@ def test_bench_two_ranks_through_self_launcher_on_one_gpu():
 
 
 @pytest.mark.timeout(900)
+def test_bench_one_rank_through_rccl():
+    """What a 1-GPU box can prove about the multi-GPU path on the REAL backend: `bench.py --force-dist` runs a world of
+    one rank through init_process_group('nccl', device_id=...), parameter broadcast, the reducer's bucket packing and
+    asynchronous all-reduces (RCCL, sum over one rank), the deferred-completion flag slot riding in the last bucket, and
+    FusedSGD reading the reduced gradients in place.  The rate must match the plain single-GPU path within a few percent
+    (the collectives are local copies): it is printed, not asserted, because boxes differ."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '6', '--warmup', '3',
+                        '--no-cpu-baseline', '--no-roofline', '--no-dropin'], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    print('one rank through RCCL:', d['value'], 'images/s;', d['config']['collectives'], d['config']['solver_completion'])
+    assert d['n_gpus'] == 1 and 'RCCL' in d['config']['collectives'] and d['value'] > 0
+    assert 'deferred' in d['config']['solver_completion'] and '0 misses' in d['config']['solver_completion']
+
+
+@pytest.mark.timeout(900)
 def test_bench_line_carries_the_contract_keys():
     """`python bench.py` (N = 1): ONE JSON line with the driver's keys, the roofline object of the dominant kernel and
     the CPU baseline; the roofline fraction is a utilisation (<= 1), the algorithmic figure lives under its own key."""
