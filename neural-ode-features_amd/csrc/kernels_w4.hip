@@ -391,6 +391,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
 // of the fp32 MFMA chain (tools/bf16x3 check in tests/test_gpu_w4.py: same 3.2e-6-of-max|y| convolution error).
 // Same decomposition, layouts of V and M, and XCD placement as k_w4_gemm64; a lane's eight K values of a step are
 // channels {8 g + 4 hi + e} of TWO consecutive g blocks (two of the 16-B loads the fp32 kernel issues too).
+// 24.4 -> 19.6 us per launch at cfg 2.  (Measured and not kept: the same products with the operands shared through LDS
+// -- 128 x 128 tiles per workgroup, three LDS buffers, fragments prefetched under the MFMAs, L2 -> CU traffic 448
+// instead of 768 KB per CU -- 21.5 - 22.8 us: what bounds the launch now is its 52 MB through the fabric plus fill and
+// drain, not the per-CU operand stream.)
 // ----------------------------------------------------------------------------
 typedef __bf16 w4_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 w4_bf16x2 __attribute__((ext_vector_type(2)));
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
   }
 }
 
+
 bool w4_uses_bf16(int N) {
   const char* g64e = getenv("NODE_TUNE_W4_GEMM64");
   const char* b16e = getenv("NODE_TUNE_W4_BF16X3");
@@ -703,6 +708,9 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
 // the layout the conv wants; a lane's 16 B of Z hold four ROWS of one co ([comp][co/32][sample][co%32][tile]: one
 // contiguous 1 KB per wave request).  Workgroup j of every tile runs on XCD j: its 4.5 components of V and Z stream
 // through that XCD's L2 once.  Needs N % 8 == 0, C % 128 == 0.
+// (Round 3, measured: the same kernel on the bf16 pipe -- both operands split into exact bf16 triples in registers, as
+// k_w4_gemm64b does -- takes the same 42 us: at 94 MB of operands and results per launch the memory side, not the
+// matrix pipe, bounds it.  So it stays on the fp32 instructions.)
 // ----------------------------------------------------------------------------
 struct W4WgOps { float4 a0, a1, a2, a3, z; };
 template <int NSUB>
@@ -831,6 +839,7 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
     }
   }
 }
+
 
 void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s) {
   const int grid = 2 * (a.C >> 7) * (a.C >> 5) * 8;
