@@ -421,6 +421,45 @@ def test_three_stacked_blocks():
         assert float((v.grad.cpu() - w.grad).abs().max()) / scale < 2e-2, k
 
 
+@pytest.mark.timeout(900)
+def test_cfg5_full_size_three_blocks_properties():
+    """BASELINE configs[4] at its per-GPU size: 64 images of 64x64, 1024 filters, three stacked ODE blocks (state
+    [64, 1024, 16, 16], 18.9 M parameters per block), one training iteration.  No CPU checker finishes this size in
+    test time, so size-independent properties: the NFE law per block (2 + 6 steps forward, 3 + 6 steps backward,
+    show.py:199 / SURVEY 8c), finite non-trivial gradients everywhere, and sample independence of a block's solve under
+    a forced step sequence (the only cross-sample coupling is the error norm)."""
+    import neural_ode_features_amd as nof
+    torch.manual_seed(23)
+    net = nof.StackedODENet(3, out=10, n_filters=1024, n_blocks=3, downsample='residual', method='dopri5', tol=1e-3,
+                            adjoint=True, t1=1, dropout=0).cuda().train()
+    gen = torch.Generator().manual_seed(51)
+    x = torch.randn(64, 3, 64, 64, generator=gen).cuda()
+    y = torch.randint(0, 10, (64,), generator=gen).cuda()
+    p = net(x)
+    loss = F.cross_entropy(p, y)
+    nfe_f = net.nfe(reset=True)
+    fst = [b.odefunc.last_forward_stats for b in net.odeblocks]
+    assert nfe_f == sum(2 + 6 * (s['accepted'] + s['rejected']) for s in fst), (nfe_f, fst)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    bst = [b.odefunc.last_backward_stats for b in net.odeblocks]
+    assert nfe_b == sum(3 + 6 * (s['accepted'] + s['rejected']) for s in bst), (nfe_b, bst)
+    assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(loss))
+    for k, v in net.named_parameters():
+        assert v.grad is not None and bool(torch.isfinite(v.grad).all()), k
+    assert all(float(b.odefunc.conv1._layer.weight.grad.abs().max()) > 0 for b in net.odeblocks)
+    print('cfg 5 full size: forward steps', [(s['accepted'], s['rejected']) for s in fst], 'backward', [(s['accepted'], s['rejected']) for s in bst])
+    f = net.odeblocks[0].odefunc
+    y0 = torch.randn(64, 1024, 16, 16, generator=gen).cuda()
+    t = torch.tensor([0.0, 1.0]).cuda()
+    dts = [0.2, 0.3, 0.5]
+    with torch.no_grad():
+        full = nof.odeint(f, y0, t, rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
+        part = nof.odeint(f, y0[8:40].contiguous(), t, rtol=1e-3, atol=1e-3, options={'forced_dts': dts})[-1]
+    assert bool(torch.isfinite(full).all())
+    assert float((full[8:40] - part).abs().max()) <= 2e-5 * float(full.abs().max())
+
+
 def test_blind_step_enqueue_over_and_under_prediction():
     """The step loop enqueues as many steps as the previous solve of the same problem class took before it reads
     anything back.  Alternating inputs that need more / fewer steps exercises both outcomes: steps enqueued past the
