@@ -207,7 +207,7 @@ def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
                       % (done, bs, nf, nb, dt)}
 
 
-def pmc_measure(state, conv_path_env, timeout=420):
+def pmc_measure(state, conv_path_env, timeout=180):
     """HBM bytes per launch of every library kernel of an augmented dynamics evaluation at this workload's state shape,
     MEASURED in this run: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no
     trace domain, the program itself behind `--`) over tools/prof_eval.py, started BEFORE this process touches the GPU.
