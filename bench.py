@@ -207,7 +207,7 @@ def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
                       % (done, bs, nf, nb, dt)}
 
 
-def pmc_measure(state, conv_path_env, timeout=180):
+def pmc_measure(state, conv_path_env, timeout=(300, 180)):
     """HBM bytes per launch of every library kernel of an augmented dynamics evaluation at this workload's state shape,
     MEASURED in this run: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no
     trace domain, the program itself behind `--`) over tools/prof_eval.py, started BEFORE this process touches the GPU.
@@ -225,12 +225,12 @@ def pmc_measure(state, conv_path_env, timeout=180):
     env.update(conv_path_env)
     env['TMPDIR'] = '/tmp'
     got = {}
-    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for ci, counter in enumerate(('FETCH_SIZE', 'WRITE_SIZE')):   # (the first child may pay the cold `import torch` of a fresh box)
         d = tempfile.mkdtemp(prefix='node_pmc_', dir='/tmp')
         cmd = [rocprof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
                os.path.join(ROOT, 'tools', 'prof_eval.py'), '--shape', ','.join(str(v) for v in state), '--iters', '4']
         try:
-            r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout)
+            r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout[ci])
             if r.returncode != 0:
                 return None
             acc = {}

@@ -36,7 +36,10 @@
 
 namespace node {
 
-constexpr int W4S_THREADS = 128;   // two waves = 32 channels of one sample: whole 128-B lines of M, V and the NHWC copies
+#ifndef W4S_THREADS_DEF
+#define W4S_THREADS_DEF 128
+#endif
+constexpr int W4S_THREADS = W4S_THREADS_DEF;   // two waves = 32 channels of one sample: whole 128-B lines of M, V and the NHWC copies
 
 template <int CTRL>
 __device__ __forceinline__ float w4s_dpp(float v) {
