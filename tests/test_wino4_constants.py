@@ -50,3 +50,52 @@ def test_header_matrices_belong_to_the_points_the_header_names():
         for j, p in enumerate(pts):
             assert abs(AT[i, j] - p ** i) < 1e-15
         assert AT[i, 5] == (1.0 if i == 3 else 0.0)
+
+
+def test_weight_gradient_identity_in_the_f4x4_domain():
+    """What k_w4_wgrad + k_theta_finalize compute (csrc/kernels_w4.hip): with V = B^T d B the conv's own row operand and
+    Z = A dz A^T of the output cotangent, dW = G^T (sum over tiles V * Z) G is the weight gradient of the 3x3 correlation
+    -- checked in fp64 on an 8x8 image (2x2 tiles with the zero halo the pipeline uses) against the direct sum."""
+    text = open(os.path.join(ROOT, 'neural-ode-features_amd', 'csrc', 'wino4.h')).read()
+    BT, AT, G = _matrix(text, 'W4_BT'), _matrix(text, 'W4_AT'), _matrix(text, 'W4_G')
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((8, 8))
+    dz = rng.standard_normal((8, 8))
+    xp = np.pad(x, 1)
+    ref = np.array([[sum(dz[i, j] * xp[i + a, j + b] for i in range(8) for j in range(8)) for b in range(3)] for a in range(3)])
+    dU = np.zeros((6, 6))
+    for ty in range(2):
+        for tx in range(2):
+            d = xp[4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6]
+            V = BT @ d @ BT.T
+            Z = AT.T @ dz[4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] @ AT
+            dU += V * Z
+    dW = G.T @ dU @ G
+    assert np.abs(dW - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_bf16_triples_are_exact_and_six_products_carry_fp32_accuracy():
+    """The scheme of k_w4_gemm64b: every fp32 value is the EXACT sum of three bf16 values (round-to-nearest splits of the
+    successive remainders), and the six products hh, hm, mh, mm, hl, lh reproduce an fp32 x fp32 product to ~2^-22: against
+    an fp64 matrix product the error from the three dropped products is far below the fp32 accumulation rounding."""
+    import torch
+    gen = torch.Generator().manual_seed(0)
+
+    def split3(x):
+        h = x.to(torch.bfloat16)
+        r = x - h.float()
+        m = r.to(torch.bfloat16)
+        s = r - m.float()
+        lo = s.to(torch.bfloat16)
+        return h.float(), m.float(), lo.float()
+
+    A = torch.randn(256, 128, generator=gen) * 3
+    B = (torch.rand(128, 64, generator=gen) * 2 - 1) / 48
+    ah, am, al = split3(A)
+    bh, bm, bl = split3(B)
+    assert torch.equal(ah + am + al, A) and torch.equal(bh + bm + bl, B)
+    ref = A.double() @ B.double()
+    six = sum(p.double() @ q.double() for p, q in ((ah, bh), (ah, bm), (am, bh), (am, bm), (ah, bl), (al, bh)))
+    assert float((six - ref).abs().max() / ref.abs().max()) < 2e-7 / 4          # truncation of the dropped terms alone
+    three = sum(p.double() @ q.double() for p, q in ((ah, bh), (ah, bm), (am, bh)))
+    assert float((three - ref).abs().max() / ref.abs().max()) > 1e-6            # ... which three products would not give
