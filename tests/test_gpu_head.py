@@ -102,29 +102,45 @@ def test_gn_relu_forward_backward_match_torch(shape, relu):
 
 
 def test_resblock_fused_matches_plain_modules():
+    """The fused GroupNorm(+ReLU) kernels inside a ResBlock against the plain modules, the convolutions on both sides
+    being MIOpen's.  MIOpen is PINNED for this test (no algorithm search, deterministic kernels, both paths warmed once):
+    on a fresh box its backward kernels for a geometry could differ between the first and the second call (search result
+    vs immediate fallback; seen once in six runs in round 2: input gradients 4e-3 apart with bit-identical GroupNorm
+    kernels), which had forced a 2e-2 bound that no longer caught a sub-percent defect of the fused backward.  The
+    GroupNorm kernels alone are held to 2e-5 by test_gn_relu_forward_backward_match_torch at the stem's own shapes."""
     import neural_ode_features_amd as nof
     from torch import nn
-    torch.manual_seed(3)
-    blk = nof.ResBlock(64, 256, stride=2, downsample=nn.Conv2d(64, 256, 1, 2, bias=False)).cuda()
-    x = torch.randn(8, 64, 15, 15, device='cuda')
-    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    fused = blk(xa)
-    pre = blk.relu(blk.norm1(xb))
-    plain = blk.conv2(blk.relu(blk.norm2(blk.conv1(pre)))) + blk.downsample(pre)
-    assert rel_err(fused, plain) < 2e-5
-    w = torch.randn_like(fused)
-    blk.zero_grad()
-    (fused * w).sum().backward()
-    gf = {k: v.grad.clone() for k, v in blk.named_parameters()}
-    blk.zero_grad()
-    (plain * w).sum().backward()
-    # The convolutions on both sides are MIOpen's.  On a fresh box its backward kernels for a geometry can differ
-    # between the first and the second call (search result vs immediate fallback); measured once in six runs: the
-    # two input gradients then differ by 4e-3 relative with bit-identical GroupNorm kernels.  A defect in the fused
-    # GroupNorm(+ReLU) backward is O(1), so the bound is set above the library's algorithm-to-algorithm spread.
-    assert rel_err(xa.grad, xb.grad) < 2e-2
-    for k, v in blk.named_parameters():
-        assert rel_err(gf[k], v.grad) < 2e-2, k
+    old = (torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic)
+    torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = False, True
+    try:
+        torch.manual_seed(3)
+        blk = nof.ResBlock(64, 256, stride=2, downsample=nn.Conv2d(64, 256, 1, 2, bias=False)).cuda()
+        x = torch.randn(8, 64, 15, 15, device='cuda')
+
+        def fused_path(inp):
+            return blk(inp)
+
+        def plain_path(inp):
+            pre = blk.relu(blk.norm1(inp))
+            return blk.conv2(blk.relu(blk.norm2(blk.conv1(pre)))) + blk.downsample(pre)
+
+        w = torch.randn(8, 256, 8, 8, device='cuda')
+        for path in (fused_path, plain_path):           # warm both: every convolution geometry has run once each way
+            xi = x.clone().requires_grad_(True)
+            (path(xi) * w).sum().backward()
+        blk.zero_grad()
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        fused, plain = fused_path(xa), plain_path(xb)
+        assert rel_err(fused, plain) < 2e-5
+        (fused * w).sum().backward()
+        gf = {k: v.grad.clone() for k, v in blk.named_parameters()}
+        blk.zero_grad()
+        (plain * w).sum().backward()
+        assert rel_err(xa.grad, xb.grad) < 1e-3
+        for k, v in blk.named_parameters():
+            assert rel_err(gf[k], v.grad) < 1e-3, k
+    finally:
+        torch.backends.cudnn.benchmark, torch.backends.cudnn.deterministic = old
 
 
 def test_stem_and_head_on_gpu_match_the_reference_logits():
