@@ -7,6 +7,20 @@ namespace node {
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
 
+// Big once-written, once-read results (M, dU): stored WRITE-THROUGH (agent scope = sc1 on gfx950) so that they leave the
+// XCD's L2 while the kernel still runs instead of as one write-back burst at its end (MI355X_MICROARCH.md, `boundary`:
+// + B / 6 TB/s behind B dirty bytes).  NODE_WT_STORES=0 at build time: plain stores (A/B measurements).
+#ifndef NODE_WT_STORES
+#define NODE_WT_STORES 1
+#endif
+__device__ __forceinline__ void st_wt(float* p, float v) {
+#if NODE_WT_STORES
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
 // ----------------------------------------------------------------------------
 // U = G g G^T for every (co, ci) pair, written in MFMA-ready blocks (wino4.h).  dgrad: the data-gradient filter
 // g'[ci][co][kh][kw] = g[co][ci][2-kh][2-kw].  Weights are [C][C+1][3][3] (input channel 0 = time, model.py:320-323).
@@ -531,10 +545,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
-      o[0] = acc[0][0][q];
-      o[36 * 128] = acc[0][1][q];
-      o[8 * sstride] = acc[1][0][q];
-      o[8 * sstride + 36 * 128] = acc[1][1][q];
+      st_wt(o, acc[0][0][q]);
+      st_wt(o + 36 * 128, acc[0][1][q]);
+      st_wt(o + 8 * sstride, acc[1][0][q]);
+      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q]);
     }
   }
   // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
@@ -571,10 +585,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
-      mrow[0] = s.x;
-      mrow[32] = s.y;
-      mrow[64] = s.z;
-      mrow[96] = s.w;
+      st_wt(mrow, s.x);
+      st_wt(mrow + 32, s.y);
+      st_wt(mrow + 64, s.z);
+      st_wt(mrow + 96, s.w);
     }
   }
 }
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * h;          // accumulator row -> ci = 8 (m >> 1) + 4 (m & 1) + e
-        o[(size_t)(8 * (m >> 1) + 4 * (m & 1) + e) * C] = acc[e][r];
+        st_wt(o + (size_t)(8 * (m >> 1) + 4 * (m & 1) + e) * C, acc[e][r]);
       }
   }
   // --- two accumulator blocks of a shared component: reduction range [wave Q/4, (wave+1) Q/4) per wave
@@ -834,7 +848,7 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = i + 8 * r4 + 4 * h;                       // register 4 r4 + i of the block
-        o[(size_t)(8 * (m >> 1) + 4 * (m & 1) + ee) * C] = sv[i];
+        st_wt(o + (size_t)(8 * (m >> 1) + 4 * (m & 1) + ee) * C, sv[i]);
       }
     }
   }

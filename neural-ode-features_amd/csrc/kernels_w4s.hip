@@ -41,6 +41,18 @@ namespace node {
 #endif
 constexpr int W4S_THREADS = W4S_THREADS_DEF;   // two waves = 32 channels of one sample: whole 128-B lines of M, V and the NHWC copies
 
+// V and Z -- written once here, read once by the next GEMM -- leave write-through (see st_wt in kernels_w4.hip)
+#ifndef NODE_WT_STORES
+#define NODE_WT_STORES 1
+#endif
+__device__ __forceinline__ void w4s_st_wt(float* p, float v) {
+#if NODE_WT_STORES
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+
 template <int CTRL>
 __device__ __forceinline__ float w4s_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -132,12 +144,12 @@ __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, 
   for (int l = 0; l < 6; ++l) {
     float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
     w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
-    vp[(size_t)(0 * 6 + l) * cstride] = v0;
-    vp[(size_t)(1 * 6 + l) * cstride] = v1;
-    vp[(size_t)(2 * 6 + l) * cstride] = v2;
-    vp[(size_t)(3 * 6 + l) * cstride] = v3;
-    vp[(size_t)(4 * 6 + l) * cstride] = v4;
-    vp[(size_t)(5 * 6 + l) * cstride] = v5;
+    w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
+    w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
+    w4s_st_wt(vp + (size_t)(2 * 6 + l) * cstride, v2);
+    w4s_st_wt(vp + (size_t)(3 * 6 + l) * cstride, v3);
+    w4s_st_wt(vp + (size_t)(4 * 6 + l) * cstride, v4);
+    w4s_st_wt(vp + (size_t)(5 * 6 + l) * cstride, v5);
   }
 }
 
@@ -163,12 +175,12 @@ __device__ __forceinline__ void w4s_emit_z(const float a[4][4], int n, int N, in
   for (int nu = 0; nu < 6; ++nu) {
     float z0, z1, z2, z3, z4, z5;   // Z[xi][nu] = sum_i A^T[i][xi] w[i][nu]
     w4s_a6(w[0][nu], w[1][nu], w[2][nu], w[3][nu], z0, z1, z2, z3, z4, z5);
-    zp[(size_t)(0 * 6 + nu) * cs] = z0;
-    zp[(size_t)(1 * 6 + nu) * cs] = z1;
-    zp[(size_t)(2 * 6 + nu) * cs] = z2;
-    zp[(size_t)(3 * 6 + nu) * cs] = z3;
-    zp[(size_t)(4 * 6 + nu) * cs] = z4;
-    zp[(size_t)(5 * 6 + nu) * cs] = z5;
+    w4s_st_wt(zp + (size_t)(0 * 6 + nu) * cs, z0);
+    w4s_st_wt(zp + (size_t)(1 * 6 + nu) * cs, z1);
+    w4s_st_wt(zp + (size_t)(2 * 6 + nu) * cs, z2);
+    w4s_st_wt(zp + (size_t)(3 * 6 + nu) * cs, z3);
+    w4s_st_wt(zp + (size_t)(4 * 6 + nu) * cs, z4);
+    w4s_st_wt(zp + (size_t)(5 * 6 + nu) * cs, z5);
   }
 }
 
@@ -204,8 +216,22 @@ __device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, int ty, 
 }
 
 __device__ __forceinline__ float4 w4s_ld4(const float* p, size_t f4) { return reinterpret_cast<const float4*>(p)[f4]; }
+// state tensors (k, k_a, y1, xhat): plain 16-B stores.  (Measured, round 3: as two 8-byte write-through stores per vector the
+// step was 3 % SLOWER -- these tensors are read again by the kernels right behind, partly out of the same L2s; the
+// write-through stores of M / V / Z / dU, read once by a kernel with another workgroup -> XCD map, gave + 1.4 %.)
+#ifndef NODE_WT_STATE
+#define NODE_WT_STATE 0
+#endif
 __device__ __forceinline__ void w4s_st4(float* p, size_t f4, const float r[4]) {
+#if NODE_WT_STORES && NODE_WT_STATE
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p + 4 * f4);
+  const f32x2_t lo = {r[0], r[1]}, hi = {r[2], r[3]};
+  __hip_atomic_store(q, __builtin_bit_cast(unsigned long long, lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, __builtin_bit_cast(unsigned long long, hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
   reinterpret_cast<float4*>(p)[f4] = make_float4(r[0], r[1], r[2], r[3]);
+#endif
 }
 
 // y + sum_j cf[j] k[j] on the thread's 16 pixels, every request issued before the first use (NK is a compile-time
