@@ -316,7 +316,7 @@ def main():
         # anything here initialises the GPU.  Single evaluations take the tolerance-gated F(4x4,3x3) pipeline only when
         # forced, so the children run with the conv path the timed solves will take.
         w4_default = os.environ.get('NODE_TUNE_WINO4', '1')
-        takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 1e-4 and side == 8 and w4_default != '0'
+        takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 0.99e-5 and side == 8 and w4_default != '0'
         pmc = pmc_measure(state, {'NODE_TUNE_WINO4': '2' if takes_w4 else '0'})
 
     import torch

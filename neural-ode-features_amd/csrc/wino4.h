@@ -121,6 +121,9 @@ __host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_C
 __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COMPS * C * C; }
 
 // launchers (kernels_w4.hip)
+// smallest rtol / atol of an adaptive solve that takes the pipeline (Solver::choose_w4 has the error budget); a hair under
+// 1e-5 so that a tolerance that went through a float keeps comparing equal
+constexpr float W4_MIN_TOL = 0.99e-5f;
 // per job ONE of u (fp32, k_w4_gemm / k_w4_gemm64) and ub (exact bf16 triples, k_w4_gemm64b) is written: ub when non-null
 struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; };
 // which form launch_w4_gemm will read for this batch (NODE_TUNE_W4_BF16X3, read on every call)

@@ -115,7 +115,7 @@ def _replay_triplet(shape, tol, seed, t_end):
 @contextlib.contextmanager
 def _wino4(mode):
     """NODE_TUNE_WINO4 for the calls inside: 0 = F(2x2,3x3) conv kernels everywhere, 1 = the library's default
-    (F(4x4,3x3) pipeline for dopri5 solves of 8x8 states at rtol, atol >= 1e-4; csrc/wino4.h)."""
+    (F(4x4,3x3) pipeline for dopri5 solves of 8x8 states at rtol, atol >= 1e-5; csrc/wino4.h)."""
     old = os.environ.get('NODE_TUNE_WINO4')
     os.environ['NODE_TUNE_WINO4'] = str(mode)
     try:
@@ -127,8 +127,9 @@ def _wino4(mode):
             os.environ['NODE_TUNE_WINO4'] = old
 
 
-def test_full_size_adjoint_solve_w4_fp64_arbiter():
-    """The same arbiter set-up on the F(4x4,3x3) pipeline (what a tol 1e-3 solve of this shape runs by default).  Its
+@pytest.mark.parametrize('tol,t_end', [(1e-3, 1.0), (1e-5, 0.3)])
+def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end):
+    """The same arbiter set-up on the F(4x4,3x3) pipeline (what a tol >= 1e-5 solve of this shape runs by default).  Its
     convolutions round at 3.2e-6 of max|y| instead of 4.9e-7, so more pre-activations land on the other side of a
     ReLU than in the fp64 run: the per-SAMPLE max-norm distance (median 7e-4; F(2x2,3x3) 1.6e-5, fp32 oracle 3e-7)
     no longer sits at the fp32 oracle's level, each flip moving a handful of entries.  In relative L2 norm -- what
@@ -136,15 +137,15 @@ def test_full_size_adjoint_solve_w4_fp64_arbiter():
     (measured: grad_y0 5.3e-4 against the oracle's 5.0e-4; parameter tensors 2.2e-4 ... 8.9e-4 against 2.3e-4 ...
     7.9e-4), the output within 10 x atol (BASELINE.json north_star), and the free-running solve must reproduce its
     own replay to rounding."""
-    tol = 1e-3
     with _wino4(1):
-        hip, o32, o64, free = _replay_triplet((128, 256, 8, 8), tol, seed=52, t_end=1.0)
+        hip, o32, o64, free = _replay_triplet((128, 256, 8, 8), tol, seed=52, t_end=t_end)
     assert float((hip['out'][-1].double() - o64['out'][-1]).abs().max()) <= 10 * tol
     l2_hip = float((hip['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
     l2_cpu = float((o32['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
     per = (hip['gy'].double() - o64['gy']).abs().flatten(1).amax(dim=1) / o64['gy'].abs().max()
-    print('F(4x4,3x3) tol 1e-3: grad_y0 relative L2 distance to fp64: HIP %.3e (fp32 oracle %.3e); per-sample max-norm '
-          'median %.3e max %.3e' % (l2_hip, l2_cpu, float(per.median()), float(per.max())))
+    print('F(4x4,3x3) tol %g: out max err %.3e; grad_y0 relative L2 distance to fp64: HIP %.3e (fp32 oracle %.3e); per-sample '
+          'max-norm median %.3e max %.3e' % (tol, float((hip['out'][-1].double() - o64['out'][-1]).abs().max()), l2_hip, l2_cpu,
+                                              float(per.median()), float(per.max())))
     assert l2_hip <= 3.0 * l2_cpu + 1e-4
     assert float(per.median()) <= 10 * tol
     C = 256

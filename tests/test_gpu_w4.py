@@ -166,12 +166,17 @@ def test_w4_odefunc_forward_and_vjp_match_oracle(shape):
     assert errs['f'] < 3e-5 and errs['vjp_y'] < 1e-4 and errs['vjp_params'] < 1e-4 and errs['vjp_t'] < 1e-4, errs
 
 
-def test_w4_solve_matches_f2_and_oracle_tolerance():
-    """dopri5 at tol 1e-3 takes the F(4x4,3x3) path by itself; with it off the same solve runs on F(2x2,3x3)."""
+@pytest.mark.parametrize('tol,gain', [(1e-3, 1.0), (1e-5, 1.0), (1e-5, 4.0), (1e-5, 12.0)])
+def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain):
+    """dopri5 at tol >= 1e-5 takes the F(4x4,3x3) path by itself; with it off the same solve runs on F(2x2,3x3).
+    `gain` scales the last GroupNorm's weight, i.e. |f|: the stiffer cases take many steps with rejections among them, so
+    that the conv noise meets a step controller that is working (Solver::choose_w4 has the error budget: <= 5 % of tol)."""
     import neural_ode_features_amd as nof
     N, Cc = 16, 64
     assert _engaged(N, Cc)
     f, _ = make_func(Cc, seed=2, device='cuda', kink_free=True)
+    with torch.no_grad():
+        f.norm3.weight.mul_(gain)
     gen = torch.Generator().manual_seed(21)
     y0 = torch.randn(N, Cc, 8, 8, generator=gen).cuda()
     t = torch.tensor([0.0, 1.0]).cuda()
@@ -182,14 +187,19 @@ def test_w4_solve_matches_f2_and_oracle_tolerance():
                 p.grad = None
             y = y0.clone().requires_grad_(True)
             f.nfe = 0
-            out = nof.odeint_adjoint(f, y, t, rtol=1e-3, atol=1e-3, method='dopri5')[-1]
+            out = nof.odeint_adjoint(f, y, t, rtol=tol, atol=tol, method='dopri5')[-1]
             nf = f.nfe
             out.square().sum().backward()
             outs.append(out.detach())
             grads.append((y.grad.detach().clone(), torch.cat([p.grad.reshape(-1) for p in f.parameters()])))
             nfes.append((nf, f.nfe - nf))
-    assert nfes[0] == nfes[1], nfes
-    assert float((outs[0] - outs[1]).abs().max()) < 1e-3           # 10 x atol would be 1e-2
+    scale = float(outs[0].abs().max())
+    print('tol %g gain %g: nfe F(2x2) %s F(4x4) %s, max|y| %.2f, out diff %.2e, grad rel %.2e / %.2e'
+          % (tol, gain, nfes[0], nfes[1], scale, float((outs[0] - outs[1]).abs().max()),
+             rel_err(grads[1][0], grads[0][0]), rel_err(grads[1][1], grads[0][1])))
+    # the same step sequence, up to one accept/reject decision that sat within the noise (6 evaluations per step)
+    assert abs(nfes[0][0] - nfes[1][0]) <= 6 and abs(nfes[0][1] - nfes[1][1]) <= 6, nfes
+    assert float((outs[0] - outs[1]).abs().max()) < 10 * tol * (1 + scale)      # north star: 10 x (atol + rtol |y|)
     assert rel_err(outs[1], outs[0]) < 1e-4
     assert rel_err(grads[1][0], grads[0][0]) < 1e-3
     assert rel_err(grads[1][1], grads[0][1]) < 1e-3
