@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
 HBM_PEAK_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s is what a streaming copy reaches)
 
 # BASELINE.json configs (1-based like SURVEY.md 8d); per-GPU batch
@@ -316,7 +317,7 @@ def main():
         # anything here initialises the GPU.  Single evaluations take the tolerance-gated F(4x4,3x3) pipeline only when
         # forced, so the children run with the conv path the timed solves will take.
         w4_default = os.environ.get('NODE_TUNE_WINO4', '1')
-        takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 0.99e-5 and side == 8 and w4_default != '0'
+        takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 0.99e-5 and side in (8, 16) and w4_default != '0'
         pmc = pmc_measure(state, {'NODE_TUNE_WINO4': '2' if takes_w4 else '0'})
 
     import torch
@@ -491,7 +492,7 @@ def main():
         k = prof['conv3x3_implicit_gemm']
         k4 = prof['w4_component_gemm']
         if k4['launches'] > k['launches']:
-            # the convs ran as the F(4x4,3x3) pipeline (dopri5 at rtol, atol >= 1e-4 on 8x8 states): the dominant kernel
+            # the convs ran as the F(4x4,3x3) pipeline (dopri5 at rtol, atol >= 1e-5 on 8x8 / 16x16 states): the dominant kernel
             # is the component GEMM; the transforms around it run inside the GroupNorm passes
             avg_ms = k4['total_ms'] / k4['launches']
             algo_per_launch = k4['flops'] / k4['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
@@ -509,27 +510,41 @@ def main():
                                                 'quoted against this launch alone'},
                         'note': 'achieved/frac = MFMA FLOPs issued (0.25 of the direct-convolution FLOPs) over the fp32 matrix '
                                 'peak, i.e. matrix-pipe utilisation of the dominant kernel'}
-            if os.environ.get('NODE_TUNE_W4_BF16X3', '1') != '0' and cfg['batch'] % 16 == 0 and os.environ.get('NODE_TUNE_W4_GEMM64', '1') != '0':
+            quads = 4 if side == 16 else 1     # a 16x16 image runs as four 8x8 quadrants = four "samples" of the GEMMs' layouts
+            if os.environ.get('NODE_TUNE_W4_BF16X3', '1') != '0' and (cfg['batch'] * quads) % 16 == 0 and os.environ.get('NODE_TUNE_W4_GEMM64', '1') != '0':
                 # k_w4_gemm64b: the same products on the bf16 matrix pipe at fp32 accuracy (every fp32 operand an exact sum
-                # of three bf16 parts, six of the nine part products).  Its arithmetic intensity -- 14.5 GFLOP issued over
-                # 52 MB (V fp32 + the filters' bf16 triples + M fp32) = 279 FLOP/B -- sits left of the bf16 ridge
-                # (2500 TFLOP/s / 8 TB/s = 312 FLOP/B): the HBM side bounds it.
-                C, Nn = cfg['filters'], cfg['batch']
+                # of three bf16 parts, six of the nine part products).  Which side bounds it depends on the reduction
+                # length C: at cfg 2 14.5 GFLOP issued over 52 MB (V fp32 + the filters' bf16 triples + M fp32) =
+                # 279 FLOP/B sits left of the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312 FLOP/B) -> HBM; at cfg 5
+                # (C = 1024) 464 GFLOP over 528 MB = 878 FLOP/B -> the matrix pipe.  The other view is reported next to it.
+                C, Nn = cfg['filters'], cfg['batch'] * quads
                 bytes_algo = 36.0 * 4 * Nn * C * 4 * 2 + 36.0 * C * C * 6
                 tbs = bytes_algo / (avg_ms * 1e-3) / 1e12
-                issued_bf16 = algo_per_launch * issued * 6.0 / (avg_ms * 1e-3) / 1e12
-                roofline.update({
-                    'bound': 'hbm', 'kernel': 'k_w4_gemm64b (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
-                                              'at fp32 accuracy: exact three-way bf16 split of both operands, six products)',
-                    'achieved': tbs, 'peak': HBM_PEAK_TBS, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS,
-                    'bytes_per_launch': bytes_algo,
-                    'mfma': {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / 2500.0,
+                flops_bf16 = algo_per_launch * issued * 6.0
+                issued_bf16 = flops_bf16 / (avg_ms * 1e-3) / 1e12
+                kname = ('k_w4_gemm64b (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
+                         'at fp32 accuracy: exact three-way bf16 split of both operands, six products)')
+                mfma_view = {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
                              'fp32_equivalent_tflops': ach, 'vs_fp32_matrix_peak': ach / MFMA_F32_PEAK_TFLOPS,
                              'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
                                      'launch time; against the fp32 matrix peak it may exceed 1 -- the products run at the '
-                                     'bf16 rate'},
-                    'note': 'achieved = algorithmic bytes per launch (row operand fp32 + filter bf16 triples + products fp32) '
-                            '/ mean launch duration (HIP events); `traffic` = the bytes counted by rocprofv3 PMC in this run'})
+                                     'bf16 rate'}
+                if flops_bf16 / bytes_algo < MFMA_BF16_PEAK_TFLOPS / HBM_PEAK_TBS:
+                    roofline.update({
+                        'bound': 'hbm', 'kernel': kname,
+                        'achieved': tbs, 'peak': HBM_PEAK_TBS, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS,
+                        'bytes_per_launch': bytes_algo, 'mfma': mfma_view,
+                        'note': 'achieved = algorithmic bytes per launch (row operand fp32 + filter bf16 triples + products fp32) '
+                                '/ mean launch duration (HIP events); `traffic` = the bytes counted by rocprofv3 PMC in this run'})
+                else:
+                    roofline.update({
+                        'bound': 'mfma', 'kernel': kname,
+                        'achieved': issued_bf16, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
+                        'flops_per_launch': flops_bf16, 'bytes_per_launch': bytes_algo, 'mfma': mfma_view,
+                        'hbm_side': {'achieved': tbs, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS},
+                        'note': 'achieved = bf16 MFMA FLOPs issued per launch (six part products per fp32 product, 0.25 of the '
+                                'direct-convolution FLOPs each) / mean launch duration (HIP events) over the dense bf16 matrix '
+                                'peak; %.0f FLOP/B sits right of the bf16 ridge' % (flops_bf16 / bytes_algo)})
         elif k['launches'] > 0:
             avg_ms = k['total_ms'] / k['launches']
             algo_per_launch = k['flops'] / k['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W

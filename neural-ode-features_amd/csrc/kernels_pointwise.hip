@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
   const int layer = gn ? job : job - 3;
   const int ncol = gn ? 2 * C : 9 * C;
   if (bxs * 64 >= ncol) return;
-  const int rows = gn ? a.gpart_rows[layer] : d.N;
+  const int rows = gn ? a.gpart_rows[layer] : (a.spart_rows > 0 ? a.spart_rows : d.N);
   const float* src = gn ? a.gpart[layer] : a.spart[layer];
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = bxs * 64 + cl;

@@ -595,6 +595,112 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 
 
 // ----------------------------------------------------------------------------
+// k_w4_gemm128b: k_w4_gemm64b's products for LONG reductions (C >= 512: cfg 5's 16x16 states at 1024 filters), as a
+// classic LDS-tiled GEMM.  k_w4_gemm64b gives every wave a component of its own, so the four waves of a workgroup share
+// nothing and an XCD works on 4.5 components at once: at C = 1024 that is 47 MB of operands against a 4 MB L2, every
+// 64-row tile streams all of the filter triples in from the Infinity Cache again (3.6 GB per launch, measured 472 us =
+// 0.39 of the bf16 pipe).  Here a workgroup owns a 128 x 128 tile of ONE component, its waves 64 x 64 quarters; per
+// K = 16 step each wave fetches one quarter of the tile's operands (2 + 3 KB instead of 4 + 6), splits its row block
+// into bf16 triples ONCE for the workgroup, and the MFMA-ready 1 KB blocks go through a two-stage LDS ring (one barrier
+// per step; two workgroups per CU cover each other's barriers).  An XCD walks through its components one at a time --
+// 64 concurrent workgroups = every tile of a component at cfg 5 -- so what is live in its L2 is one K slice of V and U.
+// Same V / Ub / M layouts.  Needs 4 N % 128 == 0 and C % 128 == 0.
+// (The first version of this kernel, round 3, was measured at cfg 2 -- C = 256, 16 steps per tile -- and lost to
+// k_w4_gemm64b there, 21.5 - 22.8 against 19.6 us: fill and drain dominate so short a loop.)
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void w4c_mac(float16_t (&acc)[2][2], const w4_u32x4 (&a)[2][3], const w4_u32x4 (&b)[2][3]) {
+  w4_bf16x8 A[2][3], B[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { A[r][q] = __builtin_bit_cast(w4_bf16x8, a[r][q]); B[r][q] = __builtin_bit_cast(w4_bf16x8, b[r][q]); }
+#define W4C_P(AP, BQ)                                                                           \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)   \
+      acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[r][AP], B[c][BQ], acc[r][c], 0, 0, 0);
+  W4C_P(2, 0) W4C_P(0, 2) W4C_P(1, 1) W4C_P(1, 0) W4C_P(0, 1) W4C_P(0, 0)   // parts 0 = h, 1 = m, 2 = l: smallest products first
+#undef W4C_P
+}
+
+struct W4CLoad { float4 a[2]; w4_u32x4 b[3]; };   // a wave's share of one K = 16 step: its row block (two g blocks), its column block (three parts)
+
+__global__ __launch_bounds__(256, 2) void k_w4_gemm128b(const float* __restrict__ V, const unsigned short* __restrict__ Ub,
+                                                        float* __restrict__ M, const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) w4_u32x4 tile_lds[];   // [2 stages][A 4 row blocks x 3 parts | B 4 column blocks x 3 parts][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 7, nRT = gm.R >> 7, nT = nRT * nCT, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5, nRB = gm.RB;
+  // workgroup -> (component, tile): XCD j (= blockIdx % 8) takes components 4 j .. 4 j + 3 one after the other, then half of the
+  // tiles of component 32 + j / 2
+  const int j = blockIdx.x & 7, i = blockIdx.x >> 3;
+  int comp, tile;
+  if (i < 4 * nT) { comp = 4 * j + i / nT; tile = i % nT; }
+  else { comp = 32 + (j >> 1); tile = (j & 1) * (nT >> 1) + (i - 4 * nT); }
+  const int RT = tile / nCT, CT = tile - RT * nCT;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  const float4* pa = reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + 4 * RT + wave) * G8) * 256 + a_off);
+  const w4_u32x4* pb = reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + 4 * CT + wave) * G2) * 192 + lane;
+  auto fetch = [&](W4CLoad& L, int g2) {
+    L.a[0] = pa[(size_t)(2 * g2) * 64];
+    L.a[1] = pa[(size_t)(2 * g2 + 1) * 64];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) L.b[q] = pb[(size_t)(g2 * 3 + q) * 64];
+  };
+  // LDS block (stage, kind 0 = A / 1 = B, block 0..3, part): 64 lanes x 16 B, every access lane * 16 B -- conflict-free
+  auto blk = [&](int stage, int kind, int b, int part) { return tile_lds + ((((stage * 2 + kind) * 4 + b) * 3 + part) * 64 + lane); };
+  auto stash = [&](const W4CLoad& L, int stage) {
+    const W4Split sp = w4_split8(L.a[0], L.a[1]);
+    *blk(stage, 0, wave, 0) = __builtin_bit_cast(w4_u32x4, sp.h);
+    *blk(stage, 0, wave, 1) = __builtin_bit_cast(w4_u32x4, sp.m);
+    *blk(stage, 0, wave, 2) = __builtin_bit_cast(w4_u32x4, sp.l);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *blk(stage, 1, wave, q) = L.b[q];
+  };
+  const int wr = wave >> 1, wc = wave & 1;
+  float16_t acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+
+  W4CLoad ld0, ld1;          // in flight: ld0 = step k + 1, ld1 = step k + 2 at the top of iteration k
+  fetch(ld0, 0);
+  fetch(ld1, 1);
+  stash(ld0, 0);
+  ld0 = ld1;
+  fetch(ld1, 2);             // (reads past the reduction's end land in the buffers' slack, as in the other kernels)
+  __syncthreads();
+  for (int k = 0; k < G2; ++k) {
+    const int st = k & 1;
+    w4_u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { fa[r][q] = *blk(st, 0, 2 * wr + r, q); fb[r][q] = *blk(st, 1, 2 * wc + r, q); }
+    w4c_mac(acc, fa, fb);
+    stash(ld0, st ^ 1);      // step k + 1 -> the other stage (everybody left it at the last barrier)
+    ld0 = ld1;
+    fetch(ld1, k + 3);
+    __syncthreads();
+  }
+  // M is [n][C/32][36][4 t][32 c] (wino4.h): this wave's 64 x 64 quarter = 64-row tile 2 RT + wr, 64-column tile 2 CT + wc
+  const int rt = 2 * RT + wr, ct = 2 * CT + wc;
+  const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+  float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+    st_wt(o, acc[0][0][q]);
+    st_wt(o + 36 * 128, acc[0][1][q]);
+    st_wt(o + 8 * sstride, acc[1][0][q]);
+    st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q]);
+  }
+}
+
+
+// ----------------------------------------------------------------------------
 // k_w4_gemm_small: the component GEMMs of a batch of at most 16 samples (the bs = 1 census, evaluate.py:97-142).  The
 // throughput kernels give every wave a whole K range however few rows there are (23.9 us per launch at ONE sample);
 // here a workgroup owns ONE 32 x 32 block of one component, its four waves split K (all operand requests of a wave in
@@ -690,6 +796,18 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
     const int grid64 = (N / 16) * (C >> 6) * 8;
     const size_t lds64 = 4 * 2048 * sizeof(float);
     if (b16 && Ub != nullptr && ab == 0) {
+      // NODE_TUNE_W4_GEMM128 = 0 never / 1 wherever it fits / unset: long reductions (C >= 512)
+      const char* g128e = getenv("NODE_TUNE_W4_GEMM128");   // (read on every call, like NODE_TUNE_W4_BF16X3: tests run both kernels)
+      const int g128 = g128e ? atoi(g128e) : -1;
+      const bool fits = N % 32 == 0 && C % 128 == 0 && (((N / 32) * (C >> 7)) & 1) == 0;
+      if (fits && (g128 == 1 || (g128 < 0 && C >= 512))) {
+        static bool attr128[MAX_DEVICES] = {};
+        const int nT = (N / 32) * (C >> 7);
+        const size_t lds128 = 2 * 24 * 64 * 16;
+        allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128b), attr128);
+        hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
+        return;
+      }
       hipLaunchKernelGGL(k_w4_gemm64b, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
       return;
     }
@@ -855,7 +973,141 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
 }
 
 
+// ----------------------------------------------------------------------------
+// k_w4_wgrad128b: k_w4_wgrad's sums on the bf16 matrix pipe at fp32 accuracy, as an LDS-tiled GEMM (the skeleton of
+// k_w4_gemm128b): a workgroup owns a (128 ci x 128 co) tile of ONE component of one layer, its waves 64 x 64 quarters,
+// and walks the reduction (rows = samples x 4 tiles) in K = 16 units.  The exact bf16 split costs more here than in the
+// forward GEMM -- BOTH operands are fp32 activations -- and in k_w4_wgrad's decomposition (a wave = a 128 x 32 tile of its
+// own component) every wave would split the same 128 ci x 16 rows again for each of the C / 32 column tiles (measured
+// earlier in round 3: no faster than fp32).  Here an operand element is split once per 128-wide tile: per unit a wave
+// splits 16 values per lane (88 VALU instructions) under its 24 MFMAs.
+// Operands without a transposed copy: a loader lane's eight 16-B loads of V ([s 2][t 4] x four channels e) hold, for
+// each e, the eight reduction rows of one channel -- the K half of an MFMA row operand -- so accumulator block e =
+// channels 8 g + 4 hic + e as in k_w4_wgrad; its two 16-B loads of Z hold the eight rows of one output channel.
+// Waves 0 / 1 load V (both all of it -- L1 serves the second -- and split blocks e = 0, 1 / 2, 3), waves 2 / 3 load and split
+// two 32-column blocks of Z each.  Needs N % 4 == 0 (whole units; the launcher asks for N % 8) and C % 128 == 0.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;
+  extern __shared__ __attribute__((aligned(16))) w4_u32x4 tile_lds[];   // [2 stages][A 4 e blocks x 3 parts | B 4 column blocks x 3 parts][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int C = a.C, N = a.N;
+  const int nCT = C >> 7, nT = nCT * nCT;            // tiles per (layer, component)
+  // XCD j (= blockIdx % 8): components 4 j .. 4 j + 3 of layer 0, then of layer 1, then half of the tiles of component 32 + j / 2
+  // of either layer
+  const int j = blockIdx.x & 7, i = blockIdx.x >> 3;
+  int layer, comp, tile;
+  if (i < 8 * nT) { layer = i / (4 * nT); const int r = i - layer * 4 * nT; comp = 4 * j + r / nT; tile = r % nT; }
+  else { const int r = i - 8 * nT; layer = r / (nT >> 1); comp = 32 + (j >> 1); tile = (j & 1) * (nT >> 1) + r % (nT >> 1); }
+  const int cit = tile / nCT, cot = tile - cit * nCT;
+  const float* __restrict__ V = layer ? a.V2 : a.V1;
+  const float4* __restrict__ Z = reinterpret_cast<const float4*>(layer ? a.Z2 : a.Z1);
+  float* __restrict__ dU = a.dU + (size_t)layer * 36 * C * C;
+  const size_t cs = (size_t)4 * N * C, rbs = (size_t)(C >> 3) * 256;   // floats per component / per 8-sample row block of V
+  const int g = l31 >> 1, hic = l31 & 1;
+  // unit u = samples 4 u .. 4 u + 3: this lane's K half h = samples 4 u + 2 h, + 1 (row block u / 2, s = 4 (u & 1) + 2 h + s')
+  const float* pa = V + (size_t)comp * cs + (size_t)(cit * 16 + g) * 256 + (2 * h) * 32 + hic * 16;
+  const float4* pz = Z + (size_t)comp * (size_t)(C >> 5) * N * 32 + (size_t)(4 * cot) * N * 32 + (2 * h) * 32 + l31;
+  const int U = N >> 2;
+  auto blk = [&](int stage, int kind, int b, int part) { return tile_lds + ((((stage * 2 + kind) * 4 + b) * 3 + part) * 64 + lane); };
+  // what this wave loads for unit u: waves 0 / 1 the V patch (8 x 16 B: [s' 2][t 4]), waves 2 / 3 two column blocks of Z
+  // (4 x 16 B: [block 2][s' 2]).  (Macros, not lambdas over the register arrays: those put the arrays in scratch.)
+  const bool ldv = wave < 2;
+  const size_t zb0 = (size_t)(2 * (wave & 1)) * N * 32, zb1 = zb0 + (size_t)N * 32;
+#define W4WG_FETCH(L, UU)                                                                                            \
+  {                                                                                                                  \
+    const int u_ = (UU) < U ? (UU) : U - 1; /* clamped: the last iterations prefetch a unit nobody consumes */        \
+    if (ldv) {                                                                                                       \
+      const float4* p_ = reinterpret_cast<const float4*>(pa + (size_t)(u_ >> 1) * rbs + (u_ & 1) * 128);             \
+      L##0 = p_[0]; L##1 = p_[1]; L##2 = p_[2]; L##3 = p_[3]; L##4 = p_[8]; L##5 = p_[9]; L##6 = p_[10]; L##7 = p_[11]; \
+    } else {                                                                                                         \
+      const float4* p_ = pz + (size_t)(4 * u_) * 32;                                                                 \
+      L##0 = p_[zb0]; L##1 = p_[zb0 + 32]; L##2 = p_[zb1]; L##3 = p_[zb1 + 32];                                      \
+    }                                                                                                                \
+  }
+#define W4WG_PUT(STAGE, KIND, B, SP)                                        \
+  {                                                                         \
+    *blk(STAGE, KIND, B, 0) = __builtin_bit_cast(w4_u32x4, (SP).h);         \
+    *blk(STAGE, KIND, B, 1) = __builtin_bit_cast(w4_u32x4, (SP).m);         \
+    *blk(STAGE, KIND, B, 2) = __builtin_bit_cast(w4_u32x4, (SP).l);         \
+  }
+#define W4WG_STASH(L, STAGE)                                                                                                  \
+  {                                                                                                                           \
+    if (ldv) {                                                                                                                \
+      /* blocks e = 2 wave, 2 wave + 1: component e of the eight vectors = the eight reduction rows of a channel */          \
+      const bool odd_ = wave & 1;                                                                                             \
+      const W4Split s0_ = w4_split8(odd_ ? make_float4((L##0).z, (L##1).z, (L##2).z, (L##3).z) : make_float4((L##0).x, (L##1).x, (L##2).x, (L##3).x), \
+                                    odd_ ? make_float4((L##4).z, (L##5).z, (L##6).z, (L##7).z) : make_float4((L##4).x, (L##5).x, (L##6).x, (L##7).x)); \
+      W4WG_PUT(STAGE, 0, 2 * wave, s0_)                                                                                       \
+      const W4Split s1_ = w4_split8(odd_ ? make_float4((L##0).w, (L##1).w, (L##2).w, (L##3).w) : make_float4((L##0).y, (L##1).y, (L##2).y, (L##3).y), \
+                                    odd_ ? make_float4((L##4).w, (L##5).w, (L##6).w, (L##7).w) : make_float4((L##4).y, (L##5).y, (L##6).y, (L##7).y)); \
+      W4WG_PUT(STAGE, 0, 2 * wave + 1, s1_)                                                                                   \
+    } else {                                                                                                                  \
+      const W4Split s0_ = w4_split8(L##0, L##1);                                                                              \
+      W4WG_PUT(STAGE, 1, 2 * (wave & 1), s0_)                                                                                 \
+      const W4Split s1_ = w4_split8(L##2, L##3);                                                                              \
+      W4WG_PUT(STAGE, 1, 2 * (wave & 1) + 1, s1_)                                                                             \
+    }                                                                                                                         \
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  float16_t acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+
+  float4 la0, la1, la2, la3, la4, la5, la6, la7, lb0, lb1, lb2, lb3, lb4, lb5, lb6, lb7;   // units in flight: la = even, lb = odd
+  la4 = la5 = la6 = la7 = lb4 = lb5 = lb6 = lb7 = make_float4(0.f, 0.f, 0.f, 0.f);
+  W4WG_FETCH(la, 0)
+  W4WG_FETCH(lb, 1)
+  W4WG_STASH(la, 0)
+  W4WG_FETCH(la, 2)
+  __syncthreads();
+  for (int u = 0; u < U; ++u) {
+    const int st = u & 1;
+    w4_u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { fa[r][q] = *blk(st, 0, 2 * wr + r, q); fb[r][q] = *blk(st, 1, 2 * wc + r, q); }
+    w4c_mac(acc, fa, fb);
+    // unit u + 1 (lb behind an even unit, la behind an odd one) -> the other stage (everybody left it at the last barrier);
+    // its registers take unit u + 3
+    if (st == 0) { W4WG_STASH(lb, 1) W4WG_FETCH(lb, u + 3) }
+    else { W4WG_STASH(la, 0) W4WG_FETCH(la, u + 3) }
+    __syncthreads();
+  }
+#undef W4WG_FETCH
+#undef W4WG_PUT
+#undef W4WG_STASH
+  // block (e = 2 wr + r, column block 2 wc + c): accumulator row m = (q & 3) + 8 (q >> 2) + 4 h <-> ci = 8 (m >> 1) + 4 (m & 1) + e
+  float* o = dU + ((size_t)comp * C + cit * 128) * C + cot * 128 + l31;
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+        st_wt(o + (size_t)(8 * (m >> 1) + 4 * (m & 1) + 2 * wr + r) * C + 32 * (2 * wc + c), acc[r][c][q]);
+      }
+}
+
 void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s) {
+  // NODE_TUNE_W4_WGRAD128 = 0 never / 1 wherever it fits / unset: long filters (C >= 512), where the fp32 kernel is bound by
+  // the matrix pipe (read on every call: tests run both)
+  {
+    const char* e = getenv("NODE_TUNE_W4_WGRAD128");
+    const int w128 = e ? atoi(e) : -1;
+    const int nT = (a.C >> 7) * (a.C >> 7);
+    if (a.N % 8 == 0 && a.C % 128 == 0 && (nT & 1) == 0 && (w128 == 1 || (w128 < 0 && a.C >= 512))) {
+      hipLaunchKernelGGL(k_w4_wgrad128b, dim3(8 * (8 * nT + nT)), dim3(256), 2 * 24 * 64 * 16, s, a);
+      return;
+    }
+  }
   const int grid = 2 * (a.C >> 7) * (a.C >> 5) * 8;
   const size_t lds = 4 * 2048 * sizeof(float);
   if (a.N % 16 == 0) hipLaunchKernelGGL(k_w4_wgrad<8>, dim3(grid), dim3(256), lds, s, a);

@@ -31,6 +31,13 @@
 //   (pixel (4 ty + i, 4 tx + j), t = 2 ty + tx, channel 16 cb + c15, lane = 16 t + c15).
 // Element-wise kernels (error norm, commit, axpy, ...) do not care; NCHW <-> W4S happens at the solve boundary.
 // M (component products) is [n][C/32][36][4 t][32 c]: what a wave pair reads is one contiguous 18 KB block.
+//
+// 16x16 images (Q = 4; cfg 5's [n, 1024, 16, 16] and the one-shot stem's [n, 256, 16, 16] states): the image is cut into
+// four 8x8 QUADRANTS q = 2 QY + QX, and quadrant q of sample n is "virtual sample" nv = 4 n + q of every layout above
+// (W4S, V, M, Z) -- the component GEMMs and the weight gradient see 4 N samples and do not change.  What changes is here:
+// a workgroup holds the four quadrant waves of a (sample, GroupNorm group set) -- 4 waves for cpg <= 16, 8 for cpg = 32
+// -- the GroupNorm sums cross the waves through LDS (one barrier per sum, two alternating slots), and the pixel ring of
+// the input transform comes out of an LDS copy of the workgroup's tiles instead of nine shuffles.
 #include "wino4.h"
 #include <cstring>
 
@@ -72,6 +79,52 @@ __device__ __forceinline__ float w4s_group_sum(float v, int cpg) {
   return w4s_tile_sum(v);
 }
 
+// Where a wave sits.  Q = 1: the wave holds the whole 8x8 image of its 16 channels.  Q = 4: one 8x8 quadrant of a 16x16 image.
+template <int Q>
+struct W4Wave {
+  int lane, t, c15, ty, tx;   // lane = 16 t + c15, tile t = 2 ty + tx of the quadrant
+  int n, q, nv, cb, c;        // sample, quadrant, virtual sample Q n + q, 16-channel block, channel 16 cb + c15
+  int TY, TX, TM;             // tile coordinates in the image, their maximum (1 or 3)
+  int w, nw;                  // Q = 4: wave of the workgroup (w = 4 cbi + q), waves per workgroup (4 or 8)
+  float* red;                 // Q = 4: LDS [2 slots][8 waves][16 channels][2]
+  float* tiles;               // Q = 4: LDS [8 waves][16 pixels][64 lanes]
+  int slot;
+};
+constexpr int W4Q_RED = 2 * 8 * 16 * 2;
+constexpr int W4Q_TILES = 8 * 16 * 64;
+
+// sum over a GroupNorm group of the IMAGE; every lane gets the result.  Q = 4: the in-wave sums of the workgroup's waves
+// (all of them hold the lane's group: cpg <= 16 -> the four quadrants of one channel block, cpg = 32 -> two blocks) meet
+// in LDS and every wave adds them in the same order
+template <int Q>
+__device__ __forceinline__ float w4s_gsum(float v, int cpg, W4Wave<Q>& wv) {
+  v = w4s_group_sum(v, cpg);
+  if (Q == 4) {
+    float* r = wv.red + (wv.slot & 1) * (W4Q_RED / 2);
+    wv.slot++;
+    if (wv.t == 0) r[(wv.w * 16 + wv.c15) * 2] = v;
+    __syncthreads();
+    float s = r[wv.c15 * 2];
+    for (int k = 1; k < wv.nw; ++k) s += r[(k * 16 + wv.c15) * 2];
+    v = s;
+  }
+  return v;
+}
+template <int Q>
+__device__ __forceinline__ void w4s_gsum2(float& a, float& b, int cpg, W4Wave<Q>& wv) {
+  a = w4s_group_sum(a, cpg);
+  b = w4s_group_sum(b, cpg);
+  if (Q == 4) {
+    float* r = wv.red + (wv.slot & 1) * (W4Q_RED / 2);
+    wv.slot++;
+    if (wv.t == 0) { r[(wv.w * 16 + wv.c15) * 2] = a; r[(wv.w * 16 + wv.c15) * 2 + 1] = b; }
+    __syncthreads();
+    float sa = r[wv.c15 * 2], sb = r[wv.c15 * 2 + 1];
+    for (int k = 1; k < wv.nw; ++k) { sa += r[(k * 16 + wv.c15) * 2]; sb += r[(k * 16 + wv.c15) * 2 + 1]; }
+    a = sa; b = sb;
+  }
+}
+
 // A^T x for the points (0, 1, -1, 1/2, -2, inf)   (W4_AT)
 __device__ __forceinline__ void w4s_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& o0, float& o1,
                                         float& o2, float& o3) {
@@ -106,8 +159,25 @@ __device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, 
   for (int i = 0; i < 4; ++i) w4s_at6(z[i][0], z[i][1], z[i][2], z[i][3], z[i][4], z[i][5], y[i][0], y[i][1], y[i][2], y[i][3]);
 }
 
-// V = B^T d B of the thread's tile (+ one pixel ring from the three other tiles of the image, zero outside) -> the
-// blocked row operand of the component GEMMs.  `vp`: the thread's element of component 0; components `cstride` apart.
+// V = B^T d B of the 6x6 patch d (the thread's tile + one pixel ring) -> the blocked row operand of the component GEMMs.
+// `vp`: the thread's element of component 0; components `cstride` apart.
+__device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restrict__ vp, size_t cstride) {
+  float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
+#pragma unroll
+  for (int j = 0; j < 6; ++j) w4s_bt6(d[j][0], d[j][1], d[j][2], d[j][3], d[j][4], d[j][5], w[j][0], w[j][1], w[j][2], w[j][3], w[j][4], w[j][5]);
+#pragma unroll
+  for (int l = 0; l < 6; ++l) {
+    float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
+    w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
+    w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
+    w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
+    w4s_st_wt(vp + (size_t)(2 * 6 + l) * cstride, v2);
+    w4s_st_wt(vp + (size_t)(3 * 6 + l) * cstride, v3);
+    w4s_st_wt(vp + (size_t)(4 * 6 + l) * cstride, v4);
+    w4s_st_wt(vp + (size_t)(5 * 6 + l) * cstride, v5);
+  }
+}
+// 8x8 image: the ring is nine values held by the three other tiles' lanes of the same wave (zero outside the image)
 __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, float* __restrict__ vp, size_t cstride) {
   float sh[4], sv[4], rh[4], rv[4];
 #pragma unroll
@@ -137,20 +207,41 @@ __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, 
   d[0][5] = (ty && !tx) ? rc : 0.f;
   d[5][0] = (!ty && tx) ? rc : 0.f;
   d[5][5] = (!ty && !tx) ? rc : 0.f;
-  float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
+  w4s_store_v(d, vp, cstride);
+}
+// 16x16 image: the workgroup's tiles go through LDS ([wave][pixel][lane]: conflict-free both ways), the ring's twenty
+// values come from up to eight neighbour tiles -- other lanes of this wave or of the other quadrants' waves
+__device__ __forceinline__ void w4s_emit_v16(const float a[4][4], const W4Wave<4>& wv, float* __restrict__ vp, size_t cstride) {
+  float* mine = wv.tiles + (size_t)wv.w * 1024 + wv.lane;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) w4s_bt6(d[j][0], d[j][1], d[j][2], d[j][3], d[j][4], d[j][5], w[j][0], w[j][1], w[j][2], w[j][3], w[j][4], w[j][5]);
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int l = 0; l < 6; ++l) {
-    float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
-    w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
-    w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
-    w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
-    w4s_st_wt(vp + (size_t)(2 * 6 + l) * cstride, v2);
-    w4s_st_wt(vp + (size_t)(3 * 6 + l) * cstride, v3);
-    w4s_st_wt(vp + (size_t)(4 * 6 + l) * cstride, v4);
-    w4s_st_wt(vp + (size_t)(5 * 6 + l) * cstride, v5);
-  }
+    for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 64] = a[i][j];
+  __syncthreads();
+  const int cb4 = (wv.w >> 2) << 2;
+  // neighbour tile (TY + dy, TX + dx): LDS offset of its pixel 0 for this lane's channel, or -1 outside the image
+  int nb[3][3];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int Yn = wv.TY + dy, Xn = wv.TX + dx;
+      const bool in = (unsigned)Yn < 4u && (unsigned)Xn < 4u;
+      const int wq = cb4 + ((Yn >> 1) << 1) + (Xn >> 1), tt = ((Yn & 1) << 1) + (Xn & 1);
+      nb[dy + 1][dx + 1] = in ? wq * 1024 + tt * 16 + wv.c15 : -1;
+    }
+  float d[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (r >= 1 && r <= 4 && k >= 1 && k <= 4) { d[r][k] = a[r - 1][k - 1]; continue; }
+      const int dy = r == 0 ? 0 : r == 5 ? 2 : 1, dx = k == 0 ? 0 : k == 5 ? 2 : 1;
+      const int ii = r == 0 ? 3 : r == 5 ? 0 : r - 1, jj = k == 0 ? 3 : k == 5 ? 0 : k - 1;
+      const int base = nb[dy][dx];
+      d[r][k] = base >= 0 ? wv.tiles[base + (ii * 4 + jj) * 64] : 0.f;
+    }
+  w4s_store_v(d, vp, cstride);
 }
 
 // Z = A dz A^T of the thread's tile (no halo: the transform of a conv OUTPUT's cotangent) for the F(4x4,3x3)-domain
@@ -184,17 +275,19 @@ __device__ __forceinline__ void w4s_emit_z(const float a[4][4], int n, int N, in
   }
 }
 
-// masked column sums of the thread's channel (node_internal.h, masked_colsum_tile): out[tap * ld] for the nine taps
-__device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, int ty, int tx, float* __restrict__ out, int ld) {
+// masked column sums of the thread's channel (node_internal.h, masked_colsum_tile): out[tap * ld] for the nine taps.
+// fr / lr / fc / lc: the thread's tile touches the image's first / last row / column.  The sum runs over the wave's four
+// tiles: the whole image (Q = 1) or one quadrant of it (Q = 4: k_theta_finalize adds the quadrants' rows like samples').
+__device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, bool fr, bool lr, bool fc, bool lc, float* __restrict__ out, int ld) {
   float R[4], Cc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) R[i] = (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
 #pragma unroll
   for (int j = 0; j < 4; ++j) Cc[j] = (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
   float T = (R[0] + R[1]) + (R[2] + R[3]);
-  float rf = ty == 0 ? R[0] : 0.f, rl = ty == 1 ? R[3] : 0.f;
-  float cf = tx == 0 ? Cc[0] : 0.f, cl = tx == 1 ? Cc[3] : 0.f;
-  float k00 = t == 0 ? v[0][0] : 0.f, k01 = t == 1 ? v[0][3] : 0.f, k10 = t == 2 ? v[3][0] : 0.f, k11 = t == 3 ? v[3][3] : 0.f;
+  float rf = fr ? R[0] : 0.f, rl = lr ? R[3] : 0.f;
+  float cf = fc ? Cc[0] : 0.f, cl = lc ? Cc[3] : 0.f;
+  float k00 = (fr && fc) ? v[0][0] : 0.f, k01 = (fr && lc) ? v[0][3] : 0.f, k10 = (lr && fc) ? v[3][0] : 0.f, k11 = (lr && lc) ? v[3][3] : 0.f;
   T = w4s_tile_sum(T); rf = w4s_tile_sum(rf); rl = w4s_tile_sum(rl); cf = w4s_tile_sum(cf); cl = w4s_tile_sum(cl);
   k00 = w4s_tile_sum(k00); k01 = w4s_tile_sum(k01); k10 = w4s_tile_sum(k10); k11 = w4s_tile_sum(k11);
   if (t == 0) {
@@ -213,6 +306,10 @@ __device__ __forceinline__ void w4s_colsums(const float v[4][4], int t, int ty, 
       out[(size_t)tap * ld] = o;
     }
   }
+}
+template <int Q>
+__device__ __forceinline__ void w4s_colsums(const float v[4][4], const W4Wave<Q>& wv, float* __restrict__ spart, int C) {
+  w4s_colsums(v, wv.t, wv.TY == 0, wv.TY == wv.TM, wv.TX == 0, wv.TX == wv.TM, spart + (size_t)wv.nv * 9 * C + wv.c, C);
 }
 
 __device__ __forceinline__ float4 w4s_ld4(const float* p, size_t f4) { return reinterpret_cast<const float4*>(p)[f4]; }
@@ -289,33 +386,37 @@ __device__ __forceinline__ void w4s_comb_any(const Comb& c, const float* cf, siz
 }
 
 // the thread's 16 pixels -> an NHWC tensor (the weight-gradient kernel's operand layout)
-__device__ __forceinline__ void w4s_store_nhwc(float* __restrict__ dst, int n, int C, int c, int ty, int tx, const float v[4][4]) {
-  float* base = dst + ((size_t)n * 64 + (4 * ty) * 8 + 4 * tx) * C + c;
+template <int Q>
+__device__ __forceinline__ void w4s_store_nhwc(float* __restrict__ dst, const W4Wave<Q>& wv, int C, const float v[4][4]) {
+  constexpr int WI = Q == 4 ? 16 : 8;   // image side
+  float* base = dst + ((size_t)wv.n * (WI * WI) + (4 * wv.TY) * WI + 4 * wv.TX) * C + wv.c;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) base[(size_t)(i * 8 + j) * C] = v[i][j];
+    for (int j = 0; j < 4; ++j) base[(size_t)(i * WI + j) * C] = v[i][j];
 }
 
 // GroupNorm statistics of the thread's group (two passes over the registers, like the reference's kernels)
-__device__ __forceinline__ void w4s_gn_stats(const float z[4][4], int cpg, float inv_m, float eps, float& mean, float& rstd) {
+template <int Q>
+__device__ __forceinline__ void w4s_gn_stats(const float z[4][4], int cpg, float inv_m, float eps, W4Wave<Q>& wv, float& mean, float& rstd) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) s += (z[i][0] + z[i][1]) + (z[i][2] + z[i][3]);
-  mean = w4s_group_sum(s, cpg) * inv_m;
+  mean = w4s_gsum(s, cpg, wv) * inv_m;
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const float dv = z[i][j] - mean; s2 += dv * dv; }
-  const float var = w4s_group_sum(s2, cpg) * inv_m;
+  const float var = w4s_gsum(s2, cpg, wv) * inv_m;
   rstd = 1.0f / sqrtf(var + eps);
 }
 
 // GroupNorm backward on the thread's pixels: g = d L / d (affine output); returns dz = osign * rstd (g gamma - m1 - xhat m2)
-// and leaves the per-sample (dgamma, dbeta) partials of the channel in gpart ([N][2][C]).
+// and leaves the per-(virtual-)sample (dgamma, dbeta) partials of the channel in gpart ([Q N][2][C]).
+template <int Q>
 __device__ __forceinline__ void w4s_gn_bwd(const float g[4][4], const float xh[4][4], float gam, float rstd, int cpg, float inv_m,
-                                           float osign, int n, int C, int c, int t, float* __restrict__ gpart, float dz[4][4]) {
+                                           float osign, W4Wave<Q>& wv, int C, float* __restrict__ gpart, float dz[4][4]) {
   float dg = 0.f, db = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -329,32 +430,73 @@ __device__ __forceinline__ void w4s_gn_bwd(const float g[4][4], const float xh[4
     }
   dg = w4s_tile_sum(dg);
   db = w4s_tile_sum(db);
-  if (t == 0) {
-    gpart[((size_t)n * 2 + 0) * C + c] = dg;
-    gpart[((size_t)n * 2 + 1) * C + c] = db;
+  if (wv.t == 0) {
+    gpart[((size_t)wv.nv * 2 + 0) * C + wv.c] = dg;
+    gpart[((size_t)wv.nv * 2 + 1) * C + wv.c] = db;
   }
-  s1 = w4s_group_sum(s1, cpg) * inv_m;
-  s2 = w4s_group_sum(s2, cpg) * inv_m;
+  w4s_gsum2(s1, s2, cpg, wv);
+  s1 *= inv_m;
+  s2 *= inv_m;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dz[i][j] = osign * (rstd * (g[i][j] * gam - s1 - xh[i][j] * s2));
 }
 
+// the wave's place in the launch (see W4Wave): Q = 1 -> independent waves, W4S_THREADS / 64 per workgroup;
+// Q = 4 -> workgroup = (sample, NB consecutive 16-channel blocks) x four quadrants, NB = blockDim / 256
+template <int Q>
+__device__ __forceinline__ void w4s_place(W4Wave<Q>& wv, int C, float* red, float* tiles) {
+  const int CB = C >> 4;
+  wv.lane = threadIdx.x & 63;
+  wv.t = wv.lane >> 4; wv.c15 = wv.lane & 15; wv.ty = wv.t >> 1; wv.tx = wv.t & 1;
+  wv.w = threadIdx.x >> 6; wv.slot = 0; wv.red = red; wv.tiles = tiles;
+  if (Q == 1) {
+    const int unit = blockIdx.x * (blockDim.x >> 6) + wv.w;
+    wv.n = unit / CB; wv.cb = unit - wv.n * CB;
+    wv.q = 0; wv.nv = wv.n; wv.nw = 1;
+    wv.TY = wv.ty; wv.TX = wv.tx; wv.TM = 1;
+  } else {
+    const int NB = blockDim.x >> 8, GS = CB / NB;
+    wv.n = blockIdx.x / GS;
+    wv.cb = (blockIdx.x - wv.n * GS) * NB + (wv.w >> 2);
+    wv.q = wv.w & 3; wv.nv = 4 * wv.n + wv.q; wv.nw = 4 * NB;
+    wv.TY = 2 * (wv.q >> 1) + wv.ty; wv.TX = 2 * (wv.q & 1) + wv.tx; wv.TM = 3;
+  }
+  wv.c = wv.cb * 16 + wv.c15;
+}
+// pointers of the thread's (virtual sample, tile, channel) element in M, V (component 0) and its first W4S vector
+template <int Q>
+__device__ __forceinline__ const float* w4s_m_ptr(const float* M, const W4Wave<Q>& wv, int C) {
+  return M + (((size_t)wv.nv * (C >> 5) + (wv.cb >> 1)) * 36) * 128 + wv.t * 32 + (wv.cb & 1) * 16 + wv.c15;
+}
+template <int Q>
+__device__ __forceinline__ float* w4s_v_ptr(float* V, const W4Wave<Q>& wv, int C) {
+  const int g8 = wv.cb * 2 + (wv.c15 >> 3), hi = (wv.c15 >> 2) & 1, e = wv.c15 & 3;
+  return V + ((size_t)((wv.nv >> 3) * (C >> 3) + g8) * 256 + (wv.nv & 7) * 32 + hi * 16 + wv.t * 4 + e);
+}
+template <int Q>
+__device__ __forceinline__ void w4s_put_v(const float v[4][4], const W4Wave<Q>& wv, float* V, int C, int Nv) {
+  float* vp = w4s_v_ptr(V, wv, C);
+  if constexpr (Q == 1) w4s_emit_v(v, wv.ty, wv.tx, vp, (size_t)4 * Nv * C);
+  else w4s_emit_v16(v, wv, vp, (size_t)4 * Nv * C);
+}
+
 // HEAD: 0 none, 1 forward (conv result -> GroupNorm), 2 backward (data gradient -> ReLU mask -> GroupNorm backward)
 // TAIL: 0 none, 1 stage combine -> GroupNorm-1 -> ReLU, 2 adjoint combine -> GroupNorm-3 backward (needs HEAD 1)
-template <int HEAD, int TAIL>
-__global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
+// Q:    1 8x8 images, 4 16x16 images (file header)
+template <int HEAD, int TAIL, int Q>
+__global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_pass(W4sArgs a) {
   if (a.ctrl != nullptr && a.ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
-  const int lane = threadIdx.x & 63;
-  const int CB = a.C >> 4;
-  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
-  const int n = unit / CB, cb = unit - n * CB;
-  const int t = lane >> 4, c15 = lane & 15, ty = t >> 1, tx = t & 1;
-  const int c = cb * 16 + c15;
+  __shared__ float s_red[Q == 4 ? W4Q_RED : 1];
+  __shared__ float s_tiles[Q == 4 ? W4Q_TILES : 1];
+  W4Wave<Q> wv;
+  w4s_place(wv, a.C, s_red, s_tiles);
+  const int lane = wv.lane, CB = a.C >> 4, n = wv.n, cb = wv.cb, t = wv.t, c = wv.c;
   const int cpg = a.cpg, G = a.C / cpg, grp = c / cpg;
-  const float inv_m = 1.0f / (float)(64 * cpg);
-  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;   // float4 index of tile row 0 in a W4S tensor (rows 64 apart)
+  const float inv_m = 1.0f / (float)(64 * Q * cpg);
+  const size_t f4 = ((size_t)wv.nv * CB + cb) * 256 + lane;   // float4 index of tile row 0 in a W4S tensor (rows 64 apart)
+  const bool stat_lane = t == 0 && wv.q == 0 && c % cpg == 0;   // the one lane of the launch that owns (sample, group)
 
   float v[4][4];     // the conv input whose transform leaves at the end
   float hx[4][4];    // HEAD 1: xhat of the head's GroupNorm
@@ -363,17 +505,16 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
 
   if (HEAD == 1) {
     const W4sHead& h = a.h;
-    const float* mp = h.M + (((size_t)n * (a.C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
     float z[4][4];
-    w4s_out_transform(mp, z);
+    w4s_out_transform(w4s_m_ptr(h.M, wv, a.C), z);
     const float tval = eval_time(h.et), bv = h.bias[c];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 tm = w4s_ld4(h.tmapS, (size_t)cb * 256 + i * 64 + lane);
+      const float4 tm = w4s_ld4(h.tmapS, ((size_t)wv.q * CB + cb) * 256 + i * 64 + lane);
       z[i][0] += fmaf(tval, tm.x, bv); z[i][1] += fmaf(tval, tm.y, bv); z[i][2] += fmaf(tval, tm.z, bv); z[i][3] += fmaf(tval, tm.w, bv);
     }
     float mean;
-    w4s_gn_stats(z, cpg, inv_m, a.eps, mean, hrstd);
+    w4s_gn_stats(z, cpg, inv_m, a.eps, wv, mean, hrstd);
     const float gam = h.gamma[c], bet = h.beta[c];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -388,12 +529,12 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w4s_st4(h.out_s, f4 + i * 64, ho[i]);
     }
-    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
+    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, wv, a.C, ho);
     if (h.xhat_s) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w4s_st4(h.xhat_s, f4 + i * 64, hx[i]);
     }
-    if (h.rstd && t == 0 && c % cpg == 0) h.rstd[(size_t)n * G + grp] = hrstd;
+    if (h.rstd && stat_lane) h.rstd[(size_t)n * G + grp] = hrstd;
     if (TAIL == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -403,27 +544,26 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
   }
   if (HEAD == 2) {
     const W4sHead& h = a.h;
-    const float* mp = h.M + (((size_t)n * (a.C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
     float4 xq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) xq[i] = w4s_ld4(h.xhat_s, f4 + i * 64);
     const float gam = h.gamma[c], bet = h.beta[c], rs = h.rstd[(size_t)n * G + grp];
     float g[4][4], xh[4][4];
-    w4s_out_transform(mp, g);
+    w4s_out_transform(w4s_m_ptr(h.M, wv, a.C), g);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       xh[i][0] = xq[i].x; xh[i][1] = xq[i].y; xh[i][2] = xq[i].z; xh[i][3] = xq[i].w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[i][j] = fmaf(xh[i][j], gam, bet) > 0.f ? g[i][j] : 0.f;   // ReLU mask of this layer's output
     }
-    w4s_gn_bwd(g, xh, gam, rs, cpg, inv_m, h.osign, n, a.C, c, t, h.gpart, ho);
+    w4s_gn_bwd(g, xh, gam, rs, cpg, inv_m, h.osign, wv, a.C, h.gpart, ho);
     if (h.out_s) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w4s_st4(h.out_s, f4 + i * 64, ho[i]);
     }
-    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, n, a.C, c, ty, tx, ho);
-    if (h.spart) w4s_colsums(ho, t, ty, tx, h.spart + (size_t)n * 9 * a.C + c, a.C);
-    if (h.z_out) w4s_emit_z(ho, n, a.Nv, a.C, c, t, h.z_out);
+    if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, wv, a.C, ho);
+    if (h.spart) w4s_colsums(ho, wv, h.spart, a.C);
+    if (h.z_out) w4s_emit_z(ho, wv.nv, a.Nv, a.C, c, t, h.z_out);
     if (TAIL == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -451,7 +591,7 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
     }
     if (TAIL == 1) {   // GroupNorm-1 -> ReLU (model.py:341-342)
       float mean, rstd;
-      w4s_gn_stats(y, cpg, inv_m, a.eps, mean, rstd);
+      w4s_gn_stats(y, cpg, inv_m, a.eps, wv, mean, rstd);
       const float gam = tl.gamma[c], bet = tl.beta[c];
       float xh[4][4];
 #pragma unroll
@@ -461,98 +601,122 @@ __global__ __launch_bounds__(W4S_THREADS) void k_w4s_pass(W4sArgs a) {
           xh[i][j] = (y[i][j] - mean) * rstd;
           v[i][j] = fmaxf(fmaf(xh[i][j], gam, bet), 0.f);
         }
-      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
+      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, wv, a.C, v);
       if (tl.xhat_s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w4s_st4(tl.xhat_s, f4 + i * 64, xh[i]);
       }
-      if (tl.rstd && t == 0 && c % cpg == 0) tl.rstd[(size_t)n * G + grp] = rstd;
+      if (tl.rstd && stat_lane) tl.rstd[(size_t)n * G + grp] = rstd;
     } else {   // cotangent g = csign * (adjoint combine) through GroupNorm-3's backward (xhat-3, 1/sigma-3 from the head)
       float g[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[i][j] = tl.csign * y[i][j];
-      w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, n, a.C, c, t, tl.gpart, v);
-      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, n, a.C, c, ty, tx, v);
-      if (tl.spart) w4s_colsums(v, t, ty, tx, tl.spart + (size_t)n * 9 * a.C + c, a.C);
-      if (tl.z_out) w4s_emit_z(v, n, a.Nv, a.C, c, t, tl.z_out);
+      w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, wv, a.C, tl.gpart, v);
+      if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, wv, a.C, v);
+      if (tl.spart) w4s_colsums(v, wv, tl.spart, a.C);
+      if (tl.z_out) w4s_emit_z(v, wv.nv, a.Nv, a.C, c, t, tl.z_out);
     }
   }
 
-  if (a.V != nullptr) {
-    const int g8 = cb * 2 + (c15 >> 3), hi = (c15 >> 2) & 1, e = c15 & 3;
-    float* vp = a.V + ((size_t)((n >> 3) * (a.C >> 3) + g8) * 256 + (n & 7) * 32 + hi * 16 + t * 4 + e);
-    w4s_emit_v(v, ty, tx, vp, (size_t)4 * a.Nv * a.C);
+  if (a.V != nullptr) w4s_put_v(v, wv, a.V, a.C, a.Nv);
+}
+
+// workgroups of the Q = 4 kernels: (sample, NB consecutive 16-channel blocks) x four quadrants, NB = 2 when a GroupNorm
+// group spans two blocks (cpg = 32)
+static inline void w4s_grid(int N, int C, int cpg, int Q, dim3& grid, dim3& block) {
+  if (Q == 1) {
+    block = dim3(W4S_THREADS);
+    grid = dim3(N * (C >> 4) / (W4S_THREADS / 64));
+  } else {
+    const int NB = cpg > 16 ? cpg / 16 : 1;
+    block = dim3(256 * NB);
+    grid = dim3(N * ((C >> 4) / NB));
   }
 }
 
 void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s) {
-  const int units = a.N * (a.C >> 4);
-  const dim3 grid(units / (W4S_THREADS / 64)), block(W4S_THREADS);
-#define W4S_GO(H, T) hipLaunchKernelGGL((k_w4s_pass<H, T>), grid, block, 0, s, a)
-  if (head == 0 && tail == 1) W4S_GO(0, 1);
-  else if (head == 1 && tail == 0) W4S_GO(1, 0);
-  else if (head == 1 && tail == 1) W4S_GO(1, 1);
-  else if (head == 1 && tail == 2) W4S_GO(1, 2);
-  else if (head == 2 && tail == 0) W4S_GO(2, 0);
-  else if (head == 2 && tail == 1) W4S_GO(2, 1);
+  dim3 grid, block;
+  w4s_grid(a.N, a.C, a.cpg, a.Q, grid, block);
+#define W4S_GO(H, T)                                                                 \
+  {                                                                                  \
+    if (a.Q == 1) hipLaunchKernelGGL((k_w4s_pass<H, T, 1>), grid, block, 0, s, a);   \
+    else hipLaunchKernelGGL((k_w4s_pass<H, T, 4>), grid, block, 0, s, a);            \
+  }
+  if (head == 0 && tail == 1) W4S_GO(0, 1)
+  else if (head == 1 && tail == 0) W4S_GO(1, 0)
+  else if (head == 1 && tail == 1) W4S_GO(1, 1)
+  else if (head == 1 && tail == 2) W4S_GO(1, 2)
+  else if (head == 2 && tail == 0) W4S_GO(2, 0)
+  else if (head == 2 && tail == 1) W4S_GO(2, 1)
 #undef W4S_GO
 }
 
 // ----------------------------------------------------------------------------
-// NCHW <-> W4S at the solve boundary: both sides of a (sample, 16-channel block) are the same contiguous 4 KB, the
-// 16-B vectors (four pixels of an image row inside one tile) permuted.
+// NCHW <-> W4S at the solve boundary: a (sample, 16-channel block) is the same 4 KB (16 KB for 16x16 images: four
+// quadrant blocks of the W4S tensor) on both sides, the 16-B vectors (four pixels of an image row inside one tile) permuted.
 // ----------------------------------------------------------------------------
-__device__ __forceinline__ int w4s_of_nchw(int f) {   // float4 index inside the block: NCHW -> W4S
-  const int c15 = f >> 4, y = (f >> 1) & 7, tx = f & 1;
-  return (y & 3) * 64 + ((y >> 2) * 2 + tx) * 16 + c15;
+// NCHW float4 position `idx` of an [N, C, 8 sqrt(Q), 8 sqrt(Q)] tensor -> its float4 index in the W4S tensor
+template <int Q>
+__device__ __forceinline__ size_t w4s_of_nchw(size_t idx, int CB) {
+  constexpr int LB = Q == 4 ? 10 : 8;              // log2 float4s per (sample, 16-channel block)
+  const size_t blk = idx >> LB;                    // = n * CB + cb
+  const int f = (int)(idx & ((1 << LB) - 1));
+  if (Q == 1) {
+    const int c15 = f >> 4, y = (f >> 1) & 7, tx = f & 1;
+    return (blk << 8) + (y & 3) * 64 + ((y >> 2) * 2 + tx) * 16 + c15;
+  }
+  const int c15 = f >> 6, y = (f >> 2) & 15, x4 = f & 3;
+  const int q = 2 * (y >> 3) + (x4 >> 1), t = 2 * ((y >> 2) & 1) + (x4 & 1);
+  const size_t n = blk / CB, cb = blk - n * CB;
+  return (((4 * n + q) * CB + cb) << 8) + (y & 3) * 64 + t * 16 + c15;
 }
-__global__ __launch_bounds__(256) void k_w4s_layout(const float4* __restrict__ src, float4* __restrict__ dst, size_t total, int to_nchw) {
+template <int Q>
+__global__ __launch_bounds__(256) void k_w4s_layout(const float4* __restrict__ src, float4* __restrict__ dst, size_t total, int CB, int to_nchw) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const size_t blk = idx >> 8;
-  const int f = (int)(idx & 255);           // NCHW position inside the block
-  const int g = w4s_of_nchw(f);
-  if (to_nchw) dst[idx] = src[(blk << 8) + g];      // coalesced writes
-  else dst[(blk << 8) + g] = src[idx];              // coalesced reads
+  const size_t g = w4s_of_nchw<Q>(idx, CB);
+  if (to_nchw) dst[idx] = src[g];      // coalesced writes
+  else dst[g] = src[idx];              // coalesced reads
 }
-void launch_w4s_from_nchw(const float* src, float* dst, int N, int C, hipStream_t s) {
-  const size_t total = (size_t)N * C * 16;
-  hipLaunchKernelGGL(k_w4s_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
-                     reinterpret_cast<float4*>(dst), total, 0);
+static void w4s_layout(const float* src, float* dst, int N, int C, int Q, int to_nchw, hipStream_t s) {
+  const size_t total = (size_t)N * C * 16 * Q;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (Q == 1) hipLaunchKernelGGL(k_w4s_layout<1>, grid, block, 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), total, C >> 4, to_nchw);
+  else hipLaunchKernelGGL(k_w4s_layout<4>, grid, block, 0, s, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), total, C >> 4, to_nchw);
 }
-void launch_w4s_to_nchw(const float* src, float* dst, int N, int C, hipStream_t s) {
-  const size_t total = (size_t)N * C * 16;
-  hipLaunchKernelGGL(k_w4s_layout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
-                     reinterpret_cast<float4*>(dst), total, 1);
-}
+void launch_w4s_from_nchw(const float* src, float* dst, int N, int C, int Q, hipStream_t s) { w4s_layout(src, dst, N, C, Q, 0, s); }
+void launch_w4s_to_nchw(const float* src, float* dst, int N, int C, int Q, hipStream_t s) { w4s_layout(src, dst, N, C, Q, 1, s); }
 
-// border-aware time-channel map [HW][C] -> the W4S blocking ([C/16][4 i][64 lanes][4 j]) the forward passes read
+// border-aware time-channel map [HW][C] -> the W4S blocking ([Q quadrants][C/16][4 i][64 lanes][4 j]) the forward passes read
 __global__ __launch_bounds__(256) void k_w4s_tmap(const float* __restrict__ tmap0, const float* __restrict__ tmap1, float* __restrict__ out0,
-                                                  float* __restrict__ out1, int C) {
+                                                  float* __restrict__ out1, int C, int Q) {
   const float* tm = blockIdx.y ? tmap1 : tmap0;
   float* out = blockIdx.y ? out1 : out0;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 64 * C) return;
-  const int j = idx & 3, lane = (idx >> 2) & 63, i = (idx >> 8) & 3, cb = idx >> 10;
+  if (idx >= 64 * Q * C) return;
+  const int CB = C >> 4, WI = Q == 4 ? 16 : 8;
+  const int j = idx & 3, lane = (idx >> 2) & 63, i = (idx >> 8) & 3, rest = idx >> 10;
+  const int q = rest / CB, cb = rest - q * CB;
   const int t = lane >> 4, c = cb * 16 + (lane & 15);
-  const int p = (4 * (t >> 1) + i) * 8 + 4 * (t & 1) + j;
+  const int p = (8 * (q >> 1) + 4 * (t >> 1) + i) * WI + 8 * (q & 1) + 4 * (t & 1) + j;
   out[idx] = tm[(size_t)p * C + c];
 }
-void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4s_tmap, dim3((64 * C + 255) / 256, 2), dim3(256), 0, s, tmap0, tmap1, out0, out1, C);
+void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, int Q, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4s_tmap, dim3((64 * Q * C + 255) / 256, 2), dim3(256), 0, s, tmap0, tmap1, out0, out1, C, Q);
 }
 
 // Dense output of the forward solve (k_emit_outputs) for W4S state: element-wise on the 16-B vectors, written at their
 // NCHW position.
-__global__ __launch_bounds__(256) void k_w4s_emit_outputs(EmitArgs a, size_t total /* float4s per tensor */) {
+template <int Q>
+__global__ __launch_bounds__(256) void k_w4s_emit_outputs(EmitArgs a, size_t total /* float4s per tensor */, int CB) {
   const Ctrl* c = a.ctrl;
   const int j0 = c->j0, j1 = c->j1;
   if (j1 <= j0) return;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // NCHW float4 position
   if (idx >= total) return;
-  const size_t src = ((idx >> 8) << 8) + w4s_of_nchw((int)(idx & 255));
+  const size_t src = w4s_of_nchw<Q>(idx, CB);
   const float dt = (float)c->dt_used;
   const float t0f = (float)c->t_prev, t1f = (float)c->t;
   const float4 y0 = w4s_ld4(a.y0, src), y1 = w4s_ld4(a.y1, src);
@@ -580,45 +744,50 @@ __global__ __launch_bounds__(256) void k_w4s_emit_outputs(EmitArgs a, size_t tot
 }
 void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s) {
   const size_t total = d.numel / 4;
-  hipLaunchKernelGGL(k_w4s_emit_outputs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (d.w4q == 1) hipLaunchKernelGGL(k_w4s_emit_outputs<1>, grid, block, 0, s, a, total, d.C >> 4);
+  else hipLaunchKernelGGL(k_w4s_emit_outputs<4>, grid, block, 0, s, a, total, d.C >> 4);
 }
 
 // ----------------------------------------------------------------------------
 // Stand-alone transforms around the GEMM (diagnostics / tests: node_conv3x3_w4): W4S tensor -> V, M -> W4S tensor
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(W4S_THREADS) void k_w4s_input(const float* __restrict__ x, float* __restrict__ V, int N, int C) {
-  const int lane = threadIdx.x & 63, CB = C >> 4;
-  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
-  const int n = unit / CB, cb = unit - n * CB;
-  const int t = lane >> 4, c15 = lane & 15, ty = t >> 1, tx = t & 1;
-  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;
+template <int Q>
+__global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_input(const float* __restrict__ x, float* __restrict__ V, int C, int Nv) {
+  __shared__ float s_tiles[Q == 4 ? W4Q_TILES : 1];
+  W4Wave<Q> wv;
+  w4s_place(wv, C, nullptr, s_tiles);
+  const size_t f4 = ((size_t)wv.nv * (C >> 4) + wv.cb) * 256 + wv.lane;
   float v[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float4 q = w4s_ld4(x, f4 + i * 64);
     v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
   }
-  const int g8 = cb * 2 + (c15 >> 3), hi = (c15 >> 2) & 1, e = c15 & 3;
-  float* vp = V + ((size_t)((n >> 3) * (C >> 3) + g8) * 256 + (n & 7) * 32 + hi * 16 + t * 4 + e);
-  w4s_emit_v(v, ty, tx, vp, (size_t)4 * N * C);
+  w4s_put_v(v, wv, V, C, Nv);
 }
-__global__ __launch_bounds__(W4S_THREADS) void k_w4s_output(const float* __restrict__ M, float* __restrict__ y, int N, int C) {
-  const int lane = threadIdx.x & 63, CB = C >> 4;
-  const int unit = blockIdx.x * (W4S_THREADS / 64) + (threadIdx.x >> 6);
-  const int n = unit / CB, cb = unit - n * CB;
-  const int t = lane >> 4, c15 = lane & 15;
-  const size_t f4 = ((size_t)n * CB + cb) * 256 + lane;
-  const float* mp = M + (((size_t)n * (C >> 5) + (cb >> 1)) * 36) * 128 + t * 32 + (cb & 1) * 16 + c15;
+template <int Q>
+__global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_output(const float* __restrict__ M, float* __restrict__ y, int C) {
+  W4Wave<Q> wv;
+  w4s_place(wv, C, nullptr, nullptr);
+  const size_t f4 = ((size_t)wv.nv * (C >> 4) + wv.cb) * 256 + wv.lane;
   float z[4][4];
-  w4s_out_transform(mp, z);
+  w4s_out_transform(w4s_m_ptr(M, wv, C), z);
 #pragma unroll
   for (int i = 0; i < 4; ++i) w4s_st4(y, f4 + i * 64, z[i]);
 }
-void launch_w4_input(const float* x_w4s, float* V, int N, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4s_input, dim3(N * (C >> 4) / (W4S_THREADS / 64)), dim3(W4S_THREADS), 0, s, x_w4s, V, N, C);
+// N: samples; Nv: virtual samples (Q N) rounded up to the GEMMs' row block
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s) {
+  dim3 grid, block;
+  w4s_grid(N, C, 1, Q, grid, block);
+  if (Q == 1) hipLaunchKernelGGL(k_w4s_input<1>, grid, block, 0, s, x_w4s, V, C, Nv);
+  else hipLaunchKernelGGL(k_w4s_input<4>, grid, block, 0, s, x_w4s, V, C, Nv);
 }
-void launch_w4_output(const float* M, float* y_w4s, int N, int C, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4s_output, dim3(N * (C >> 4) / (W4S_THREADS / 64)), dim3(W4S_THREADS), 0, s, M, y_w4s, N, C);
+void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s) {
+  dim3 grid, block;
+  w4s_grid(N, C, 1, Q, grid, block);
+  if (Q == 1) hipLaunchKernelGGL(k_w4s_output<1>, grid, block, 0, s, M, y_w4s, C);
+  else hipLaunchKernelGGL(k_w4s_output<4>, grid, block, 0, s, M, y_w4s, C);
 }
 
 }  // namespace node

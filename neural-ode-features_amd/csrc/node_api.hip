@@ -175,8 +175,14 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // the other switches) so that one test process can run both conv paths on the same inputs.
     const char* w4e = getenv("NODE_TUNE_WINO4");
     const int w4_env = w4e ? atoi(w4e) : 1;
-    d.wino4 = (w4_env != 0 && d.H == 8 && d.W == 8 && d.C % 64 == 0 && 16 % d.cpg == 0) ? w4_env : 0;
-    d.N8 = (d.N + 7) & ~7;
+    // 16x16 images: four 8x8 quadrants per image (w4q), each a virtual sample of the GEMM-side layouts; the passes
+    // hold a GroupNorm group in one workgroup (cpg | 16 or cpg == 32) and only the F(4x4,3x3)-domain weight gradient
+    // (C % 128 == 0) is wired behind them
+    const bool fit8 = d.H == 8 && d.W == 8 && d.C % 64 == 0 && 16 % d.cpg == 0;
+    const bool fit16 = d.H == 16 && d.W == 16 && d.C % 128 == 0 && (16 % d.cpg == 0 || d.cpg == 32);
+    d.wino4 = (w4_env != 0 && (fit8 || fit16)) ? w4_env : 0;
+    d.w4q = fit16 ? 4 : 1;
+    d.N8 = (d.N * d.w4q + 7) & ~7;
   }
   d.RB = 64 / d.W;
   if (d.RB < 1) d.RB = 1;
@@ -317,6 +323,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
       p.r1b = b.take<float>((size_t)d.N * d.G);
     }
   }
+  const size_t prow = d.wino4 ? (size_t)d.N * d.w4q : (size_t)d.N;   // rows of the per-sample partials (F(4x4,3x3) passes: per quadrant)
   if (adjoint) {
     for (int i = 0; i < 2; ++i) p.wd[i] = b.take<float>(wsz);
     p.A = b.take<float>(d.numel);
@@ -336,14 +343,14 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.G = b.take<float>(d.numel);
     for (int i = 0; i < 2; ++i) {
       p.wpart[i] = b.take<float>((size_t)d.nsplit * 9 * d.C * d.C);
-      p.spart[i] = b.take<float>((size_t)d.N * 9 * d.C);
+      p.spart[i] = b.take<float>(prow * 9 * d.C);
     }
     p.sred = b.take<float>((size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64) + 4);   // + vjp_t partials + arrival counter
     for (int i = 0; i < 2; ++i) p.wtime[i] = b.take<float>((size_t)9 * d.C);
-    const size_t grows = d.wino4 && d.N > d.mtiles ? d.N : d.mtiles;   // (F(4x4,3x3) passes: per-sample partials)
+    const size_t grows = prow > (size_t)d.mtiles ? prow : (size_t)d.mtiles;
     p.gpart[0] = b.take<float>(grows * 2 * d.C);
     p.gpart[1] = b.take<float>(grows * 2 * d.C);
-    p.gpart[2] = b.take<float>((size_t)d.N * 2 * d.C);
+    p.gpart[2] = b.take<float>(prow * 2 * d.C);
     p.dots = b.take<float>((size_t)(n_t > 0 ? n_t : 1));
   }
   p.bytes = ((b.off + 255) & ~(size_t)255);
@@ -435,11 +442,11 @@ struct Solver {
   float* xh1_of(int i) const { return i ? p.xh1b : p.xh1; }
   float* r1_of(int i) const { return i ? p.r1b : p.r1; }
   void to_state(const float* nchw, float* dst) {    // NCHW -> the solve's internal state layout
-    if (w4) launch_w4s_from_nchw(nchw, dst, d.N, d.C, st);
+    if (w4) launch_w4s_from_nchw(nchw, dst, d.N, d.C, d.w4q, st);
     else launch_nchw_to_nhwc(d, nchw, dst, st);
   }
   void from_state(const float* src, float* nchw) {
-    if (w4) launch_w4s_to_nchw(src, nchw, d.N, d.C, st);
+    if (w4) launch_w4s_to_nchw(src, nchw, d.N, d.C, d.w4q, st);
     else launch_nhwc_to_nchw(d, src, nchw, st);
   }
   struct NextComb { Comb cy; float* y_out; };
@@ -505,8 +512,8 @@ struct Solver {
     }
     launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
                      nz, st);
-    if (w4) launch_w4s_tmap(p.tmap[0], p.tmap[1], p.tmapS[0], p.tmapS[1], d.C, st);
-    if (w4 && aug && d.N != d.N8 && p.W4dU != nullptr) {
+    if (w4) launch_w4s_tmap(p.tmap[0], p.tmap[1], p.tmapS[0], p.tmapS[1], d.C, d.w4q, st);
+    if (w4 && aug && d.N * d.w4q != d.N8 && p.W4dU != nullptr) {
       // the weight gradient SUMS over the GEMM rows: the rows of the padding samples (never written by a pass) must be zero
       for (int i = 0; i < 2; ++i) {
         launch_fill(p.W4Va[i], 0.f, w4_v_elems(d.N8, d.C), st);
@@ -568,7 +575,7 @@ struct Solver {
   W4sArgs w4_args() const {
     W4sArgs a;
     memset(&a, 0, sizeof(a));
-    a.ctrl = p.ctrl; a.N = d.N; a.Nv = d.N8; a.C = d.C; a.cpg = d.cpg; a.eps = d.eps;
+    a.ctrl = p.ctrl; a.N = d.N; a.Q = d.w4q; a.Nv = d.N8; a.C = d.C; a.cpg = d.cpg; a.eps = d.eps;
     return a;
   }
   // tail 1 of a pass: stage combine -> GroupNorm-1 -> ReLU -> V (+ act1, xhat-1, 1/sigma-1 of set `set` when training)
@@ -582,7 +589,7 @@ struct Solver {
   void w4_pass(int head, int tail, const W4sArgs& a) {
     double bytes = 0.0;
     if (g_prof.on) {
-      const double state = (double)d.numel * sizeof(float), comp = 36.0 * 4.0 * d.N * d.C * sizeof(float);
+      const double state = (double)d.numel * sizeof(float), comp = 36.0 * 4.0 * d.N * d.w4q * d.C * sizeof(float);
       int tensors = 0;
       if (head) {
         tensors += (a.h.out_s != nullptr) + (a.h.out_nhwc != nullptr);
@@ -696,7 +703,7 @@ struct Solver {
     tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
     tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
     tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
-    tf.gpart_rows[0] = tf.gpart_rows[1] = tf.gpart_rows[2] = d.N;   // per-sample partials from the GroupNorm passes
+    tf.gpart_rows[0] = tf.gpart_rows[1] = tf.gpart_rows[2] = tf.spart_rows = d.N * d.w4q;   // per-sample (per-quadrant) partials from the GroupNorm passes
     tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
     tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
     tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
@@ -1062,7 +1069,8 @@ int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t
 size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape) {
   if (!shape) return 0;
   const size_t numel = (size_t)shape->n * shape->c * shape->h * shape->w;
-  return (2 * numel + 2 * w4_v_elems(shape->n, shape->c) + w4_u_elems(shape->c)) * sizeof(float) +
+  const int nv = (shape->n * (shape->h == 16 ? 4 : 1) + 7) & ~7;
+  return (2 * numel + 2 * w4_v_elems(nv, shape->c) + w4_u_elems(shape->c)) * sizeof(float) +
          w4_ub_elems(shape->c) * sizeof(unsigned short) + 6 * 256;
 }
 int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y, void* ws,
@@ -1070,28 +1078,30 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   if (!shape || !weight || !x || !y || !ws) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   Dims d;
   TRY(make_dims(shape, &d));
-  if (!(d.H == 8 && d.W == 8 && d.C % 64 == 0 && d.N % 8 == 0))
-    return fail(NODE_ERR_UNSUPPORTED, "the F(4x4,3x3) pipeline takes 8x8 images, C %% 64 == 0, N %% 8 == 0");
+  const bool sq8 = d.H == 8 && d.W == 8, sq16 = d.H == 16 && d.W == 16;
+  if (!((sq8 || sq16) && d.C % 64 == 0 && (d.N * (sq16 ? 4 : 1)) % 8 == 0))
+    return fail(NODE_ERR_UNSUPPORTED, "the F(4x4,3x3) pipeline takes 8x8 (N %% 8 == 0) or 16x16 (N %% 2 == 0) images, C %% 64 == 0");
+  const int Q = sq16 ? 4 : 1, Nv = d.N * Q;
   if (ws_bytes < node_conv3x3_w4_workspace_bytes(shape)) return fail(NODE_ERR_ARG, "workspace too small");
   if (((uintptr_t)ws) & 255) return fail(NODE_ERR_ARG, "workspace must be 256-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   Bump b(ws);
   float* xn = b.take<float>(d.numel);
   float* yn = b.take<float>(d.numel);
-  float* V = b.take<float>(w4_v_elems(d.N, d.C));
-  float* M = b.take<float>(w4_v_elems(d.N, d.C));
+  float* V = b.take<float>(w4_v_elems(Nv, d.C));
+  float* M = b.take<float>(w4_v_elems(Nv, d.C));
   float* U = b.take<float>(w4_u_elems(d.C));
   unsigned short* Ub = b.take<unsigned short>(w4_ub_elems(d.C));
   W4PackJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
-  const bool b16 = w4_uses_bf16(d.N);
+  const bool b16 = w4_uses_bf16(Nv);
   jobs.w[0] = weight; jobs.u[0] = U; jobs.ub[0] = b16 ? Ub : nullptr; jobs.dgrad[0] = dgrad ? 1 : 0;
   launch_w4_pack(jobs, 1, d.C, st);
-  launch_w4s_from_nchw(x, xn, d.N, d.C, st);
-  launch_w4_input(xn, V, d.N, d.C, st);
-  launch_w4_gemm(V, U, M, nullptr, d.N, d.C, st, b16 ? Ub : nullptr);
-  launch_w4_output(M, yn, d.N, d.C, st);
-  launch_w4s_to_nchw(yn, y, d.N, d.C, st);
+  launch_w4s_from_nchw(x, xn, d.N, d.C, Q, st);
+  launch_w4_input(xn, V, d.N, d.C, Q, Nv, st);
+  launch_w4_gemm(V, U, M, nullptr, Nv, d.C, st, b16 ? Ub : nullptr);
+  launch_w4_output(M, yn, d.N, d.C, Q, st);
+  launch_w4s_to_nchw(yn, y, d.N, d.C, Q, st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
   return NODE_OK;

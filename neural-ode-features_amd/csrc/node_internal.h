@@ -29,10 +29,11 @@ struct Dims {
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
   int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
                     // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
-  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, cpg | 16.  Any batch: the
-                    // component GEMMs run on N8 = N rounded up to 8 samples (their rows are independent; the weight gradient,
-                    // which sums over rows, sees zero rows for the padding samples)
-  int N8;
+  int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, cpg | 16 -- or 16x16 images,
+                    // C % 128 == 0, cpg | 16 or cpg == 32 (w4q = 4 quadrants per image, each a virtual sample of the GEMMs).
+                    // Any batch: the component GEMMs run on N8 = w4q N rounded up to 8 samples (their rows are independent; the
+                    // weight gradient, which sums over rows, sees zero rows for the padding samples)
+  int w4q, N8;
                     // Whether a solve USES it depends on its tolerance (Solver::w4)
   int csplit;       // 2-D Winograd conv on images larger than its 128-pixel tile: workgroups per sample (0: whole samples per tile).
                     // The conv then writes its raw output and GroupNorm runs as a pointwise pass (k_combine_gn / k_gn_bwd)
@@ -399,6 +400,7 @@ struct ThetaFinalizeArgs {
   const float* spart[2];   // [N][9][C] each
   const float* gpart[3];   // GN1 (mtiles), GN2 (mtiles), GN3 (N)
   int gpart_rows[3];
+  int spart_rows;          // rows of spart (0: N) -- the F(4x4,3x3) passes of 16x16 images leave one row per quadrant
   const float* wtime[2];   // time-channel weights [tap][co] gathered from the raw conv weights (launch_wtime)
   float* sred;             // [2][9][C] split-reduced masked column sums (scratch)
   EvalTime et;

@@ -1,5 +1,7 @@
-// Winograd F(4x4, 3x3) as a three-stage pipeline (gfx950 only): the 3x3 convolutions of an 8x8 state whose
-// solver tolerance leaves room for the transform's rounding (see Solver::choose_w4, node_api.hip).
+// Winograd F(4x4, 3x3) as a three-stage pipeline (gfx950 only): the 3x3 convolutions of an 8x8 or 16x16 state whose
+// solver tolerance leaves room for the transform's rounding (see Solver::choose_w4, node_api.hip).  A 16x16 image is
+// four 8x8 quadrants, each a "virtual sample" of the layouts below (kernels_w4s.hip has the quadrant logic): wherever
+// this file says N or "sample" for V, U, M, Z and the GEMM-side kernels, a 16x16 solve passes 4 N.
 //
 //   V = B^T d B   6x6 input transform of every 4x4 output tile's 6x6 patch -- written by the PRODUCER of the conv
 //                 input (the GroupNorm passes, kernels_w4s.hip), not by the conv
@@ -89,7 +91,8 @@ struct W4sTail {          // what follows the head inside the same launch
 struct W4sArgs {
   const Ctrl* ctrl;       // nullable: the launch returns at once when ctrl->done
   int N, C, cpg;
-  int Nv;                 // N rounded up to the component GEMMs' row block (8 samples): strides of V, Z (rows of the padding
+  int Q;                  // 1: 8x8 images; 4: 16x16 images, four quadrant waves per (sample, channel block)
+  int Nv;                 // Q N rounded up to the component GEMMs' row block (8 samples): strides of V, Z (rows of the padding
                           // samples are never written and never read by anything that leaves the GEMM's own rows)
   float eps;
   W4sHead h;
@@ -98,9 +101,9 @@ struct W4sArgs {
 };
 // head: 0 none / 1 forward / 2 backward; tail: 0 none / 1 stage combine + GroupNorm-1 + ReLU / 2 adjoint combine + GroupNorm-3 backward
 void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s);
-void launch_w4s_from_nchw(const float* src_nchw, float* dst_w4s, int N, int C, hipStream_t s);
-void launch_w4s_to_nchw(const float* src_w4s, float* dst_nchw, int N, int C, hipStream_t s);
-void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, hipStream_t s);
+void launch_w4s_from_nchw(const float* src_nchw, float* dst_w4s, int N, int C, int Q, hipStream_t s);
+void launch_w4s_to_nchw(const float* src_w4s, float* dst_nchw, int N, int C, int Q, hipStream_t s);
+void launch_w4s_tmap(const float* tmap0, const float* tmap1, float* out0, float* out1, int C, int Q, hipStream_t s);
 void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
 
 // F(4x4,3x3)-domain weight gradient of both conv layers (k_w4_wgrad, kernels_w4.hip).
@@ -133,7 +136,7 @@ void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s,
                     const unsigned short* Ub = nullptr);
 // stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
-void launch_w4_input(const float* x_w4s, float* V, int N, int C, hipStream_t s);
-void launch_w4_output(const float* M, float* y_w4s, int N, int C, hipStream_t s);
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s);
+void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s);
 
 }  // namespace node

@@ -160,7 +160,7 @@ def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end):
     assert rel_err(free['gy'], hip['gy']) < 1e-4 and rel_err(free['gp'], hip['gp']) < 1e-4
 
 
-@pytest.mark.parametrize('tol,t_end', [(1e-3, 1.0), (1e-5, 0.3)])
+@pytest.mark.parametrize('tol,t_end', [(1e-3, 1.0)])     # (tol 1e-5, 160 s of CPU oracle, ran here too until the F(4x4,3x3) arbiter test above took both tolerances)
 def test_full_size_adjoint_solve_fp64_arbiter(tol, t_end):
     """configs[1] / configs[2] state [128,256,8,8], ordinary parameters: the ReLU masks DO switch inside the solve, so
     two correct fp32 implementations disagree wherever a pre-activation lands within rounding of zero (measured: every

@@ -44,7 +44,9 @@ def _conv_w4(x, w, dgrad):
     return y
 
 
-@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8)])
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8),
+                                   (2, 128, 16, 16), (8, 128, 16, 16), (4, 256, 16, 16), (2, 1024, 16, 16),
+                                   (16, 128, 16, 16), (8, 1024, 16, 16)])
 @pytest.mark.parametrize('dgrad', [0, 1])
 def test_w4_convolution_matches_fp64(shape, dgrad):
     N, Cc, H, W = shape
@@ -66,17 +68,33 @@ def test_w4_convolution_matches_fp64(shape, dgrad):
     finally:
         del os.environ['NODE_TUNE_W4_BF16X3']
     err32 = float((got32.double() - ref).abs().max() / ref.abs().max())
+    # ... and on the LDS-tiled kernel of the long reductions (k_w4_gemm128b; by itself from C = 512), where the shape fits it:
+    # the same six part products per element in the same order (only the four components whose reduction k_w4_gemm64b cuts
+    # into K slices are summed in another order): the two kernels may differ by the rounding of those sums alone
+    if (N * (4 if H == 16 else 1)) % 32 == 0 and Cc % 128 == 0 and ((N * (4 if H == 16 else 1) // 32) * (Cc // 128)) % 2 == 0:
+        outs = {}
+        for mode in ('0', '1'):
+            os.environ['NODE_TUNE_W4_GEMM128'] = mode
+            try:
+                outs[mode] = _conv_w4(x, w, dgrad)
+            finally:
+                del os.environ['NODE_TUNE_W4_GEMM128']
+        e128 = float((outs['1'].double() - ref).abs().max() / ref.abs().max())
+        d128 = float((outs['0'] - outs['1']).abs().max() / ref.abs().max())
+        print('  k_w4_gemm128b: max err / max|y| %.2e, against k_w4_gemm64b %.2e' % (e128, d128))
+        assert e128 < 2e-5 and d128 < 1e-5, (e128, d128)
+        assert torch.equal(outs['1' if Cc >= 512 else '0'], got)     # which of the two the library picks by itself
     print('F(4x4,3x3) conv', shape, 'dgrad' if dgrad else 'fwd', 'max err / max|y|: bf16 triples %.2e, fp32 MFMA %.2e, between them %.2e'
           % (err, err32, float((got - got32).abs().max() / ref.abs().max())))
     assert err < 2e-5 and err32 < 2e-5, (err, err32)
     assert err < 1.5 * err32 + 1e-6, (err, err32)
 
 
-def _engaged(N, Cc):
+def _engaged(N, Cc, side=8):
     """The workspace grows by the pipeline's buffers exactly when the geometry takes it."""
     from neural_ode_features_amd import _lib
     lib = _lib.load()
-    shape = _lib.NodeShape(N, Cc, 8, 8, min(32, Cc), 1e-5)
+    shape = _lib.NodeShape(N, Cc, side, side, min(32, Cc), 1e-5)
     with wino4(0):
         a = lib.node_workspace_bytes(C.byref(shape), 0, 1, 2)
     with wino4(2):
@@ -143,16 +161,21 @@ def test_w4_pipeline_matches_reference_odefunc_fixture(golden_dir, name):
 
 
 @pytest.mark.parametrize('shape', [(8, 64, 8, 8), (8, 128, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8),
-                                   (1, 64, 8, 8), (3, 128, 8, 8), (12, 256, 8, 8), (1, 256, 8, 8)])
+                                   (1, 64, 8, 8), (3, 128, 8, 8), (12, 256, 8, 8), (1, 256, 8, 8),
+                                   (2, 128, 16, 16), (1, 128, 16, 16), (8, 128, 16, 16), (4, 256, 16, 16), (3, 256, 16, 16),
+                                   (2, 512, 16, 16), (2, 1024, 16, 16)])
 def test_w4_odefunc_forward_and_vjp_match_oracle(shape):
     """The pipeline's single evaluation and VJP against the CPU oracle (oracle/dynamics.py, pinned by the reference's
     fixtures), kink-free parameters, at the smallest and at the configs[1] shape: max-norm bounds.  C = 64 takes the
     F(2x2,3x3)-domain weight gradient behind the pipeline, C % 128 == 0 the F(4x4,3x3)-domain one (k_w4_wgrad; N = 8:
     its short operand ring).  Batches that are no multiple of 8 (the bs = 1 census, evaluate.py:97-142) run the component
-    GEMMs on padding rows nobody reads; the weight gradient sees zero rows there."""
+    GEMMs on padding rows nobody reads; the weight gradient sees zero rows there.
+    16x16 states (the one-shot stem's [n, 256, 16, 16], cfg 5's [n, 1024, 16, 16]) run as four 8x8 quadrants per image: 4, 8,
+    16 and 32 channels per GroupNorm group = 4 (cpg <= 16) or 8 (cpg = 32) quadrant waves per workgroup, sums and the
+    input transform's pixel ring through LDS (kernels_w4s.hip); odd batches pad the virtual-sample count there too."""
     from neural_ode_features_amd import integrate
     N, Cc, H, W = shape
-    assert _engaged(N, Cc)
+    assert _engaged(N, Cc, H)
     f, twin = make_func(Cc, seed=7, device='cuda', kink_free=True)
     gen = torch.Generator().manual_seed(13)
     y = torch.randn(N, Cc, H, W, generator=gen)
@@ -166,19 +189,43 @@ def test_w4_odefunc_forward_and_vjp_match_oracle(shape):
     assert errs['f'] < 3e-5 and errs['vjp_y'] < 1e-4 and errs['vjp_params'] < 1e-4 and errs['vjp_t'] < 1e-4, errs
 
 
-@pytest.mark.parametrize('tol,gain', [(1e-3, 1.0), (1e-5, 1.0), (1e-5, 4.0), (1e-5, 12.0)])
-def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain):
+@pytest.mark.parametrize('shape', [(128, 256, 8, 8), (12, 256, 8, 8), (4, 256, 16, 16), (3, 256, 16, 16)])
+def test_w4_wgrad128_matches_oracle(shape):
+    """k_w4_wgrad128b (the weight gradient on bf16 triples, LDS-tiled; by itself from C = 512 -- the C = 512 / 1024 shapes of the
+    test above run it) forced on at C = 256, against the oracle and against k_w4_wgrad on the same inputs."""
+    from neural_ode_features_amd import integrate
+    N, Cc, H, W = shape
+    f, twin = make_func(Cc, seed=7, device='cuda', kink_free=True)
+    gen = torch.Generator().manual_seed(13)
+    y = torch.randn(N, Cc, H, W, generator=gen)
+    cot = torch.randn(N, Cc, H, W, generator=gen)
+    _, _, _, ref_vp = oracle_vjp(torch.tensor(0.3), y, dict(twin.named_parameters()), cot)
+    got = {}
+    for mode in ('0', '1'):
+        os.environ['NODE_TUNE_W4_WGRAD128'] = mode
+        try:
+            with wino4(2):
+                got[mode] = integrate.odefunc_vjp(f, 0.3, y.cuda(), cot.cuda())[3]
+        finally:
+            del os.environ['NODE_TUNE_W4_WGRAD128']
+    e0, e1 = rel_err(got['0'], ref_vp), rel_err(got['1'], ref_vp)
+    print('weight gradient vs oracle at', shape, 'k_w4_wgrad %.2e, k_w4_wgrad128b %.2e, between them %.2e' % (e0, e1, rel_err(got['1'], got['0'])))
+    assert e0 < 1e-4 and e1 < 1e-4 and e1 < 2 * e0 + 1e-6
+
+
+@pytest.mark.parametrize('tol,gain,side', [(1e-3, 1.0, 8), (1e-5, 1.0, 8), (1e-5, 4.0, 8), (1e-5, 12.0, 8), (1e-3, 1.0, 16), (1e-5, 4.0, 16)])
+def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
     """dopri5 at tol >= 1e-5 takes the F(4x4,3x3) path by itself; with it off the same solve runs on F(2x2,3x3).
     `gain` scales the last GroupNorm's weight, i.e. |f|: the stiffer cases take many steps with rejections among them, so
     that the conv noise meets a step controller that is working (Solver::choose_w4 has the error budget: <= 5 % of tol)."""
     import neural_ode_features_amd as nof
-    N, Cc = 16, 64
-    assert _engaged(N, Cc)
+    N, Cc = (16, 64) if side == 8 else (4, 128)     # (16x16 states: four 8x8 quadrants per image, kernels_w4s.hip)
+    assert _engaged(N, Cc, side)
     f, _ = make_func(Cc, seed=2, device='cuda', kink_free=True)
     with torch.no_grad():
         f.norm3.weight.mul_(gain)
     gen = torch.Generator().manual_seed(21)
-    y0 = torch.randn(N, Cc, 8, 8, generator=gen).cuda()
+    y0 = torch.randn(N, Cc, side, side, generator=gen).cuda()
     t = torch.tensor([0.0, 1.0]).cuda()
     outs, grads, nfes = [], [], []
     for mode in (0, 1):
@@ -194,8 +241,8 @@ def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain):
             grads.append((y.grad.detach().clone(), torch.cat([p.grad.reshape(-1) for p in f.parameters()])))
             nfes.append((nf, f.nfe - nf))
     scale = float(outs[0].abs().max())
-    print('tol %g gain %g: nfe F(2x2) %s F(4x4) %s, max|y| %.2f, out diff %.2e, grad rel %.2e / %.2e'
-          % (tol, gain, nfes[0], nfes[1], scale, float((outs[0] - outs[1]).abs().max()),
+    print('tol %g gain %g side %d: nfe F(2x2) %s F(4x4) %s, max|y| %.2f, out diff %.2e, grad rel %.2e / %.2e'
+          % (tol, gain, side, nfes[0], nfes[1], scale, float((outs[0] - outs[1]).abs().max()),
              rel_err(grads[1][0], grads[0][0]), rel_err(grads[1][1], grads[0][1])))
     # the same step sequence, up to one accept/reject decision that sat within the noise (6 evaluations per step)
     assert abs(nfes[0][0] - nfes[1][0]) <= 6 and abs(nfes[0][1] - nfes[1][1]) <= 6, nfes

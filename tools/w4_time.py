@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Run the F(4x4,3x3) diagnostic convolution a few times at the cfg-2 shape (under rocprofv3 --kernel-trace --stats:
-per-kernel durations of k_w4_gemm and the stand-alone transforms)."""
+"""Run the F(4x4,3x3) diagnostic convolution a few times (under rocprofv3 --kernel-trace --stats: per-kernel durations of
+the component GEMM and the stand-alone transforms):  w4_time.py [iterations] [N,C,side]   (default: the cfg-2 shape)."""
 import ctypes as C
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,9 +8,9 @@ import torch
 from neural_ode_features_amd import _lib
 
 lib = _lib.load()
-N, Cc = 128, 256
-shape = _lib.NodeShape(N, Cc, 8, 8, 32, 1e-5)
-x = torch.randn(N, Cc, 8, 8, device='cuda')
+N, Cc, side = (int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else (128, 256, 8)))    # cfg 5: 64,1024,16
+shape = _lib.NodeShape(N, Cc, side, side, 32, 1e-5)
+x = torch.randn(N, Cc, side, side, device='cuda')
 w = torch.randn(Cc, Cc + 1, 3, 3, device='cuda') / 48
 nbytes = lib.node_conv3x3_w4_workspace_bytes(C.byref(shape))
 ws = torch.empty(nbytes + 256, dtype=torch.uint8, device='cuda')
