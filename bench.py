@@ -522,8 +522,11 @@ def main():
                 tbs = bytes_algo / (avg_ms * 1e-3) / 1e12
                 flops_bf16 = algo_per_launch * issued * 6.0
                 issued_bf16 = flops_bf16 / (avg_ms * 1e-3) / 1e12
-                kname = ('k_w4_gemm64b (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
-                         'at fp32 accuracy: exact three-way bf16 split of both operands, six products)')
+                lds_tiled = C >= 512 and Nn % 32 == 0 and C % 128 == 0 and os.environ.get('NODE_TUNE_W4_GEMM128', '1') != '0'
+                kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
+                         'at fp32 accuracy: exact three-way bf16 split of both operands, six products%s)'
+                         % (('k_w4_gemm128b', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
+                            else ('k_w4_gemm64b', '')))
                 mfma_view = {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
                              'fp32_equivalent_tflops': ach, 'vs_fp32_matrix_peak': ach / MFMA_F32_PEAK_TFLOPS,
                              'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
@@ -576,6 +579,12 @@ def main():
                 wissued, wname = 36.0 / 144.0, 'k_w4_wgrad (F(4x4,3x3) domain, both conv layers per launch, no split-K slabs)'
             roofline['wgrad'] = {'kernel': wname, 'achieved': walgo * wissued, 'frac': walgo * wissued / MFMA_F32_PEAK_TFLOPS,
                                  'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
+            if wname.startswith('k_w4_wgrad') and cfg['filters'] >= 512 and os.environ.get('NODE_TUNE_W4_WGRAD128', '1') != '0':
+                # long filters: the same sums on bf16 triples, LDS-tiled (k_w4_wgrad128b): six bf16 MFMA products per fp32 product
+                roofline['wgrad'].update({
+                    'kernel': 'k_w4_wgrad128b (F(4x4,3x3) domain, both conv layers per launch, bf16 MFMA at fp32 accuracy, LDS-tiled)',
+                    'achieved': walgo * wissued * 6.0, 'frac': walgo * wissued * 6.0 / MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s of bf16 MFMA issued',
+                    'fp32_equivalent_tflops': walgo * wissued})
         # the HBM-bound side ("report both fractions separately"): the GroupNorm / transform passes of the
         # F(4x4,3x3) pipeline, per kernel instance, ALGORITHMIC bytes (every tensor a pass must read or write, once)
         # over the mean launch duration between HIP events
@@ -589,7 +598,8 @@ def main():
             dom = max(passes, key=lambda n: passes[n]['total_ms'])
             tot = {'launches': sum(v['launches'] for v in passes.values()), 'total_ms': sum(v['total_ms'] for v in passes.values()),
                    'flops': sum(v['flops'] for v in passes.values())}
-            inst = dom[dom.index('<'):dom.index('>') + 1].replace(',', ', ')      # 'w4s_pass<1,2> ...' -> '<1, 2>' as rocprofv3 prints it
+            # 'w4s_pass<1,2> ...' -> '<1, 2, ' as rocprofv3 prints the instance (third argument: 1 = 8x8 images, 4 = 16x16)
+            inst = dom[dom.index('<'):dom.index('>')].replace(',', ', ') + ', '
             roofline['hbm'] = dict(hb(passes[dom]), bound='hbm', kernel='k_' + dom, peak=HBM_PEAK_TBS, unit='TB/s',
                                    traffic=(pmc_lookup(pmc, 'k_w4s_pass' + inst) or {}).get('bytes'),
                                    all_passes=dict(hb(tot), ms_per_step=tot['total_ms'] / min(args.steps, 5)),

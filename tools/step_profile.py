@@ -90,7 +90,7 @@ def report(title, steps, thr, show_gaps):
         if c:
             print('  %-64s %8.1f %8.1f %10.2f %9.3f %6.2f' % (n, c / k, dead / k, d / c / 1e3, d / 1e6 / k, 100.0 * d / tot))
     edges = [2, 5, 10, 20, 40, 60]
-    for name in ('node::k_conv3x3_w2', 'node::k_w4_wgrad<8>', 'node::k_w4s_pass<1, 0>'):
+    for name in ('node::k_conv3x3_w2', 'node::k_w4_wgrad<8>', 'node::k_w4_wgrad128b', 'node::k_w4s_pass<1, 0, 1>', 'node::k_w4s_pass<1, 0, 4>'):
         d = [(e - s) / 1e3 for s, e, n in flat if n == name]
         if d:
             hist = [sum(1 for x in d if lo <= x < hi) for lo, hi in zip([0] + edges, edges + [1e9])]
