@@ -250,3 +250,37 @@ def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
     assert rel_err(outs[1], outs[0]) < 1e-4
     assert rel_err(grads[1][0], grads[0][0]) < 1e-3
     assert rel_err(grads[1][1], grads[0][1]) < 1e-3
+
+
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (2, 128, 16, 16), (3, 256, 16, 16)])
+def test_w4_dense_output_many_time_points(shape):
+    """evaluate.py:56-94: features at many interior time points from ONE solve (dense output of the accepted steps), here
+    through the pipeline's own emit kernel (W4S state -> NCHW slices; 16x16: the quadrant blocking) and with a gradient
+    entering at every slice.  Against the oracle solver on the CPU and against the F(2x2,3x3) path on the same inputs."""
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    N, Cc, H, W = shape
+    assert _engaged(N, Cc, H)
+    f, twin = make_func(Cc, seed=4, device='cuda', kink_free=True)
+    gen = torch.Generator().manual_seed(31)
+    y0 = torch.randn(N, Cc, H, W, generator=gen)
+    t = torch.linspace(0.0, 1.0, 7)
+    wgt = torch.randn(7, N, Cc, H, W, generator=gen)
+    yo = y0.clone().requires_grad_(True)
+    out_o = tdq.odeint_adjoint(twin, yo, t, rtol=1e-3, atol=1e-3, method='dopri5')
+    (out_o * wgt).sum().backward()
+    outs, gys = [], []
+    for mode in (0, 1):
+        with wino4(mode):
+            y = y0.cuda().requires_grad_(True)
+            out = nof.odeint_adjoint(f, y, t.cuda(), rtol=1e-3, atol=1e-3, method='dopri5')
+            (out * wgt.cuda()).sum().backward()
+            outs.append(out.detach().cpu())
+            gys.append(y.grad.detach().cpu())
+    assert outs[1].shape == (7, N, Cc, H, W)
+    assert torch.equal(outs[1][0], y0)
+    print(shape, 'dense output: vs oracle %.2e, vs F(2x2) %.2e; grad_y0 vs oracle %.2e'
+          % (float((outs[1] - out_o.detach()).abs().max()), float((outs[1] - outs[0]).abs().max()), rel_err(gys[1], yo.grad)))
+    assert float((outs[1] - out_o.detach()).abs().max()) <= 1e-2          # 10 x atol (BASELINE.json north_star)
+    assert rel_err(outs[1], out_o.detach()) < 2e-4 and rel_err(outs[1], outs[0]) < 2e-4
+    assert rel_err(gys[1], yo.grad) < 1e-3 and rel_err(gys[1], gys[0]) < 1e-3
