@@ -180,6 +180,11 @@ size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape);
 int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y,
                     void* ws, size_t ws_bytes, void* stream);
 
+/* Diagnostics (tests): the exact three-way bf16 split (x = h + m + l) the component GEMMs of that pipeline apply to
+ * their fp32 operands on the device, element by element: out[3 i + p] = part p of x[i], widened to float.
+ * x: n floats, out: 3 n floats (device); n a positive multiple of 8. */
+int node_w4_split3(const float* x, float* out, size_t n, void* stream);
+
 /* torchdiffeq.odeint(ODEfunc, y0, t, rtol, atol, method)  -- model.py:367
  * t_pts: host array of n_t strictly monotonic times; y_out: [n_t, n, c, h, w]
  * with y_out[0] = y0. */

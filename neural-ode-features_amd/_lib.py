@@ -29,7 +29,7 @@ EXPORTS = [
     'node_backprop_workspace_bytes', 'node_solve_backprop',
     'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
     'node_sgd_step', 'node_profile_begin', 'node_profile_end',
-    'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4',
+    'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3',
 ]
 
 
@@ -136,6 +136,8 @@ def load():
     lib.node_conv3x3_w4_workspace_bytes.argtypes = [P(NodeShape)]
     lib.node_conv3x3_w4.restype = i32
     lib.node_conv3x3_w4.argtypes = [P(NodeShape), vp, i32, vp, vp, vp, sz, vp]
+    lib.node_w4_split3.restype = i32
+    lib.node_w4_split3.argtypes = [vp, vp, sz, vp]
     ver = lib.node_abi_version()
     if ver != NODE_ABI_VERSION:
         raise RuntimeError('libnode_hip ABI %d != binding ABI %d' % (ver, NODE_ABI_VERSION))

@@ -416,15 +416,22 @@ typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned w4_u32x4 __attribute__((ext_vector_type(4)));
 
 struct W4Split { w4_bf16x8 h, m, l; };
+// (Measured and not kept, round 3: the remainders as v_dot2_f32_bf16(part, (-1, 0) | (0, -1), x) -- three instructions per pair
+// and level instead of four.  No launch got faster (cfg 2 GEMM 23.2 vs 22.5 us by events, cfg 5 382 vs 383), and the compiler
+// folded the (-1, 0) pair into an inline constant the instruction reads as (0, -1): wrong remainders for every even element,
+// caught by tests/test_gpu_w4.py::test_w4_split_is_exact_on_the_device, which stays.)
+__device__ __forceinline__ w4_f32x2 w4_minus_part(const w4_f32x2& x, const w4_bf16x2& part) {
+  return x - __builtin_convertvector(part, w4_f32x2);
+}
 __device__ __forceinline__ W4Split w4_split8(const float4& p, const float4& q) {
   const w4_f32x2 v[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
   w4_u32x4 hh, mm, ll;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const w4_bf16x2 h = __builtin_convertvector(v[i], w4_bf16x2);
-    const w4_f32x2 r = v[i] - __builtin_convertvector(h, w4_f32x2);
+    const w4_f32x2 r = w4_minus_part(v[i], h);
     const w4_bf16x2 m = __builtin_convertvector(r, w4_bf16x2);
-    const w4_f32x2 t = r - __builtin_convertvector(m, w4_f32x2);
+    const w4_f32x2 t = w4_minus_part(r, m);
     const w4_bf16x2 l = __builtin_convertvector(t, w4_bf16x2);
     hh[i] = __builtin_bit_cast(unsigned, h);
     mm[i] = __builtin_bit_cast(unsigned, m);
@@ -435,6 +442,23 @@ __device__ __forceinline__ W4Split w4_split8(const float4& p, const float4& q) {
   o.m = __builtin_bit_cast(w4_bf16x8, mm);
   o.l = __builtin_bit_cast(w4_bf16x8, ll);
   return o;
+}
+// diagnostics (node_w4_split3): the three parts of every element, as floats
+__global__ __launch_bounds__(256) void k_w4_split_check(const float* __restrict__ x, float* __restrict__ out, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float4 p = reinterpret_cast<const float4*>(x)[2 * i], q = reinterpret_cast<const float4*>(x)[2 * i + 1];
+  const W4Split sp = w4_split8(p, q);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    out[(8 * i + k) * 3 + 0] = (float)sp.h[k];
+    out[(8 * i + k) * 3 + 1] = (float)sp.m[k];
+    out[(8 * i + k) * 3 + 2] = (float)sp.l[k];
+  }
+}
+void launch_w4_split_check(const float* x, float* out, size_t n, hipStream_t s) {
+  const size_t n8 = n / 8;
+  hipLaunchKernelGGL(k_w4_split_check, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, x, out, n8);
 }
 // acc += a * b over one K = 16 step, smallest products first
 __device__ __forceinline__ void w4_mac6(float16_t& acc, const W4Split& a, const w4_u32x4& bh, const w4_u32x4& bm, const w4_u32x4& bl) {

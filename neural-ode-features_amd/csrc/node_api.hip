@@ -1107,6 +1107,17 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   return NODE_OK;
 }
 
+// Diagnostics: the exact three-way bf16 split the component GEMMs apply to their fp32 row operands (k_w4_gemm64b and its
+// siblings), element by element: out[3 i + p] = part p of x[i] as a float.
+int node_w4_split3(const float* x, float* out, size_t n, void* stream) {
+  if (!x || !out) return fail(NODE_ERR_NULL, "a required pointer is NULL");
+  if (n == 0 || n % 8 != 0) return fail(NODE_ERR_ARG, "n must be a positive multiple of 8");
+  launch_w4_split_check(x, out, n, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
+  return NODE_OK;
+}
+
 int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t, const float* y, const float* cot,
                      float* f, float* vjp_y, float* vjp_t, float* vjp_params, void* ws, size_t ws_bytes, void* stream) {
   if (!y || !cot || !f || !vjp_y || !vjp_t || !vjp_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");

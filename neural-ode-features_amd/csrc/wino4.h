@@ -135,6 +135,8 @@ __host__ __device__ inline size_t w4_ub_elems(int C) { return (size_t)W4_COMPS *
 void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s,
                     const unsigned short* Ub = nullptr);
+// diagnostics (node_w4_split3): out[3 i .. 3 i + 2] = the three bf16 parts of x[i] as the GEMM kernels split it; n % 8 == 0
+void launch_w4_split_check(const float* x, float* out, size_t n, hipStream_t s);
 // stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
 void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s);
 void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s);

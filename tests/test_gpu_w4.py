@@ -284,3 +284,34 @@ def test_w4_dense_output_many_time_points(shape):
     assert float((outs[1] - out_o.detach()).abs().max()) <= 1e-2          # 10 x atol (BASELINE.json north_star)
     assert rel_err(outs[1], out_o.detach()) < 2e-4 and rel_err(outs[1], outs[0]) < 2e-4
     assert rel_err(gys[1], yo.grad) < 1e-3 and rel_err(gys[1], gys[0]) < 1e-3
+
+
+def test_w4_split_is_exact_on_the_device():
+    """The component GEMMs run on the bf16 matrix pipe "at fp32 accuracy" only if the in-register split of their row
+    operands is EXACT: x = h + m + l with three bf16 values (k_w4_gemm64b / k_w4_gemm128b / k_w4_wgrad128b: w4_split8, three
+    v_cvt_pk_bf16_f32 roundings and the two remainders between them).  node_w4_split3 runs that very function on
+    the device: normal values over 60 binades, exact bf16 values, zeros, both signs -- the identity must hold bit for bit."""
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(17)
+    n = 1 << 20
+    mant = torch.rand(n, generator=gen) + 1.0
+    expo = torch.randint(-30, 30, (n,), generator=gen).float()
+    sign = torch.where(torch.rand(n, generator=gen) < 0.5, -1.0, 1.0)
+    x = sign * mant * torch.exp2(expo)
+    x[:4096] = x[:4096].bfloat16().float()          # values that ARE bf16: m = l = 0
+    x[4096:8192] = 0.0
+    x[8192:12288] = (x[8192:12288].bfloat16().float() + x[8192:12288].bfloat16().float() * 2.0 ** -9)   # a tie of the first rounding
+    xd = x.cuda()
+    out = torch.empty(n * 3, device='cuda')
+    _lib.check(lib.node_w4_split3(xd.data_ptr(), out.data_ptr(), n, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    parts = out.view(n, 3).cpu()
+    assert torch.equal(parts.bfloat16().float(), parts)                                   # every part is a bf16 value
+    total = parts[:, 0].double() + parts[:, 1].double() + parts[:, 2].double()
+    bad = (total != x.double()).nonzero()
+    assert bad.numel() == 0, (bad[:5], x[bad[:5, 0]], parts[bad[:5, 0]])
+    assert torch.equal(parts[:4096, 1:], torch.zeros(4096, 2)) and torch.equal(parts[4096:8192], torch.zeros(4096, 3))
+    # each part carries what the one before left: |m| <= 2^-8 |h|, |l| <= 2^-8 |m| (half an ulp of an 8-bit mantissa)
+    h, m, l = parts[:, 0].double().abs(), parts[:, 1].double().abs(), parts[:, 2].double().abs()
+    assert bool((m <= h * 2.0 ** -8).all()) and bool((l <= m * 2.0 ** -8 + 0.0).all() or (l <= h * 2.0 ** -16).all())
