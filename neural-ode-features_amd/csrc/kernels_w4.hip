@@ -645,7 +645,23 @@ __device__ __forceinline__ void w4c_mac(float16_t (&acc)[2][2], const w4_u32x4 (
 #undef W4C_P
 }
 
-struct W4CLoad { float4 a[2]; w4_u32x4 b[3]; };   // a wave's share of one K = 16 step: its row block (two g blocks), its column block (three parts)
+// A wave's share of one K = 16 step: its row block (two g blocks of V), its column block (three parts of Ub).  The five
+// requests are inline asm with HAND-PLACED waits: left to the compiler, the wait state of the loop entry merged into the
+// steady state made every other step wait for all but one of the ten requests in flight -- the step's own prefetch
+// (s_waitcnt vmcnt(1) where vmcnt(5) is exact).  W4C_WAIT ties the wait to the registers, so no use can move above it, and
+// the registers stay allocated to the request while it is in flight.
+typedef float w4_f32x4 __attribute__((ext_vector_type(4)));
+struct W4CLoad { w4_f32x4 a0, a1; w4_u32x4 b0, b1, b2; };
+#define W4C_FETCH(L, PA, PB)                                                                        \
+  {                                                                                                 \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a0) : "v"(PA) : "memory");            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a1) : "v"(PA) : "memory"); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b0) : "v"(PB) : "memory");            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b1) : "v"(PB) : "memory"); \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"((L).b2) : "v"(PB) : "memory"); \
+  }
+#define W4C_WAIT(N, L) \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((L).a0), "+v"((L).a1), "+v"((L).b0), "+v"((L).b1), "+v"((L).b2) : : "memory")
 
 __global__ __launch_bounds__(256, 2) void k_w4_gemm128b(const float* __restrict__ V, const unsigned short* __restrict__ Ub,
                                                         float* __restrict__ M, const Ctrl* ctrl, W4Geom gm) {
@@ -662,24 +678,22 @@ __global__ __launch_bounds__(256, 2) void k_w4_gemm128b(const float* __restrict_
   else { comp = 32 + (j >> 1); tile = (j & 1) * (nT >> 1) + (i - 4 * nT); }
   const int RT = tile / nCT, CT = tile - RT * nCT;
   const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
-  const float4* pa = reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + 4 * RT + wave) * G8) * 256 + a_off);
-  const w4_u32x4* pb = reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + 4 * CT + wave) * G2) * 192 + lane;
-  auto fetch = [&](W4CLoad& L, int g2) {
-    L.a[0] = pa[(size_t)(2 * g2) * 64];
-    L.a[1] = pa[(size_t)(2 * g2 + 1) * 64];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) L.b[q] = pb[(size_t)(g2 * 3 + q) * 64];
-  };
+  // this lane's requests of step g2: V at pa + g2 * 2 KB (+ 1 KB: the second g block), Ub at pb + g2 * 3 KB (+ 1, 2 KB: the parts)
+  const char* pa = reinterpret_cast<const char*>(V + (((size_t)comp * nRB + 4 * RT + wave) * G8) * 256 + a_off);
+  const char* pb = reinterpret_cast<const char*>(reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + 4 * CT + wave) * G2) * 192 + lane);
   // LDS block (stage, kind 0 = A / 1 = B, block 0..3, part): 64 lanes x 16 B, every access lane * 16 B -- conflict-free
   auto blk = [&](int stage, int kind, int b, int part) { return tile_lds + ((((stage * 2 + kind) * 4 + b) * 3 + part) * 64 + lane); };
-  auto stash = [&](const W4CLoad& L, int stage) {
-    const W4Split sp = w4_split8(L.a[0], L.a[1]);
-    *blk(stage, 0, wave, 0) = __builtin_bit_cast(w4_u32x4, sp.h);
-    *blk(stage, 0, wave, 1) = __builtin_bit_cast(w4_u32x4, sp.m);
-    *blk(stage, 0, wave, 2) = __builtin_bit_cast(w4_u32x4, sp.l);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) *blk(stage, 1, wave, q) = L.b[q];
-  };
+#define W4C_STASH(L, STAGE)                                                                                  \
+  {                                                                                                          \
+    const W4Split sp_ = w4_split8(make_float4((L).a0.x, (L).a0.y, (L).a0.z, (L).a0.w),                       \
+                                  make_float4((L).a1.x, (L).a1.y, (L).a1.z, (L).a1.w));                      \
+    *blk(STAGE, 0, wave, 0) = __builtin_bit_cast(w4_u32x4, sp_.h);                                           \
+    *blk(STAGE, 0, wave, 1) = __builtin_bit_cast(w4_u32x4, sp_.m);                                           \
+    *blk(STAGE, 0, wave, 2) = __builtin_bit_cast(w4_u32x4, sp_.l);                                           \
+    *blk(STAGE, 1, wave, 0) = (L).b0;                                                                        \
+    *blk(STAGE, 1, wave, 1) = (L).b1;                                                                        \
+    *blk(STAGE, 1, wave, 2) = (L).b2;                                                                        \
+  }
   const int wr = wave >> 1, wc = wave & 1;
   float16_t acc[2][2];
 #pragma unroll
@@ -689,26 +703,38 @@ __global__ __launch_bounds__(256, 2) void k_w4_gemm128b(const float* __restrict_
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
 
-  W4CLoad ld0, ld1;          // in flight: ld0 = step k + 1, ld1 = step k + 2 at the top of iteration k
-  fetch(ld0, 0);
-  fetch(ld1, 1);
-  stash(ld0, 0);
-  ld0 = ld1;
-  fetch(ld1, 2);             // (reads past the reduction's end land in the buffers' slack, as in the other kernels)
+  // Two register sets, never copied: at the top of an even step k, ldx holds step k + 1 and ldy step k + 2 (five requests
+  // each, ldx's the older) -- two steps of cover.  (Reads past the reduction's end land in the buffers' slack.)
+  W4CLoad ldx, ldy;
+  W4C_FETCH(ldx, pa, pb)
+  W4C_WAIT(0, ldx);
+  W4C_STASH(ldx, 0)
+  W4C_FETCH(ldx, pa + 2048, pb + 3072)
+  W4C_FETCH(ldy, pa + 4096, pb + 6144)
+  pa += 3 * 2048; pb += 3 * 3072;          // -> step 3
   __syncthreads();
-  for (int k = 0; k < G2; ++k) {
-    const int st = k & 1;
-    w4_u32x4 fa[2][3], fb[2][3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { fa[r][q] = *blk(st, 0, 2 * wr + r, q); fb[r][q] = *blk(st, 1, 2 * wc + r, q); }
-    w4c_mac(acc, fa, fb);
-    stash(ld0, st ^ 1);      // step k + 1 -> the other stage (everybody left it at the last barrier)
-    ld0 = ld1;
-    fetch(ld1, k + 3);
-    __syncthreads();
+#define W4C_STEP(ST, LD)                                                                                          \
+  {                                                                                                               \
+    w4_u32x4 fa[2][3], fb[2][3];                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int q = 0; q < 3; ++q) {                 \
+      fa[r][q] = *blk(ST, 0, 2 * wr + r, q);                                                                      \
+      fb[r][q] = *blk(ST, 1, 2 * wc + r, q);                                                                      \
+    }                                                                                                             \
+    w4c_mac(acc, fa, fb);                                                                                         \
+    W4C_WAIT(5, LD); /* the older five of the ten in flight */                                                    \
+    W4C_STASH(LD, (ST) ^ 1) /* the next step -> the other stage (everybody left it at the last barrier) */        \
+    W4C_FETCH(LD, pa, pb)                                                                                         \
+    pa += 2048; pb += 3072;                                                                                       \
+    __syncthreads();                                                                                              \
   }
+  for (int k = 0; k < G2; k += 2) {   // (G2 = C / 16 is even: C % 128 == 0)
+    W4C_STEP(0, ldx)
+    W4C_STEP(1, ldy)
+  }
+  W4C_WAIT(0, ldx);                   // nothing may still be landing in registers the epilogue reuses
+  W4C_WAIT(0, ldy);
+#undef W4C_STEP
+#undef W4C_STASH
   // M is [n][C/32][36][4 t][32 c] (wino4.h): this wave's 64 x 64 quarter = 64-row tile 2 RT + wr, 64-column tile 2 CT + wc
   const int rt = 2 * RT + wr, ct = 2 * CT + wc;
   const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
@@ -1035,20 +1061,45 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
   const float4* pz = Z + (size_t)comp * (size_t)(C >> 5) * N * 32 + (size_t)(4 * cot) * N * 32 + (2 * h) * 32 + l31;
   const int U = N >> 2;
   auto blk = [&](int stage, int kind, int b, int part) { return tile_lds + ((((stage * 2 + kind) * 4 + b) * 3 + part) * 64 + lane); };
-  // what this wave loads for unit u: waves 0 / 1 the V patch (8 x 16 B: [s' 2][t 4]), waves 2 / 3 two column blocks of Z
-  // (4 x 16 B: [block 2][s' 2]).  (Macros, not lambdas over the register arrays: those put the arrays in scratch.)
+  // What this wave loads for unit u: waves 0 / 1 the V patch (8 x 16 B: [s' 2][t 4]), waves 2 / 3 two column blocks of Z
+  // (4 x 16 B: [block 2][s' 2]).  Requests as inline asm with hand-placed waits, two register sets that are never copied,
+  // as in k_w4_gemm128b (left to the compiler this loop waited for vmcnt(0) at the top of every unit: no prefetch at all).
   const bool ldv = wave < 2;
-  const size_t zb0 = (size_t)(2 * (wave & 1)) * N * 32, zb1 = zb0 + (size_t)N * 32;
-#define W4WG_FETCH(L, UU)                                                                                            \
-  {                                                                                                                  \
-    const int u_ = (UU) < U ? (UU) : U - 1; /* clamped: the last iterations prefetch a unit nobody consumes */        \
-    if (ldv) {                                                                                                       \
-      const float4* p_ = reinterpret_cast<const float4*>(pa + (size_t)(u_ >> 1) * rbs + (u_ & 1) * 128);             \
-      L##0 = p_[0]; L##1 = p_[1]; L##2 = p_[2]; L##3 = p_[3]; L##4 = p_[8]; L##5 = p_[9]; L##6 = p_[10]; L##7 = p_[11]; \
-    } else {                                                                                                         \
-      const float4* p_ = pz + (size_t)(4 * u_) * 32;                                                                 \
-      L##0 = p_[zb0]; L##1 = p_[zb0 + 32]; L##2 = p_[zb1]; L##3 = p_[zb1 + 32];                                      \
-    }                                                                                                                \
+  const char* pvb = reinterpret_cast<const char*>(pa);
+  const char* pz0 = reinterpret_cast<const char*>(pz + (size_t)(2 * (wave & 1)) * N * 32);
+  const char* pz1 = pz0 + (size_t)N * 32 * 16;
+#define W4WG_FETCH(L, UU)                                                                                              \
+  {                                                                                                                    \
+    const int u_ = (UU) < U ? (UU) : U - 1; /* clamped: the last units prefetch one nobody consumes */                 \
+    if (ldv) {                                                                                                         \
+      const char* p_ = pvb + ((size_t)(u_ >> 1) * rbs + (u_ & 1) * 128) * 4;                                           \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L##0) : "v"(p_) : "memory");                               \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(L##1) : "v"(p_) : "memory");                     \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(L##2) : "v"(p_) : "memory");                     \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(L##3) : "v"(p_) : "memory");                     \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(L##4) : "v"(p_) : "memory");                    \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(L##5) : "v"(p_) : "memory");                    \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:160" : "=v"(L##6) : "v"(p_) : "memory");                    \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:176" : "=v"(L##7) : "v"(p_) : "memory");                    \
+    } else {                                                                                                           \
+      const char* q0_ = pz0 + (size_t)u_ * 2048;                                                                       \
+      const char* q1_ = pz1 + (size_t)u_ * 2048;                                                                       \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L##0) : "v"(q0_) : "memory");                              \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(L##1) : "v"(q0_) : "memory");                   \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(L##2) : "v"(q1_) : "memory");                              \
+      asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(L##3) : "v"(q1_) : "memory");                   \
+    }                                                                                                                  \
+  }
+  // wait until only the younger set's requests are in flight (V waves: 8 of 16, Z waves: 4 of 8); NALL: wait for everything
+#define W4WG_WAIT(L, NALL)                                                                                                      \
+  {                                                                                                                             \
+    if (ldv) {                                                                                                                  \
+      if (NALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3), "+v"(L##4), "+v"(L##5), "+v"(L##6), "+v"(L##7) : : "memory"); \
+      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3), "+v"(L##4), "+v"(L##5), "+v"(L##6), "+v"(L##7) : : "memory");     \
+    } else {                                                                                                                    \
+      if (NALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");               \
+      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");                    \
+    }                                                                                                                           \
   }
 #define W4WG_PUT(STAGE, KIND, B, SP)                                        \
   {                                                                         \
@@ -1056,21 +1107,22 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
     *blk(STAGE, KIND, B, 1) = __builtin_bit_cast(w4_u32x4, (SP).m);         \
     *blk(STAGE, KIND, B, 2) = __builtin_bit_cast(w4_u32x4, (SP).l);         \
   }
+#define W4WG_F4(A, B, C, D) make_float4(A, B, C, D)
 #define W4WG_STASH(L, STAGE)                                                                                                  \
   {                                                                                                                           \
     if (ldv) {                                                                                                                \
       /* blocks e = 2 wave, 2 wave + 1: component e of the eight vectors = the eight reduction rows of a channel */          \
       const bool odd_ = wave & 1;                                                                                             \
-      const W4Split s0_ = w4_split8(odd_ ? make_float4((L##0).z, (L##1).z, (L##2).z, (L##3).z) : make_float4((L##0).x, (L##1).x, (L##2).x, (L##3).x), \
-                                    odd_ ? make_float4((L##4).z, (L##5).z, (L##6).z, (L##7).z) : make_float4((L##4).x, (L##5).x, (L##6).x, (L##7).x)); \
+      const W4Split s0_ = w4_split8(odd_ ? W4WG_F4((L##0).z, (L##1).z, (L##2).z, (L##3).z) : W4WG_F4((L##0).x, (L##1).x, (L##2).x, (L##3).x), \
+                                    odd_ ? W4WG_F4((L##4).z, (L##5).z, (L##6).z, (L##7).z) : W4WG_F4((L##4).x, (L##5).x, (L##6).x, (L##7).x)); \
       W4WG_PUT(STAGE, 0, 2 * wave, s0_)                                                                                       \
-      const W4Split s1_ = w4_split8(odd_ ? make_float4((L##0).w, (L##1).w, (L##2).w, (L##3).w) : make_float4((L##0).y, (L##1).y, (L##2).y, (L##3).y), \
-                                    odd_ ? make_float4((L##4).w, (L##5).w, (L##6).w, (L##7).w) : make_float4((L##4).y, (L##5).y, (L##6).y, (L##7).y)); \
+      const W4Split s1_ = w4_split8(odd_ ? W4WG_F4((L##0).w, (L##1).w, (L##2).w, (L##3).w) : W4WG_F4((L##0).y, (L##1).y, (L##2).y, (L##3).y), \
+                                    odd_ ? W4WG_F4((L##4).w, (L##5).w, (L##6).w, (L##7).w) : W4WG_F4((L##4).y, (L##5).y, (L##6).y, (L##7).y)); \
       W4WG_PUT(STAGE, 0, 2 * wave + 1, s1_)                                                                                   \
     } else {                                                                                                                  \
-      const W4Split s0_ = w4_split8(L##0, L##1);                                                                              \
+      const W4Split s0_ = w4_split8(W4WG_F4((L##0).x, (L##0).y, (L##0).z, (L##0).w), W4WG_F4((L##1).x, (L##1).y, (L##1).z, (L##1).w)); \
       W4WG_PUT(STAGE, 1, 2 * (wave & 1), s0_)                                                                                 \
-      const W4Split s1_ = w4_split8(L##2, L##3);                                                                              \
+      const W4Split s1_ = w4_split8(W4WG_F4((L##2).x, (L##2).y, (L##2).z, (L##2).w), W4WG_F4((L##3).x, (L##3).y, (L##3).z, (L##3).w)); \
       W4WG_PUT(STAGE, 1, 2 * (wave & 1) + 1, s1_)                                                                             \
     }                                                                                                                         \
   }
@@ -1083,29 +1135,39 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
 
-  float4 la0, la1, la2, la3, la4, la5, la6, la7, lb0, lb1, lb2, lb3, lb4, lb5, lb6, lb7;   // units in flight: la = even, lb = odd
-  la4 = la5 = la6 = la7 = lb4 = lb5 = lb6 = lb7 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // units in flight: at the top of an even unit u, la holds unit u + 1 and lb unit u + 2 (la's requests the older)
+  w4_f32x4 la0, la1, la2, la3, la4, la5, la6, la7, lb0, lb1, lb2, lb3, lb4, lb5, lb6, lb7;
+  la4 = la5 = la6 = la7 = lb4 = lb5 = lb6 = lb7 = w4_f32x4{0.f, 0.f, 0.f, 0.f};
   W4WG_FETCH(la, 0)
-  W4WG_FETCH(lb, 1)
+  W4WG_WAIT(la, 1)
   W4WG_STASH(la, 0)
-  W4WG_FETCH(la, 2)
+  W4WG_FETCH(la, 1)
+  W4WG_FETCH(lb, 2)
   __syncthreads();
-  for (int u = 0; u < U; ++u) {
-    const int st = u & 1;
-    w4_u32x4 fa[2][3], fb[2][3];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { fa[r][q] = *blk(st, 0, 2 * wr + r, q); fb[r][q] = *blk(st, 1, 2 * wc + r, q); }
-    w4c_mac(acc, fa, fb);
-    // unit u + 1 (lb behind an even unit, la behind an odd one) -> the other stage (everybody left it at the last barrier);
-    // its registers take unit u + 3
-    if (st == 0) { W4WG_STASH(lb, 1) W4WG_FETCH(lb, u + 3) }
-    else { W4WG_STASH(la, 0) W4WG_FETCH(la, u + 3) }
-    __syncthreads();
+#define W4WG_STEP(ST, L, UNEXT)                                                                                   \
+  {                                                                                                               \
+    w4_u32x4 fa[2][3], fb[2][3];                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int q = 0; q < 3; ++q) {                 \
+      fa[r][q] = *blk(ST, 0, 2 * wr + r, q);                                                                      \
+      fb[r][q] = *blk(ST, 1, 2 * wc + r, q);                                                                      \
+    }                                                                                                             \
+    w4c_mac(acc, fa, fb);                                                                                         \
+    W4WG_WAIT(L, 0)                                                                                               \
+    W4WG_STASH(L, (ST) ^ 1) /* the next unit -> the other stage (everybody left it at the last barrier) */        \
+    W4WG_FETCH(L, UNEXT)                                                                                          \
+    __syncthreads();                                                                                              \
   }
+  for (int u = 0; u < U; u += 2) {   // (U = N / 4 is even: N % 8 == 0)
+    W4WG_STEP(0, la, u + 3)
+    W4WG_STEP(1, lb, u + 4)
+  }
+  W4WG_WAIT(la, 1)                    // nothing may still be landing in registers the epilogue reuses
+  W4WG_WAIT(lb, 1)
+#undef W4WG_STEP
 #undef W4WG_FETCH
+#undef W4WG_WAIT
 #undef W4WG_PUT
+#undef W4WG_F4
 #undef W4WG_STASH
   // block (e = 2 wr + r, column block 2 wc + c): accumulator row m = (q & 3) + 8 (q >> 2) + 4 h <-> ci = 8 (m >> 1) + 4 (m & 1) + e
   float* o = dU + ((size_t)comp * C + cit * 128) * C + cot * 128 + l31;
