@@ -173,7 +173,8 @@ int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t
                      float* f, float* vjp_y, float* vjp_t, float* vjp_params,
                      void* ws, size_t ws_bytes, void* stream);
 
-/* Diagnostics (tests, tools): y = conv3x3(x, weight[:, 1:], padding = 1) for an [n, c, 8, 8] tensor through the
+/* Diagnostics (tests, tools): y = conv3x3(x, weight[:, 1:], padding = 1) for an [n, c, 8, 8] (n % 8 == 0) or [n, c, 16, 16]
+ * (n % 2 == 0) tensor, c % 64 == 0, through the
  * Winograd F(4x4,3x3) pipeline the solver uses when its tolerance allows (csrc/wino4.h); dgrad != 0: the data
  * gradient (transposed convolution) instead.  weight is a ConcatConv2d filter [c][c+1][3][3] (model.py:320-323). */
 size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape);
@@ -213,7 +214,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params,
  * grad_out [n_t, n, c, h, w] is carried back through every step: grad_y0 [n, c, h, w], grad_params flat in
  * parameters() order.  Step sizes are constants of the differentiation.  `rtol`, `atol`: the forward solve's -- they
  * select the convolution kernels exactly as node_solve_fwd did (the F(4x4,3x3) pipeline for dopri5 at rtol, atol >=
- * 1e-4 on 8x8 states), so the replayed stage values are the ones the forward output was computed from.  Workspace:
+ * 1e-5 on 8x8 and 16x16 states), so the replayed stage values are the ones the forward output was computed from.  Workspace:
  * node_backprop_workspace_bytes (it holds the tape: 7 state-sized tensors per step). */
 size_t node_backprop_workspace_bytes(const node_shape* shape, int method, int n_t, int n_steps);
 int node_solve_backprop(const node_shape* shape, const node_params* params,
