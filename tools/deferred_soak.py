@@ -19,9 +19,9 @@ import neural_ode_features_amd as nof  # noqa: E402
 from neural_ode_features_amd import integrate  # noqa: E402
 
 
-def run(steps, lr, deferred_on, seed=0):
+def run(steps, lr, deferred_on, seed=0, config=2):
     dev = torch.device('cuda', 0)
-    cfg = dict(bench.CONFIGS[2])
+    cfg = dict(bench.CONFIGS[config])
     model = bench.build_model(dev, cfg, 'dopri5')
     model.train()
     opt = nof.FusedSGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
@@ -60,6 +60,7 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--lr', type=float, default=0.05)
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3), help='BASELINE.json config: 2 = tol 1e-3, 3 = tol 1e-5')
     a = ap.parse_args()
     for mode in (False, True):
-        print(run(a.steps, a.lr, mode), flush=True)
+        print(run(a.steps, a.lr, mode, config=a.config), flush=True)
