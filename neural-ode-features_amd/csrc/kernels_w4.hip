@@ -1034,8 +1034,8 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
 // Operands without a transposed copy: a loader lane's eight 16-B loads of V ([s 2][t 4] x four channels e) hold, for
 // each e, the eight reduction rows of one channel -- the K half of an MFMA row operand -- so accumulator block e =
 // channels 8 g + 4 hic + e as in k_w4_wgrad; its two 16-B loads of Z hold the eight rows of one output channel.
-// Waves 0 / 1 load V (both all of it -- L1 serves the second -- and split blocks e = 0, 1 / 2, 3), waves 2 / 3 load and split
-// two 32-column blocks of Z each.  Needs N % 4 == 0 (whole units; the launcher asks for N % 8) and C % 128 == 0.
+// Waves 0 / 1 load and split the V patch of the first / second sample of the K half (half of every block's LDS entries each),
+// waves 2 / 3 two 32-column blocks of Z each.  Needs N % 4 == 0 (whole units; the launcher asks for N % 8) and C % 128 == 0.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
   if (a.ctrl != nullptr && a.ctrl->done) return;
@@ -1061,11 +1061,13 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
   const float4* pz = Z + (size_t)comp * (size_t)(C >> 5) * N * 32 + (size_t)(4 * cot) * N * 32 + (2 * h) * 32 + l31;
   const int U = N >> 2;
   auto blk = [&](int stage, int kind, int b, int part) { return tile_lds + ((((stage * 2 + kind) * 4 + b) * 3 + part) * 64 + lane); };
-  // What this wave loads for unit u: waves 0 / 1 the V patch (8 x 16 B: [s' 2][t 4]), waves 2 / 3 two column blocks of Z
-  // (4 x 16 B: [block 2][s' 2]).  Requests as inline asm with hand-placed waits, two register sets that are never copied,
-  // as in k_w4_gemm128b (left to the compiler this loop waited for vmcnt(0) at the top of every unit: no prefetch at all).
+  // What this wave loads for unit u, four 16-B requests each: wave 0 / 1 the V patch of sample s' = 0 / 1 of the lane's K half
+  // ([t 4] x four channels e: the first / second four of the eight reduction rows of the four blocks e -- it writes the
+  // first / second 8 bytes of their lanes' LDS entries), waves 2 / 3 two column blocks of Z ([block 2][s' 2]).  Requests as
+  // inline asm with hand-placed waits, two register sets that are never copied, as in k_w4_gemm128b (left to the compiler
+  // this loop waited for vmcnt(0) at the top of every unit: no prefetch at all).
   const bool ldv = wave < 2;
-  const char* pvb = reinterpret_cast<const char*>(pa);
+  const char* pvb = reinterpret_cast<const char*>(pa + (wave & 1) * 32);
   const char* pz0 = reinterpret_cast<const char*>(pz + (size_t)(2 * (wave & 1)) * N * 32);
   const char* pz1 = pz0 + (size_t)N * 32 * 16;
 #define W4WG_FETCH(L, UU)                                                                                              \
@@ -1077,10 +1079,6 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
       asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(L##1) : "v"(p_) : "memory");                     \
       asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(L##2) : "v"(p_) : "memory");                     \
       asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "=v"(L##3) : "v"(p_) : "memory");                     \
-      asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(L##4) : "v"(p_) : "memory");                    \
-      asm volatile("global_load_dwordx4 %0, %1, off offset:144" : "=v"(L##5) : "v"(p_) : "memory");                    \
-      asm volatile("global_load_dwordx4 %0, %1, off offset:160" : "=v"(L##6) : "v"(p_) : "memory");                    \
-      asm volatile("global_load_dwordx4 %0, %1, off offset:176" : "=v"(L##7) : "v"(p_) : "memory");                    \
     } else {                                                                                                           \
       const char* q0_ = pz0 + (size_t)u_ * 2048;                                                                       \
       const char* q1_ = pz1 + (size_t)u_ * 2048;                                                                       \
@@ -1090,16 +1088,11 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
       asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(L##3) : "v"(q1_) : "memory");                   \
     }                                                                                                                  \
   }
-  // wait until only the younger set's requests are in flight (V waves: 8 of 16, Z waves: 4 of 8); NALL: wait for everything
-#define W4WG_WAIT(L, NALL)                                                                                                      \
-  {                                                                                                                             \
-    if (ldv) {                                                                                                                  \
-      if (NALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3), "+v"(L##4), "+v"(L##5), "+v"(L##6), "+v"(L##7) : : "memory"); \
-      else asm volatile("s_waitcnt vmcnt(8)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3), "+v"(L##4), "+v"(L##5), "+v"(L##6), "+v"(L##7) : : "memory");     \
-    } else {                                                                                                                    \
-      if (NALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");               \
-      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");                    \
-    }                                                                                                                           \
+  // wait until only the younger set's four requests are in flight; NALL: wait for everything
+#define W4WG_WAIT(L, NALL)                                                                                              \
+  {                                                                                                                     \
+    if (NALL) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");         \
+    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(L##0), "+v"(L##1), "+v"(L##2), "+v"(L##3) : : "memory");              \
   }
 #define W4WG_PUT(STAGE, KIND, B, SP)                                        \
   {                                                                         \
@@ -1107,18 +1100,26 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
     *blk(STAGE, KIND, B, 1) = __builtin_bit_cast(w4_u32x4, (SP).m);         \
     *blk(STAGE, KIND, B, 2) = __builtin_bit_cast(w4_u32x4, (SP).l);         \
   }
+  // V waves: the split of (block e, block e + 1) x four rows each; the first 8 bytes of a part belong to block e, the last to e + 1
+#define W4WG_PUT_HALVES(STAGE, E, SP)                                                                                     \
+  {                                                                                                                       \
+    const w4_u32x4 h_ = __builtin_bit_cast(w4_u32x4, (SP).h), m_ = __builtin_bit_cast(w4_u32x4, (SP).m),                  \
+                   l_ = __builtin_bit_cast(w4_u32x4, (SP).l);                                                             \
+    typedef unsigned w4_u32x2_ __attribute__((ext_vector_type(2)));                                                       \
+    w4_u32x2_* d0_ = reinterpret_cast<w4_u32x2_*>(blk(STAGE, 0, E, 0)) + (wave & 1);                                      \
+    w4_u32x2_* d1_ = reinterpret_cast<w4_u32x2_*>(blk(STAGE, 0, (E) + 1, 0)) + (wave & 1);                                \
+    d0_[0] = w4_u32x2_{h_[0], h_[1]};   d1_[0] = w4_u32x2_{h_[2], h_[3]};                                                 \
+    d0_[128] = w4_u32x2_{m_[0], m_[1]}; d1_[128] = w4_u32x2_{m_[2], m_[3]};   /* parts are 64 lanes x 16 B apart */       \
+    d0_[256] = w4_u32x2_{l_[0], l_[1]}; d1_[256] = w4_u32x2_{l_[2], l_[3]};                                               \
+  }
 #define W4WG_F4(A, B, C, D) make_float4(A, B, C, D)
 #define W4WG_STASH(L, STAGE)                                                                                                  \
   {                                                                                                                           \
     if (ldv) {                                                                                                                \
-      /* blocks e = 2 wave, 2 wave + 1: component e of the eight vectors = the eight reduction rows of a channel */          \
-      const bool odd_ = wave & 1;                                                                                             \
-      const W4Split s0_ = w4_split8(odd_ ? W4WG_F4((L##0).z, (L##1).z, (L##2).z, (L##3).z) : W4WG_F4((L##0).x, (L##1).x, (L##2).x, (L##3).x), \
-                                    odd_ ? W4WG_F4((L##4).z, (L##5).z, (L##6).z, (L##7).z) : W4WG_F4((L##4).x, (L##5).x, (L##6).x, (L##7).x)); \
-      W4WG_PUT(STAGE, 0, 2 * wave, s0_)                                                                                       \
-      const W4Split s1_ = w4_split8(odd_ ? W4WG_F4((L##0).w, (L##1).w, (L##2).w, (L##3).w) : W4WG_F4((L##0).y, (L##1).y, (L##2).y, (L##3).y), \
-                                    odd_ ? W4WG_F4((L##4).w, (L##5).w, (L##6).w, (L##7).w) : W4WG_F4((L##4).y, (L##5).y, (L##6).y, (L##7).y)); \
-      W4WG_PUT(STAGE, 0, 2 * wave + 1, s1_)                                                                                   \
+      const W4Split s0_ = w4_split8(W4WG_F4((L##0).x, (L##1).x, (L##2).x, (L##3).x), W4WG_F4((L##0).y, (L##1).y, (L##2).y, (L##3).y)); \
+      W4WG_PUT_HALVES(STAGE, 0, s0_)                                                                                          \
+      const W4Split s1_ = w4_split8(W4WG_F4((L##0).z, (L##1).z, (L##2).z, (L##3).z), W4WG_F4((L##0).w, (L##1).w, (L##2).w, (L##3).w)); \
+      W4WG_PUT_HALVES(STAGE, 2, s1_)                                                                                          \
     } else {                                                                                                                  \
       const W4Split s0_ = w4_split8(W4WG_F4((L##0).x, (L##0).y, (L##0).z, (L##0).w), W4WG_F4((L##1).x, (L##1).y, (L##1).z, (L##1).w)); \
       W4WG_PUT(STAGE, 1, 2 * (wave & 1), s0_)                                                                                 \
@@ -1136,8 +1137,7 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
       for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
 
   // units in flight: at the top of an even unit u, la holds unit u + 1 and lb unit u + 2 (la's requests the older)
-  w4_f32x4 la0, la1, la2, la3, la4, la5, la6, la7, lb0, lb1, lb2, lb3, lb4, lb5, lb6, lb7;
-  la4 = la5 = la6 = la7 = lb4 = lb5 = lb6 = lb7 = w4_f32x4{0.f, 0.f, 0.f, 0.f};
+  w4_f32x4 la0, la1, la2, la3, lb0, lb1, lb2, lb3;
   W4WG_FETCH(la, 0)
   W4WG_WAIT(la, 1)
   W4WG_STASH(la, 0)
@@ -1167,6 +1167,7 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
 #undef W4WG_FETCH
 #undef W4WG_WAIT
 #undef W4WG_PUT
+#undef W4WG_PUT_HALVES
 #undef W4WG_F4
 #undef W4WG_STASH
   // block (e = 2 wr + r, column block 2 wc + c): accumulator row m = (q & 3) + 8 (q >> 2) + 4 h <-> ci = 8 (m >> 1) + 4 (m & 1) + e
