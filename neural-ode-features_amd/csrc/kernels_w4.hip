@@ -405,7 +405,9 @@ __global__ __launch_bounds__(256) void k_w4_gemm64(const float* __restrict__ V, 
 // of the fp32 MFMA chain (tools/bf16x3 check in tests/test_gpu_w4.py: same 3.2e-6-of-max|y| convolution error).
 // Same decomposition, layouts of V and M, and XCD placement as k_w4_gemm64; a lane's eight K values of a step are
 // channels {8 g + 4 hi + e} of TWO consecutive g blocks (two of the 16-B loads the fp32 kernel issues too).
-// 24.4 -> 19.6 us per launch at cfg 2.  (Measured and not kept: the same products with the operands shared through LDS
+// 24.4 -> 19.6 us per launch at cfg 2.  (Measured and not kept, end of round 3: this loop's forty operand requests as inline asm
+// with ONE exact wait per step -- s_waitcnt vmcnt(26), where the compiler's placement waits for up to vmcnt(20) -- as in
+// k_w4_gemm128b below, where that gave 8 %: 22.5 us by events either way at cfg 2, whose 16 steps per tile are not what bounds it.)  (Measured and not kept: the same products with the operands shared through LDS
 // -- 128 x 128 tiles per workgroup, three LDS buffers, fragments prefetched under the MFMAs, L2 -> CU traffic 448
 // instead of 768 KB per CU -- 21.5 - 22.8 us: what bounds the launch now is its 52 MB through the fabric plus fill and
 // drain, not the per-CU operand stream.)
