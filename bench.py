@@ -27,15 +27,20 @@ read-back per solve.
 
 Prints ONE JSON line (rank 0).  `value` = images of all ranks / wall time of exactly
 K steps (barrier + synchronize on both sides, max over ranks); `step_ms` holds the
-per-step median / min / max from HIP events on the compute stream.  `roofline` is
-for the dominant kernel (the 3x3 conv, fp32 MFMA): `achieved` = MFMA FLOPs the kernel
-ISSUES per launch / average launch duration from HIP events recorded by the library
-on the launch stream over a repeat of the timed steps, `frac` = achieved / the fp32
-matrix peak -- the utilisation of the matrix pipe.  The kernel is a Winograd
-F(2x2,3x3) convolution, so it issues 16/36 of the direct-convolution FLOPs SURVEY.md
-8(d) counts; that algorithmic rate is reported under `roofline.algorithmic` and is
-NOT a utilisation.  `cpu_baseline` is the oracle (CPU restatement of the torchdiffeq
-path driving PyTorch-CPU conv/group_norm) on this box's host cores.
+per-step median / min / max from HIP events on the compute stream.  A solve that misses
+its enqueued step count costs TIME, not an update: integrate.DeferredLoop keeps every
+batch until its verdict is in and repeats voided batches in order (`config.retries`).
+`fresh_batches` is the same loop on a NEW synthetic batch per step (moving step counts),
+`dropin` the same steps with a read-back per solve (the drop-in odeint / ODEBlock API).
+`roofline` is for the dominant kernel -- at the BASELINE configs `k_w4_gemm64b`, the 36
+component GEMMs of a Winograd F(4x4,3x3) convolution on bf16 MFMA at fp32 accuracy
+(exact three-way split, six products), bounded by its bytes through the fabric at
+C = 256 (`bound: hbm`, achieved = algorithmic bytes per launch / mean launch duration
+from HIP events recorded by the library on the launch stream) and by the matrix pipe
+at C = 1024 (`k_w4_gemm128b`, `bound: mfma`); `roofline.hbm` prices the HBM-bound
+GroupNorm / transform passes, `roofline.wgrad` the weight gradient.  `cpu_baseline` is
+the oracle (CPU restatement of the torchdiffeq path driving PyTorch-CPU conv /
+group_norm) on this box's host cores.
 """
 import argparse
 import json
@@ -286,6 +291,7 @@ def main():
                          'runs blind without a spare step (integrate.Deferred.settled), so that the timed region is the '
                          'steady state; reported as config.settle_steps')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed region with a read-back per solve')
+    ap.add_argument('--no-fresh', action='store_true', help='skip the timed region on a fresh synthetic batch per step')
     ap.add_argument('--no-deferred', action='store_true',
                     help='every solve ends with a read-back of the device controller (the drop-in default) instead of '
                          'deferred completion with a device-predicated optimizer step (integrate.Deferred)')
@@ -381,20 +387,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # Deferred completion: the solves enqueue the step count of the previous iteration and return without a
-    # read-back; a miss (wrong count) bumps a device flag on which the optimizer step is predicated, so a step with
-    # a miss commits nothing.  A timed region that contains a miss did less than K full steps and is measured again.
-    import contextlib
+    # Deferred completion: the solves enqueue the step count of the previous iterations and return without a
+    # read-back; a miss (too few steps) raises a STICKY device flag on which the optimizer step is predicated, so that
+    # update and every later one is skipped until the host -- one iteration late, no stall -- sees the flag and repeats
+    # the voided batches in order with a read-back per solve (integrate.DeferredLoop).  A miss costs time, never an update.
     deferred = None if args.no_deferred else integrate.Deferred(device)
-    if deferred is not None:
-        opt.use_deferred(deferred, reducer)
-    scope = deferred if deferred is not None else contextlib.nullcontext()
-    for _ in range(args.warmup):
-        with scope:
-            train_step(model, opt, x, y, reducer)
-    # Deferred completion enqueues ONE spare step per solve (launches that return at once) until a solve's step count
-    # has been predicted exactly CALM times in a row; on this fixed batch that takes ~10 iterations.  Those iterations
-    # are not the steady state a training run spends its time in, so they stay outside the timed region.
+
+    def one_step(xx, yy):
+        return train_step(model, opt, xx, yy, reducer)
+
+    loop = integrate.DeferredLoop(deferred, opt, one_step, reducer) if deferred is not None else None
+
+    def run_steps(batches, events=None):
+        """K training steps; returns (sum NFE-F, sum NFE-B) over the K committed updates."""
+        nf = nb = 0
+        for i, (xx, yy) in enumerate(batches):
+            done = loop.step(xx, yy) if loop is not None else [one_step(xx, yy)]
+            if events is not None:
+                events[i + 1].record()
+            for _, a, b in done:
+                nf += a
+                nb += b
+        if loop is not None:
+            for _, a, b in loop.flush():      # (inside the timed region: the last verdicts, and their repeats if any)
+                nf += a
+                nb += b
+        return nf, nb
+
+    fixed = [(x, y)] * args.steps
+    run_steps([(x, y)] * args.warmup)
+    # While a solve's step-count history is young ONE spare step is enqueued (launches that return at once); on this
+    # fixed batch that takes ~10 iterations.  Those iterations are not the steady state a training run spends its
+    # time in, so they stay outside the timed region.
     settle_steps = 0
     if deferred is not None:
         while settle_steps < args.settle:
@@ -407,74 +431,111 @@ def main():
                 calm = deferred.settled()
             if calm:
                 break
-            with scope:
-                train_step(model, opt, x, y, reducer)
+            run_steps([(x, y)])
             settle_steps += 1
-    for attempt in range(4):
-        if attempt == 3 and deferred is not None:
-            # the step counts keep changing on this workload (every region so far contained a skipped update):
-            # measure with a read-back per solve instead -- a region with a miss is never reported
+
+    def counters():
+        return (loop.retries, loop.miss_events, deferred.dead_steps, deferred.blind_solves) if loop is not None else (0, 0, 0, 0)
+
+    def timed_region(batches, events=None):
+        sync()
+        if deferred is not None:
             deferred.resolve()
-            deferred = None
-            opt.skip_flag = None
-            opt.flags_to_reset = []
-            scope = contextlib.nullcontext()
-        with scope:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-            sync()
-            if deferred is not None:
-                deferred.resolve()
-            misses0 = deferred.misses if deferred is not None else 0
-            t0 = time.perf_counter()
-            nfe_f = nfe_b = 0
-            ev[0].record()
-            for i in range(args.steps):
-                _, a, b = train_step(model, opt, x, y, reducer)
-                ev[i + 1].record()
-                nfe_f += a
-                nfe_b += b
-            sync()
-            elapsed = time.perf_counter() - t0
-            timed_misses = (deferred.resolve() - misses0) if deferred is not None else 0
-            if world > 1:
-                mm = torch.tensor([float(timed_misses)], device=device)
-                dist.all_reduce(mm)
-                timed_misses = int(mm.item())
-            if timed_misses == 0:
-                break
+        c0 = counters()
+        t0 = time.perf_counter()
+        if events is not None:
+            events[0].record()
+        nf, nb = run_steps(batches, events)
+        torch.cuda.synchronize(device)
+        own = time.perf_counter() - t0          # this rank's own time for its K steps (before the barrier)
+        sync()
+        el = time.perf_counter() - t0
+        if deferred is not None:
+            deferred.resolve()
+        c1 = counters()
+        return {'elapsed': el, 'own': own, 'nfe_f': nf, 'nfe_b': nb, 'retries': c1[0] - c0[0], 'miss_events': c1[1] - c0[1],
+                'dead_steps': c1[2] - c0[2], 'blind_solves': c1[3] - c0[3]}
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    region = timed_region(fixed, ev)
+    elapsed, nfe_f, nfe_b = region['elapsed'], region['nfe_f'], region['nfe_b']
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+
+    def over_ranks(value, op):
+        if world == 1:
+            return value
+        tt = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=op)
+        return float(tt.item())
+
+    elapsed = over_ranks(elapsed, dist.ReduceOp.MAX)
     blocks = list(model.odeblocks) if hasattr(model, 'odeblocks') else [model.odeblock]
-    fstats = [b.odefunc.last_forward_stats for b in blocks]
-    bstats = [b.odefunc.last_backward_stats for b in blocks]
+    # what a multi-GPU line needs to be diagnosable: every rank's own time and step counts (stragglers at the
+    # gradient barrier, per-shard step-count divergence, who missed)
+    mine = [float(rank), region['own'] / args.steps * 1e3, float(region['retries']), float(region['miss_events']),
+            float(region['dead_steps']), region['nfe_f'] / args.steps, region['nfe_b'] / args.steps]
+    for b in blocks:
+        fs, bs_ = b.odefunc.last_forward_stats, b.odefunc.last_backward_stats
+        mine += [float(fs['accepted'] + fs['rejected']), float(bs_['accepted'] + bs_['rejected'])]
+    if world > 1:
+        gathered = [torch.zeros(len(mine), dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor(mine, dtype=torch.float64, device=device))
+        rows = [g.tolist() for g in gathered]
+    else:
+        rows = [mine]
+    per_rank = [{'rank': int(r[0]), 'ms_per_step_own': r[1], 'retries': int(r[2]), 'miss_events': int(r[3]),
+                 'dead_steps': int(r[4]), 'nfe_forward_per_step': r[5], 'nfe_backward_per_step': r[6],
+                 'last_steps_fwd_bwd_per_block': [[int(r[7 + 2 * i]), int(r[8 + 2 * i])] for i in range(len(blocks))]}
+                for r in rows]
+
+    # The same loop on a FRESH synthetic batch every step (class-dependent means, as tools/deferred_soak.py): the step
+    # counts move with the data, which is what a training run sees; the fixed batch above is the friendliest case for
+    # predicting them.
+    fresh = None
+    if not args.no_fresh:
+        gen_d = torch.Generator(device=device).manual_seed(4321 + rank)
+        means = torch.randn(10, 3, 1, 1, device=device, generator=gen_d)
+
+        def fresh_batches(k):
+            out = []
+            for _ in range(k):
+                yy = torch.randint(0, 10, (cfg['batch'],), device=device, generator=gen_d)
+                out.append((torch.randn(cfg['batch'], 3, cfg['image'], cfg['image'], device=device, generator=gen_d) + means[yy], yy))
+            return out
+
+        run_steps(fresh_batches(max(2, args.warmup)))
+        fr = timed_region(fresh_batches(args.steps))
+        fel = over_ranks(fr['elapsed'], dist.ReduceOp.MAX)
+        fresh = {'value': args.steps * cfg['batch'] * world / fel, 'unit': 'images/sec', 'ms_per_step': fel / args.steps * 1e3,
+                 'steps': args.steps, 'retries': fr['retries'], 'miss_events': fr['miss_events'],
+                 'dead_steps_per_step': fr['dead_steps'] / args.steps,
+                 'nfe_forward_per_step': fr['nfe_f'] / args.steps, 'nfe_backward_per_step': fr['nfe_b'] / args.steps,
+                 'note': 'a NEW synthetic batch every step (class-dependent means), same model right behind the headline region; '
+                         'a missed solve is repeated (retries), never skipped'}
+        run_steps([(x, y)] * 3)                 # back on the fixed batch for the regions below
+    blocks = list(model.odeblocks) if hasattr(model, 'odeblocks') else [model.odeblock]
 
     # The same K steps through the DROP-IN behaviour (what the reference's loop gets without opting in to anything):
-    # every solve ends with a read-back of the device controller.  Same process, same model, right behind the region above.
+    # every solve ends with a read-back of the device controller.  Same process, same model, right behind the regions above.
     dropin = None
     if deferred is not None and not args.no_dropin:
         deferred.resolve()
-        opt.skip_flag = None
-        opt.flags_to_reset = []
+        flag_saved, opt.skip_flag = opt.skip_flag, None
+        deferred.armed = False
         for _ in range(2):
-            train_step(model, opt, x, y, reducer)     # untimed: the library's own step-count guesses
+            one_step(x, y)                        # untimed: the library's own step-count guesses
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            train_step(model, opt, x, y, reducer)
+            one_step(x, y)
         sync()
-        el = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
+        el = over_ranks(time.perf_counter() - t0, dist.ReduceOp.MAX)
         dropin = {'value': args.steps * cfg['batch'] * world / el, 'unit': 'images/sec', 'ms_per_step': el / args.steps * 1e3,
                   'steps': args.steps,
                   'note': 'the same steps with a read-back per solve (the drop-in odeint / ODEBlock behaviour; --no-deferred), '
                           'timed in the same run right behind the headline region'}
-        opt.use_deferred(deferred, reducer)        # (armed again for the roofline repeat's bookkeeping below)
+        opt.skip_flag = flag_saved
+        deferred.armed = True
 
     roofline = None
     if not args.no_roofline:
@@ -483,6 +544,8 @@ def main():
         # at once, and those empty launches would be averaged into the per-launch duration
         if deferred is not None:
             deferred.resolve()
+            opt.skip_flag = None
+            deferred.armed = False
         train_step(model, opt, x, y, reducer)     # unprofiled: refreshes the library's own step-count guesses
         integrate.profile_begin()
         for _ in range(min(args.steps, 5)):
@@ -628,18 +691,23 @@ def main():
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),
                 'global_batch': global_batch, 'state': state, 'ode_blocks': cfg['blocks'],
-                'timed_region': attempt + 1,      # 1 unless an earlier region held a skipped update and was measured again
                 'settle_steps': settle_steps,     # untimed steps beyond `warmup` until no solve enqueued a spare step any more
                 'solver_completion': 'read-back per solve' if deferred is None else
-                                     'deferred (device-predicated optimizer step; %d blind solves, %d misses in the timed region)'
-                                     % (deferred.blind_solves, timed_misses),
+                                     'deferred (sticky device flag predicates the optimizer step; a missed solve voids the '
+                                     'iteration and it is REPEATED, never skipped): %d blind solves, %d miss events, %d batches '
+                                     'repeated in the timed region' % (region['blind_solves'], region['miss_events'], region['retries']),
+                'retries': region['retries'], 'miss_events': region['miss_events'],
+                # steps enqueued past the end of their interval (every kernel of such a step returns at its first
+                # instruction): forward ones are ~28 launches each, augmented ones ~60
+                'dead_steps_per_step': region['dead_steps'] / args.steps,
                 'collectives': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if dist_on else 'none (one rank)',
                 'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'hipGraph' if args.graphs else 'eager',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
-                'last_forward_steps': [[s['accepted'], s['rejected']] for s in fstats],
-                'last_backward_steps': [[s['accepted'], s['rejected']] for s in bstats],
+                'per_rank': per_rank,
             },
         }
+        if fresh is not None:
+            result['fresh_batches'] = fresh
         if dropin is not None:
             result['dropin'] = dropin
         if roofline is not None:

@@ -811,25 +811,29 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 }
 
 
+// The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
+// prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
+// switch between solves (the tests do) can never pack for one kernel and launch another.
+struct W4Switches { int g64, b16, ablate, small; };
+static W4Switches w4_switches() {
+  auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1)};
+}
+static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }
 bool w4_uses_bf16(int N) {
-  const char* g64e = getenv("NODE_TUNE_W4_GEMM64");
-  const char* b16e = getenv("NODE_TUNE_W4_BF16X3");
-  const char* abe = getenv("NODE_TUNE_W4_ABLATE");
-  const char* sme = getenv("NODE_TUNE_W4_SMALL");
-  if (N <= 16 && (sme ? atoi(sme) : 1) != 0) return false;   // (k_w4_gemm_small reads the fp32 filters)
-  return N % 16 == 0 && (g64e ? atoi(g64e) : 1) != 0 && (b16e ? atoi(b16e) : 1) != 0 && (abe ? atoi(abe) : 0) == 0;
+  const W4Switches sw = w4_switches();
+  if (w4_takes_small(sw, N)) return false;   // (k_w4_gemm_small reads the fp32 filters)
+  return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && sw.ablate == 0;
 }
 
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {
   static bool attr[4][MAX_DEVICES] = {};
-  static int ab = -1;
-  if (ab < 0) { const char* e = getenv("NODE_TUNE_W4_ABLATE"); ab = e ? atoi(e) : 0; }
+  const W4Switches sw = w4_switches();
+  const int ab = sw.ablate;
   static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
-  static int smallg = -1;   // NODE_TUNE_W4_SMALL = 0: never the small-batch kernel (A/B measurements)
-  if (smallg < 0) { const char* e = getenv("NODE_TUNE_W4_SMALL"); smallg = e ? atoi(e) : 1; }
-  if (smallg && N <= 16 && ab == 0) {
+  if (w4_takes_small(sw, N)) {   // NODE_TUNE_W4_SMALL = 0: never the small-batch kernel (A/B measurements)
     hipLaunchKernelGGL(k_w4_gemm_small, dim3(gm.RB * W4_COMPS * (C >> 5)), dim3(256), 0, s, V, U, M, ctrl, gm);
     return;
   }
@@ -840,8 +844,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
     allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm<AB>), attr[SLOT]);               \
     hipLaunchKernelGGL(k_w4_gemm<AB>, dim3(grid), dim3(512), lds, s, V, U, M, ctrl, gm, xm); \
   }
-  static int g64 = -1;   // NODE_TUNE_W4_GEMM64 = 0: k_w4_gemm (eight waves, 32 x 64 tiles) everywhere
-  if (g64 < 0) { const char* e = getenv("NODE_TUNE_W4_GEMM64"); g64 = e ? atoi(e) : 1; }
+  const int g64 = sw.g64;   // NODE_TUNE_W4_GEMM64 = 0: k_w4_gemm (eight waves, 32 x 64 tiles) everywhere
   // NODE_TUNE_W4_BF16X3 = 0: the fp32 MFMA kernel (A/B measurements, tests; read on every call like NODE_TUNE_WINO4)
   const bool b16 = w4_uses_bf16(N);
   if (g64 && N % 16 == 0) {

@@ -335,24 +335,32 @@ class Deferred:
     epoch are exact); `last_*_stats` of a deferred solve hold the prediction."""
 
     active = None      # the instance whose `with` block is open
-    # Exact predictions in a row after which no spare step is enqueued any more.  A spare step costs ~0.5 ms of empty
-    # launches per training step at cfg 2, a miss one whole step (7.5 ms) AND a skipped update.  Measured on fresh
-    # batches with moving weights (tools/deferred_soak.py, 400 steps): 8 -> 0 misses in 818 blind solves, 4 -> 4 misses
-    # in 814; on bench.py's fixed batch 4 is ~1 % faster over the first 25 iterations.  Skipped updates weigh more.
-    CALM = 8
+    # How many steps to enqueue for a solve whose true count nobody knows yet.  A step past the end of the interval returns
+    # at its first instruction in every kernel, but its ~40 launches still cost ~0.1 ms; a miss costs the iteration (and,
+    # through DeferredLoop, its repetition): ~100x more.  So: enqueue the LARGEST count of the last HIST solves of this
+    # kind (a count that wobbles by one between iterations -- tol 1e-5 -- then never misses and wastes half a step on
+    # average), plus ONE spare step while the history is short or its maximum is young (a new maximum within the last
+    # TREND solves: the count is growing).  Round 3 enqueued last count + 1 until eight exact predictions in a row --
+    # at tol 1e-5 that never happened, and every solve carried one or two dead steps (profiles/r03_r_cfg3_steps.txt).
+    HIST = 16
+    TREND = 4
+    CALM = 8           # solves of a kind before the spare step can go
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.miss_flag = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.guess: Dict[tuple, Optional[int]] = {}
-        self.calm: Dict[tuple, int] = {}          # consecutive solves of a key whose step count equalled the guess
+        self.calm: Dict[tuple, int] = {}          # solves of a key since its history was last reset
+        self.hist: Dict[tuple, List[int]] = {}    # true step counts of the last HIST solves of a key
         self.pending: Dict[tuple, tuple] = {}
         self._seq: Dict[tuple, int] = {}
         self.records: Dict[tuple, tuple] = {}
         self.misses = 0
         self.blind_solves = 0
+        self.dead_steps = 0        # steps enqueued past the end of their interval (read from the records)
         self.verdicts: List[tuple] = []   # (blind solve index, key kind, missed?) in the order the records were read
         self.armed = False         # set by FusedSGD.use_deferred: without a predicated commit point nothing runs blind
+        self._last_enqueued: Dict[tuple, int] = {}
 
     def __enter__(self):
         Deferred.active = self
@@ -379,7 +387,7 @@ class Deferred:
         interval returns at once on the device: ~0.1 ms of launches) so that a count that grows by one is no miss."""
         pend = self.pending.pop(key, None)
         if pend is not None:
-            guessed, fref = pend
+            guessed, fref, enqueued = pend
             if func is None and fref is not None:
                 func = fref()
             dev, host, event = self._buffers(key)
@@ -392,31 +400,71 @@ class Deferred:
                 self.misses += 1
                 self.guess[key] = None
                 self.calm[key] = 0
+                self.hist[key] = []
             else:
                 if func is not None and r.steps != guessed:
                     func.nfe = getattr(func, 'nfe', 0) + 6 * (r.steps - guessed)    # late, but sums stay exact
-                self.calm[key] = self.calm.get(key, 0) + 1 if r.steps == guessed else 0
-                self.guess[key] = int(r.steps)
+                self.dead_steps += max(0, enqueued - int(r.steps))
+                self._observe(key, int(r.steps))
         g = self.guess.get(key)
         if not g or not self.armed:
             return None
-        return g, g + (0 if self.calm.get(key, 0) >= self.CALM else 1)
+        return g, self._enqueue(key)
+
+    def _observe(self, key, steps):
+        h = self.hist.setdefault(key, [])
+        h.append(int(steps))
+        del h[:-self.HIST]
+        self.calm[key] = self.calm.get(key, 0) + 1
+        self.guess[key] = int(steps)
+
+    def _spare(self, key):
+        """One spare step while the history is short or its maximum is young (the count is growing)."""
+        h = self.hist.get(key) or []
+        if len(h) < self.CALM:
+            return True
+        return max(h[-self.TREND:]) > max(h[:-self.TREND])
+
+    def _enqueue(self, key):
+        h = self.hist.get(key) or [self.guess[key]]
+        return max(h) + (1 if self._spare(key) else 0)
 
     def blind_args(self, key, enqueue):
         dev, _, _ = self._buffers(key)
+        self._last_enqueued[key] = int(enqueue)
         return (enqueue, dev, self.miss_flag)
 
     def launched(self, key, guessed, func=None):
         dev, host, event = self._buffers(key)
         host.copy_(dev, non_blocking=True)
         event.record(torch.cuda.current_stream(self.device))
-        self.pending[key] = (guessed, weakref.ref(func) if func is not None else None)
+        self.pending[key] = (guessed, weakref.ref(func) if func is not None else None, self._last_enqueued.pop(key, guessed))
         self._seq[key] = self.blind_solves
         self.blind_solves += 1
 
     def learned(self, key, steps):
-        self.guess[key] = int(steps)
+        """A solve of `key` ran with a read-back: its count starts a new history."""
+        self.hist[key] = []
         self.calm[key] = 0
+        self._observe(key, int(steps))
+
+    def forget(self):
+        """Drop every step-count guess (the next solve of each kind runs with a read-back and learns its count anew)."""
+        for k in list(self.guess):
+            self.guess[k] = None
+            self.calm[k] = 0
+            self.hist[k] = []
+
+    def force_counts(self, counts):
+        """Tests: pretend every kind of solve (or those in the {key: n} mapping) has needed exactly n steps for a long
+        time -- the next blind solve enqueues n steps and no spare one."""
+        for k in list(self.guess):
+            n = counts.get(k) if isinstance(counts, dict) else counts
+            if n is None:
+                continue
+            self.guess[k] = int(n)
+            self.hist[k] = [int(n)] * self.CALM
+            self.calm[k] = self.CALM
 
     def step_verdicts(self):
         """[(blind solve index, 'fwd' | 'bwd', missed)] for the records read so far (one iteration late): a caller that
@@ -424,9 +472,9 @@ class Deferred:
         return list(self.verdicts)
 
     def settled(self):
-        """True once every kind of solve seen so far runs blind WITHOUT a spare step (CALM exact predictions in a row):
+        """True once every kind of solve seen so far runs blind WITHOUT a spare step (history long enough, its maximum old):
         from then on a training step enqueues no launch that returns at once."""
-        return bool(self.guess) and all(g and self.calm.get(k, 0) >= self.CALM for k, g in self.guess.items())
+        return bool(self.guess) and all(g and not self._spare(k) for k, g in self.guess.items())
 
     def resolve(self):
         """Wait for every outstanding record (a synchronisation point) and count the misses."""
@@ -435,20 +483,109 @@ class Deferred:
         return self.misses
 
 
+class DeferredLoop:
+    """Training steps under deferred completion that never lose an update: a miss costs time, not training data.
+
+    `Deferred` alone SKIPS the optimizer step of an iteration one of whose solves missed.  Here the device flag is
+    STICKY -- nothing zeroes it behind the optimizer step, so once a solve has missed, that update and every later one
+    is skipped on the device -- and the host keeps each batch until its verdict is in.  `lag` iterations later (the copy
+    of the flag as the optimizer step saw it is long complete by then: no stall) the host reads the verdict; on a miss
+    it drains the queue, zeroes the flag, forgets the step-count guesses, and runs the voided batches again IN ORDER
+    with a read-back per solve, each under the random-generator state its first attempt started from.  The sequence
+    of committed updates is therefore exactly the synchronous run's (tests/test_gpu_deferred.py: parameters
+    bit-identical after a forced miss).  Under data parallelism the flag every rank reads is the all-reduced one
+    (`dp.GradientReducer.carry_flag`), so all ranks void and repeat the same batches together.
+
+        loop = integrate.DeferredLoop(deferred, opt, step_fn, reducer)     # step_fn(*batch) -> anything
+        for x, y in loader:
+            for result in loop.step(x, y):      # results of batches whose update is now known to be committed
+                log(result)
+        for result in loop.flush(): log(result)
+    """
+
+    def __init__(self, deferred: 'Deferred', opt, step_fn, reducer=None, lag: int = 1):
+        self.d, self.opt, self.step_fn, self.lag = deferred, opt, step_fn, max(0, int(lag))
+        opt.use_deferred(deferred, reducer)
+        opt.flags_to_reset = []            # sticky: only the host clears the flag, after it has seen the miss
+        self.queue: List[list] = []        # [batch, result, rng state, pinned flag copy, event]
+        self.retries = 0                   # batches run a second time
+        self.miss_events = 0
+        self.steps = 0
+        self._pool: List[tuple] = []       # (pinned float, event) pairs of settled entries, reused
+
+    def _rng(self):
+        return torch.cuda.get_rng_state(self.d.device), torch.get_rng_state()
+
+    def _set_rng(self, st):
+        torch.cuda.set_rng_state(st[0], self.d.device)
+        torch.set_rng_state(st[1])
+
+    def _run(self, batch):
+        with self.d:
+            return self.step_fn(*batch)
+
+    def _settle(self, keep: int):
+        """Pop committed entries until `keep` remain; on a miss repeat everything queued.  Returns committed results."""
+        out = []
+        while len(self.queue) > keep:
+            batch, result, rng, host, event = self.queue[0]
+            event.synchronize()
+            if float(host[0]) == 0.0:
+                self.queue.pop(0)
+                self._pool.append((host, event))
+                out.append(result)
+                continue
+            # a solve of this iteration (on some rank) missed: its update and every later one were skipped on the device
+            self.miss_events += 1
+            torch.cuda.synchronize(self.d.device)
+            self.d.resolve()
+            self.d.miss_flag.zero_()
+            self.d.forget()
+            voided, self.queue = self.queue, []
+            flag, self.opt.skip_flag = self.opt.skip_flag, None
+            armed, self.d.armed = self.d.armed, False
+            try:
+                for b, _, r, _, _ in voided:
+                    self._set_rng(r)      # the generator state the first attempt started from: after the last repeat
+                    out.append(self._run(b))   # it stands where the synchronous run's stands
+                    self.retries += 1
+            finally:
+                self.opt.skip_flag = flag
+                self.d.armed = armed
+        return out
+
+    def step(self, *batch):
+        done = self._settle(self.lag)
+        rng = self._rng()
+        result = self._run(batch)
+        host, event = self._pool.pop() if self._pool else (torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+        src = self.opt.skip_flag if self.opt.skip_flag is not None else self.d.miss_flag
+        host.copy_(src, non_blocking=True)      # the flag as this iteration's optimizer step saw it
+        event.record(torch.cuda.current_stream(self.d.device))
+        self.queue.append([batch, result, rng, host, event])
+        self.steps += 1
+        return done
+
+    def flush(self):
+        return self._settle(0)
+
+
 _TOKENS = itertools.count(1)
+_TOKEN_OF: 'weakref.WeakKeyDictionary' = weakref.WeakKeyDictionary()
 
 
 def _func_token(func):
-    """A key for `func` that is never reused: id() can be handed to a new object after the old one was collected,
-    and a new dynamics function would then inherit a stale step-count guess."""
-    tok = getattr(func, '_node_token', None)
-    if tok is None:
-        tok = next(_TOKENS)
-        try:
-            object.__setattr__(func, '_node_token', tok)
-        except Exception:
-            return id(func)
-    return tok
+    """A key for `func` that is never reused and never shared: id() can be handed to a new object after the old one
+    was collected (a new dynamics function would inherit a stale step-count guess), and an attribute on the module
+    would travel with `copy.deepcopy(model)` (an EMA / evaluation copy would share its original's pending record).
+    Tokens therefore live in a weak-keyed table beside the modules, not on them."""
+    try:
+        tok = _TOKEN_OF.get(func)
+        if tok is None:
+            tok = _TOKEN_OF[func] = next(_TOKENS)
+        return tok
+    except TypeError:          # not weak-referenceable / unhashable: fall back to identity
+        return id(func)
 
 
 BACKPROP_LOG = 4096      # step sizes the forward solve can record for the non-adjoint backward (csrc: STEP_LIST_CAP)

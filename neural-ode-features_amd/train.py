@@ -64,12 +64,27 @@ class Tally:
         self.seen += target.shape[0]
 
 
-def train(data, model, optimizer, args, gen):
+def train(data, model, optimizer, args, gen, loop=None):
     """One epoch; semantics of train.py:26-72 (loss read per batch, NFE counter read and reset after the forward and
-    after the backward, optimizer stepped every `batch_accumulation` batches)."""
+    after the backward, optimizer stepped every `batch_accumulation` batches).  With `loop` (--deferred:
+    integrate.DeferredLoop) the solves run with deferred completion: nothing is read back per batch, a solve that
+    missed its step count is REPEATED (never skipped), and the per-batch numbers are tallied when their update is
+    known to be committed -- the same sums, one iteration late."""
     model.train()
     optimizer.zero_grad()
     tally = Tally()
+    if loop is not None:
+        def tally_done(results):
+            for logits, target, loss, nf, nb in results:
+                tally.count(logits, target, loss.item())
+                tally.nfe[0] += nf
+                tally.nfe[1] += nb
+                tally.batches += 1
+        for images, target in batches(data[0], data[1], args.batch_size, True, gen):
+            tally_done(loop.step(images.to(args.device), target.to(args.device)))
+        tally_done(loop.flush())
+        nb = tally.batches
+        return {'loss': tally.loss_sum / nb, 'acc': tally.hits / tally.seen, 'nfe-f': tally.nfe[0] / nb, 'nfe-b': tally.nfe[1] / nb}
     for images, target in batches(data[0], data[1], args.batch_size, True, gen):
         images, target = images.to(args.device), target.to(args.device)
         logits = model(images)
@@ -84,6 +99,27 @@ def train(data, model, optimizer, args, gen):
             optimizer.zero_grad()
     nb = tally.batches
     return {'loss': tally.loss_sum / nb, 'acc': tally.hits / tally.seen, 'nfe-f': tally.nfe[0] / nb, 'nfe-b': tally.nfe[1] / nb}
+
+
+def deferred_loop(model, optimizer, args):
+    """--deferred: the training step as a closure for integrate.DeferredLoop (needs FusedSGD: its launch is the one
+    commit point the device flag predicates; one optimizer step per batch)."""
+    from . import integrate
+    from .optim import FusedSGD
+    if not isinstance(optimizer, FusedSGD) or args.batch_accumulation != 1 or not args.adjoint or args.method != 'dopri5':
+        raise SystemExit('--deferred needs -o sgd, --batch-accumulation 1, --adjoint and --method dopri5')
+
+    def step(images, target):
+        logits = model(images)
+        loss = F.cross_entropy(logits, target)
+        nf = model.nfe(reset=True)
+        loss.backward()
+        nb = model.nfe(reset=True)
+        optimizer.step()
+        optimizer.zero_grad()
+        return logits.detach(), target, loss.detach(), nf, nb
+
+    return integrate.DeferredLoop(integrate.Deferred(args.device), optimizer, step)
 
 
 def evaluate(data, model, args):
@@ -148,6 +184,8 @@ def main(argv=None):
         (('--data',), dict(type=str, default=None, help='.pt file with x_train, y_train, x_test, y_test')),
         (('--synthetic-size',), dict(type=int, default=512)),
         (('--run-dir',), dict(type=str, default=None)),
+        # not in the reference: solves without a read-back per batch; missed step counts are repeated, never skipped
+        (('--deferred',), dict(action='store_true', default=False)),
     ]
     for names, kw in flags:
         parser.add_argument(*names, **kw)
@@ -194,9 +232,10 @@ def main(argv=None):
         scheduler = CosineAnnealingLR(optimizer, args.lrcycle, last_epoch=start_epoch - 2)
 
     gen = torch.Generator().manual_seed(args.seed + start_epoch)
+    loop = deferred_loop(model, optimizer, args) if args.deferred else None
     for epoch in range(start_epoch, args.epochs + 1):
         metrics = {'epoch': epoch}
-        metrics.update(train((xtr, ytr), model, optimizer, args, gen))
+        metrics.update(train((xtr, ytr), model, optimizer, args, gen, loop))
         metrics.update(evaluate((xte, yte), model, args))
         is_best = metrics['test_acc'] > best_accuracy
         best_accuracy = max(metrics['test_acc'], best_accuracy)

@@ -55,9 +55,7 @@ def main():
         assert not torch.equal(p1, p2) and same_on_all_ranks(p2)
         d.resolve()
         if rank == 1:                              # a miss on THIS rank only: one step, no spare, on a much stiffer input
-            for k in d.guess:
-                d.guess[k] = 1
-                d.calm[k] = d.CALM
+            d.force_counts(1)
         p3 = step(x * 40.0 if rank == 1 else x)
         assert torch.equal(p2, p3), 'rank %d committed an update although rank 1 missed' % rank
         assert same_on_all_ranks(p3)

@@ -86,9 +86,7 @@ def test_deferred_miss_commits_nothing_and_relearns():
         steps_easy = (blk.odefunc.last_forward_stats['accepted'], blk.odefunc.last_backward_stats['accepted'])
         assert any(not torch.equal(a, b) for a, b in zip(p1, p2))
         d.resolve()                      # consume the records of the step above (they would refresh the guesses)
-        for k in d.guess:                # make the miss certain whatever the two inputs need: one step, no spare
-            d.guess[k] = 1
-            d.calm[k] = d.CALM
+        d.force_counts(1)                # make the miss certain whatever the two inputs need: one step, no spare
         p3 = step(hard)                  # blind with too few steps -> miss -> nothing committed
         for a, b in zip(p2, p3):
             assert torch.equal(a, b)
@@ -107,8 +105,7 @@ def test_deferred_miss_commits_nothing_and_relearns():
         # and nfe is corrected by the record to what a synchronous solve counts
         d.resolve()
         truth = {k: v for k, v in d.guess.items()}
-        for k in d.guess:
-            d.guess[k] = truth[k] + 3
+        d.force_counts({k: truth[k] + 3 for k in truth})
         misses = d.misses
         blk.nfe = 0
         p6 = step(hard)
@@ -117,8 +114,64 @@ def test_deferred_miss_commits_nothing_and_relearns():
         counts = {k[0]: v for k, v in d.guess.items()}               # from the records: steps actually tried
         assert blk.nfe == (2 + 6 * counts['fwd']) + (3 + 6 * counts['bwd'])
         assert all(abs(d.guess[k] - truth[k]) <= 1 for k in truth)    # the guesses came back down
+        assert d.dead_steps >= 6                                      # ... and the surplus steps were counted as dead
     for p in p5:
         assert bool(torch.isfinite(p).all())
+
+
+def test_loop_repeats_a_missed_batch_and_matches_the_synchronous_run_bit_for_bit():
+    """integrate.DeferredLoop: a miss costs time, not an update.  Eight batches, the sixth enqueued with ONE step where
+    several are needed (a certain miss): the loop voids that iteration and the one already enqueued
+    behind it (the device flag is sticky), then repeats both in order with a read-back per solve, under the random
+    generator state of their first attempt (the loss goes through a dropout mask).  Parameters, momentum and every
+    loss are bit-identical to eight synchronous steps; no update is lost, two batches ran twice."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    a = _block()
+    b = copy.deepcopy(a)
+    oa = nof.FusedSGD(a.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    ob = nof.FusedSGD(b.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    gen = torch.Generator().manual_seed(11)
+    xs = [torch.randn(4, 32, 8, 8, generator=gen).cuda() for i in range(8)]
+
+    def make_step(blk, opt):
+        def step(x):
+            loss = F.dropout(blk(x), 0.5, training=True).square().mean()
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            return loss.detach()
+        return step
+
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(3)
+    sync_step = make_step(b, ob)
+    losses_b = [sync_step(x) for x in xs]
+
+    torch.manual_seed(3)
+    torch.cuda.manual_seed(3)
+    d = integrate.Deferred(xs[0].device)
+    loop = integrate.DeferredLoop(d, oa, make_step(a, oa))
+    losses_a = []
+    for i, x in enumerate(xs):
+        if i == 5:                       # make the miss certain: one step enqueued, no spare, for a solve that needs several
+            d.resolve()
+            d.force_counts(1)
+        losses_a += loop.step(x)
+    losses_a += loop.flush()
+    assert len(losses_a) == 8
+    assert loop.miss_events >= 1 and loop.retries >= 1 and d.misses >= 1, (loop.miss_events, loop.retries, d.misses)
+    for i, (la, lb) in enumerate(zip(losses_a, losses_b)):
+        assert float(la) == float(lb), i
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(oa.state[p]['momentum_buffer'], ob.state[q]['momentum_buffer'])
+    assert float(d.miss_flag) == 0.0 and a.nfe > 0
+    # a copy of the block (an EMA / evaluation copy) must not share the original's pending record: tokens live beside
+    # the modules, not on them
+    c = copy.deepcopy(a)
+    assert integrate._func_token(c.odefunc) != integrate._func_token(a.odefunc)
 
 
 def test_nothing_runs_blind_without_a_predicated_commit_point():

@@ -131,6 +131,7 @@ def test_bench_two_ranks_through_self_launcher_on_one_gpu():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
+    assert [r['rank'] for r in d['config']['per_rank']] == [0, 1] and all(r['ms_per_step_own'] > 0 for r in d['config']['per_rank'])
     assert 'SHARE' in d['config']['parallelism']
 
 
@@ -154,7 +155,8 @@ def test_bench_one_rank_through_rccl():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     print('one rank through RCCL:', d['value'], 'images/s;', d['config']['collectives'], d['config']['solver_completion'])
     assert d['n_gpus'] == 1 and 'RCCL' in d['config']['collectives'] and d['value'] > 0
-    assert 'deferred' in d['config']['solver_completion'] and '0 misses' in d['config']['solver_completion']
+    assert 'deferred' in d['config']['solver_completion'] and d['config']['retries'] == 0 and d['config']['miss_events'] == 0
+    assert d['config']['per_rank'][0]['rank'] == 0 and d['config']['per_rank'][0]['ms_per_step_own'] > 0
 
 
 @pytest.mark.timeout(900)
@@ -190,7 +192,9 @@ def test_bench_line_carries_the_contract_keys():
     # the HBM-bound passes (both fractions), the drop-in rate of the same run, the settle accounting
     assert rf['hbm']['bound'] == 'hbm' and 0.05 < rf['hbm']['frac'] < 1.0 and rf['hbm']['all_passes']['ms_per_step'] > 0
     assert d['dropin']['value'] > 0 and d['dropin']['value'] < 1.05 * d['value']
-    assert d['config']['settle_steps'] >= 0
+    assert d['config']['settle_steps'] >= 0 and d['config']['dead_steps_per_step'] >= 0 and d['config']['retries'] >= 0
+    assert d['fresh_batches']['value'] > 0 and d['fresh_batches']['retries'] >= 0      # a new batch every step, misses repeated
+    assert len(d['config']['per_rank']) == 1 and d['config']['per_rank'][0]['last_steps_fwd_bwd_per_block'][0][0] >= 1
     # the direct-convolution count behind the launch lives under its own key; a rate against it is quoted only where
     # one launch IS the whole convolution (the fused kernels), not for the component GEMMs of the F(4x4,3x3) pipeline
     assert rf['algorithmic']['flops_per_launch'] > rf['flops_per_launch']

@@ -55,6 +55,24 @@ def test_train_resume_and_checkpoint_layout(tmp_path):
     assert abs(ck['optim']['param_groups'][0]['lr'] - saved['param_groups'][0]['lr']) < 1e-12
 
 
+def test_train_with_deferred_completion_matches_the_read_back_loop(tmp_path):
+    """`--deferred` (integrate.DeferredLoop): the same epochs without a read-back per batch.  Every batch is tallied
+    once (a missed solve is repeated, not skipped), the NFE sums are the synchronous loop's, and loss / accuracy
+    agree with it to the noise of the stem's library convolutions."""
+    from neural_ode_features_amd import train as T
+    common = ['--dataset', 'mnist', '-f', '16', '-b', '32', '--synthetic-size', '160', '-a', '--lr', '0.05', '--wd', '1e-4',
+              '--lrschedule', 'fixed', '-e', '2']
+    assert T.main(common + ['--run-dir', str(tmp_path / 'sync')]) == 0
+    assert T.main(common + ['--run-dir', str(tmp_path / 'blind'), '--deferred']) == 0
+    a = list(csv.DictReader(open(os.path.join(str(tmp_path / 'sync'), 'log.csv'))))
+    b = list(csv.DictReader(open(os.path.join(str(tmp_path / 'blind'), 'log.csv'))))
+    assert len(a) == len(b) == 2
+    for ra, rb in zip(a, b):
+        assert abs(float(ra['loss']) - float(rb['loss'])) < 2e-2 * max(1.0, abs(float(ra['loss'])))
+        assert abs(float(ra['nfe-f']) - float(rb['nfe-f'])) <= 6.0 and abs(float(ra['nfe-b']) - float(rb['nfe-b'])) <= 6.0
+        assert abs(float(ra['test_acc']) - float(rb['test_acc'])) <= 0.1
+
+
 def test_features_and_nfe_evaluations_on_a_trained_run(tmp_path):
     """evaluate.py:24-142 on the HIP backend: dense-output feature extraction over a tolerance sweep, and the bs=1
     NFE census, from a run directory written by the training loop."""
