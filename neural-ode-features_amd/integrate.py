@@ -338,13 +338,13 @@ class Deferred:
     # How many steps to enqueue for a solve whose true count nobody knows yet.  A step past the end of the interval returns
     # at its first instruction in every kernel, but its ~40 launches still cost ~0.1 ms; a miss costs the iteration (and,
     # through DeferredLoop, its repetition): ~100x more.  So: enqueue the LARGEST count of the last HIST solves of this
-    # kind (a count that wobbles by one between iterations -- tol 1e-5 -- then never misses and wastes half a step on
-    # average), plus ONE spare step while the history is short or its maximum is young (a new maximum within the last
-    # TREND solves: the count is growing).  Round 3 enqueued last count + 1 until eight exact predictions in a row --
-    # at tol 1e-5 that never happened, and every solve carried one or two dead steps (profiles/r03_r_cfg3_steps.txt).
-    HIST = 16
-    TREND = 4
-    CALM = 8           # solves of a kind before the spare step can go
+    # kind (a count that wobbles by one between iterations -- tol 1e-5 -- then rarely misses and wastes half a step on
+    # average; a count that DROPS is followed after HIST iterations), plus ONE spare step while the history is short
+    # or the last count was a new maximum (the count is growing).  Round 3 enqueued last count + 1 until eight exact
+    # predictions in a row -- at tol 1e-5 that never happened, and every solve carried one or two dead steps
+    # (profiles/r03_r_cfg3_steps.txt).
+    HIST = 8
+    CALM = 4           # solves of a kind before the spare step can go
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -419,11 +419,11 @@ class Deferred:
         self.guess[key] = int(steps)
 
     def _spare(self, key):
-        """One spare step while the history is short or its maximum is young (the count is growing)."""
+        """One spare step while the history is short or the last count was a new maximum (the count is growing)."""
         h = self.hist.get(key) or []
         if len(h) < self.CALM:
             return True
-        return max(h[-self.TREND:]) > max(h[:-self.TREND])
+        return h[-1] > max(h[:-1])
 
     def _enqueue(self, key):
         h = self.hist.get(key) or [self.guess[key]]
@@ -472,9 +472,11 @@ class Deferred:
         return list(self.verdicts)
 
     def settled(self):
-        """True once every kind of solve seen so far runs blind WITHOUT a spare step (history long enough, its maximum old):
+        """True once every kind of solve seen so far runs blind with exactly its last count (no spare step, no larger count
+        in the history window):
         from then on a training step enqueues no launch that returns at once."""
-        return bool(self.guess) and all(g and not self._spare(k) for k, g in self.guess.items())
+        return bool(self.guess) and all(g and not self._spare(k) and max(self.hist[k]) == self.hist[k][-1]
+                                        for k, g in self.guess.items())
 
     def resolve(self):
         """Wait for every outstanding record (a synchronisation point) and count the misses."""
