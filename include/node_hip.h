@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define NODE_ABI_VERSION 2
+#define NODE_ABI_VERSION 3
 
 /* method -- the two solver names that reach model.py:367 on the graded configs
  * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
@@ -265,6 +265,63 @@ typedef struct node_sgd_tensor {
 } node_sgd_tensor;
 int node_sgd_step(const node_sgd_tensor* tensors, int count, float lr, float momentum, float weight_decay,
                   float grad_scale, const float* skip_if_nonzero, void* stream);
+
+/* The residual stem in front of the ODE block -- model.py:167-178 (`ResDownsample`):
+ *     nn.Conv2d(in_ch, 64, 3, 1)                                              bias, no padding
+ *     ResBlock(64, 64,      stride=2, downsample=conv1x1(64, 64, 2))          model.py:284-310
+ *     ResBlock(64, filters, stride=2, downsample=conv1x1(64, filters, 2))
+ * with ResBlock.forward (model.py:297-310): out = relu(norm1(x)); shortcut = downsample(out);
+ * out = conv2(relu(norm2(conv1(out)))); return out + shortcut  -- conv3x3 / conv1x1 without bias (model.py:255-265),
+ * norm = nn.GroupNorm(min(32, C), C) (model.py:268-271).  Forward and backward as hand-written gfx950 kernels, NHWC
+ * inside the workspace: every convolution and data gradient on the bf16 matrix pipe at fp32 accuracy (activations,
+ * gradients and filters as exact three-way bf16 splits, six products), weight gradients on the fp32 matrix
+ * instructions.  x: [n, in_ch, h, w] NCHW (in_ch <= 3), out / grad_out: [n, filters, h2, w2] NCHW with
+ * h0 = h - 2, h1 = (h0 - 1) / 2 + 1, h2 = (h1 - 1) / 2 + 1 (32 -> 30 -> 15 -> 8); filters % 64 == 0.
+ * node_stem_bwd needs the workspace exactly as node_stem_fwd left it (the caller keeps it between the two calls);
+ * every gradient pointer receives the full gradient (written, not accumulated). */
+typedef struct node_stem_shape {
+  int32_t n, in_ch, h, w, filters;
+  float eps;
+} node_stem_shape;
+typedef struct node_stem_params {       /* state_dict keys under `downsample.module.` */
+  const float* conv0_w;  /* 0.weight            [64, in_ch, 3, 3] */
+  const float* conv0_b;  /* 0.bias              [64]              */
+  const float* b1_n1_w;  /* 1.norm1.weight      [64]              */
+  const float* b1_n1_b;  /* 1.norm1.bias        [64]              */
+  const float* b1_c1_w;  /* 1.conv1.weight      [64, 64, 3, 3]    */
+  const float* b1_n2_w;  /* 1.norm2.weight      [64]              */
+  const float* b1_n2_b;  /* 1.norm2.bias        [64]              */
+  const float* b1_c2_w;  /* 1.conv2.weight      [64, 64, 3, 3]    */
+  const float* b1_ds_w;  /* 1.downsample.weight [64, 64, 1, 1]    */
+  const float* b2_n1_w;  /* 2.norm1.weight      [64]              */
+  const float* b2_n1_b;  /* 2.norm1.bias        [64]              */
+  const float* b2_c1_w;  /* 2.conv1.weight      [filters, 64, 3, 3] */
+  const float* b2_n2_w;  /* 2.norm2.weight      [filters]         */
+  const float* b2_n2_b;  /* 2.norm2.bias        [filters]         */
+  const float* b2_c2_w;  /* 2.conv2.weight      [filters, filters, 3, 3] */
+  const float* b2_ds_w;  /* 2.downsample.weight [filters, 64, 1, 1] */
+} node_stem_params;
+typedef struct node_stem_grads {        /* same order and shapes as node_stem_params; device pointers, all required */
+  float* conv0_w; float* conv0_b;
+  float* b1_n1_w; float* b1_n1_b; float* b1_c1_w; float* b1_n2_w; float* b1_n2_b; float* b1_c2_w; float* b1_ds_w;
+  float* b2_n1_w; float* b2_n1_b; float* b2_c1_w; float* b2_n2_w; float* b2_n2_b; float* b2_c2_w; float* b2_ds_w;
+} node_stem_grads;
+size_t node_stem_workspace_bytes(const node_stem_shape* shape);
+int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* params, const float* x, float* out,
+                  void* ws, size_t ws_bytes, void* stream);
+int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* params, const float* x, const float* grad_out,
+                  const node_stem_grads* grads, void* ws, size_t ws_bytes, void* stream);
+
+/* Diagnostics (tests): ONE convolution of the stem's kernel family on NCHW fp32 tensors, through the same layout /
+ * split / MFMA kernels node_stem_fwd and node_stem_bwd use.  what: 0 forward y = conv2d(x, w, stride, pad);
+ * 1 data gradient dx = conv_transpose of dy (x_h, x_w: the input's spatial size); 2 weight gradient dw.
+ * x: [n, cin, x_h, x_w]; w / dw: [cout, cin, k, k]; y / dy: [n, cout, y_h, y_w]; k in {1, 3}; cin, cout % 64 == 0. */
+typedef struct node_conv_geom {
+  int32_t n, cin, cout, x_h, x_w, k, stride, pad;
+} node_conv_geom;
+size_t node_stem_conv_workspace_bytes(const node_conv_geom* g);
+int node_stem_conv(const node_conv_geom* g, int what, const float* x, const float* w, const float* dy, float* result,
+                   void* ws, size_t ws_bytes, void* stream);
 
 /* Event-based per-kernel-class timing (off by default; adds two event records
  * per profiled launch).  begin() resets the counters; end() synchronises the

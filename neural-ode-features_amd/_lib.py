@@ -13,7 +13,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
 
-NODE_ABI_VERSION = 2
+NODE_ABI_VERSION = 3
 METHOD_DOPRI5, METHOD_RK4 = 0, 1
 METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
 
@@ -30,6 +30,7 @@ EXPORTS = [
     'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
     'node_sgd_step', 'node_profile_begin', 'node_profile_end',
     'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3',
+    'node_stem_workspace_bytes', 'node_stem_fwd', 'node_stem_bwd', 'node_stem_conv_workspace_bytes', 'node_stem_conv',
 ]
 
 
@@ -72,6 +73,23 @@ class NodeProfile(C.Structure):
 
 class NodeSgdTensor(C.Structure):
     _fields_ = [('param', C.c_void_p), ('grad', C.c_void_p), ('momentum_buf', C.c_void_p), ('n', C.c_size_t)]
+
+
+STEM_PARAM_FIELDS = ('conv0_w', 'conv0_b', 'b1_n1_w', 'b1_n1_b', 'b1_c1_w', 'b1_n2_w', 'b1_n2_b', 'b1_c2_w', 'b1_ds_w',
+                     'b2_n1_w', 'b2_n1_b', 'b2_c1_w', 'b2_n2_w', 'b2_n2_b', 'b2_c2_w', 'b2_ds_w')
+
+
+class NodeStemShape(C.Structure):
+    _fields_ = [('n', C.c_int32), ('in_ch', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('filters', C.c_int32),
+                ('eps', C.c_float)]
+
+
+class NodeStemParams(C.Structure):          # node_stem_params and node_stem_grads share this layout
+    _fields_ = [(k, C.c_void_p) for k in STEM_PARAM_FIELDS]
+
+
+class NodeConvGeom(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ('n', 'cin', 'cout', 'x_h', 'x_w', 'k', 'stride', 'pad')]
 
 
 class NodeHipError(RuntimeError):
@@ -138,6 +156,16 @@ def load():
     lib.node_conv3x3_w4.argtypes = [P(NodeShape), vp, i32, vp, vp, vp, sz, vp]
     lib.node_w4_split3.restype = i32
     lib.node_w4_split3.argtypes = [vp, vp, sz, vp]
+    lib.node_stem_workspace_bytes.restype = sz
+    lib.node_stem_workspace_bytes.argtypes = [P(NodeStemShape)]
+    lib.node_stem_fwd.restype = i32
+    lib.node_stem_fwd.argtypes = [P(NodeStemShape), P(NodeStemParams), vp, vp, vp, sz, vp]
+    lib.node_stem_bwd.restype = i32
+    lib.node_stem_bwd.argtypes = [P(NodeStemShape), P(NodeStemParams), vp, vp, P(NodeStemParams), vp, sz, vp]
+    lib.node_stem_conv_workspace_bytes.restype = sz
+    lib.node_stem_conv_workspace_bytes.argtypes = [P(NodeConvGeom)]
+    lib.node_stem_conv.restype = i32
+    lib.node_stem_conv.argtypes = [P(NodeConvGeom), i32, vp, vp, vp, vp, vp, sz, vp]
     ver = lib.node_abi_version()
     if ver != NODE_ABI_VERSION:
         raise RuntimeError('libnode_hip ABI %d != binding ABI %d' % (ver, NODE_ABI_VERSION))

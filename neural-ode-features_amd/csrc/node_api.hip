@@ -37,6 +37,13 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// the same thread-local message for the entry points that live in other translation units (stem_api.hip)
+namespace node {
+int set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+}  // namespace node
 #define HIP_TRY(expr)                                                                        \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \

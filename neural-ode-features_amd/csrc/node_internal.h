@@ -154,9 +154,13 @@ inline void allow_full_lds(const void* fn, bool (&done)[MAX_DEVICES]) {
   (void)hipGetDevice(&dev);
   const bool tracked = dev >= 0 && dev < MAX_DEVICES;
   if (tracked && done[dev]) return;
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    (void)hipGetLastError();     // (a kernel with static __shared__ arrays: refused; do not leave the error for the next launch check)
   if (tracked) done[dev] = true;
 }
+
+// thread-local error text of the C ABI (node_last_error), set from any translation unit; returns `code`
+int set_error(int code, const char* msg);
 
 // ----------------------------------------------------------------------------
 // kernel launchers (defined in the kernels_*.hip units)

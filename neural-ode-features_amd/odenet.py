@@ -42,8 +42,9 @@ class ResBlock(nn.Module):
 
 def _stem(kind, in_ch, out_ch, norm):
     """Stem bodies keyed like the reference's `--downsample` choices."""
-    if kind == 'residual':       # model.py:167-178
-        return nn.Sequential(
+    if kind == 'residual':       # model.py:167-178; forward / backward through the HIP library on a HIP device (stem.py)
+        from .stem import ResidualStem
+        return ResidualStem(
             nn.Conv2d(in_ch, 64, 3, 1),
             ResBlock(64, 64, stride=2, downsample=nn.Conv2d(64, 64, 1, 2, bias=False), norm=norm),
             ResBlock(64, out_ch, stride=2, downsample=nn.Conv2d(64, out_ch, 1, 2, bias=False), norm=norm))

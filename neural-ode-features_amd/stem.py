@@ -1,0 +1,123 @@
+"""The residual stem in front of the ODE block -- `ResDownsample`, `/root/reference/model.py:167-178`, built from
+`ResBlock` (`model.py:284-310`) -- forward and backward through the HIP library (`node_stem_fwd / node_stem_bwd`,
+csrc/kernels_stem.hip): ONE autograd node for the whole stem, NHWC inside, no MIOpen call, no layout transposes, no
+PyTorch reductions.  The module keeps the reference's sub-modules as parameter containers (same state_dict keys:
+`0.weight`, `1.norm1.weight`, `1.conv1.weight`, `1.downsample.weight`, ...), so checkpoints load unchanged; CPU
+tensors, non-fp32 inputs and geometries the kernels do not take run the plain module sequence (what the CPU baseline
+and the gloo tests use) -- on a HIP device with the library missing, the fused path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_WS = {}
+
+
+def _params_of(seq):
+    """The sixteen tensors of the stem in node_stem_params order, or None if `seq` is not the reference's layout."""
+    try:
+        c0, b1, b2 = seq[0], seq[1], seq[2]
+        ps = [c0.weight, c0.bias,
+              b1.norm1.weight, b1.norm1.bias, b1.conv1.weight, b1.norm2.weight, b1.norm2.bias, b1.conv2.weight, b1.downsample.weight,
+              b2.norm1.weight, b2.norm1.bias, b2.conv1.weight, b2.norm2.weight, b2.norm2.bias, b2.conv2.weight, b2.downsample.weight]
+    except (AttributeError, IndexError, TypeError):
+        return None
+    if any(p is None for p in ps):
+        return None
+    for gn in (b1.norm1, b1.norm2, b2.norm1, b2.norm2):
+        if not isinstance(gn, nn.GroupNorm) or gn.num_groups != min(32, gn.num_channels) or gn.eps != b1.norm1.eps:
+            return None
+    if c0.kernel_size != (3, 3) or c0.stride != (1, 1) or c0.padding != (0, 0) or c0.out_channels != 64:
+        return None
+    for blk, cin in ((b1, 64), (b2, 64)):
+        if (blk.conv1.kernel_size, blk.conv1.stride, blk.conv1.padding, blk.conv1.bias) != ((3, 3), (2, 2), (1, 1), None):
+            return None
+        if (blk.conv2.kernel_size, blk.conv2.stride, blk.conv2.padding, blk.conv2.bias) != ((3, 3), (1, 1), (1, 1), None):
+            return None
+        ds = blk.downsample
+        if not isinstance(ds, nn.Conv2d) or (ds.kernel_size, ds.stride, ds.padding, ds.bias) != ((1, 1), (2, 2), (0, 0), None):
+            return None
+        if blk.conv1.in_channels != cin:
+            return None
+    if b1.conv1.out_channels != 64 or b2.conv1.out_channels != b2.conv2.out_channels:
+        return None
+    return ps
+
+
+def _struct(tensors):
+    return _lib.NodeStemParams(*[t.data_ptr() for t in tensors])
+
+
+class _StemFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, *params):
+        lib = _lib.load()
+        x = x.detach().contiguous()
+        n, cin, h, w = x.shape
+        filters = params[-1].shape[0]
+        shape = _lib.NodeStemShape(n, cin, h, w, filters, eps)
+        dev = x.device
+        ps = [p.detach().contiguous() for p in params]
+        with torch.cuda.device(dev):
+            nbytes = lib.node_stem_workspace_bytes(C.byref(shape))
+            if nbytes == 0:
+                raise _lib.NodeHipError(-3, lib.node_last_error().decode())
+            # the workspace carries the forward's activations to the backward: one per (device, shape) in flight.  A
+            # training step runs forward then backward, so the buffer of the previous step is free again; a second
+            # forward before the backward (two models, gradient accumulation over stems) takes a fresh buffer.
+            key = (dev.index, n, cin, h, w, filters)
+            ws = _WS.pop(key, None)
+            if ws is None or ws.numel() < nbytes + 256:
+                ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            h2 = ((h - 2 - 1) // 2 + 1 - 1) // 2 + 1
+            w2 = ((w - 2 - 1) // 2 + 1 - 1) // 2 + 1
+            out = torch.empty(n, filters, h2, w2, dtype=torch.float32, device=dev)
+            wsp = (ws.data_ptr() + 255) & ~255
+            _lib.check(lib.node_stem_fwd(C.byref(shape), C.byref(_struct(ps)), x.data_ptr(), out.data_ptr(), wsp, nbytes,
+                                         torch.cuda.current_stream(dev).cuda_stream))
+        ctx.shape_args = (n, cin, h, w, filters, eps)
+        ctx.ws, ctx.nbytes, ctx.key = ws, nbytes, key
+        ctx.save_for_backward(x, *ps)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, *ps = ctx.saved_tensors
+        shape = _lib.NodeStemShape(*ctx.shape_args)
+        dev = x.device
+        grad_out = grad_out.contiguous()
+        grads = [torch.empty_like(p) for p in ps]
+        ws = ctx.ws
+        with torch.cuda.device(dev):
+            wsp = (ws.data_ptr() + 255) & ~255
+            _lib.check(lib.node_stem_bwd(C.byref(shape), C.byref(_struct(ps)), x.data_ptr(), grad_out.data_ptr(),
+                                         C.byref(_struct(grads)), wsp, ctx.nbytes, torch.cuda.current_stream(dev).cuda_stream))
+        _WS[ctx.key] = ws            # free for the next forward of this shape (stream-ordered behind this backward)
+        ctx.ws = None
+        return (None, None, *grads)
+
+
+def fusable(seq, x) -> bool:
+    return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 3
+            and min(x.shape[2], x.shape[3]) >= 5 and _params_of(seq) is not None
+            and (x.shape[2] - 2) * (x.shape[3] - 2) <= 2400
+            and all(p.is_cuda and p.dtype == torch.float32 for p in seq.parameters()))
+
+
+class ResidualStem(nn.Sequential):
+    """`nn.Sequential(Conv2d(in_ch, 64, 3, 1), ResBlock(64, 64, 2, conv1x1), ResBlock(64, out_ch, 2, conv1x1))` with the
+    reference's state_dict keys; on a HIP device its forward and backward are the library's (one autograd node)."""
+
+    def forward(self, x):
+        if not fusable(self, x):
+            return super().forward(x)
+        ps = _params_of(self)
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in ps)):
+            return _StemFn.apply(x, float(self[1].norm1.eps), *[p.detach() for p in ps])
+        return _StemFn.apply(x, float(self[1].norm1.eps), *ps)
