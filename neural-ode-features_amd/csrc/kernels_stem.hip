@@ -52,24 +52,33 @@ __device__ __forceinline__ void split8(const float4& p, const float4& q, u32x4& 
 __device__ __forceinline__ float bf16_f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 
 // ============================================================================
-// k_stem_conv<NB>: out[row][co] = sum_{tap, ci} in[row @ tap][ci] * w[tap][co][ci]
-//   tile: 128 rows x 32 NB columns, four waves, wave w = rows 32 w .. 32 w + 31 x all columns (NB accumulator blocks)
-//   K chunk: one tap x 32 input channels = two MFMA K steps; operands double-buffered in LDS, one barrier per chunk:
-//     A [plane 3][row 128][32 ch] bf16: 64-B rows, 16-B piece p of row r at p ^ ((r >> 2) & 3) -- a ds_read_b128 of 16
-//       lanes (rows r .. r + 3 of four row quads) then touches every bank once
-//     B [plane 3][col 32 NB][32 ch] likewise
-//   a thread stages the same A row for every chunk (row -> pixel decode once); a tap outside the image reads the zero row
+// LDS images of the two MFMA kernels below: [row][64 channels] bf16 = 128-B rows, one image per bf16 part, filled by
+// LDS-DMA (global_load_lds_dwordx4: one wave instruction = 1 KB = eight whole rows; the destination is lane-linear, so the
+// XOR swizzle sits on the per-lane SOURCE address): 16-B piece p of row r lives at slot p ^ ((r >> 1) & 7).  Both the
+// row reads (ds_read_b128, forward / data gradient) and the transposed reads (ds_read_b64_tr_b16, weight gradient) of a
+// 32-lane half then touch every bank once.
 // ============================================================================
-__device__ __forceinline__ int swz(int row, int piece) { return (piece ^ ((row >> 2) & 3)) << 4; }
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int img_off(int row, int piece) { return row * 128 + ((piece ^ ((row >> 1) & 7)) << 4); }
+// eight rows (row0 .. row0 + 7) of one image: lane L brings piece (L & 7) ^ swizzle of row row0 + (L >> 3)
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_dst) {
+  __builtin_amdgcn_global_load_lds(reinterpret_cast<const void*>(src), (lds_ptr_t)lds_dst, 16, 0, 0);
+}
 
-template <int NB>
+// ============================================================================
+// k_stem_conv: out[row][co] = sum_{tap, ci} in[row @ tap][ci] * w[tap][co][ci]
+//   tile: 128 rows x 64 columns, four waves, wave w = rows 32 w .. 32 w + 31 x both 32-column blocks
+//   K chunk: one tap x 64 input channels = four MFMA K steps of six part products; both operands double-buffered in LDS
+//   (2 x 72 KB), chunk q + 1 in flight (LDS-DMA) while chunk q is multiplied, one barrier per chunk
+//   a lane stages the same four A rows for every chunk (row -> pixel decode once); a tap outside the image reads the zero row
+// ============================================================================
 __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
-  constexpr int BM = 128, BN = 32 * NB;
-  constexpr int A_BYTES = 3 * BM * 64, B_BYTES = 3 * BN * 64, BUF = A_BYTES + B_BYTES;
-  constexpr int BJ = NB / 2;     // 16-B pieces of B per thread and plane
+  constexpr int BM = 128, BN = 64;
+  constexpr int A_PLANE = BM * 128, B_PLANE = BN * 128, A_BYTES = 3 * A_PLANE, BUF = A_BYTES + 3 * B_PLANE;
   extern __shared__ __align__(16) unsigned char smem[];
   int* out_off = reinterpret_cast<int*>(smem + 2 * BUF);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntn = a.Cout / BN;
   int b = blockIdx.x;
   const int nblk = gridDim.x;
@@ -86,98 +95,89 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
     }
   const int row0 = (tile_m - tile0) * BM;
   const int Mc = a.N * ch * cw;
-  // the A row this thread stages
-  const int ra = t >> 1, pa = (t & 1) * 2;
-  const int r = row0 + ra;
-  const bool rvalid = r < Mc;
-  int n = 0, oy = 0, ox = 0;
-  if (rvalid) {
-    n = r / (ch * cw);
-    const int rem = r - n * ch * cw;
-    const int cy = rem / cw;
-    oy = cy * a.step + cpy;
-    ox = (rem - cy * cw) * a.step + cpx;
+  // the four A rows this lane stages: 32 wave + 8 j + lane / 8
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int rn[4], roy[4], rox[4];
+  bool rval[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rl = 32 * wave + 8 * j + lrow, r = row0 + rl;
+    rval[j] = r < Mc;
+    rn[j] = roy[j] = rox[j] = 0;
+    if (rval[j]) {
+      rn[j] = r / (ch * cw);
+      const int rem = r - rn[j] * ch * cw;
+      const int cy = rem / cw;
+      roy[j] = cy * a.step + cpy;
+      rox[j] = (rem - cy * cw) * a.step + cpx;
+    }
+    if (lslot == 0) out_off[rl] = rval[j] ? (rn[j] * a.OH + roy[j]) * a.OW + rox[j] : -1;
   }
-  if ((t & 1) == 0) out_off[ra] = rvalid ? (n * a.OH + oy) * a.OW + ox : -1;
-  const int ncc = a.Cin >> 5;
+  const int ncc = a.Cin >> 6;
   const int nchunk = ntap * ncc;
 
-  u32x4 ga[3][2], gb[3][BJ];
-  auto fetch = [&](int q) {
-    const int ti = q / ncc, c0 = (q - ti * ncc) << 5;
-    const int tap = (int)((taps >> (4 * ti)) & 15);
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
-    int iy, ix;
-    bool ok = rvalid;
-    if (a.mode == 0) {
-      iy = (oy << a.sshift) + ky - a.pad;
-      ix = (ox << a.sshift) + kx - a.pad;
-    } else {
-      const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;   // divisible by the stride: the class' tap list guarantees it
-      ok = ok && ty >= 0 && tx >= 0;
-      iy = ty >> a.sshift;
-      ix = tx >> a.sshift;
-    }
-    ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-    const int irow = ok ? (n * a.IH + iy) * a.IW + ix : a.zero_row;
-    const bf16_t* src = a.in + (size_t)irow * a.Cin + c0 + pa * 8;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const u32x4* s4 = reinterpret_cast<const u32x4*>(src + p * a.in_plane);
-      ga[p][0] = s4[0];
-      ga[p][1] = s4[1];
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const int item = t + 256 * j, col = item >> 2, piece = item & 3;
-      const bf16_t* ws = a.w + ((size_t)tap * a.Cout + tile_n * BN + col) * a.Cin + c0 + piece * 8;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) gb[p][j] = *reinterpret_cast<const u32x4*>(ws + p * a.w_plane);
-    }
-  };
-  auto stash = [&](int buf) {
+  auto issue = [&](int q, int buf) {
     unsigned char* A = smem + buf * BUF;
     unsigned char* B = A + A_BYTES;
+    const int ti = q / ncc, c0 = (q - ti * ncc) << 6;
+    const int tap = (int)((taps >> (4 * ti)) & 15);
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      *reinterpret_cast<u32x4*>(A + p * (BM * 64) + ra * 64 + swz(ra, pa)) = ga[p][0];
-      *reinterpret_cast<u32x4*>(A + p * (BM * 64) + ra * 64 + swz(ra, pa + 1)) = ga[p][1];
-#pragma unroll
-      for (int j = 0; j < BJ; ++j) {
-        const int item = t + 256 * j, col = item >> 2, piece = item & 3;
-        *reinterpret_cast<u32x4*>(B + p * (BN * 64) + col * 64 + swz(col, piece)) = gb[p][j];
+    for (int j = 0; j < 4; ++j) {
+      int iy, ix;
+      bool ok = rval[j];
+      if (a.mode == 0) {
+        iy = (roy[j] << a.sshift) + ky - a.pad;
+        ix = (rox[j] << a.sshift) + kx - a.pad;
+      } else {
+        const int ty = roy[j] + a.pad - ky, tx = rox[j] + a.pad - kx;   // divisible by the stride: the class' tap list guarantees it
+        ok = ok && ty >= 0 && tx >= 0;
+        iy = ty >> a.sshift;
+        ix = tx >> a.sshift;
       }
+      ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const int irow = ok ? (rn[j] * a.IH + iy) * a.IW + ix : a.zero_row;
+      const int rl = 32 * wave + 8 * j + lrow;
+      const bf16_t* src = a.in + (size_t)irow * a.Cin + c0 + ((lslot ^ ((rl >> 1) & 7)) << 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) glds16(src + p * a.in_plane, A + p * A_PLANE + (32 * wave + 8 * j) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = 16 * wave + 8 * j + lrow;
+      const bf16_t* ws = a.w + ((size_t)tap * a.Cout + tile_n * BN + col) * a.Cin + c0 + ((lslot ^ ((col >> 1) & 7)) << 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) glds16(ws + p * a.w_plane, B + p * B_PLANE + (16 * wave + 8 * j) * 128);
     }
   };
 
-  f32x16 acc[NB];
+  f32x16 acc[2];
 #pragma unroll
-  for (int c = 0; c < NB; ++c)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
 
-  fetch(0);
-  stash(0);
-  __syncthreads();
+  issue(0, 0);
   const int li = lane & 31, lg = lane >> 5;
   const int arow = 32 * wave + li;
   for (int q = 0; q < nchunk; ++q) {
-    if (q + 1 < nchunk) fetch(q + 1);
+    __syncthreads();                 // chunk q has landed (the barrier's fence drains the LDS-DMA); buffer (q + 1) & 1 is free
+    if (q + 1 < nchunk) issue(q + 1, (q + 1) & 1);
     const unsigned char* A = smem + (q & 1) * BUF;
     const unsigned char* B = A + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       bf16x8 fa[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        fa[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A + p * (BM * 64) + arow * 64 + swz(arow, 2 * ks + lg)));
+        fa[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A + p * A_PLANE + img_off(arow, 2 * ks + lg)));
 #pragma unroll
-      for (int c = 0; c < NB; ++c) {
+      for (int c = 0; c < 2; ++c) {
         const int brow = 32 * c + li;
         bf16x8 fb[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(B + p * (BN * 64) + brow * 64 + swz(brow, 2 * ks + lg)));
+          fb[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(B + p * B_PLANE + img_off(brow, 2 * ks + lg)));
         // smallest products first
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[c], 0, 0, 0);
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[c], 0, 0, 0);
@@ -187,13 +187,11 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[c], 0, 0, 0);
       }
     }
-    if (q + 1 < nchunk) stash((q + 1) & 1);
-    __syncthreads();
   }
 
   // epilogue: register r of a 32 x 32 block = row 8 (r / 4) + 4 (lane / 32) + r % 4, column lane % 32: 128-B row stores
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
+  for (int c = 0; c < 2; ++c) {
     const int col = tile_n * BN + 32 * c + li;
     const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
@@ -211,96 +209,146 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
 }
 
 // ============================================================================
-// k_stem_wgrad<T, EXTRA>: dW[tap][co][ci] = sum_rows dy[row][co] * in[row @ tap][ci]   (T = KH * KW taps: 9 or 1)
-//   a wave owns one (32 co x 32 ci) block for ALL taps over its share of the rows: T (+1) accumulators; lanes run over
-//   channels, so both operands are 128-B runs of NHWC rows, straight from L2 (the activation is rebuilt from its bf16
-//   triple: h + m + l is exact).  A K step is two consecutive pixels (lane halves); their (n, oy, ox) advance incrementally.
-//   The four waves of a workgroup split the workgroup's rows and meet through LDS; a workgroup writes one slab.
-//   EXTRA: the shortcut's 1x1 stride-s filter (no padding) reads input pixel (s oy, s ox) -- the centre tap of the 3x3
-//   pad-1 filter -- so its weight gradient is one more accumulator fed by the same activation operand.
+// k_stem_wgrad<TG, EXTRA>: dW[tap][co][ci] = sum_pixels dy[pixel][co] * in[pixel @ tap][ci] on the bf16 matrix pipe at fp32
+//   accuracy.  Both operands are triples that already exist (the data gradient reads dy, the forward conv read `in`).
+//   The reduction runs over PIXELS, so an MFMA operand is eight consecutive pixels of one channel: the [pixel][channel]
+//   LDS images above, read with ds_read_b64_tr_b16 (a 4-row x 16-column block delivered column-major: the transpose is free).
+//   workgroup = (64 co x 64 ci tile, one kernel row ky = TG taps, one share of the pixels); wave w = the 32 x 32 block
+//   (w / 2, w % 2) for the TG taps; K chunk = 16 pixels = ONE MFMA K step: a dy image (6 KB) + TG gathered input images,
+//   double-buffered, filled by LDS-DMA while the previous chunk is multiplied.  Every workgroup writes its TG blocks of
+//   one slab; k_stem_reduce sums the slabs.
+//   EXTRA (ky == 1 only): the shortcut's 1x1 stride-s filter reads the pixel the centre tap reads -- one more accumulator,
+//   fed by the centre tap's input image and a second dy image.
 // ============================================================================
-template <int T, bool EXTRA>
+template <int TG, bool EXTRA>
 __global__ __launch_bounds__(256) void k_stem_wgrad(const SWgradArgs a) {
-  constexpr int NA = T + (EXTRA ? 1 : 0);
+  constexpr int IMG = 3 * 16 * 128;                 // one image: three parts x 16 pixels x 128 B
+  constexpr int NIMG = 1 + TG + (EXTRA ? 1 : 0);    // dy, TG inputs, dy2
+  constexpr int BUF = NIMG * IMG;
   extern __shared__ __align__(16) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int li = lane & 31, hh = lane >> 5;
-  const int ncib = a.Cin >> 5, ncob = a.Cout >> 5;
-  const int pair = blockIdx.x % (ncib * ncob), split = blockIdx.x / (ncib * ncob);
-  const int cob = pair / ncib, cib = pair - cob * ncib;
-  const int co0 = cob * 32, ci0 = cib * 32;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nct = a.Cin >> 6, npair = nct * (a.Cout >> 6);
+  const int ngrp = TG == 3 ? 3 : 1;
+  int bb = blockIdx.x;
+  const int pair = bb % npair; bb /= npair;
+  const int ky = bb % ngrp;
+  const int split = bb / ngrp;
+  const int cot = pair / nct, cit = pair - cot * nct;
+  const bool extra = EXTRA && ky == 1;
   const int rows = a.N * a.OH * a.OW;
-  const int per_wave = a.rows_per_split >> 2;
-  const int rbeg = split * a.rows_per_split + wave * per_wave;
-  const int rend = min(rbeg + per_wave, rows);
+  const int rbeg = split * a.rows_per_split;
+  const int rend = min(rbeg + a.rows_per_split, rows);
+  const int nchunk = rbeg < rend ? (rend - rbeg + 15) >> 4 : 0;
+
+  // staging: one wave instruction = 8 pixel rows of one part of one image; lane -> pixel row lane / 8 (+ 8 for the second
+  // half of the chunk), piece (lane & 7) ^ swizzle.  The pixel coordinates of both rows advance by 16 per chunk.
+  const int lrow = lane >> 3, lslot = lane & 7;
+  int pn[2], py[2], px[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = rbeg + 8 * h + lrow;
+    pn[h] = r / (a.OH * a.OW);
+    const int rem = r - pn[h] * a.OH * a.OW;
+    py[h] = rem / a.OW;
+    px[h] = rem - py[h] * a.OW;
+  }
+  auto issue = [&](int q, int buf) {
+    unsigned char* base = smem + buf * BUF;
+    const int r0 = rbeg + 16 * q;
+    constexpr int NINST = NIMG * 6;      // (image, part, half)
+#pragma unroll
+    for (int ii = 0; ii < (NINST + 3) / 4; ++ii) {
+      const int inst = wave + 4 * ii;
+      if (inst >= NINST) break;
+      const int im = inst / 6, part = (inst % 6) >> 1, h = inst & 1;
+      if (EXTRA && !extra && im == NIMG - 1) continue;
+      const int rl = 8 * h + lrow;
+      const bool valid = r0 + rl < rend;
+      const int sw = (lslot ^ ((rl >> 1) & 7)) << 3;
+      const bf16_t* src;
+      if (im == 0 || (EXTRA && im == NIMG - 1)) {
+        const bf16_t* d = im == 0 ? a.dy3 : a.dy23;
+        src = d + part * a.dy_plane + (size_t)(valid ? r0 + rl : a.dy_zero_row) * a.Cout + cot * 64 + sw;
+      } else {
+        const int kx = TG == 3 ? im - 1 : 0;
+        const int iy = py[h] * a.stride - a.pad + (TG == 3 ? ky : 0), ix = px[h] * a.stride - a.pad + kx;
+        const bool ok = valid && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        src = a.in + part * a.in_plane + (size_t)(ok ? (pn[h] * a.IH + iy) * a.IW + ix : a.zero_row) * a.Cin + cit * 64 + sw;
+      }
+      glds16(src, base + im * IMG + part * 2048 + h * 1024);
+    }
+    // the next chunk's pixels
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      px[h] += 16;
+      while (px[h] >= a.OW) { px[h] -= a.OW; py[h] += 1; }
+      while (py[h] >= a.OH) { py[h] -= a.OH; pn[h] += 1; }
+    }
+  };
+
+  constexpr int NA = TG + (EXTRA ? 1 : 0);
   f32x16 acc[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  int r = rbeg + hh;
-  int n = 0, oy = 0, ox = 0;
-  if (r < rows) {
-    n = r / (a.OH * a.OW);
-    const int rem = r - n * a.OH * a.OW;
-    oy = rem / a.OW;
-    ox = rem - oy * a.OW;
-  }
-  const bf16_t* in0 = a.in + ci0 + li;
-  const bf16_t* in1 = in0 + a.in_plane;
-  const bf16_t* in2 = in1 + a.in_plane;
-  for (; r - hh < rend; r += 2) {
-    const bool valid = r < rend;
-    const float av = valid ? a.dy[(size_t)r * a.Cout + co0 + li] : 0.f;
-    float av2 = 0.f;
-    if (EXTRA) av2 = valid ? a.dy2[(size_t)r * a.Cout + co0 + li] : 0.f;
-    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-    const int base = (n * a.IH + iy0) * a.IW + ix0;
-    float bv[T];
-#pragma unroll
-    for (int tap = 0; tap < T; ++tap) {
-      const int ky = T == 9 ? tap / 3 : 0, kx = T == 9 ? tap % 3 : 0;
-      const bool ok = valid && (unsigned)(iy0 + ky) < (unsigned)a.IH && (unsigned)(ix0 + kx) < (unsigned)a.IW;
-      const size_t e = (size_t)(ok ? base + ky * a.IW + kx : a.zero_row) * a.Cin;
-      bv[tap] = (bf16_f(in0[e]) + bf16_f(in1[e])) + bf16_f(in2[e]);
-    }
-#pragma unroll
-    for (int tap = 0; tap < T; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[tap], acc[tap], 0, 0, 0);
-    if (EXTRA) acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(av2, bv[T == 9 ? 4 : 0], acc[T], 0, 0, 0);
-    ox += 2;
-    if (ox >= a.OW) {
-      ox -= a.OW;
-      oy += 1;
-      if (oy >= a.OH) { oy = 0; n += 1; }
-    }
-  }
-  // waves 1..3 hand their blocks to wave 0, one after the other (NA * 4 KB of LDS)
-  for (int w = 1; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int j = 0; j < NA; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) red[(j * 16 + i) * 64 + lane] = acc[j][i];
-    }
+  // transposed fragment reads: lane l -> channel column (l & 31) of the wave's block, pixels 8 (l >> 5) .. + 7
+  const int cob = wave >> 1, cib = wave & 1;
+  const int kg = lane >> 5, g16 = (lane >> 4) & 1, m = lane & 15, tq = m >> 2, tp = m & 3;
+  auto frag = [&](const unsigned char* img, int part, int cb0) -> bf16x8 {
+    const int piece = ((cb0 + 16 * g16) >> 3) + (tp >> 1), inb = (tp & 1) << 3;
+    const int r0 = 8 * kg + tq, r1 = r0 + 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + part * 2048 + img_off(r0, piece) + inb));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + part * 2048 + img_off(r1, piece) + inb));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  if (nchunk > 0) issue(0, 0);
+  for (int q = 0; q < nchunk; ++q) {
     __syncthreads();
-    if (wave == 0) {
+    if (q + 1 < nchunk) issue(q + 1, (q + 1) & 1);
+    const unsigned char* base = smem + (q & 1) * BUF;
+    bf16x8 fa[3];
 #pragma unroll
-      for (int j = 0; j < NA; ++j)
+    for (int p = 0; p < 3; ++p) fa[p] = frag(base, p, 32 * cob);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] += red[(j * 16 + i) * 64 + lane];
+    for (int j = 0; j < TG; ++j) {
+      bf16x8 fb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[p] = frag(base + (1 + j) * IMG, p, 32 * cib);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[j], 0, 0, 0);
+      if (EXTRA && j == 1 && extra) {      // the centre tap's input image once more, against the shortcut's dy
+        bf16x8 f2[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f2[p] = frag(base + (NIMG - 1) * IMG, p, 32 * cob);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[2], fb[0], acc[TG], 0, 0, 0);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[0], fb[2], acc[TG], 0, 0, 0);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[1], fb[1], acc[TG], 0, 0, 0);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[1], fb[0], acc[TG], 0, 0, 0);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[0], fb[1], acc[TG], 0, 0, 0);
+        acc[TG] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[0], fb[0], acc[TG], 0, 0, 0);
+      }
     }
-    __syncthreads();
   }
-  if (wave != 0) return;
+  const int li = lane & 31, hh = lane >> 5;
+  const int taps_total = TG == 3 ? 9 : 1;
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    float* dst = j < T ? a.slab + ((size_t)split * T + j) * a.Cout * a.Cin : a.slab2 + (size_t)split * a.Cout * a.Cin;
+    if (j == TG && !extra) continue;
+    float* dst = j < TG ? a.slab + ((size_t)split * taps_total + (TG == 3 ? ky * 3 + j : 0)) * a.Cout * a.Cin
+                        : a.slab2 + (size_t)split * a.Cout * a.Cin;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int co = co0 + 8 * (i >> 2) + 4 * hh + (i & 3);
-      dst[(size_t)co * a.Cin + ci0 + li] = acc[j][i];
+      const int co = cot * 64 + 32 * cob + 8 * (i >> 2) + 4 * hh + (i & 3);
+      dst[(size_t)co * a.Cin + cit * 64 + 32 * cib + li] = acc[j][i];
     }
   }
 }
@@ -667,31 +715,63 @@ __global__ __launch_bounds__(256) void k_stem_prep(const SPrepArgs a) {
 }
 
 // ============================================================================
-// slab / partial sums into the caller's gradient tensors
+// slab / partial sums into the caller's gradient tensors.  kind 0: one workgroup per (output channel co, tap): thread =
+// (ci % 64, quarter of the splits); the slabs are read in their own order (runs of 64 floats), the four quarters meet in
+// LDS, and the sums go to PyTorch's [co][ci][tap] order.  (A first version gave every thread ALL splits of nine taps: chains
+// of 500+ dependent loads, 120 us for 50 MB.)
 // ============================================================================
 __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
+  __shared__ float part[4][64];
   const SReduceJob& j = a.job[blockIdx.y];
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int t = threadIdx.x;
   if (j.kind == 0) {
+    const int co = blockIdx.x / j.taps, tap = blockIdx.x - co * j.taps;
+    if (co >= j.Co) return;
     const size_t total = (size_t)j.taps * j.Co * j.Ci;
-    if (idx >= total) return;
-    float s = 0.f;
-    for (int k = 0; k < j.ns; ++k) s += j.slab[(size_t)k * total + idx];
-    const int ci = (int)(idx % j.Ci);
-    const size_t r = idx / j.Ci;
-    const int co = (int)(r % j.Co), tap = (int)(r / j.Co);
-    j.out[((size_t)co * j.Ci + ci) * j.taps + tap] = s;
+    const int cl = t & 63, sub = t >> 6;
+    for (int c0 = 0; c0 < j.Ci; c0 += 64) {
+      const float* src = j.slab + ((size_t)tap * j.Co + co) * j.Ci + c0 + cl;
+      float s0 = 0.f, s1 = 0.f;
+      int k = sub;
+      for (; k + 4 < j.ns; k += 8) {
+        s0 += src[(size_t)k * total];
+        s1 += src[(size_t)(k + 4) * total];
+      }
+      if (k < j.ns) s0 += src[(size_t)k * total];
+      part[sub][cl] = s0 + s1;
+      __syncthreads();
+      if (sub == 0) j.out[((size_t)co * j.Ci + c0 + cl) * j.taps + tap] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+      __syncthreads();
+    }
   } else if (j.kind == 1) {
+    const size_t idx = (size_t)blockIdx.x * 256 + t;
     if (idx >= 64 * 32) return;
-    float s = 0.f;
-    for (int k = 0; k < j.ns; ++k) s += j.slab[(size_t)k * 64 * 32 + idx];
-    const int co = (int)(idx >> 5), k = (int)(idx & 31);
-    if (k < j.Ci) j.out[co * j.Ci + k] = s;
-    else if (k == j.Ci) j.out2[co] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= j.ns; k += 4) {
+      s0 += j.slab[(size_t)k * 2048 + idx];
+      s1 += j.slab[(size_t)(k + 1) * 2048 + idx];
+      s2 += j.slab[(size_t)(k + 2) * 2048 + idx];
+      s3 += j.slab[(size_t)(k + 3) * 2048 + idx];
+    }
+    for (; k < j.ns; ++k) s0 += j.slab[(size_t)k * 2048 + idx];
+    const float s = (s0 + s1) + (s2 + s3);
+    const int co = (int)(idx >> 5), kk = (int)(idx & 31);
+    if (kk < j.Ci) j.out[co * j.Ci + kk] = s;
+    else if (kk == j.Ci) j.out2[co] = s;
   } else {
+    const size_t idx = (size_t)blockIdx.x * 256 + t;
     if (idx >= (size_t)2 * j.Co) return;
-    float s = 0.f;
-    for (int k = 0; k < j.ns; ++k) s += j.slab[(size_t)k * 2 * j.Co + idx];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= j.ns; k += 4) {
+      s0 += j.slab[(size_t)k * 2 * j.Co + idx];
+      s1 += j.slab[(size_t)(k + 1) * 2 * j.Co + idx];
+      s2 += j.slab[(size_t)(k + 2) * 2 * j.Co + idx];
+      s3 += j.slab[(size_t)(k + 3) * 2 * j.Co + idx];
+    }
+    for (; k < j.ns; ++k) s0 += j.slab[(size_t)k * 2 * j.Co + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     if (idx < (size_t)j.Co) j.out[idx] = s;
     else j.out2[idx - j.Co] = s;
   }
@@ -704,34 +784,25 @@ __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
 // ============================================================================
 void launch_stem_conv(const SConvArgs& a, hipStream_t s) {
   const int mt = a.cls_tile0[a.nclass];
-  // 128-column tiles halve the A traffic per MFMA but need twice the LDS (one workgroup per CU): only where the grid
-  // still covers the chip twice
-  const bool wide = a.Cout % 128 == 0 && (size_t)mt * (a.Cout / 128) >= 512;
-  if (wide) {
-    static bool attr[MAX_DEVICES] = {};
-    allow_full_lds(reinterpret_cast<const void*>(k_stem_conv<4>), attr);
-    const size_t lds = 2 * (3 * 128 * 64 + 3 * 128 * 64) + 512;
-    hipLaunchKernelGGL(k_stem_conv<4>, dim3(mt * (a.Cout / 128)), dim3(256), lds, s, a);
-  } else {
-    static bool attr[MAX_DEVICES] = {};
-    allow_full_lds(reinterpret_cast<const void*>(k_stem_conv<2>), attr);
-    const size_t lds = 2 * (3 * 128 * 64 + 3 * 64 * 64) + 512;
-    hipLaunchKernelGGL(k_stem_conv<2>, dim3(mt * (a.Cout / 64)), dim3(256), lds, s, a);
-  }
+  static bool attr[MAX_DEVICES] = {};
+  allow_full_lds(reinterpret_cast<const void*>(k_stem_conv), attr);
+  const size_t lds = 2 * (3 * 128 * 128 + 3 * 64 * 128) + 512;
+  hipLaunchKernelGGL(k_stem_conv, dim3(mt * (a.Cout / 64)), dim3(256), lds, s, a);
 }
 
 void launch_stem_wgrad(const SWgradArgs& a, hipStream_t s) {
-  const int grid = (a.Cin / 32) * (a.Cout / 32) * a.nsplit;
   const int taps = a.KH * a.KW;
-  const size_t lds = (size_t)(taps + (a.dy2 ? 1 : 0)) * 16 * 64 * sizeof(float);
+  const int grid = (a.Cin / 64) * (a.Cout / 64) * (taps == 9 ? 3 : 1) * a.nsplit;
+  const int nimg = 1 + (taps == 9 ? 3 : 1) + (a.dy23 ? 1 : 0);
+  const size_t lds = (size_t)2 * nimg * 3 * 16 * 128;
 #define STEM_WG(T, EX)                                                                   \
   {                                                                                       \
     static bool attr[MAX_DEVICES] = {};                                                   \
     allow_full_lds(reinterpret_cast<const void*>(k_stem_wgrad<T, EX>), attr);             \
     hipLaunchKernelGGL((k_stem_wgrad<T, EX>), dim3(grid), dim3(256), lds, s, a);           \
   }
-  if (taps == 9 && a.dy2) STEM_WG(9, true)
-  else if (taps == 9) STEM_WG(9, false)
+  if (taps == 9 && a.dy23) STEM_WG(3, true)
+  else if (taps == 9) STEM_WG(3, false)
   else STEM_WG(1, false)
 #undef STEM_WG
 }
@@ -779,12 +850,12 @@ void launch_stem_to_nchw(const float* src_nhwc, float* dst, int N, int C, int HW
   hipLaunchKernelGGL(k_stem_to_nchw, dim3(N * (C / 64) * ((HW + 63) / 64)), dim3(256), 0, s, src_nhwc, dst, C, HW);
 }
 void launch_stem_reduce(const SReduceArgs& a, hipStream_t s) {
-  size_t most = 64 * 32;
+  int most = 8;
   for (int i = 0; i < a.njobs; ++i) {
     const SReduceJob& j = a.job[i];
-    most = max(most, j.kind == 0 ? (size_t)j.taps * j.Co * j.Ci : (size_t)2 * j.Co);
+    most = max(most, j.kind == 0 ? j.Co * j.taps : (2 * j.Co + 255) / 256);
   }
-  hipLaunchKernelGGL(k_stem_reduce, dim3((unsigned)((most + 255) / 256), a.njobs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_stem_reduce, dim3(most, a.njobs), dim3(256), 0, s, a);
 }
 
 }  // namespace node

@@ -42,22 +42,25 @@ struct SConvArgs {
   int cls_ntap[4];
   unsigned long long cls_taps[4];   // taps (ky * KW + kx) that reach the class, four bits each, first tap in the low bits
 };
-void launch_stem_conv(const SConvArgs& a, hipStream_t s);   // picks the column tile (64 / 128) from Cout
+void launch_stem_conv(const SConvArgs& a, hipStream_t s);
 
 // ----------------------------------------------------------------------------
-// k_stem_wgrad: weight gradient dW[tap][co][ci] = sum_rows dy[row][co] * in[row @ tap][ci], fp32 MFMA, split-K slabs
+// k_stem_wgrad: weight gradient dW[tap][co][ci] = sum_rows dy[row][co] * in[row @ tap][ci]; both operands triples, bf16
+// MFMA with transposed LDS reads, split-K slabs
 // ----------------------------------------------------------------------------
 struct SWgradArgs {
-  const float* dy;         // fp32 NHWC [rows][Cout], rows = N * OH * OW
-  const float* dy2;        // nullable: the shortcut's output gradient [rows][Cout] -- its 1x1 stride-s filter reads the pixel the
-                           // centre tap of the 3x3 pad-1 filter reads, so it rides as a tenth accumulator
+  const bf16_t* dy3;       // triples [3][rows + 1][Cout], rows = N * OH * OW
+  size_t dy_plane;
+  int dy_zero_row;
+  const bf16_t* dy23;      // nullable: the shortcut's output gradient (same shape) -- its 1x1 stride-s filter reads the pixel the
+                           // centre tap of the 3x3 pad-1 filter reads, so it rides as one more accumulator of the ky = 1 workgroups
   const bf16_t* in;        // triples [3][N * IH * IW + 1][Cin]
   size_t in_plane;
   int zero_row;
   float* slab;             // [nsplit][KH * KW][Cout][Cin]
-  float* slab2;            // [nsplit][Cout][Cin] (with dy2)
+  float* slab2;            // [nsplit][Cout][Cin] (with dy23)
   int N, IH, IW, OH, OW, Cin, Cout, KH, KW, stride, pad;
-  int nsplit, rows_per_split;   // rows_per_split % 8 == 0
+  int nsplit, rows_per_split;   // rows_per_split % 16 == 0
 };
 void launch_stem_wgrad(const SWgradArgs& a, hipStream_t s);
 

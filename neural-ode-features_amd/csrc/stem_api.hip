@@ -67,13 +67,17 @@ struct Wg {              // split-K plan + slabs of one weight gradient
   float* slab; float* slab2;
 };
 Wg take_wg(Bump& b, int rows, int Cout, int Cin, int taps, bool extra) {
+  // workgroups = (64 x 64 tiles) x (kernel rows) x splits: aim at ~1.5 workgroups per CU, shares of >= 64 pixels,
+  // and keep the slabs (written once, read once by k_stem_reduce) under ~16 MB
   Wg w;
-  const int pairs = (Cout / 32) * (Cin / 32);
-  int ns = (512 + pairs - 1) / pairs;
+  const int pairs = (Cout / 64) * (Cin / 64) * (taps == 9 ? 3 : 1);
+  int ns = (384 + pairs - 1) / pairs;
   if (ns > rows / 64) ns = rows / 64;
+  const size_t per = (size_t)(taps + (extra ? 1 : 0)) * Cout * Cin * sizeof(float);
+  while (ns > 4 && ns * per > ((size_t)16 << 20)) ns = (ns + 1) / 2;
   if (ns < 1) ns = 1;
   int rps = (rows + ns - 1) / ns;
-  rps = (rps + 7) & ~7;
+  rps = (rps + 15) & ~15;
   w.rps = rps;
   w.nsplit = (rows + rps - 1) / rps;
   w.slab = b.take<float>((size_t)w.nsplit * taps * Cout * Cin);
@@ -93,7 +97,7 @@ struct StemPlan {
   Trip a0, a1, a2, a3;
   float* stats[4];
   // backward
-  float *g, *da3, *dh3, *da2, *dx1, *da1, *dh1, *da0, *dh0;
+  float *da3, *da2, *da1, *da0, *dh0;
   Trip g3, dh3t, dx1t, dh1t;
   float* gpart[4];
   Wg w4, w3, w2, w1, w0;
@@ -133,16 +137,12 @@ StemPlan make_stem_plan(const node_stem_shape* sh, void* base) {
   p.stats[2] = b.take<float>((size_t)p.N * G64 * 2);
   p.stats[3] = b.take<float>((size_t)p.N * GF * 2);
   // backward
-  p.g = b.take<float>((size_t)p.R2 * F);
   p.g3 = take_trip(b, p.R2, F);
   p.da3 = b.take<float>((size_t)p.R2 * F);
-  p.dh3 = b.take<float>((size_t)p.R2 * F);
   p.dh3t = take_trip(b, p.R2, F);
   p.da2 = b.take<float>((size_t)p.R1 * 64);
-  p.dx1 = b.take<float>((size_t)p.R1 * 64);
   p.dx1t = take_trip(b, p.R1, 64);
   p.da1 = b.take<float>((size_t)p.R1 * 64);
-  p.dh1 = b.take<float>((size_t)p.R1 * 64);
   p.dh1t = take_trip(b, p.R1, 64);
   p.da0 = b.take<float>((size_t)p.R0 * 64);
   p.dh0 = b.take<float>((size_t)p.R0 * 64);
@@ -242,11 +242,13 @@ SConvArgs conv_dgrad_args(const Trip& dy, const Filt& f, float* dx, int N, int Y
   a.cls_tile0[nc] = tiles;
   return a;
 }
-SWgradArgs wgrad_args(const float* dy, const float* dy2, const Trip& in, const Wg& w, int N, int IH, int IW, int OH, int OW, int Cin,
+SWgradArgs wgrad_args(const Trip& dy, const Trip* dy2, const Trip& in, const Wg& w, int N, int IH, int IW, int OH, int OW, int Cin,
                       int Cout, int k, int stride, int pad) {
   SWgradArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = dy; a.dy2 = dy2; a.in = in.p; a.in_plane = in.plane; a.zero_row = in.rows;
+  a.dy3 = dy.p; a.dy_plane = dy.plane; a.dy_zero_row = dy.rows;
+  a.dy23 = dy2 ? dy2->p : nullptr;
+  a.in = in.p; a.in_plane = in.plane; a.zero_row = in.rows;
   a.slab = w.slab; a.slab2 = w.slab2;
   a.N = N; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.Cin = Cin; a.Cout = Cout; a.KH = a.KW = k; a.stride = stride; a.pad = pad;
   a.nsplit = w.nsplit; a.rows_per_split = w.rps;
@@ -376,21 +378,21 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   const int HW0 = p.H0 * p.W0, HW1 = p.H1 * p.W1, HW2 = p.H2 * p.W2;
 
   // dL/d out: also the gradient of the second block's shortcut s2
-  launch_stem_from_nchw(grad_out, p.g, p.g3.p, p.g3.plane, N, F, HW2, st);
+  launch_stem_from_nchw(grad_out, nullptr, p.g3.p, p.g3.plane, N, F, HW2, st);
   if ((rc = launch_ok("stem_from_nchw")) != NODE_OK) return rc;
   // block 2, conv2 (3x3, F -> F) : weight gradient, data gradient -> da3
-  launch_stem_wgrad(wgrad_args(p.g, nullptr, p.a3, p.w4, N, p.H2, p.W2, p.H2, p.W2, F, F, 3, 1, 1), st);
+  launch_stem_wgrad(wgrad_args(p.g3, nullptr, p.a3, p.w4, N, p.H2, p.W2, p.H2, p.W2, F, F, 3, 1, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
   launch_stem_conv(conv_dgrad_args(p.g3, p.c4, p.da3, N, p.H2, p.W2, p.H2, p.W2, 3, 1, 1), st);
   if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   {
     SGnArgs g = gn_args(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.stats[3], N, HW2, F, p.eps);
-    g.da = p.da3; g.dh = p.dh3; g.dh3 = p.dh3t.p; g.dh_plane = p.dh3t.plane; g.gpart = p.gpart[3];
+    g.da = p.da3; g.dh = nullptr; g.dh3 = p.dh3t.p; g.dh_plane = p.dh3t.plane; g.gpart = p.gpart[3];
     launch_stem_gn_bwd(g, st);
     if ((rc = launch_ok("stem_gn_bwd")) != NODE_OK) return rc;
   }
   // block 2, conv1 (3x3 / 2, 64 -> F) + shortcut (1x1 / 2, 64 -> F): both read a2
-  launch_stem_wgrad(wgrad_args(p.dh3, p.g, p.a2, p.w3, N, p.H1, p.W1, p.H2, p.W2, 64, F, 3, 2, 1), st);
+  launch_stem_wgrad(wgrad_args(p.dh3t, &p.g3, p.a2, p.w3, N, p.H1, p.W1, p.H2, p.W2, 64, F, 3, 2, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
   launch_stem_conv(conv_dgrad_args(p.dh3t, p.c3, p.da2, N, p.H2, p.W2, p.H1, p.W1, 3, 2, 1), st);
   if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
@@ -402,23 +404,23 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   }
   {
     SGnArgs g = gn_args(p.x1, prm->b2_n1_w, prm->b2_n1_b, p.stats[2], N, HW1, 64, p.eps);
-    g.da = p.da2; g.dh = p.dx1; g.dh3 = p.dx1t.p; g.dh_plane = p.dx1t.plane; g.gpart = p.gpart[2];
+    g.da = p.da2; g.dh = nullptr; g.dh3 = p.dx1t.p; g.dh_plane = p.dx1t.plane; g.gpart = p.gpart[2];
     launch_stem_gn_bwd(g, st);
     if ((rc = launch_ok("stem_gn_bwd")) != NODE_OK) return rc;
   }
   // block 1, conv2 (3x3, 64 -> 64): dx1 is the gradient of its output AND of the shortcut s1
-  launch_stem_wgrad(wgrad_args(p.dx1, nullptr, p.a1, p.w2, N, p.H1, p.W1, p.H1, p.W1, 64, 64, 3, 1, 1), st);
+  launch_stem_wgrad(wgrad_args(p.dx1t, nullptr, p.a1, p.w2, N, p.H1, p.W1, p.H1, p.W1, 64, 64, 3, 1, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
   launch_stem_conv(conv_dgrad_args(p.dx1t, p.c2, p.da1, N, p.H1, p.W1, p.H1, p.W1, 3, 1, 1), st);
   if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   {
     SGnArgs g = gn_args(p.h1, prm->b1_n2_w, prm->b1_n2_b, p.stats[1], N, HW1, 64, p.eps);
-    g.da = p.da1; g.dh = p.dh1; g.dh3 = p.dh1t.p; g.dh_plane = p.dh1t.plane; g.gpart = p.gpart[1];
+    g.da = p.da1; g.dh = nullptr; g.dh3 = p.dh1t.p; g.dh_plane = p.dh1t.plane; g.gpart = p.gpart[1];
     launch_stem_gn_bwd(g, st);
     if ((rc = launch_ok("stem_gn_bwd")) != NODE_OK) return rc;
   }
   // block 1, conv1 (3x3 / 2) + shortcut (1x1 / 2): both read a0
-  launch_stem_wgrad(wgrad_args(p.dh1, p.dx1, p.a0, p.w1, N, p.H0, p.W0, p.H1, p.W1, 64, 64, 3, 2, 1), st);
+  launch_stem_wgrad(wgrad_args(p.dh1t, &p.dx1t, p.a0, p.w1, N, p.H0, p.W0, p.H1, p.W1, 64, 64, 3, 2, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
   launch_stem_conv(conv_dgrad_args(p.dh1t, p.c1, p.da0, N, p.H1, p.W1, p.H0, p.W0, 3, 2, 1), st);
   if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
@@ -531,8 +533,8 @@ int node_stem_conv(const node_conv_geom* g, int what, const float* x, const floa
     launch_stem_to_nchw(p.resn, result, g->n, g->cin, XHW, st);
   } else {
     launch_stem_from_nchw(x, nullptr, p.xin.p, p.xin.plane, g->n, g->cin, XHW, st);
-    launch_stem_from_nchw(dy, p.dyn, nullptr, 0, g->n, g->cout, YHW, st);
-    launch_stem_wgrad(wgrad_args(p.dyn, nullptr, p.xin, p.wg, g->n, g->x_h, g->x_w, p.YH, p.YW, g->cin, g->cout, g->k, g->stride, g->pad), st);
+    launch_stem_from_nchw(dy, nullptr, p.dyt.p, p.dyt.plane, g->n, g->cout, YHW, st);
+    launch_stem_wgrad(wgrad_args(p.dyt, nullptr, p.xin, p.wg, g->n, g->x_h, g->x_w, p.YH, p.YW, g->cin, g->cout, g->k, g->stride, g->pad), st);
     SReduceArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.job[0] = {p.wg.slab, result, nullptr, 0, p.wg.nsplit, g->cout, g->cin, g->k * g->k};

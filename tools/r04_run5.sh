@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04e
+R=$GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_stem.py -q -m gpu -s > gpurun_out/r04e/stem_tests.log 2>&1
+grep "what\|stem (\|passed\|failed\|Error" gpurun_out/r04e/stem_tests.log | tail -60
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/st -- python3 $R/tools/stem_time.py --run > /tmp/st.log 2>&1 || tail -20 /tmp/st.log
+cd $R
+python3 tools/stem_time.py --report /tmp/st > gpurun_out/r04e/stem_time.txt
+cat gpurun_out/r04e/stem_time.txt
