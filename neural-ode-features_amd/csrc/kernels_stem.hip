@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
   int b = blockIdx.x;
   const int nblk = gridDim.x;
   if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);   // blocks b, b + 8, .. share an XCD: neighbouring tiles (the same A rows)
-  const int tile_m = b / ntn, tile_n = b - tile_m * ntn;
+  const int ntn_all = (a.mode == 0 && a.w2 != nullptr) ? 2 * ntn : ntn;
+  const int tile_m = b / ntn_all;
+  int tile_n = b - tile_m * ntn_all;
+  const bool shortcut_tile = tile_n >= ntn;        // forward: the shortcut's column tiles
+  if (shortcut_tile) tile_n -= ntn;
   // class of this tile (static indices only: a dynamically indexed kernel-argument array would be copied to scratch)
   int tile0 = 0, ch = a.cls_h[0], cw = a.cls_w[0], cpy = a.cls_py[0], cpx = a.cls_px[0], ntap = a.cls_ntap[0];
   unsigned long long taps = a.cls_taps[0];
@@ -93,6 +97,12 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
       tile0 = a.cls_tile0[c]; ch = a.cls_h[c]; cw = a.cls_w[c]; cpy = a.cls_py[c]; cpx = a.cls_px[c]; ntap = a.cls_ntap[c];
       taps = a.cls_taps[c];
     }
+  if (shortcut_tile) { ntap = 1; taps = (unsigned long long)((a.KH >> 1) * a.KW + (a.KW >> 1)); }   // the centre tap
+  const bf16_t* wsel = shortcut_tile ? a.w2 : a.w;
+  const size_t wsel_plane = shortcut_tile ? a.w2_plane : a.w_plane;
+  const int wtaps_one = shortcut_tile ? 1 : 0;     // the shortcut's filter has ONE tap block
+  // data gradient: the shortcut's K segment, for the (even, even) class
+  const bool extra_k = a.mode == 1 && a.in2 != nullptr && cpy == 0 && cpx == 0 && a.step == 2;
   const int row0 = (tile_m - tile0) * BM;
   const int Mc = a.N * ch * cw;
   // the four A rows this lane stages: 32 wave + 8 j + lane / 8
@@ -114,23 +124,31 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
     if (lslot == 0) out_off[rl] = rval[j] ? (rn[j] * a.OH + roy[j]) * a.OW + rox[j] : -1;
   }
   const int ncc = a.Cin >> 6;
-  const int nchunk = ntap * ncc;
+  const int nmain = ntap * ncc;
+  const int nchunk = nmain + (extra_k ? ncc : 0);
 
   auto issue = [&](int q, int buf) {
     unsigned char* A = smem + buf * BUF;
     unsigned char* B = A + A_BYTES;
-    const int ti = q / ncc, c0 = (q - ti * ncc) << 6;
-    const int tap = (int)((taps >> (4 * ti)) & 15);
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const bool xk = q >= nmain;                      // the shortcut's segment of a data gradient
+    const int qq = xk ? q - nmain : q;
+    const int ti = qq / ncc, c0 = (qq - ti * ncc) << 6;
+    const int tap = xk ? 0 : (int)((taps >> (4 * ti)) & 15);
+    const int ky = xk ? 0 : tap / a.KW, kx = xk ? 0 : tap - ky * a.KW;
+    const int pad = xk ? 0 : a.pad;
+    const bf16_t* in = xk ? a.in2 : a.in;
+    const bf16_t* wq = xk ? a.w2 : wsel;
+    const size_t wq_plane = xk ? a.w2_plane : wsel_plane;
+    const int wtap = (xk || wtaps_one) ? 0 : tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int iy, ix;
       bool ok = rval[j];
       if (a.mode == 0) {
-        iy = (roy[j] << a.sshift) + ky - a.pad;
-        ix = (rox[j] << a.sshift) + kx - a.pad;
+        iy = (roy[j] << a.sshift) + ky - pad;
+        ix = (rox[j] << a.sshift) + kx - pad;
       } else {
-        const int ty = roy[j] + a.pad - ky, tx = rox[j] + a.pad - kx;   // divisible by the stride: the class' tap list guarantees it
+        const int ty = roy[j] + pad - ky, tx = rox[j] + pad - kx;   // divisible by the stride: the class' tap list guarantees it
         ok = ok && ty >= 0 && tx >= 0;
         iy = ty >> a.sshift;
         ix = tx >> a.sshift;
@@ -138,16 +156,16 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
       ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
       const int irow = ok ? (rn[j] * a.IH + iy) * a.IW + ix : a.zero_row;
       const int rl = 32 * wave + 8 * j + lrow;
-      const bf16_t* src = a.in + (size_t)irow * a.Cin + c0 + ((lslot ^ ((rl >> 1) & 7)) << 3);
+      const bf16_t* src = in + (size_t)irow * a.Cin + c0 + ((lslot ^ ((rl >> 1) & 7)) << 3);
 #pragma unroll
       for (int p = 0; p < 3; ++p) glds16(src + p * a.in_plane, A + p * A_PLANE + (32 * wave + 8 * j) * 128);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = 16 * wave + 8 * j + lrow;
-      const bf16_t* ws = a.w + ((size_t)tap * a.Cout + tile_n * BN + col) * a.Cin + c0 + ((lslot ^ ((col >> 1) & 7)) << 3);
+      const bf16_t* ws = wq + ((size_t)wtap * a.Cout + tile_n * BN + col) * a.Cin + c0 + ((lslot ^ ((col >> 1) & 7)) << 3);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) glds16(ws + p * a.w_plane, B + p * B_PLANE + (16 * wave + 8 * j) * 128);
+      for (int p = 0; p < 3; ++p) glds16(ws + p * wq_plane, B + p * B_PLANE + (16 * wave + 8 * j) * 128);
     }
   };
 
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(256) void k_stem_conv(const SConvArgs a) {
       const int off = out_off[rl];
       if (off < 0) continue;
       const size_t o = (size_t)off * a.Cout + col;
+      if (shortcut_tile) { a.out2[o] = acc[c][i]; continue; }
       float v = acc[c][i] + bv;
       if (a.res) v += a.res[o];
       if (a.accumulate) v += a.out[o];
@@ -787,7 +806,8 @@ void launch_stem_conv(const SConvArgs& a, hipStream_t s) {
   static bool attr[MAX_DEVICES] = {};
   allow_full_lds(reinterpret_cast<const void*>(k_stem_conv), attr);
   const size_t lds = 2 * (3 * 128 * 128 + 3 * 64 * 128) + 512;
-  hipLaunchKernelGGL(k_stem_conv, dim3(mt * (a.Cout / 64)), dim3(256), lds, s, a);
+  const int ntn = (a.Cout / 64) * ((a.mode == 0 && a.w2 != nullptr) ? 2 : 1);
+  hipLaunchKernelGGL(k_stem_conv, dim3(mt * ntn), dim3(256), lds, s, a);
 }
 
 void launch_stem_wgrad(const SWgradArgs& a, hipStream_t s) {

@@ -508,9 +508,63 @@ __device__ __forceinline__ void w4b_mac(float16_t (&acc)[2][2], const W4Split (&
 // bf16 split of the NEXT step's row operand (v_cvt_pk_bf16_f32 + subtracts: ~44 VALU instructions per row block) is
 // interleaved with the CURRENT step's MFMAs -- one matrix instruction, then a few vector ones -- so that a wave that
 // has its SIMD to itself keeps both pipes busy.
-template <int D, int NRB>
+// timing-only ablations (NODE_TUNE_W4_ABLATE, results are wrong): AB bit 2 -- requests without the split / MFMA work (every
+// loaded register is folded into one accumulator element, so the requests and their waits stay); AB bit 8 -- the split /
+// MFMA work on whatever the registers hold, no requests
+template <int D, int NRB, int AB = 0>
 __device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p, int g0, int n) {
   W4BStage ring[D];
+  if (AB & 8) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { ring[i].a[r][0] = make_float4(lane, i, r, 1.f); ring[i].a[r][1] = make_float4(1.f, lane, i, r); }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ring[i].b[c][q] = w4_u32x4{(unsigned)lane, (unsigned)i, (unsigned)c, (unsigned)q};
+    }
+    W4Split cur8[2];
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) cur8[r] = w4_split8(ring[0].a[r][0], ring[0].a[r][1]);
+    for (int g = g0; g < g0 + n; g += D) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        W4Split nx[2];
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) nx[r] = w4_split8(ring[(i + 1) % D].a[r][0], ring[(i + 1) % D].a[r][1]);
+        w4b_mac<NRB>(acc, cur8, ring[i]);
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) cur8[r] = nx[r];
+        ring[i].a[0][0].x += acc[0][0][0];     // (keeps the chain data-dependent: nothing folds away)
+      }
+    }
+    return;
+  }
+  if (AB & 2) {
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      w4b_load<NRB>(ring[i], p, g0 + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int g = g0; g < g0 + n; g += D) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) sink += ring[i].a[r][0].x + ring[i].a[r][1].w;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) sink += __builtin_bit_cast(float, ring[i].b[c][q][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        w4b_load<NRB>(ring[i], p, g + D + i);
+      }
+    }
+    acc[0][0][0] += sink;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     w4b_load<NRB>(ring[i], p, g0 + i);
@@ -539,6 +593,7 @@ __device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p
   }
 }
 
+template <int AB>
 __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
                                                     const Ctrl* ctrl, W4Geom gm) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
@@ -565,9 +620,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
-    w4b_run<W4B_DEPTH, 2>(acc, p, 0, G2);
+    w4b_run<W4B_DEPTH, 2, AB>(acc, p, 0, G2);
     const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
     float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+    if (!(AB & 4) || acc[0][0][0] == 123.456f)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
@@ -578,7 +634,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     }
   }
   // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
-  {
+  if (!(AB & 1)) {
     const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
     const int ng = G2 >> 2, g0 = wave * ng;
     W4BPtrs p;
@@ -589,9 +645,9 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
-    if (ng % 4 == 0) w4b_run<4, 1>(acc, p, g0, ng);
-    else if (ng % 2 == 0) w4b_run<2, 1>(acc, p, g0, ng);
-    else w4b_run<1, 1>(acc, p, g0, ng);
+    if (ng % 4 == 0) w4b_run<4, 1, AB>(acc, p, g0, ng);
+    else if (ng % 2 == 0) w4b_run<2, 1, AB>(acc, p, g0, ng);
+    else w4b_run<1, 1, AB>(acc, p, g0, ng);
     float* red = smem + wave * 2048;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -611,6 +667,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
+      if ((AB & 4) && s.x != 123.456f) continue;
       st_wt(mrow, s.x);
       st_wt(mrow + 32, s.y);
       st_wt(mrow + 64, s.z);
@@ -819,11 +876,11 @@ static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1)};
 }
-static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }
+static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 bool w4_uses_bf16(int N) {
   const W4Switches sw = w4_switches();
   if (w4_takes_small(sw, N)) return false;   // (k_w4_gemm_small reads the fp32 filters)
-  return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && sw.ablate == 0;
+  return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && (sw.ablate == 0 || sw.ablate >= 16);
 }
 
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {
@@ -850,6 +907,16 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   if (g64 && N % 16 == 0) {
     const int grid64 = (N / 16) * (C >> 6) * 8;
     const size_t lds64 = 4 * 2048 * sizeof(float);
+    if (b16 && Ub != nullptr && ab >= 16) {      // NODE_TUNE_W4_ABLATE = 16 + bits: timing-only ablations of k_w4_gemm64b (results are wrong)
+      switch (ab - 16) {
+#define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm); return;
+        W4B_AB(1) W4B_AB(2) W4B_AB(4) W4B_AB(5) W4B_AB(6) W4B_AB(7) W4B_AB(8) W4B_AB(12) W4B_AB(13) W4B_AB(14) W4B_AB(15) W4B_AB(3) W4B_AB(9) W4B_AB(10) W4B_AB(11)
+#undef W4B_AB
+        default: break;
+      }
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
+      return;
+    }
     if (b16 && Ub != nullptr && ab == 0) {
       // NODE_TUNE_W4_GEMM128 = 0 never / 1 wherever it fits / unset: long reductions (C >= 512)
       const char* g128e = getenv("NODE_TUNE_W4_GEMM128");   // (read on every call, like NODE_TUNE_W4_BF16X3: tests run both kernels)
@@ -863,7 +930,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
         return;
       }
-      hipLaunchKernelGGL(k_w4_gemm64b, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
       return;
     }
     if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);

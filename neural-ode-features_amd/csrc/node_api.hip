@@ -117,9 +117,14 @@ static int make_dims(const node_shape* sh, Dims* out) {
   d.ntile = (d.C + d.BNE - 1) / d.BNE;
   d.nchunk = (d.C + KCH - 1) / KCH;
   d.csplit = 0;
+  // images larger than 256 pixels (the reference's one-shot / ODE stems on 64x64 inputs give 32x32 states, model.py:119-126,
+  // 181-196, utils.py:168-195) run the 2-D Winograd conv in bands of 128 pixels (csplit below) with GroupNorm as a pass
+  const bool banded = d.HW > 256 && d.HW <= 1024 && d.HW % 128 == 0 && d.H % 2 == 0 && d.W % 2 == 0 && 32 % (d.W / 2) == 0 && d.C % 32 == 0;
   if (d.HW <= 128) d.BM = 128;
   else if (d.HW <= 256) d.BM = 256;
-  else return fail(NODE_ERR_UNSUPPORTED, "H*W = %d > 256 is not tiled yet", d.HW);
+  else if (banded) d.BM = 128;
+  else return fail(NODE_ERR_UNSUPPORTED, "H*W = %d > 256: only even-sided images of up to 1024 pixels whose tile rows divide 32 "
+                   "(16x16, 32x32, 16x32) with C %% 32 == 0 are tiled", d.HW);
   if (d.HW <= 64) {
     // grids that cannot fill the chip with 128-row tiles (MNIST-sized states, bs=1 census) use 64-row
     // tiles in four-wave workgroups: twice the workgroups (measured [32,64,7,7]: 31 -> 22.6 us).  Once
@@ -145,7 +150,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // ... or, for 256-pixel images, two workgroups per sample (32 tiles = whole tile rows = 128 consecutive
     // pixels each) with the GroupNorm as a pointwise pass behind the conv: 16x16 at C = 256 runs the 1-D kernel
     // at 109 algorithmic TFLOP/s (one sample per 256-pixel tile), the 2-D kernel + pass is ~1.5x faster
-    if ((want < 0 || want == 2) && d.HW == 256 && d.H % 2 == 0 && d.W % 2 == 0 && 32 % (d.W / 2) == 0 && d.C % 32 == 0 &&
+    if ((want < 0 || want == 2 || banded) && (d.HW == 256 || banded) && d.H % 2 == 0 && d.W % 2 == 0 && 32 % (d.W / 2) == 0 && d.C % 32 == 0 &&
         ((size_t)d.N * d.HW * d.C + d.C) * sizeof(float) < ((size_t)1 << 32)) {
       d.wino = 2;
       d.BM = 128;
@@ -192,6 +197,7 @@ static int make_dims(const node_shape* sh, Dims* out) {
     d.N8 = (d.N * d.w4q + 7) & ~7;
   }
   d.RB = 64 / d.W;
+  if (d.W >= 32) d.RB = 1;      // (the generic weight-gradient kernel stages RB + 2 rows in registers: 3 x 32 pixels is its limit)
   if (d.RB < 1) d.RB = 1;
   if (d.RB > d.H) d.RB = d.H;
   {

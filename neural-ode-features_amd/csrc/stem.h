@@ -30,7 +30,16 @@ struct SConvArgs {
   float* out;              // fp32 NHWC [N * OH * OW][Cout]
   const float* res;        // nullable: added to the result (residual connection), same layout as out
   const float* bias;       // nullable [Cout]
-  int accumulate;          // out += result (the shortcut's data gradient on top of the main path's)
+  int accumulate;          // out += result
+  // The block's shortcut convolution (1x1, same stride, no padding) rides in the 3x3's launch:
+  //   forward (mode 0): it reads the pixel the 3x3's centre tap reads, so it is a second set of column tiles
+  //     (tile_n >= Cout / 64) with ONE tap, filter w2, output out2 -- no launch of its own, the A rows already in L2;
+  //   data gradient (mode 1): its gradient lands on the pixels of class (even row, even column) only: one more K segment of
+  //     that class, gathered from in2 (the shortcut's output gradient, same shape as `in`) with filter w2
+  const bf16_t* w2;        // nullable; triples [3][1][Cout][Cin] (forward) / [3][1][Cin_f][Cout_f] (data gradient)
+  size_t w2_plane;
+  float* out2;             // forward only
+  const bf16_t* in2;       // data gradient only
   int N, IH, IW;           // spatial size of `in`
   int OH, OW;              // spatial size of `out`
   int Cin, Cout;

@@ -318,10 +318,12 @@ int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* prm, con
     launch_stem_gn_fwd(g, st);
     if ((rc = launch_ok("stem_gn_fwd")) != NODE_OK) return rc;
   }
-  launch_stem_conv(conv_fwd_args(p.a0, p.c1, p.h1, N, p.H0, p.W0, p.H1, p.W1, 3, 2, 1), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
-  launch_stem_conv(conv_fwd_args(p.a0, p.d1, p.s1, N, p.H0, p.W0, p.H1, p.W1, 1, 2, 0), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
+  {   // conv1 (3x3 / 2) and the shortcut (1x1 / 2) in one launch
+    SConvArgs c = conv_fwd_args(p.a0, p.c1, p.h1, N, p.H0, p.W0, p.H1, p.W1, 3, 2, 1);
+    c.w2 = p.d1.wf; c.w2_plane = p.d1.plane; c.out2 = p.s1;
+    launch_stem_conv(c, st);
+    if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
+  }
   {
     SGnArgs g = gn_args(p.h1, prm->b1_n2_w, prm->b1_n2_b, p.stats[1], N, p.H1 * p.W1, 64, p.eps);
     g.a3 = p.a1.p; g.a_plane = p.a1.plane;
@@ -340,10 +342,12 @@ int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* prm, con
     launch_stem_gn_fwd(g, st);
     if ((rc = launch_ok("stem_gn_fwd")) != NODE_OK) return rc;
   }
-  launch_stem_conv(conv_fwd_args(p.a2, p.c3, p.h3, N, p.H1, p.W1, p.H2, p.W2, 3, 2, 1), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
-  launch_stem_conv(conv_fwd_args(p.a2, p.d2, p.s2, N, p.H1, p.W1, p.H2, p.W2, 1, 2, 0), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
+  {
+    SConvArgs c = conv_fwd_args(p.a2, p.c3, p.h3, N, p.H1, p.W1, p.H2, p.W2, 3, 2, 1);
+    c.w2 = p.d2.wf; c.w2_plane = p.d2.plane; c.out2 = p.s2;
+    launch_stem_conv(c, st);
+    if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
+  }
   {
     SGnArgs g = gn_args(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.stats[3], N, p.H2 * p.W2, F, p.eps);
     g.a3 = p.a3.p; g.a_plane = p.a3.plane;
@@ -394,11 +398,9 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   // block 2, conv1 (3x3 / 2, 64 -> F) + shortcut (1x1 / 2, 64 -> F): both read a2
   launch_stem_wgrad(wgrad_args(p.dh3t, &p.g3, p.a2, p.w3, N, p.H1, p.W1, p.H2, p.W2, 64, F, 3, 2, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
-  launch_stem_conv(conv_dgrad_args(p.dh3t, p.c3, p.da2, N, p.H2, p.W2, p.H1, p.W1, 3, 2, 1), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
-  {
-    SConvArgs c = conv_dgrad_args(p.g3, p.d2, p.da2, N, p.H2, p.W2, p.H1, p.W1, 1, 2, 0);
-    c.accumulate = 1;
+  {   // data gradient of conv1 (3x3 / 2) + the shortcut's (1x1 / 2: one more K segment of the (even, even) pixels)
+    SConvArgs c = conv_dgrad_args(p.dh3t, p.c3, p.da2, N, p.H2, p.W2, p.H1, p.W1, 3, 2, 1);
+    c.in2 = p.g3.p; c.w2 = p.d2.wd; c.w2_plane = p.d2.plane;
     launch_stem_conv(c, st);
     if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   }
@@ -422,11 +424,9 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   // block 1, conv1 (3x3 / 2) + shortcut (1x1 / 2): both read a0
   launch_stem_wgrad(wgrad_args(p.dh1t, &p.dx1t, p.a0, p.w1, N, p.H0, p.W0, p.H1, p.W1, 64, 64, 3, 2, 1), st);
   if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
-  launch_stem_conv(conv_dgrad_args(p.dh1t, p.c1, p.da0, N, p.H1, p.W1, p.H0, p.W0, 3, 2, 1), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   {
-    SConvArgs c = conv_dgrad_args(p.dx1t, p.d1, p.da0, N, p.H1, p.W1, p.H0, p.W0, 1, 2, 0);
-    c.accumulate = 1;
+    SConvArgs c = conv_dgrad_args(p.dh1t, p.c1, p.da0, N, p.H1, p.W1, p.H0, p.W0, 3, 2, 1);
+    c.in2 = p.dx1t.p; c.w2 = p.d1.wd; c.w2_plane = p.d1.plane;
     launch_stem_conv(c, st);
     if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   }

@@ -51,6 +51,9 @@ def _adjoint_both(shape, tol, seed, kink_free, tpts=(0.0, 1.0)):
            (fs_o.accepted, fs_o.rejected, bs_o.accepted, bs_o.rejected)
     print(shape, tol, 'kink_free', kink_free, 'fwd steps', (fs_h['accepted'], fs_h['rejected']), (fs_o.accepted, fs_o.rejected),
           'bwd steps', (bs_h['accepted'], bs_h['rejected']), (bs_o.accepted, bs_o.rejected))
+    apart = max(abs(fs_h['accepted'] + fs_h['rejected'] - fs_o.accepted - fs_o.rejected),
+                abs(bs_h['accepted'] + bs_h['rejected'] - bs_o.accepted - bs_o.rejected))
+    assert apart <= 1, 'step histories more than one accept / reject decision apart'
     return dict(out_o=out_o.detach(), out_h=out_h.detach(), gy_o=yo.grad, gy_h=yh.grad, gp_o=gp_o, gp_h=gp_h, same=same,
                 twin=twin, nfe_b=bs_h['nfe'], steps_b=bs_h['accepted'] + bs_h['rejected'])
 
@@ -69,6 +72,30 @@ def test_full_size_adjoint_solve_kink_free(tol):
         assert e_y < 1e-3 and e_p < 1e-3
     else:       # an accept/reject flip moves both trajectories by O(tol)
         assert e_y < 5e-2 and e_p < 5e-2
+
+
+@pytest.mark.parametrize('tol', [1e-5])
+def test_full_size_free_running_pipeline_vs_oracle_ordinary_parameters(tol):
+    """The F(4x4,3x3) pipeline (what a tol >= 1e-5 solve of this shape runs) FREE-RUNNING against the free-running fp32
+    oracle at the full cfg-3 state [128,256,8,8], tol 1e-5, ORDINARY parameters -- no replay, no step sizes borrowed from
+    the run being judged, no other conv path of this package in the comparison.  The advisor's round-3 concern: the
+    pipeline's convolution noise (3.2e-6 of max|y|) is the order of the tolerance, and the step controller does not see
+    it -- so the accept / reject history itself is the observable: it must equal the oracle's, or differ by one decision
+    (which moves both trajectories by O(tol)).  Output within 10 x atol either way; gradients in the robust statistics
+    of tests/helpers.py (ReLU masks of pre-activations within rounding of zero differ between any two fp32
+    implementations at this size), tight only when the histories are identical."""
+    r = _adjoint_both((128, 256, 8, 8), tol, seed=53, kink_free=False)
+    out_err = float((r['out_h'].cpu() - r['out_o']).abs().max())
+    print('free-running pipeline vs oracle, tol %g: same history %s, |out - oracle|_max %.3e' % (tol, r['same'], out_err))
+    assert out_err <= 10 * tol
+    assert r['nfe_b'] == 3 + 6 * r['steps_b']
+    (l2_y, frac_y), (l2_p, frac_p) = robust_grad_err(r['gy_h'], r['gy_o']), robust_grad_err(r['gp_h'], r['gp_o'])
+    print('  grad_y0: relative L2 %.3e, %.2f %% of entries off by > 1e-3 max; grad_theta: %.3e, %.2f %%'
+          % (l2_y, 100 * frac_y, l2_p, 100 * frac_p))
+    if r['same']:
+        assert l2_y < 2e-2 and l2_p < 2e-2 and frac_y < 0.05 and frac_p < 0.05
+    else:
+        assert l2_y < 0.1 and l2_p < 0.1
 
 
 def _replay_triplet(shape, tol, seed, t_end):
@@ -127,8 +154,8 @@ def _wino4(mode):
             os.environ['NODE_TUNE_WINO4'] = old
 
 
-@pytest.mark.parametrize('tol,t_end', [(1e-3, 1.0), (1e-5, 0.3)])
-def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end):
+@pytest.mark.parametrize('tol,t_end,batch', [(1e-3, 1.0, 128), (1e-5, 1.0, 64)])
+def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end, batch):
     """The same arbiter set-up on the F(4x4,3x3) pipeline (what a tol >= 1e-5 solve of this shape runs by default).  Its
     convolutions round at 3.2e-6 of max|y| instead of 4.9e-7, so more pre-activations land on the other side of a
     ReLU than in the fp64 run: the per-SAMPLE max-norm distance (median 7e-4; F(2x2,3x3) 1.6e-5, fp32 oracle 3e-7)
@@ -136,9 +163,12 @@ def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end):
     an optimizer step sees -- every gradient must still be as close to the fp64 result as the fp32 oracle is
     (measured: grad_y0 5.3e-4 against the oracle's 5.0e-4; parameter tensors 2.2e-4 ... 8.9e-4 against 2.3e-4 ...
     7.9e-4), the output within 10 x atol (BASELINE.json north_star), and the free-running solve must reproduce its
-    own replay to rounding."""
+    own replay to rounding.  Both tolerances over the WHOLE interval [0, 1] (round 3 stopped the tol 1e-5 case at t = 0.3);
+    the tol 1e-5 case runs half the batch so that its two CPU replays (fp32 and fp64, ~25 backward steps) stay within
+    the suite's time budget -- the free-running comparison at the full batch is
+    test_full_size_free_running_pipeline_vs_oracle_ordinary_parameters."""
     with _wino4(1):
-        hip, o32, o64, free = _replay_triplet((128, 256, 8, 8), tol, seed=52, t_end=t_end)
+        hip, o32, o64, free = _replay_triplet((batch, 256, 8, 8), tol, seed=52, t_end=t_end)
     assert float((hip['out'][-1].double() - o64['out'][-1]).abs().max()) <= 10 * tol
     l2_hip = float((hip['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
     l2_cpu = float((o32['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
@@ -241,6 +271,44 @@ def test_16x16_split_conv_forward_and_vjp(shape):
     es = per_sample_err(vy, vy_ref)
     assert int((es > 5e-5).sum()) <= 1, es
     assert robust_grad_err(vp, vp_ref)[0] < 5e-2
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (2, 256, 32, 32), (3, 128, 16, 32)])
+def test_32x32_states_forward_and_vjp(shape):
+    """1024-pixel states: what the reference's one-shot / ODE stems (model.py:119-126, 181-196: Conv2d(in, filters, 4, 2, 1))
+    hand the ODE block on 64x64 inputs (TinyImageNet, utils.py:17,168-195).  The 2-D Winograd conv runs them in bands of
+    128 pixels (eight workgroups per sample), GroupNorm as a pass, the weight gradient on the generic kernel."""
+    import neural_ode_features_amd as nof
+    N, C, H, W = shape
+    gen = torch.Generator().manual_seed(71)
+    y = torch.randn(N, C, H, W, generator=gen)
+    cot = torch.randn(N, C, H, W, generator=gen)
+    f, twin = make_func(C, seed=72, device='cuda', kink_free=True)
+    fo, vy, vt, vp = nof.odefunc_vjp(f, 0.4, y.cuda(), cot.cuda())
+    f_ref, vy_ref, vt_ref, vp_ref = oracle_vjp(0.4, y, dict(twin.named_parameters()), cot)
+    print(shape, 'f', rel_err(fo, f_ref), 'vjp_y', rel_err(vy, vy_ref), 'vjp_theta', rel_err(vp, vp_ref),
+          'vjp_t', float(vt), float(vt_ref))
+    assert rel_err(fo, f_ref) < 3e-5 and rel_err(vy, vy_ref) < 1e-4 and rel_err(vp, vp_ref) < 1e-4
+    assert abs(float(vt) - float(vt_ref)) < 1e-4 * abs(float(vt_ref)) + 1e-3
+    assert rel_err(nof.odefunc_forward(f, 0.4, y.cuda()), f_ref) < 3e-5
+
+
+def test_32x32_adjoint_solve_and_one_shot_stem():
+    """An adjoint solve on a 32x32 state within 10 x atol of the oracle's, and the reference's `one-shot` stem on a 64x64
+    input feeding the ODE block end to end (forward + backward run, NFE law holds)."""
+    import neural_ode_features_amd as nof
+    r = _adjoint_both((2, 64, 32, 32), 1e-3, seed=73, kink_free=True)
+    assert float((r['out_h'].cpu() - r['out_o']).abs().max()) <= 10 * 1e-3
+    e_y, e_p = rel_err(r['gy_h'], r['gy_o']), rel_err(r['gp_h'], r['gp_o'])
+    print('32x32 adjoint solve: same history', r['same'], 'grad_y rel', e_y, 'grad_theta rel', e_p)
+    assert (e_y < 1e-3 and e_p < 1e-3) if r['same'] else (e_y < 5e-2 and e_p < 5e-2)
+    torch.manual_seed(5)
+    net = nof.ODENet(3, out=10, n_filters=64, downsample='one-shot', method='dopri5', tol=1e-3, adjoint=True).cuda()
+    x = torch.randn(2, 3, 64, 64).cuda()
+    net(x).square().mean().backward()
+    st = net.odeblock.odefunc.last_forward_stats
+    assert st['status'] == 0 and st['nfe'] == 2 + 6 * (st['accepted'] + st['rejected'])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
 
 
 @pytest.mark.parametrize('shape,tol', [((4, 256, 16, 16), 1e-3), ((2, 64, 16, 16), 1e-4)])

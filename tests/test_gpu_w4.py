@@ -217,16 +217,26 @@ def test_w4_wgrad128_matches_oracle(shape):
 def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
     """dopri5 at tol >= 1e-5 takes the F(4x4,3x3) path by itself; with it off the same solve runs on F(2x2,3x3).
     `gain` scales the last GroupNorm's weight, i.e. |f|: the stiffer cases take many steps with rejections among them, so
-    that the conv noise meets a step controller that is working (Solver::choose_w4 has the error budget: <= 5 % of tol)."""
+    that the conv noise meets a step controller that is working (Solver::choose_w4 has the error budget: <= 5 % of tol).
+    Both paths are held against each other AND against the free-running ORACLE solve of the same problem (CPU, fp32):
+    step counts within one accept / reject decision, output within 10 (atol + rtol |y|), kink-free gradients to 1e-3."""
     import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
     N, Cc = (16, 64) if side == 8 else (4, 128)     # (16x16 states: four 8x8 quadrants per image, kernels_w4s.hip)
     assert _engaged(N, Cc, side)
-    f, _ = make_func(Cc, seed=2, device='cuda', kink_free=True)
+    f, twin = make_func(Cc, seed=2, device='cuda', kink_free=True)
     with torch.no_grad():
         f.norm3.weight.mul_(gain)
+        twin.norm3.weight.mul_(gain)
     gen = torch.Generator().manual_seed(21)
     y0 = torch.randn(N, Cc, side, side, generator=gen).cuda()
     t = torch.tensor([0.0, 1.0]).cuda()
+    yo = y0.cpu().clone().requires_grad_(True)
+    fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
+    out_o = tdq.odeint_adjoint(twin, yo, t.cpu(), rtol=tol, atol=tol, method='dopri5', fwd_stats=fs_o, bwd_stats=bs_o)[-1]
+    out_o.square().sum().backward()
+    gp_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
+    nfe_o = (2 + 6 * (fs_o.accepted + fs_o.rejected), 3 + 6 * (bs_o.accepted + bs_o.rejected))
     outs, grads, nfes = [], [], []
     for mode in (0, 1):
         with wino4(mode):
@@ -250,6 +260,16 @@ def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
     assert rel_err(outs[1], outs[0]) < 1e-4
     assert rel_err(grads[1][0], grads[0][0]) < 1e-3
     assert rel_err(grads[1][1], grads[0][1]) < 1e-3
+    # ... and the pipeline (and F(2x2,3x3)) against the oracle's own free-running solve
+    for mode in (0, 1):
+        d_out = float((outs[mode].cpu() - out_o.detach()).abs().max())
+        same = nfes[mode] == nfe_o
+        print('  vs oracle, path %d: nfe %s oracle %s, out diff %.2e, grad rel %.2e / %.2e'
+              % (mode, nfes[mode], nfe_o, d_out, rel_err(grads[mode][0], yo.grad), rel_err(grads[mode][1], gp_o)))
+        assert abs(nfes[mode][0] - nfe_o[0]) <= 6 and abs(nfes[mode][1] - nfe_o[1]) <= 6, (mode, nfes[mode], nfe_o)
+        assert d_out < 10 * tol * (1 + scale)
+        if same:        # (a flipped accept / reject decision moves both trajectories by O(tol))
+            assert rel_err(grads[mode][0], yo.grad) < 1e-3 and rel_err(grads[mode][1], gp_o) < 1e-3
 
 
 @pytest.mark.parametrize('shape', [(8, 64, 8, 8), (2, 128, 16, 16), (3, 256, 16, 16)])
