@@ -508,6 +508,71 @@ __device__ __forceinline__ void w4b_mac(float16_t (&acc)[2][2], const W4Split (&
 // bf16 split of the NEXT step's row operand (v_cvt_pk_bf16_f32 + subtracts: ~44 VALU instructions per row block) is
 // interleaved with the CURRENT step's MFMAs -- one matrix instruction, then a few vector ones -- so that a wave that
 // has its SIMD to itself keeps both pipes busy.
+// --- variant (NODE_TUNE_W4_UF32 = 1): the FILTER operand fp32 as well (the layout k_w4_gemm64 reads), split into its bf16
+// triple in registers like the row operand.  The launch is bound by operand delivery, not by the matrix pipe (ablations,
+// the requests alone take the whole 20 us): fp32 filters are 4 instead of 6 bytes per element -- 8 instead
+// of 10 KB per K = 16 step and wave -- for ~60 more VALU instructions per step under MFMAs that wait anyway.  Results are
+// bit-identical (k_w4_pack's triples are split from the same fp32 values).
+struct W4FStage { float4 a[2][2]; float4 b[2][2]; };
+struct W4FPtrs { const float4* a[2]; const float4* b[2]; };
+template <int NRB>
+__device__ __forceinline__ void w4f_load(W4FStage& s, const W4FPtrs& p, int g2) {
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) {
+    s.a[r][0] = p.a[r][(size_t)(2 * g2) * 64];
+    s.a[r][1] = p.a[r][(size_t)(2 * g2 + 1) * 64];
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    s.b[c][0] = p.b[c][(size_t)(2 * g2) * 64];
+    s.b[c][1] = p.b[c][(size_t)(2 * g2 + 1) * 64];
+  }
+}
+template <int NRB>
+__device__ __forceinline__ void w4f_mac(float16_t (&acc)[2][2], const W4Split (&a)[2], const W4Split (&b)[2]) {
+#define W4F_P(AP, BQ)                                                                             \
+  _Pragma("unroll") for (int r = 0; r < NRB; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)   \
+      acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r].AP, b[c].BQ, acc[r][c], 0, 0, 0);
+  W4F_P(l, h) W4F_P(h, l) W4F_P(m, m) W4F_P(m, h) W4F_P(h, m) W4F_P(h, h)   // smallest products first (as w4b_mac)
+#undef W4F_P
+}
+template <int D, int NRB>
+__device__ __forceinline__ void w4f_run(float16_t (&acc)[2][2], const W4FPtrs& p, int g0, int n) {
+  W4FStage ring[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    w4f_load<NRB>(ring[i], p, g0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  W4Split ca[2], cb[2], na[2], nb[2];
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) ca[r] = w4_split8(ring[0].a[r][0], ring[0].a[r][1]);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) cb[c] = w4_split8(ring[0].b[c][0], ring[0].b[c][1]);
+  for (int g = g0; g < g0 + n; g += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const W4FStage& ns = ring[(i + 1) % D];
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) na[r] = w4_split8(ns.a[r][0], ns.a[r][1]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) nb[c] = w4_split8(ns.b[c][0], ns.b[c][1]);
+      w4f_mac<NRB>(acc, ca, cb);
+#pragma unroll
+      for (int k = 0; k < 12 * NRB; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // ... then up to eight VALU instructions of the splits
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      w4f_load<NRB>(ring[i], p, g + D + i);
+#pragma unroll
+      for (int r = 0; r < NRB; ++r) ca[r] = na[r];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) cb[c] = nb[c];
+    }
+  }
+}
+
 // timing-only ablations (NODE_TUNE_W4_ABLATE, results are wrong): AB bit 2 -- requests without the split / MFMA work (every
 // loaded register is folded into one accumulator element, so the requests and their waits stay); AB bit 8 -- the split /
 // MFMA work on whatever the registers hold, no requests
@@ -675,6 +740,89 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     }
   }
 }
+
+
+// k_w4_gemm64c: k_w4_gemm64b with fp32 filters split in registers (see w4f_run)
+__global__ __launch_bounds__(256) void k_w4_gemm64c(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                    const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 6, nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rt = tile / nCT, ct = tile - rt * nCT;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const float4*>(U + (((size_t)comp * CB + cb) * G8) * 256) + lane; };
+
+  // --- this wave's own component: the whole 64 x 64 tile over the whole K range
+  {
+    const int comp = 4 * j + wave;
+    W4FPtrs p;
+    p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
+    p.b[0] = ublk(comp, 2 * ct); p.b[1] = ublk(comp, 2 * ct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+    w4f_run<W4B_DEPTH, 2>(acc, p, 0, G2);
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      st_wt(o, acc[0][0][q]);
+      st_wt(o + 36 * 128, acc[0][1][q]);
+      st_wt(o + 8 * sstride, acc[1][0][q]);
+      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q]);
+    }
+  }
+  // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
+  {
+    const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
+    const int ng = G2 >> 2, g0 = wave * ng;
+    W4FPtrs p;
+    p.a[0] = vblk(scomp, rb); p.a[1] = p.a[0];
+    p.b[0] = ublk(scomp, 2 * ct); p.b[1] = ublk(scomp, 2 * ct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
+    if (ng % 4 == 0) w4f_run<4, 1>(acc, p, g0, ng);
+    else if (ng % 2 == 0) w4f_run<2, 1>(acc, p, g0, ng);
+    else w4f_run<1, 1>(acc, p, g0, ng);
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + c * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(acc[0][c][4 * r4], acc[0][c][4 * r4 + 1], acc[0][c][4 * r4 + 2], acc[0][c][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk = u >> 8, r4 = (u >> 6) & 3;
+      float4 s = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
+      st_wt(mrow, s.x);
+      st_wt(mrow + 32, s.y);
+      st_wt(mrow + 64, s.z);
+      st_wt(mrow + 96, s.w);
+    }
+  }
+}
+
 
 
 // ----------------------------------------------------------------------------
@@ -871,15 +1019,22 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
-struct W4Switches { int g64, b16, ablate, small; };
+struct W4Switches { int g64, b16, ablate, small, uf32; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1)};
+  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
+          rd("NODE_TUNE_W4_UF32", 0)};
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
-bool w4_uses_bf16(int N) {
+// fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
+// shares its split filter blocks through LDS and keeps the packed triples)
+static bool w4_takes_uf32(const W4Switches& sw, int N, int C) {
+  return sw.uf32 != 0 && !w4_takes_small(sw, N) && N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && sw.ablate == 0 && C < 512;
+}
+bool w4_uses_bf16(int N, int C) {
   const W4Switches sw = w4_switches();
   if (w4_takes_small(sw, N)) return false;   // (k_w4_gemm_small reads the fp32 filters)
+  if (w4_takes_uf32(sw, N, C)) return false; // (k_w4_gemm64c splits them in registers)
   return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && (sw.ablate == 0 || sw.ablate >= 16);
 }
 
@@ -903,10 +1058,14 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   }
   const int g64 = sw.g64;   // NODE_TUNE_W4_GEMM64 = 0: k_w4_gemm (eight waves, 32 x 64 tiles) everywhere
   // NODE_TUNE_W4_BF16X3 = 0: the fp32 MFMA kernel (A/B measurements, tests; read on every call like NODE_TUNE_WINO4)
-  const bool b16 = w4_uses_bf16(N);
+  const bool b16 = w4_uses_bf16(N, C);
   if (g64 && N % 16 == 0) {
     const int grid64 = (N / 16) * (C >> 6) * 8;
     const size_t lds64 = 4 * 2048 * sizeof(float);
+    if (w4_takes_uf32(sw, N, C) && Ub == nullptr) {
+      hipLaunchKernelGGL(k_w4_gemm64c, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+      return;
+    }
     if (b16 && Ub != nullptr && ab >= 16) {      // NODE_TUNE_W4_ABLATE = 16 + bits: timing-only ablations of k_w4_gemm64b (results are wrong)
       switch (ab - 16) {
 #define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm); return;

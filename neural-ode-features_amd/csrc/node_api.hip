@@ -507,7 +507,7 @@ struct Solver {
       W4PackJobs jobs;
       memset(&jobs, 0, sizeof(jobs));
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
-      w4_b16 = w4_uses_bf16(d.N8);
+      w4_b16 = w4_uses_bf16(d.N8, d.C);
       for (int i = 0; i < (aug ? 4 : 2); ++i) { jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr; jobs.dgrad[i] = i >= 2; }
       launch_w4_pack(jobs, aug ? 4 : 2, d.C, st);
     } else if (d.wino == 2) {   // every packing of the solve in one launch
@@ -1107,7 +1107,7 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   unsigned short* Ub = b.take<unsigned short>(w4_ub_elems(d.C));
   W4PackJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
-  const bool b16 = w4_uses_bf16(Nv);
+  const bool b16 = w4_uses_bf16(Nv, d.C);
   jobs.w[0] = weight; jobs.u[0] = U; jobs.ub[0] = b16 ? Ub : nullptr; jobs.dgrad[0] = dgrad ? 1 : 0;
   launch_w4_pack(jobs, 1, d.C, st);
   launch_w4s_from_nchw(x, xn, d.N, d.C, Q, st);

@@ -130,7 +130,7 @@ constexpr float W4_MIN_TOL = 0.99e-5f;
 // per job ONE of u (fp32, k_w4_gemm / k_w4_gemm64) and ub (exact bf16 triples, k_w4_gemm64b) is written: ub when non-null
 struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; };
 // which form launch_w4_gemm will read for this batch (NODE_TUNE_W4_BF16X3, read on every call)
-bool w4_uses_bf16(int N);
+bool w4_uses_bf16(int N, int C);
 __host__ __device__ inline size_t w4_ub_elems(int C) { return (size_t)W4_COMPS * C * C * 3 + 8 * 1536; }   // bf16 values (+ ring slack)
 void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s,
