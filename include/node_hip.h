@@ -108,6 +108,9 @@ typedef struct node_stats {
 typedef struct node_step_record {
   int32_t done, status, steps, accepted, rejected, miss;
   double t, dt, first_dt;
+  double t_prev, dt_used;   /* start and size of the last step tried (solver time: -t for a solve towards smaller t): when it was
+                             * accepted, t_prev + dt_used - (end of the interval) is how far the solve overshot its end -- a small
+                             * fraction of dt_used means the NEXT solve of this kind may need one step more */
 } node_step_record;
 
 /* Optional knobs (pass NULL for upstream behaviour). */

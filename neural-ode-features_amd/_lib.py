@@ -55,7 +55,8 @@ class NodeStats(C.Structure):
 
 class NodeStepRecord(C.Structure):
     _fields_ = [('done', C.c_int32), ('status', C.c_int32), ('steps', C.c_int32), ('accepted', C.c_int32),
-                ('rejected', C.c_int32), ('miss', C.c_int32), ('t', C.c_double), ('dt', C.c_double), ('first_dt', C.c_double)]
+                ('rejected', C.c_int32), ('miss', C.c_int32), ('t', C.c_double), ('dt', C.c_double), ('first_dt', C.c_double),
+                ('t_prev', C.c_double), ('dt_used', C.c_double)]
 
 
 class NodeSolveOpts(C.Structure):

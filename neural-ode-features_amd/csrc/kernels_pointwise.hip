@@ -784,7 +784,7 @@ void launch_set_target(double* targets, double t_end, hipStream_t s) {
 __global__ void k_export_record(const Ctrl* c, node_step_record* r, float* miss_flag, int expect) {
   const int miss = !(c->done && c->status == 0 && c->step_idx <= expect);   // (steps past the end did nothing)
   r->done = c->done; r->status = c->status; r->steps = c->step_idx; r->accepted = c->n_acc; r->rejected = c->n_rej;
-  r->miss = miss; r->t = c->t; r->dt = c->dt; r->first_dt = c->first_dt;
+  r->miss = miss; r->t = c->t; r->dt = c->dt; r->first_dt = c->first_dt; r->t_prev = c->t_prev; r->dt_used = c->dt_used;
   if (miss && miss_flag != nullptr) *miss_flag += 1.f;
 }
 void launch_export_record(const Ctrl* ctrl, node_step_record* rec, float* miss_flag, int expect_steps, hipStream_t s) {

@@ -336,15 +336,21 @@ class Deferred:
 
     active = None      # the instance whose `with` block is open
     # How many steps to enqueue for a solve whose true count nobody knows yet.  A step past the end of the interval returns
-    # at its first instruction in every kernel, but its ~40 launches still cost ~0.1 ms; a miss costs the iteration (and,
-    # through DeferredLoop, its repetition): ~100x more.  So: enqueue the LARGEST count of the last HIST solves of this
-    # kind (a count that wobbles by one between iterations -- tol 1e-5 -- then rarely misses and wastes half a step on
-    # average; a count that DROPS is followed after HIST iterations), plus ONE spare step while the history is short
-    # or the last count was a new maximum (the count is growing).  Round 3 enqueued last count + 1 until eight exact
-    # predictions in a row -- at tol 1e-5 that never happened, and every solve carried one or two dead steps
-    # (profiles/r03_r_cfg3_steps.txt).
+    # at its first instruction in every kernel, but its ~40 launches still cost ~0.1 ms; a miss costs the iteration and
+    # (DeferredLoop) the repetition of two batches: ~150x more.  So: enqueue the LARGEST count of the last HIST solves of
+    # this kind (a count that wobbles by one between iterations then wastes half a step on average; a count that DROPS is
+    # followed after HIST iterations), plus ONE spare step whenever a larger count is not unlikely:
+    #   * the history is short (CALM);
+    #   * the last solve overshot the end of its interval by less than FRAGILE of its last step (the record carries the
+    #     last step: node_step_record.t_prev / dt_used) -- step sizes that come out a few percent smaller on the next batch
+    #     then need one step more;
+    #   * a count above everything in the history was seen within the last QUIET solves.
+    # Round 3 enqueued last count + 1 until eight exact predictions in a row -- at tol 1e-5 that never happened, and every
+    # solve carried one or two dead steps (profiles/r03_r_cfg3_steps.txt: 29 dead component GEMMs per step).
     HIST = 8
-    CALM = 4           # solves of a kind before the spare step can go
+    CALM = 4
+    FRAGILE = 0.15
+    QUIET = 16
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -352,6 +358,8 @@ class Deferred:
         self.guess: Dict[tuple, Optional[int]] = {}
         self.calm: Dict[tuple, int] = {}          # solves of a key since its history was last reset
         self.hist: Dict[tuple, List[int]] = {}    # true step counts of the last HIST solves of a key
+        self.fragile: Dict[tuple, bool] = {}      # the last solve of a key barely reached the end of its interval
+        self.quiet: Dict[tuple, int] = {}         # solves of a key since one needed more steps than any in its history
         self.pending: Dict[tuple, tuple] = {}
         self._seq: Dict[tuple, int] = {}
         self.records: Dict[tuple, tuple] = {}
@@ -405,6 +413,10 @@ class Deferred:
                 if func is not None and r.steps != guessed:
                     func.nfe = getattr(func, 'nfe', 0) + 6 * (r.steps - guessed)    # late, but sums stay exact
                 self.dead_steps += max(0, enqueued - int(r.steps))
+                # solver time runs upwards in both directions (a solve towards smaller t integrates -t): how far past the
+                # end of the interval did the last step land, in units of that step?
+                end = key[-1][-1] if key[0] == 'fwd' else -key[-1][0]
+                self.fragile[key] = bool(r.dt_used > 0.0 and (r.t - end) < self.FRAGILE * r.dt_used)
                 self._observe(key, int(r.steps))
         g = self.guess.get(key)
         if not g or not self.armed:
@@ -413,17 +425,16 @@ class Deferred:
 
     def _observe(self, key, steps):
         h = self.hist.setdefault(key, [])
+        self.quiet[key] = 0 if (h and int(steps) > max(h)) else self.quiet.get(key, self.QUIET) + 1
         h.append(int(steps))
         del h[:-self.HIST]
         self.calm[key] = self.calm.get(key, 0) + 1
         self.guess[key] = int(steps)
 
     def _spare(self, key):
-        """One spare step while the history is short or the last count was a new maximum (the count is growing)."""
+        """One spare step while a count above the history's maximum is not unlikely (see the class constants)."""
         h = self.hist.get(key) or []
-        if len(h) < self.CALM:
-            return True
-        return h[-1] > max(h[:-1])
+        return len(h) < self.CALM or self.fragile.get(key, False) or self.quiet.get(key, self.QUIET) < self.QUIET
 
     def _enqueue(self, key):
         h = self.hist.get(key) or [self.guess[key]]
@@ -446,6 +457,8 @@ class Deferred:
         """A solve of `key` ran with a read-back: its count starts a new history."""
         self.hist[key] = []
         self.calm[key] = 0
+        self.fragile[key] = False
+        self.quiet[key] = 0
         self._observe(key, int(steps))
 
     def forget(self):
@@ -465,6 +478,8 @@ class Deferred:
             self.guess[k] = int(n)
             self.hist[k] = [int(n)] * self.CALM
             self.calm[k] = self.CALM
+            self.fragile[k] = False
+            self.quiet[k] = self.QUIET
 
     def step_verdicts(self):
         """[(blind solve index, 'fwd' | 'bwd', missed)] for the records read so far (one iteration late): a caller that
