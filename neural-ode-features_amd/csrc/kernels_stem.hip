@@ -682,6 +682,18 @@ __global__ __launch_bounds__(256) void k_stem_from_nchw(const float* __restrict_
   }
 }
 
+// fp32 -> triples, element for element (n % 8 == 0)
+__global__ __launch_bounds__(256) void k_stem_split(const float* __restrict__ src, bf16_t* __restrict__ dst3, size_t plane, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a0 = reinterpret_cast<const float4*>(src)[2 * i], a1 = reinterpret_cast<const float4*>(src)[2 * i + 1];
+  u32x4 hh, mm, ll;
+  split8(a0, a1, hh, mm, ll);
+  *reinterpret_cast<u32x4*>(dst3 + 8 * i) = hh;
+  *reinterpret_cast<u32x4*>(dst3 + 8 * i + plane) = mm;
+  *reinterpret_cast<u32x4*>(dst3 + 8 * i + 2 * plane) = ll;
+}
+
 __global__ __launch_bounds__(256) void k_stem_to_nchw(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
   __shared__ float tile[64][65];
   const int t = threadIdx.x;
@@ -865,6 +877,9 @@ void launch_stem_prep(const SPrepArgs& a, hipStream_t s) {
 }
 void launch_stem_from_nchw(const float* src, float* dst_nhwc, bf16_t* dst3, size_t plane, int N, int C, int HW, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_from_nchw, dim3(N * (C / 64) * ((HW + 63) / 64)), dim3(256), 0, s, src, dst_nhwc, dst3, plane, C, HW);
+}
+void launch_stem_split(const float* src, bf16_t* dst3, size_t plane, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_stem_split, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, s, src, dst3, plane, n / 8);
 }
 void launch_stem_to_nchw(const float* src_nhwc, float* dst, int N, int C, int HW, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_to_nchw, dim3(N * (C / 64) * ((HW + 63) / 64)), dim3(256), 0, s, src_nhwc, dst, C, HW);

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
   float* __restrict__ U = jobs.u[blockIdx.y];
   unsigned short* __restrict__ Ub = jobs.ub[blockIdx.y];
   const int dgrad = jobs.dgrad[blockIdx.y];
+  const int CI = jobs.plain[blockIdx.y] ? C : C + 1, c_off = jobs.plain[blockIdx.y] ? 0 : 1;   // input-channel stride / first data channel
   const int G8 = C >> 3;
   const size_t total = (size_t)C * C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
-        gg[kh][kw] = dgrad ? (double)w[(((size_t)kidx * (C + 1) + 1 + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
-                           : (double)w[(((size_t)nidx * (C + 1) + 1 + kidx) * 3 + kh) * 3 + kw];
+        gg[kh][kw] = dgrad ? (double)w[(((size_t)kidx * CI + c_off + nidx) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                           : (double)w[(((size_t)nidx * CI + c_off + kidx) * 3 + kh) * 3 + kw];
     double gt[6][3];   // G g
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -1421,12 +1422,12 @@ void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s) {
     const char* e = getenv("NODE_TUNE_W4_WGRAD128");
     const int w128 = e ? atoi(e) : -1;
     const int nT = (a.C >> 7) * (a.C >> 7);
-    if (a.N % 8 == 0 && a.C % 128 == 0 && (nT & 1) == 0 && (w128 == 1 || (w128 < 0 && a.C >= 512))) {
+    if (a.V2 != nullptr && a.N % 8 == 0 && a.C % 128 == 0 && (nT & 1) == 0 && (w128 == 1 || (w128 < 0 && a.C >= 512))) {
       hipLaunchKernelGGL(k_w4_wgrad128b, dim3(8 * (8 * nT + nT)), dim3(256), 2 * 24 * 64 * 16, s, a);
       return;
     }
   }
-  const int grid = 2 * (a.C >> 7) * (a.C >> 5) * 8;
+  const int grid = (a.V2 != nullptr ? 2 : 1) * (a.C >> 7) * (a.C >> 5) * 8;     // (layer = tile / tiles per layer)
   const size_t lds = 4 * 2048 * sizeof(float);
   if (a.N % 16 == 0) hipLaunchKernelGGL(k_w4_wgrad<8>, dim3(grid), dim3(256), lds, s, a);
   else hipLaunchKernelGGL(k_w4_wgrad<4>, dim3(grid), dim3(256), lds, s, a);

@@ -790,4 +790,129 @@ void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStre
   else hipLaunchKernelGGL(k_w4s_output<4>, grid, block, 0, s, M, y_w4s, C);
 }
 
+// ----------------------------------------------------------------------------
+// The residual stem's last convolution (model.py:284-310: conv2 of ResBlock(64, filters, stride 2) -- 3x3, stride 1, pad 1,
+// filters -> filters on an 8x8 image, the ODE conv's own shape) through the F(4x4,3x3) pipeline: the same component GEMMs
+// and weight-gradient kernel as the ODE block (stem_api.hip), with these transforms around them.  The stem is NHWC fp32,
+// so the transforms read / write NHWC (or the caller's NCHW at the stem's boundary) directly -- no W4S detour.
+// ----------------------------------------------------------------------------
+// h (NHWC, the GroupNorm's input) -> xhat (W4S, kept for the backward), 1/sigma, V = B^T relu(GN(h)) B
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_stem_in(const float* __restrict__ h, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int cpg, float* __restrict__ xhat_s,
+                                                             float* __restrict__ rstd, float* __restrict__ V, int C, int Nv) {
+  W4Wave<1> wv;
+  w4s_place(wv, C, nullptr, nullptr);
+  const float* base = h + ((size_t)wv.n * 64 + (4 * wv.TY) * 8 + 4 * wv.TX) * C + wv.c;
+  float y[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[i][j] = base[(size_t)(i * 8 + j) * C];
+  float mean, rs;
+  w4s_gn_stats(y, cpg, 1.0f / (float)(64 * cpg), eps, wv, mean, rs);
+  const float gam = gamma[wv.c], bet = beta[wv.c];
+  float xh[4][4], v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[i][j] = (y[i][j] - mean) * rs;
+      v[i][j] = fmaxf(fmaf(xh[i][j], gam, bet), 0.f);
+    }
+  const size_t f4 = ((size_t)wv.nv * (C >> 4) + wv.cb) * 256 + wv.lane;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w4s_st4(xhat_s, f4 + i * 64, xh[i]);
+  if (wv.t == 0 && wv.c % cpg == 0) rstd[(size_t)wv.n * (C / cpg) + wv.c / cpg] = rs;
+  w4s_put_v(v, wv, V, C, Nv);
+}
+// M -> A^T M A + shortcut (NHWC) -> the stem's output, NCHW
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_stem_out(const float* __restrict__ M, const float* __restrict__ res, float* __restrict__ out, int C) {
+  W4Wave<1> wv;
+  w4s_place(wv, C, nullptr, nullptr);
+  float z[4][4];
+  w4s_out_transform(w4s_m_ptr(M, wv, C), z);
+  const float* rb = res + ((size_t)wv.n * 64 + (4 * wv.TY) * 8 + 4 * wv.TX) * C + wv.c;
+  float* ob = out + ((size_t)wv.n * C + wv.c) * 64 + (4 * wv.TY) * 8 + 4 * wv.TX;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 o;
+    o.x = z[i][0] + rb[(size_t)(i * 8 + 0) * C];
+    o.y = z[i][1] + rb[(size_t)(i * 8 + 1) * C];
+    o.z = z[i][2] + rb[(size_t)(i * 8 + 2) * C];
+    o.w = z[i][3] + rb[(size_t)(i * 8 + 3) * C];
+    *reinterpret_cast<float4*>(ob + i * 8) = o;
+  }
+}
+// dL/d out (NCHW) -> its row operand V (for the data gradient) and Z = A g A^T (for the weight gradient)
+__global__ __launch_bounds__(W4S_THREADS) void k_w4s_stem_gin(const float* __restrict__ g, float* __restrict__ V, float* __restrict__ Z, int C, int Nv) {
+  W4Wave<1> wv;
+  w4s_place(wv, C, nullptr, nullptr);
+  const float* gb = g + ((size_t)wv.n * C + wv.c) * 64 + (4 * wv.TY) * 8 + 4 * wv.TX;
+  float v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 q = *reinterpret_cast<const float4*>(gb + i * 8);
+    v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
+  }
+  w4s_emit_z(v, wv.nv, Nv, C, wv.c, wv.t, Z);
+  w4s_put_v(v, wv, V, C, Nv);
+}
+// dU [36][ci][co] (k_w4_wgrad) -> dW [co][ci][3][3] = G^T dU G in PyTorch's layout
+__global__ __launch_bounds__(256) void k_w4_du_to_dw(const float* __restrict__ dU, float* __restrict__ dW, int C) {
+  const size_t CC = (size_t)C * C;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;    // ci * C + co (co fastest: the reads are coalesced)
+  if (idx >= CC) return;
+  const int ci = (int)(idx / C), co = (int)(idx - (size_t)ci * C);
+  float tq[6][3];   // t[xi][kw] = sum_nu dU[xi][nu] G[nu][kw]
+#pragma unroll
+  for (int xi = 0; xi < 6; ++xi) {
+    float u[6];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) u[nu] = dU[(size_t)(xi * 6 + nu) * CC + idx];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) {
+        const float gq = (float)W4_G[nu][kw];
+        if (gq != 0.f) sacc += gq * u[nu];
+      }
+      tq[xi][kw] = sacc;
+    }
+  }
+  float* o = dW + ((size_t)co * C + ci) * 9;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi) {
+        const float gq = (float)W4_G[xi][kh];
+        if (gq != 0.f) sacc += gq * tq[xi][kw];
+      }
+      o[kh * 3 + kw] = sacc;
+    }
+}
+void launch_w4s_stem_in(const float* h_nhwc, const float* gamma, const float* beta, float eps, int cpg, float* xhat_s, float* rstd, float* V,
+                        int N, int C, int Nv, hipStream_t s) {
+  dim3 grid, block;
+  w4s_grid(N, C, cpg, 1, grid, block);
+  hipLaunchKernelGGL(k_w4s_stem_in, grid, block, 0, s, h_nhwc, gamma, beta, eps, cpg, xhat_s, rstd, V, C, Nv);
+}
+void launch_w4s_stem_out(const float* M, const float* res_nhwc, float* out_nchw, int N, int C, hipStream_t s) {
+  dim3 grid, block;
+  w4s_grid(N, C, 1, 1, grid, block);
+  hipLaunchKernelGGL(k_w4s_stem_out, grid, block, 0, s, M, res_nhwc, out_nchw, C);
+}
+void launch_w4s_stem_gin(const float* g_nchw, float* V, float* Z, int N, int C, int Nv, hipStream_t s) {
+  dim3 grid, block;
+  w4s_grid(N, C, 1, 1, grid, block);
+  hipLaunchKernelGGL(k_w4s_stem_gin, grid, block, 0, s, g_nchw, V, Z, C, Nv);
+}
+void launch_w4_du_to_dw(const float* dU, float* dW, int C, hipStream_t s) {
+  const size_t CC = (size_t)C * C;
+  hipLaunchKernelGGL(k_w4_du_to_dw, dim3((unsigned)((CC + 255) / 256)), dim3(256), 0, s, dU, dW, C);
+}
+
 }  // namespace node

@@ -121,6 +121,7 @@ void launch_stem_prep(const SPrepArgs& a, hipStream_t s);
 // NCHW fp32 -> NHWC fp32 (nullable) + triples (nullable); NHWC fp32 -> NCHW fp32
 void launch_stem_from_nchw(const float* src, float* dst_nhwc, bf16_t* dst3, size_t plane, int N, int C, int HW, hipStream_t s);
 void launch_stem_to_nchw(const float* src_nhwc, float* dst, int N, int C, int HW, hipStream_t s);
+void launch_stem_split(const float* src, bf16_t* dst3, size_t plane, size_t n /* % 8 == 0 */, hipStream_t s);   // fp32 -> triples
 // sums over split-K slabs / per-sample partials into the caller's gradient tensors
 //   kind 0: slab [ns][taps][Co][Ci] -> dW [Co][Ci][taps] (PyTorch layout); kind 1: conv0 slab [ns][64][32] -> dW0 [64][k0] + db [64];
 //   kind 2: GroupNorm partials [ns = N][2][C] -> dgamma [C], dbeta [C]

@@ -6,6 +6,7 @@
 // backward: NCHW -> NHWC (+ triples) | per convolution: data gradient (+ the shortcut's on top) and weight gradient (the
 //           shortcut's rides in the 3x3's launch) | per GroupNorm: backward pass | ONE reduction launch for every slab
 #include "stem.h"
+#include "wino4.h"
 #include "../../include/node_hip.h"
 #include <cstdarg>
 #include <cstdio>
@@ -101,8 +102,21 @@ struct StemPlan {
   Trip g3, dh3t, dx1t, dh1t;
   float* gpart[4];
   Wg w4, w3, w2, w1, w0;
+  // the last convolution (3x3, filters -> filters on an 8x8 image: the ODE conv's own shape) through the F(4x4,3x3)
+  // pipeline of the ODE block (wino4.h): component GEMMs k_w4_gemm64b, weight gradient k_w4_wgrad
+  bool f4;
+  bool f4_b16;
+  float *xh4, *rs4, *Va, *Vg, *M4, *Z4, *dU4, *U4[2], *dh3n;
+  unsigned short* Ub4[2];
   size_t bytes;
 };
+
+bool stem_takes_w4(const node_stem_shape* sh) {
+  const char* e = getenv("NODE_TUNE_STEM_W4");       // 0: the stem's own gather-GEMM kernels for the last convolution too (A/B, tests)
+  if (e && atoi(e) == 0) return false;
+  const int h2 = ((sh->h - 2 - 1) / 2 + 1 - 1) / 2 + 1, w2 = ((sh->w - 2 - 1) / 2 + 1 - 1) / 2 + 1;
+  return h2 == 8 && w2 == 8 && sh->filters % 128 == 0 && sh->n % 8 == 0 && 16 % (sh->filters / 32) == 0;
+}
 
 StemPlan make_stem_plan(const node_stem_shape* sh, void* base) {
   StemPlan p;
@@ -163,6 +177,23 @@ StemPlan make_stem_plan(const node_stem_shape* sh, void* base) {
     p.w0.nsplit = (p.R0 + rps - 1) / rps;
     p.w0.slab = b.take<float>((size_t)p.w0.nsplit * 64 * 32);
     p.w0.slab2 = nullptr;
+  }
+  p.f4 = stem_takes_w4(sh);
+  if (p.f4) {
+    const int Nv = p.N;
+    p.f4_b16 = w4_uses_bf16(Nv, F);
+    p.xh4 = b.take<float>((size_t)p.R2 * F);
+    p.rs4 = b.take<float>((size_t)p.N * GF);
+    p.Va = b.take<float>(w4_v_elems(Nv, F));
+    p.Vg = b.take<float>(w4_v_elems(Nv, F));
+    p.M4 = b.take<float>(w4_v_elems(Nv, F));
+    p.Z4 = b.take<float>(w4_z_elems(Nv, F));
+    p.dU4 = b.take<float>((size_t)W4_COMPS * F * F);
+    for (int i = 0; i < 2; ++i) {
+      p.U4[i] = b.take<float>(w4_u_elems(F));
+      p.Ub4[i] = b.take<unsigned short>(w4_ub_elems(F));
+    }
+    p.dh3n = b.take<float>((size_t)p.R2 * F);
   }
   p.bytes = b.off + 256;
   return p;
@@ -348,6 +379,21 @@ int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* prm, con
     launch_stem_conv(c, st);
     if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
   }
+  if (p.f4) {
+    W4PackJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    for (int i = 0; i < 2; ++i) {
+      jobs.w[i] = prm->b2_c2_w; jobs.u[i] = p.U4[i]; jobs.ub[i] = p.f4_b16 ? p.Ub4[i] : nullptr; jobs.dgrad[i] = i; jobs.plain[i] = 1;
+    }
+    launch_w4_pack(jobs, 2, F, st);
+    if ((rc = launch_ok("w4_pack")) != NODE_OK) return rc;
+    launch_w4s_stem_in(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.eps, F / 32, p.xh4, p.rs4, p.Va, N, F, N, st);
+    if ((rc = launch_ok("w4s_stem_in")) != NODE_OK) return rc;
+    launch_w4_gemm(p.Va, p.U4[0], p.M4, nullptr, N, F, st, p.f4_b16 ? p.Ub4[0] : nullptr);
+    if ((rc = launch_ok("w4_gemm")) != NODE_OK) return rc;
+    launch_w4s_stem_out(p.M4, p.s2, out, N, F, st);
+    return launch_ok("node_stem_fwd");
+  }
   {
     SGnArgs g = gn_args(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.stats[3], N, p.H2 * p.W2, F, p.eps);
     g.a3 = p.a3.p; g.a_plane = p.a3.plane;
@@ -384,16 +430,41 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   // dL/d out: also the gradient of the second block's shortcut s2
   launch_stem_from_nchw(grad_out, nullptr, p.g3.p, p.g3.plane, N, F, HW2, st);
   if ((rc = launch_ok("stem_from_nchw")) != NODE_OK) return rc;
+  if (p.f4) {
+    // block 2, conv2 through the F(4x4,3x3) pipeline: V and Z of dL/d out, data-gradient GEMM, then ONE pass for the ReLU mask and
+    // GroupNorm's backward (k_w4s_pass<2, 0>, the ODE block's own), the weight gradient in the transform domain
+    launch_w4s_stem_gin(grad_out, p.Vg, p.Z4, N, F, N, st);
+    if ((rc = launch_ok("w4s_stem_gin")) != NODE_OK) return rc;
+    launch_w4_gemm(p.Vg, p.U4[1], p.M4, nullptr, N, F, st, p.f4_b16 ? p.Ub4[1] : nullptr);
+    if ((rc = launch_ok("w4_gemm")) != NODE_OK) return rc;
+    W4sArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.Q = 1; a.Nv = N; a.C = F; a.cpg = F / 32; a.eps = p.eps;
+    a.h.M = p.M4; a.h.gamma = prm->b2_n2_w; a.h.beta = prm->b2_n2_b; a.h.xhat_s = p.xh4; a.h.rstd = p.rs4; a.h.osign = 1.f;
+    a.h.gpart = p.gpart[3]; a.h.out_nhwc = p.dh3n;
+    launch_w4s_pass(2, 0, a, st);
+    if ((rc = launch_ok("w4s_pass")) != NODE_OK) return rc;
+    launch_stem_split(p.dh3n, p.dh3t.p, p.dh3t.plane, (size_t)p.R2 * F, st);
+    if ((rc = launch_ok("stem_split")) != NODE_OK) return rc;
+    W4WgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.V1 = p.Va; wa.Z1 = p.Z4; wa.dU = p.dU4; wa.N = N; wa.C = F;
+    launch_w4_wgrad(wa, st);
+    if ((rc = launch_ok("w4_wgrad")) != NODE_OK) return rc;
+    launch_w4_du_to_dw(p.dU4, gr->b2_c2_w, F, st);
+    if ((rc = launch_ok("w4_du_to_dw")) != NODE_OK) return rc;
+  } else {
   // block 2, conv2 (3x3, F -> F) : weight gradient, data gradient -> da3
-  launch_stem_wgrad(wgrad_args(p.g3, nullptr, p.a3, p.w4, N, p.H2, p.W2, p.H2, p.W2, F, F, 3, 1, 1), st);
-  if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
-  launch_stem_conv(conv_dgrad_args(p.g3, p.c4, p.da3, N, p.H2, p.W2, p.H2, p.W2, 3, 1, 1), st);
-  if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
-  {
-    SGnArgs g = gn_args(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.stats[3], N, HW2, F, p.eps);
-    g.da = p.da3; g.dh = nullptr; g.dh3 = p.dh3t.p; g.dh_plane = p.dh3t.plane; g.gpart = p.gpart[3];
-    launch_stem_gn_bwd(g, st);
-    if ((rc = launch_ok("stem_gn_bwd")) != NODE_OK) return rc;
+    launch_stem_wgrad(wgrad_args(p.g3, nullptr, p.a3, p.w4, N, p.H2, p.W2, p.H2, p.W2, F, F, 3, 1, 1), st);
+    if ((rc = launch_ok("stem_wgrad")) != NODE_OK) return rc;
+    launch_stem_conv(conv_dgrad_args(p.g3, p.c4, p.da3, N, p.H2, p.W2, p.H2, p.W2, 3, 1, 1), st);
+    if ((rc = launch_ok("stem_conv")) != NODE_OK) return rc;
+    {
+      SGnArgs g = gn_args(p.h3, prm->b2_n2_w, prm->b2_n2_b, p.stats[3], N, HW2, F, p.eps);
+      g.da = p.da3; g.dh = nullptr; g.dh3 = p.dh3t.p; g.dh_plane = p.dh3t.plane; g.gpart = p.gpart[3];
+      launch_stem_gn_bwd(g, st);
+      if ((rc = launch_ok("stem_gn_bwd")) != NODE_OK) return rc;
+    }
   }
   // block 2, conv1 (3x3 / 2, 64 -> F) + shortcut (1x1 / 2, 64 -> F): both read a2
   launch_stem_wgrad(wgrad_args(p.dh3t, &p.g3, p.a2, p.w3, N, p.H1, p.W1, p.H2, p.W2, 64, F, 3, 2, 1), st);
@@ -442,7 +513,7 @@ int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, con
   SReduceArgs ra;
   memset(&ra, 0, sizeof(ra));
   int nj = 0;
-  ra.job[nj++] = {p.w4.slab, gr->b2_c2_w, nullptr, 0, p.w4.nsplit, F, F, 9};
+  if (!p.f4) ra.job[nj++] = {p.w4.slab, gr->b2_c2_w, nullptr, 0, p.w4.nsplit, F, F, 9};
   ra.job[nj++] = {p.w3.slab, gr->b2_c1_w, nullptr, 0, p.w3.nsplit, F, 64, 9};
   ra.job[nj++] = {p.w3.slab2, gr->b2_ds_w, nullptr, 0, p.w3.nsplit, F, 64, 1};
   ra.job[nj++] = {p.w2.slab, gr->b1_c2_w, nullptr, 0, p.w2.nsplit, 64, 64, 9};

@@ -114,7 +114,7 @@ void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
 //      k_theta_finalize
 struct W4WgradArgs {
   const float* V1; const float* Z1;   // conv1: V of act1, Z of dz1
-  const float* V2; const float* Z2;   // conv2: V of act2, Z of dz2
+  const float* V2; const float* Z2;   // conv2: V of act2, Z of dz2 (nullable: ONE layer -- the stem's -- half the grid)
   float* dU;
   const Ctrl* ctrl;                   // nullable: the launch returns at once when ctrl->done
   int N, C;
@@ -128,7 +128,8 @@ __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COM
 // 1e-5 so that a tolerance that went through a float keeps comparing equal
 constexpr float W4_MIN_TOL = 0.99e-5f;
 // per job ONE of u (fp32, k_w4_gemm / k_w4_gemm64) and ub (exact bf16 triples, k_w4_gemm64b) is written: ub when non-null
-struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; };
+// plain[i] != 0: a [C][C][3][3] filter (the stem's conv3x3, model.py:255-258) instead of ConcatConv2d's [C][C + 1][3][3]
+struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; int plain[4]; };
 // which form launch_w4_gemm will read for this batch (NODE_TUNE_W4_BF16X3, read on every call)
 bool w4_uses_bf16(int N, int C);
 __host__ __device__ inline size_t w4_ub_elems(int C) { return (size_t)W4_COMPS * C * C * 3 + 8 * 1536; }   // bf16 values (+ ring slack)
@@ -140,5 +141,12 @@ void launch_w4_split_check(const float* x, float* out, size_t n, hipStream_t s);
 // stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
 void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s);
 void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s);
+// the stem's 8x8 filters -> filters convolution through the pipeline (kernels_w4s.hip, stem_api.hip): transforms that read / write
+// the stem's NHWC tensors (and the caller's NCHW tensors at the stem's boundary) directly
+void launch_w4s_stem_in(const float* h_nhwc, const float* gamma, const float* beta, float eps, int cpg, float* xhat_s, float* rstd, float* V,
+                        int N, int C, int Nv, hipStream_t s);
+void launch_w4s_stem_out(const float* M, const float* res_nhwc, float* out_nchw, int N, int C, hipStream_t s);
+void launch_w4s_stem_gin(const float* g_nchw, float* V, float* Z, int N, int C, int Nv, hipStream_t s);
+void launch_w4_du_to_dw(const float* dU, float* dW, int C, hipStream_t s);
 
 }  // namespace node

@@ -70,15 +70,23 @@ def _stem_pair(in_ch, filters, seed, kink_free=False):
     return stem, copy.deepcopy(stem).double()
 
 
-@pytest.mark.parametrize('case', [(3, 32, 256, 6, False), (1, 28, 64, 5, False), (3, 32, 128, 128, True), (3, 32, 128, 128, False)],
+@pytest.mark.parametrize('case', [(3, 32, 256, 6, False), (1, 28, 64, 5, False), (3, 32, 256, 8, False), (3, 32, 128, 128, True),
+                                  (3, 32, 128, 128, False)],
                          ids=lambda c: 'in%d_%dpx_f%d_n%d%s' % (c[:4] + ('_kinkfree' if c[4] else '',)))
-def test_whole_stem_forward_and_every_gradient_match_fp64(case):
+@pytest.mark.parametrize('w4', [1, 0], ids=['last_conv_w4', 'last_conv_gather'])
+def test_whole_stem_forward_and_every_gradient_match_fp64(case, w4, monkeypatch):
     """Max-norm parity of the output and of all sixteen parameter gradients with the fp64 run.  At the full batch the
     stem evaluates ~12 M pre-activations: a dozen land within fp32 rounding of zero, their ReLU masks differ from the
     fp64 run's, and a single flipped element moves a GroupNorm-bias gradient (a sum of 8192 terms of random sign) by
     ~1 % -- so the full-batch case is asserted in max norm on kink-free parameters (biases in front of the ReLUs at +8) and
     in relative L2 on ordinary ones."""
     in_ch, side, filters, n, kink_free = case
+    # the block's last convolution (filters -> filters on 8x8) takes the ODE block's F(4x4,3x3) pipeline where its shape
+    # allows (batch % 8 == 0, filters % 128 == 0); NODE_TUNE_STEM_W4 = 0 keeps it on the stem's own gather-GEMM kernels
+    takes_w4 = w4 == 1 and side == 32 and n % 8 == 0 and filters % 128 == 0
+    if w4 == 0 and not (side == 32 and n % 8 == 0 and filters % 128 == 0):
+        pytest.skip('this shape never takes the pipeline: covered by the other parametrization')
+    monkeypatch.setenv('NODE_TUNE_STEM_W4', str(w4))
     stem, ref = _stem_pair(in_ch, filters, seed=in_ch + filters, kink_free=kink_free)
     stem = stem.cuda()
     gen = torch.Generator().manual_seed(99)
@@ -90,7 +98,7 @@ def test_whole_stem_forward_and_every_gradient_match_fp64(case):
     out.backward(cot.cuda())
     out_ref.backward(cot.double())
     err = float((out.detach().cpu().double() - out_ref.detach()).abs().max() / out_ref.detach().abs().max())
-    print('stem %s: output max error %.2e' % (case, err))
+    print('stem %s (w4 %s): output max error %.2e' % (case, takes_w4, err))
     assert err <= 2e-5
     errs, l2 = {}, {}
     for (name, p), (_, q) in zip(stem.named_parameters(), ref.named_parameters()):
@@ -101,7 +109,7 @@ def test_whole_stem_forward_and_every_gradient_match_fp64(case):
     if n >= 64 and not kink_free:
         assert max(l2.values()) <= 2e-2, l2
     else:
-        assert max(errs.values()) <= 2e-5, errs
+        assert max(errs.values()) <= (5e-5 if takes_w4 else 2e-5), errs
 
 
 def test_stem_runs_no_library_convolution():
