@@ -26,6 +26,11 @@ name first.  What the fixtures pin:
   odenet_ode2_train.pt    reference ``ODENet(3, downsample='ode2')`` (``ODEDownsample2``, model.py:199-223) trained one
                           step end-to-end (two adjoint solves per backward), oracle standing in for torchdiffeq
 
+  stem_residual_c64.pt    reference ``ResDownsample(1, 64)`` (model.py:167-178: Conv2d(1, 64, 3, 1) + two stride-2 ``ResBlock``s,
+                          model.py:284-310) on a [2, 1, 28, 28] input: output and the gradient of every parameter for a fixed
+                          cotangent (round 4: ``python tests/golden/make_golden.py stem``) -- what the library's own stem
+                          kernels (csrc/kernels_stem.hip) are held against
+
 Fixtures are data (tensors / json).  No reference source text is stored.
 """
 import json
@@ -198,8 +203,26 @@ def make_ode2_train(ref):
     print('odenet_ode2_train loss %.5f nfe_f %s nfe_b %s' % (loss, nfe_f, nfe_b))
 
 
+def make_stem(ref):
+    torch.manual_seed(47)
+    gen = torch.Generator().manual_seed(47)
+    stem = ref.ResDownsample(1, out_ch=64)
+    randomize_(stem, gen)
+    x = torch.rand(2, 1, 28, 28, generator=gen)
+    out = stem(x)
+    cot = torch.randn(out.shape, generator=gen)
+    out.backward(cot)
+    torch.save({'x': x, 'cot': cot, 'out': out.detach(), 'state_dict': stem.state_dict(),
+                'grads': {k: v.grad.clone() for k, v in stem.named_parameters()}},
+               os.path.join(HERE, 'stem_residual_c64.pt'))
+    print('stem_residual_c64: out %s, %d parameter tensors' % (tuple(out.shape), len(list(stem.parameters()))))
+
+
 def main():
     ref = import_reference_model()
+    if 'stem' in sys.argv[1:]:         # only the fixture added in round 4
+        make_stem(ref)
+        return
     if 'w4' in sys.argv[1:]:           # only the fixtures added in round 3
         make_odefunc(ref, 64, 8, 8, 8, seed=41, name='odefunc_c64_n8.pt')
         make_odefunc(ref, 64, 8, 8, 8, seed=42, name='odefunc_c64_n8_kf.pt', kink_free=True)
@@ -220,6 +243,7 @@ def main():
     make_odenet_e2e(ref, 'odenet_dopri5.pt', 'dopri5', 1e-3, 3, 8, 32, 2, 1, seed=29)
     make_ode_stem_features(ref)
     make_ode2_train(ref)
+    make_stem(ref)
 
 
 if __name__ == '__main__':

@@ -53,13 +53,16 @@ def test_hip_end_to_end_matches_reference_run(golden_dir, name):
     # (~1e-9 against a largest gradient of ~0.2), so each tensor is compared relative to
     # max(its own scale, 1e-4 x the largest gradient of the net).
     gmax = max(float(v.abs().max()) for v in g['grads'].values())
-    # The stem's convolutions are MIOpen's: its backward kernels were measured to differ by up to 4e-3 relative between
-    # algorithm choices on a fresh box (tests/test_gpu_head.py), so the stem's parameters get a wider bound than the
-    # ODE block's and the head's, whose gradients come out of this package's kernels.
+    # Stems of at least 64 filters run on this package's own kernels (stem.py, csrc/kernels_stem.hip) and are held to the
+    # bound of the ODE block and the head; the toy widths of some fixtures (8, 16 filters) fall back to PyTorch's library
+    # convolutions, whose backward kernels were measured to differ by up to 4e-3 relative between algorithm choices on a
+    # fresh box (tests/test_gpu_head.py): those keep the wider bound.
+    from neural_ode_features_amd import stem as stem_mod
+    own_stem = isinstance(net.downsample.module, stem_mod.ResidualStem) and stem_mod.fusable(net.downsample.module, g['x'].cuda())
     for k, v in net.named_parameters():
         ref = g['grads'][k]
         scale = max(float(ref.abs().max()), 1e-4 * gmax)
-        bound = 2e-2 if k.startswith('downsample') else 5e-3
+        bound = 2e-2 if (k.startswith('downsample') and not own_stem) else 5e-3
         assert float((v.grad.detach().cpu() - ref).abs().max()) / scale < bound, k
 
 

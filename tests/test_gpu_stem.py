@@ -112,6 +112,30 @@ def test_whole_stem_forward_and_every_gradient_match_fp64(case, w4, monkeypatch)
         assert max(errs.values()) <= (5e-5 if takes_w4 else 2e-5), errs
 
 
+def test_stem_matches_the_reference_fixture(golden_dir):
+    """tests/golden/stem_residual_c64.pt: the reference's own `ResDownsample(1, 64)` (model.py:167-178, imported by
+    tests/golden/make_golden.py) on a [2, 1, 28, 28] input -- output and every parameter gradient.  The reference's
+    state_dict loads unchanged (same keys); the library's stem kernels must reproduce its numbers."""
+    import os
+    import neural_ode_features_amd as nof
+    g = torch.load(os.path.join(golden_dir, 'stem_residual_c64.pt'), map_location='cpu', weights_only=False)
+    net = nof.ODENet(1, out=10, n_filters=64, downsample='residual', adjoint=True)
+    stem = net.downsample           # (the wrapper holds the body under `.module`, like the reference's ResDownsample)
+    stem.load_state_dict(g['state_dict'])
+    stem = stem.cuda()
+    out = stem(g['x'].cuda())
+    assert type(out.grad_fn).__name__ == '_StemFnBackward'
+    out.backward(g['cot'].cuda())
+    err = float((out.detach().cpu() - g['out']).abs().max() / g['out'].abs().max())
+    print('reference stem fixture: output max error / max|ref| = %.2e' % err)
+    assert err <= 2e-5
+    for name, p in stem.named_parameters():
+        ref = g['grads'][name]
+        e = float((p.grad.cpu() - ref).abs().max() / ref.abs().max())
+        print('  grad %-28s %.2e' % (name, e))
+        assert e <= 1e-4, (name, e)       # (the fixture itself is fp32: PyTorch-CPU's own rounding sits at ~1e-6)
+
+
 def test_stem_runs_no_library_convolution():
     """The fused stem is ONE autograd node whose forward and backward are calls into libnode_hip.so: PyTorch dispatches no
     convolution, no GroupNorm and no layout transpose for it (its dispatcher trace of a forward + backward holds no

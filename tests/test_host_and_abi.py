@@ -22,9 +22,28 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.node_abi_version() == _lib.NODE_ABI_VERSION == 2
+    assert lib.node_abi_version() == _lib.NODE_ABI_VERSION == 3
     m = re.search(r'#define NODE_ABI_VERSION (\d+)', header)
     assert int(m.group(1)) == _lib.NODE_ABI_VERSION
+
+
+def test_stem_entry_points_host_side():
+    """node_stem_workspace_bytes / argument checks of the stem's C ABI need no GPU: sizes for the BASELINE shapes, refusals
+    with a message for what the kernels do not take."""
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    cifar = lib.node_stem_workspace_bytes(C.byref(_lib.NodeStemShape(128, 3, 32, 32, 256, 1e-5)))
+    mnist = lib.node_stem_workspace_bytes(C.byref(_lib.NodeStemShape(32, 1, 28, 28, 64, 1e-5)))
+    assert 0 < mnist < cifar < (2 << 30)
+    for bad, word in ((_lib.NodeStemShape(8, 4, 32, 32, 64, 1e-5), 'in_ch'), (_lib.NodeStemShape(8, 3, 32, 32, 24, 1e-5), 'filters'),
+                      (_lib.NodeStemShape(8, 3, 64, 64, 64, 1e-5), 'LDS'), (_lib.NodeStemShape(0, 3, 32, 32, 64, 1e-5), 'shape')):
+        assert lib.node_stem_workspace_bytes(C.byref(bad)) == 0
+        assert word in lib.node_last_error().decode(), (word, lib.node_last_error())
+    shape = _lib.NodeStemShape(8, 3, 32, 32, 64, 1e-5)
+    assert lib.node_stem_fwd(C.byref(shape), None, None, None, None, 0, None) == -1          # NODE_ERR_NULL
+    geom = _lib.NodeConvGeom(8, 64, 64, 30, 30, 3, 2, 1)
+    assert lib.node_stem_conv_workspace_bytes(C.byref(geom)) > 0
+    assert lib.node_stem_conv_workspace_bytes(C.byref(_lib.NodeConvGeom(8, 48, 64, 30, 30, 3, 2, 1))) == 0
 
 
 def test_host_only_entry_points():

@@ -149,3 +149,23 @@ def test_ode2_stem_training_fixture(golden_dir):
     assert torch.allclose(p, g['logits'], rtol=1e-4, atol=1e-5)
     for k, v in net.named_parameters():
         assert torch.allclose(v.grad, g['grads'][k], rtol=2e-3, atol=2e-5), k
+
+
+def test_package_stem_modules_reproduce_the_reference_stem_fixture(golden_dir):
+    """CPU: the package's stem modules (the parameter containers the HIP stem reads, and the path CPU tensors take) hold
+    the reference's state_dict keys and reproduce `ResDownsample(1, 64)`'s output and gradients
+    (tests/golden/stem_residual_c64.pt, generated from the imported reference)."""
+    import os
+    import torch
+    import neural_ode_features_amd as nof
+    g = torch.load(os.path.join(golden_dir, 'stem_residual_c64.pt'), map_location='cpu', weights_only=False)
+    net = nof.ODENet(1, out=10, n_filters=64, downsample='residual', adjoint=True)
+    stem = net.downsample           # (the wrapper holds the body under `.module`, like the reference's ResDownsample)
+    assert list(stem.state_dict().keys()) == list(g['state_dict'].keys())
+    stem.load_state_dict(g['state_dict'])
+    out = stem(g['x'])
+    out.backward(g['cot'])
+    assert float((out.detach() - g['out']).abs().max()) <= 1e-5 * float(g['out'].abs().max())
+    for name, p in stem.named_parameters():
+        ref = g['grads'][name]
+        assert float((p.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), name
