@@ -673,6 +673,26 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
   auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
   auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
 
+  // The shared component's operands (four K = 16 steps per wave at C = 256: 128 registers -- the kernel runs one wave per
+  // SIMD, so the file's other half is free) are requested BEFORE the own component's loop: nothing else would cover their
+  // latency behind it (the ablation of DESIGN.md 4.7: the second ring fill cost ~3 of the shared component's 4.7 us).
+  constexpr int SH = 4;
+  const bool early = !(AB & 1) && !(AB & 2) && !(AB & 8) && (G2 >> 2) == SH;
+  W4BStage shr[SH];
+  {
+    const int scomp = 32 + (j >> 1), srb = 2 * rt + (j & 1);
+    W4BPtrs sp;
+    sp.a[0] = vblk(scomp, srb); sp.a[1] = sp.a[0];
+    sp.b[0] = ublk(scomp, 2 * ct); sp.b[1] = ublk(scomp, 2 * ct + 1);
+    if (early) {
+#pragma unroll
+      for (int i = 0; i < SH; ++i) {
+        w4b_load<1>(shr[i], sp, wave * SH + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("" ::: "memory");   // (the compiler may not sink these requests to their first use behind the loop)
+    }
+  }
   // --- this wave's own component: the whole 64 x 64 tile over the whole K range
   {
     const int comp = 4 * j + wave;
@@ -711,7 +731,14 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
-    if (ng % 4 == 0) w4b_run<4, 1, AB>(acc, p, g0, ng);
+    if (early) {
+      W4Split cs[2];
+#pragma unroll
+      for (int i = 0; i < SH; ++i) {
+        cs[0] = w4_split8(shr[i].a[0][0], shr[i].a[0][1]);
+        w4b_mac<1>(acc, cs, shr[i]);
+      }
+    } else if (ng % 4 == 0) w4b_run<4, 1, AB>(acc, p, g0, ng);
     else if (ng % 2 == 0) w4b_run<2, 1, AB>(acc, p, g0, ng);
     else w4b_run<1, 1, AB>(acc, p, g0, ng);
     float* red = smem + wave * 2048;

@@ -29,11 +29,12 @@ def report(d, per_iter):
     f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
     rows.sort()
-    rows = [r for r in rows if 'k_stem' in r[2]]
-    last = rows[-per_iter:]
+    rows = [r for r in rows if 'node::' in r[2]]
+    idx = max(i for i, r in enumerate(rows) if 'k_stem_prep' in r[2])     # the last iteration starts at its preparation launch
+    last = rows[idx:]
     tot = 0.0
     for s, e, name in last:
-        short = name.split('k_stem_')[1].split('(')[0]
+        short = name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('node::', '')
         print('%-28s %8.1f us' % (short, (e - s) / 1e3))
         tot += (e - s) / 1e3
     print('total %.1f us over %d launches; span %.1f us' % (tot, len(last), (last[-1][1] - last[0][0]) / 1e3))

@@ -22,7 +22,7 @@ def load(path):
     rows = []
     for r in csv.DictReader(open(path)):
         s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-        rows.append((s, e, r['Kernel_Name'].split('(')[0].replace('void ', '')[:64]))
+        rows.append((s, e, r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')[:64]))
     rows.sort()
     return rows
 
