@@ -856,6 +856,9 @@ int stem_gn_cb(int HW, int C, int cpg) {
   while (cb < cpg) cb *= 2;
   if (cb > C || cb > 128 || (size_t)HW * cb * 2 * sizeof(float) > budget) return 0;
   while (cb * 2 <= C && cb * 2 <= 128 && (size_t)HW * cb * 4 * sizeof(float) <= budget) cb *= 2;
+  static int cap = -2;      // NODE_TUNE_STEM_GNCB: upper limit of the channel block (A/B measurements)
+  if (cap == -2) { const char* e = getenv("NODE_TUNE_STEM_GNCB"); cap = e ? atoi(e) : -1; }
+  while (cap > 0 && cb > cap && cb / 2 >= cpg && cb / 2 >= 8) cb /= 2;
   return cb;
 }
 void launch_stem_gn_fwd(const SGnArgs& a, hipStream_t s) {
