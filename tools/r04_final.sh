@@ -27,3 +27,8 @@ except Exception as e:
     print('$f failed', e)
 "; done
 tail -3 $O/stem_time.txt; tail -2 $O/deferred_soak_cfg3.txt; tail -4 $O/latency_bs1.txt
+cd /tmp && rm -rf /tmp/st8
+NODE_TUNE_STEM_GNCB=8 rocprofv3 --kernel-trace --output-format csv -d /tmp/st8 -- python3 $R/tools/stem_time.py --run > /tmp/st8.log 2>&1
+cd $R
+python3 tools/stem_time.py --report /tmp/st8 > $O/stem_time_gncb8.txt
+grep "gn_\|total" $O/stem_time.txt | tr '\n' ' '; echo; grep "gn_\|total" $O/stem_time_gncb8.txt | tr '\n' ' '; echo
