@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -347,10 +348,10 @@ class Deferred:
     #   * a count above everything in the history was seen within the last QUIET solves.
     # Round 3 enqueued last count + 1 until eight exact predictions in a row -- at tol 1e-5 that never happened, and every
     # solve carried one or two dead steps (profiles/r03_r_cfg3_steps.txt: 29 dead component GEMMs per step).
-    HIST = 8
+    HIST = int(os.environ.get('NODE_DEFERRED_HIST', 8))
     CALM = 4
-    FRAGILE = 0.15
-    QUIET = 16
+    FRAGILE = float(os.environ.get('NODE_DEFERRED_FRAGILE', 0.15))      # (environment: A/B measurements, tools/deferred_soak.py)
+    QUIET = int(os.environ.get('NODE_DEFERRED_QUIET', 16))
 
     def __init__(self, device):
         self.device = torch.device(device)

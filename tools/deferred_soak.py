@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""How often does deferred completion miss when the data changes every step?  N optimizer steps of the cfg-2 model on a
+"""How often does deferred completion miss when the data changes every step?  N optimizer steps of the cfg-2 / cfg-3 model on a
 FRESH synthetic batch per step (class-dependent means, so the loss falls and the weights move), with deferred
-completion and with a read-back per solve; reports throughput, misses (skipped updates) and the loss trajectory.
+completion (integrate.DeferredLoop: a missed batch is repeated, never skipped) and with a read-back per solve; reports
+throughput, miss events, batches repeated, dead steps and the loss trajectory -- every one of the N updates is committed in
+both modes, so the two trajectories are the same.
 
     python tools/deferred_soak.py [--steps 300] [--lr 0.05]
 """
@@ -28,30 +30,37 @@ def run(steps, lr, deferred_on, seed=0, config=2):
     gen = torch.Generator(device='cuda').manual_seed(seed)
     means = torch.randn(10, 3, 1, 1, device=dev, generator=gen)
     d = integrate.Deferred(dev) if deferred_on else None
-    if d is not None:
-        opt.use_deferred(d)
+    loop = integrate.DeferredLoop(d, opt, lambda xx, yy: bench.train_step(model, opt, xx, yy)) if d is not None else None
     losses = []
-    import contextlib
-    with (d if d is not None else contextlib.nullcontext()):
-        for i in range(10):              # MIOpen's first-use searches, allocator warm-up
-            y = torch.randint(0, 10, (128,), device=dev, generator=gen)
-            x = torch.randn(128, 3, 32, 32, device=dev, generator=gen) + means[y]
-            bench.train_step(model, opt, x, y)
-        torch.cuda.synchronize()
-        m0 = d.resolve() if d is not None else 0
-        t0 = time.perf_counter()
-        for i in range(steps):
-            y = torch.randint(0, 10, (128,), device=dev, generator=gen)
-            x = torch.randn(128, 3, 32, 32, device=dev, generator=gen) + means[y]
-            loss, nf, nb = bench.train_step(model, opt, x, y)
-            losses.append(loss.detach())
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-    misses = (d.resolve() - m0) if d is not None else 0
+
+    def batch():
+        y = torch.randint(0, 10, (128,), device=dev, generator=gen)
+        return torch.randn(128, 3, 32, 32, device=dev, generator=gen) + means[y], y
+
+    def step(x, y):
+        done = loop.step(x, y) if loop is not None else [bench.train_step(model, opt, x, y)]
+        losses.extend(r[0].detach() for r in done)
+
+    for i in range(10):              # first-use warm-up
+        step(*batch())
+    if loop is not None:
+        losses.extend(r[0].detach() for r in loop.flush())
+    torch.cuda.synchronize()
+    losses.clear()
+    c0 = (loop.retries, loop.miss_events, d.dead_steps, d.blind_solves) if loop is not None else (0, 0, 0, 0)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(*batch())
+    if loop is not None:
+        losses.extend(r[0].detach() for r in loop.flush())
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    c1 = (loop.retries, loop.miss_events, d.dead_steps, d.blind_solves) if loop is not None else (0, 0, 0, 0)
     ls = torch.stack(losses).float().cpu()
     finite = torch.isfinite(ls)
-    return dict(mode='deferred' if deferred_on else 'read-back', steps=steps, images_per_s=steps * 128 / wall,
-                misses=misses, blind=d.blind_solves if d is not None else 0,
+    return dict(mode='deferred (DeferredLoop: misses are repeated)' if deferred_on else 'read-back', steps=steps, updates=len(losses),
+                images_per_s=steps * 128 / wall, miss_events=c1[1] - c0[1], batches_repeated=c1[0] - c0[0],
+                dead_steps_per_step=(c1[2] - c0[2]) / steps, blind=c1[3] - c0[3],
                 loss_first10=float(ls[:10][finite[:10]].mean()), loss_last10=float(ls[-10:][finite[-10:]].mean()),
                 nonfinite_losses=int((~finite).sum()))
 
