@@ -477,9 +477,15 @@ __device__ __forceinline__ void w4_mac6(float16_t& acc, const W4Split& a, const 
 constexpr int W4B_DEPTH = 4;   // K = 16 steps (two g blocks each) in flight
 
 struct W4BStage { float4 a[2][2]; w4_u32x4 b[2][3]; };   // [row block][g of the pair], [column block][part]
-struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; };
+// rot / mask (NODE_TUNE_W4_ROT = 1, measured and NOT kept, round 4): the K steps of a wave's own component in ROTATED order, step
+// (g + rot) & mask.  The idea: every wave walks its operand streams with the same power-of-two strides (512 KB between
+// components, 32 KB between row blocks), so all of an XCD's waves might camp on a few L2 channels.  Measured: 18.2 -> 19.8 us
+// per launch, cfg 2 24 870 -> 24 480 images/s -- the waves that SHARE an operand block (4 column tiles read a V block, 8 row
+// tiles a U block) ask for it at the same time in the lock-step order and are served by one L2 fill; rotated, they are not.
+struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; int rot, mask; };
 template <int NRB>
-__device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2) {
+__device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2in) {
+  const int g2 = p.mask >= 0 ? ((g2in + p.rot) & p.mask) : g2in;
 #pragma unroll
   for (int r = 0; r < NRB; ++r) {
     s.a[r][0] = p.a[r][(size_t)(2 * g2) * 64];
@@ -661,7 +667,7 @@ __device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p
 
 template <int AB>
 __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
-                                                    const Ctrl* ctrl, W4Geom gm) {
+                                                    const Ctrl* ctrl, W4Geom gm, int rot_on) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -684,6 +690,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     W4BPtrs sp;
     sp.a[0] = vblk(scomp, srb); sp.a[1] = sp.a[0];
     sp.b[0] = ublk(scomp, 2 * ct); sp.b[1] = ublk(scomp, 2 * ct + 1);
+    sp.rot = 0; sp.mask = -1;
     if (early) {
 #pragma unroll
       for (int i = 0; i < SH; ++i) {
@@ -699,6 +706,8 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     W4BPtrs p;
     p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
     p.b[0] = ublk(comp, 2 * ct); p.b[1] = ublk(comp, 2 * ct + 1);
+    p.mask = (rot_on && (G2 & (G2 - 1)) == 0) ? G2 - 1 : -1;
+    p.rot = (5 * wave + 3 * tile + 7 * j) & (G2 - 1);
     float16_t acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -726,6 +735,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     W4BPtrs p;
     p.a[0] = vblk(scomp, rb); p.a[1] = p.a[0];
     p.b[0] = ublk(scomp, 2 * ct); p.b[1] = ublk(scomp, 2 * ct + 1);
+    p.rot = 0; p.mask = -1;
     float16_t acc[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1047,11 +1057,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
-struct W4Switches { int g64, b16, ablate, small, uf32; };
+struct W4Switches { int g64, b16, ablate, small, uf32, rot; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
-          rd("NODE_TUNE_W4_UF32", 0)};
+          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_ROT", 0)};
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1070,6 +1080,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   static bool attr[4][MAX_DEVICES] = {};
   const W4Switches sw = w4_switches();
   const int ab = sw.ablate;
+  const int rot_on = sw.rot;
   static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
@@ -1096,12 +1107,12 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
     }
     if (b16 && Ub != nullptr && ab >= 16) {      // NODE_TUNE_W4_ABLATE = 16 + bits: timing-only ablations of k_w4_gemm64b (results are wrong)
       switch (ab - 16) {
-#define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm); return;
+#define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on); return;
         W4B_AB(1) W4B_AB(2) W4B_AB(4) W4B_AB(5) W4B_AB(6) W4B_AB(7) W4B_AB(8) W4B_AB(12) W4B_AB(13) W4B_AB(14) W4B_AB(15) W4B_AB(3) W4B_AB(9) W4B_AB(10) W4B_AB(11)
 #undef W4B_AB
         default: break;
       }
-      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on);
       return;
     }
     if (b16 && Ub != nullptr && ab == 0) {
@@ -1117,7 +1128,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
         return;
       }
-      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm);
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on);
       return;
     }
     if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
