@@ -700,13 +700,19 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       asm volatile("" ::: "memory");   // (the compiler may not sink these requests to their first use behind the loop)
     }
   }
-  // --- this wave's own component: the whole 64 x 64 tile over the whole K range
+  // --- this wave's own component: the whole 64 x 64 tile over the whole K range.
+  // rot_on bit 1 (NODE_TUNE_W4_SHAREV, four column tiles only): the four waves of a workgroup take the SAME component and
+  // row tile and one column tile each -- they walk the same V blocks in lock-step, so three of their four requests for a
+  // block are served by the CU's own L1 / merged in flight -- instead of four components of one tile (nothing shared
+  // inside the CU).  The workgroup's place (tile % nCT) then names the component, the wave the column tile.
   {
-    const int comp = 4 * j + wave;
+    const bool sharev = (rot_on & 2) != 0 && nCT == 4;
+    const int comp = 4 * j + (sharev ? ct : wave);
+    const int oct = sharev ? wave : ct;
     W4BPtrs p;
     p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
-    p.b[0] = ublk(comp, 2 * ct); p.b[1] = ublk(comp, 2 * ct + 1);
-    p.mask = (rot_on && (G2 & (G2 - 1)) == 0) ? G2 - 1 : -1;
+    p.b[0] = ublk(comp, 2 * oct); p.b[1] = ublk(comp, 2 * oct + 1);
+    p.mask = ((rot_on & 1) && (G2 & (G2 - 1)) == 0) ? G2 - 1 : -1;
     p.rot = (5 * wave + 3 * tile + 7 * j) & (G2 - 1);
     float16_t acc[2][2];
 #pragma unroll
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
         for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
     w4b_run<W4B_DEPTH, 2, AB>(acc, p, 0, G2);
     const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
-    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
     if (!(AB & 4) || acc[0][0][0] == 123.456f)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1057,11 +1063,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
-struct W4Switches { int g64, b16, ablate, small, uf32, rot; };
+struct W4Switches { int g64, b16, ablate, small, uf32, rot, sharev; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
-          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_ROT", 0)};
+          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_ROT", 0), rd("NODE_TUNE_W4_SHAREV", 1)};
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1080,7 +1086,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   static bool attr[4][MAX_DEVICES] = {};
   const W4Switches sw = w4_switches();
   const int ab = sw.ablate;
-  const int rot_on = sw.rot;
+  const int rot_on = (sw.rot ? 1 : 0) | (sw.sharev ? 2 : 0);
   static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
