@@ -1239,16 +1239,20 @@ __global__ __launch_bounds__(256) void k_w4_wgrad(W4WgradArgs a) {
   const float4* pz0 = Z + (size_t)cot * N * 32 + h * 32 + l31;
   const size_t zcs = (size_t)nCO * N * 32;                     // float4s per component of Z
 
-  // --- this wave's own component over the whole reduction
+  // --- this wave's own component over the whole reduction.  a.sharev (NODE_TUNE_W4_SHAREV, nCO % 4 == 0): the four waves of a
+  // workgroup take ONE component and four neighbouring co tiles -- they walk the same V blocks (the 128-ci operand, 80 % of the
+  // launch's operand bytes) in lock-step and share them inside the CU -- instead of four components of one tile.
   {
-    const int comp = 4 * j + wave;
+    const bool sharev = a.sharev != 0 && (nCO & 3) == 0;
+    const int comp = 4 * j + (sharev ? (cot & 3) : wave);
+    const int ocot = sharev ? (cot & ~3) + wave : cot;
     float16_t acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-    w4_wg_run<R, 4>(acc, pa0 + (size_t)comp * cs, pz0 + (size_t)comp * zcs, 0, Q, rbs, 0);
-    float* o = dU + ((size_t)comp * C + cit * 128) * C + cot * 32 + l31;
+    w4_wg_run<R, 4>(acc, pa0 + (size_t)comp * cs, Z + (size_t)ocot * N * 32 + h * 32 + l31 + (size_t)comp * zcs, 0, Q, rbs, 0);
+    float* o = dU + ((size_t)comp * C + cit * 128) * C + ocot * 32 + l31;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -1459,7 +1463,9 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
       }
 }
 
-void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s) {
+void launch_w4_wgrad(const W4WgradArgs& a_in, hipStream_t s) {
+  W4WgradArgs a = a_in;
+  a.sharev = w4_switches().sharev;
   // NODE_TUNE_W4_WGRAD128 = 0 never / 1 wherever it fits / unset: long filters (C >= 512), where the fp32 kernel is bound by
   // the matrix pipe (read on every call: tests run both)
   {

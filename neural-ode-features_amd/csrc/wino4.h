@@ -118,6 +118,7 @@ struct W4WgradArgs {
   float* dU;
   const Ctrl* ctrl;                   // nullable: the launch returns at once when ctrl->done
   int N, C;
+  int sharev;                         // set by launch_w4_wgrad (NODE_TUNE_W4_SHAREV): the waves of a workgroup share one component's V stream
 };
 void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s);
 __host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C; }
