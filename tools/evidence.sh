@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 evidence: bench lines of cfg 2 / 3 / 5 (PMC traffic + CPU baseline at cfg 2), rocprofv3 step profiles, stem launch
-# times, deferred soak at tol 1e-5, bs = 1 latency.  Run from the repo root on the GPU box; writes gpurun_out/r04final/.
+# Per-round evidence: bench lines of cfg 2 / 3 / 5 (PMC traffic + CPU baseline at cfg 2), rocprofv3 step profiles, stem launch
+# times, deferred soak at tol 1e-5, bs = 1 latency.  Run from the repo root on the GPU box; writes gpurun_out/evidence/.
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04final
+O=gpurun_out/evidence
 mkdir -p $O
 R=$GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $O/bench_cfg2.json 2> $O/bench_cfg2.err
