@@ -54,7 +54,20 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        _check_asm_loads(verbose)
     return LIB
+
+
+def _check_asm_loads(verbose):
+    """After a relink: the in-flight-register guard for the kernels with inline-asm loads (tools/check_asm_loads.py)."""
+    tool = os.path.join(os.path.dirname(HERE), 'tools', 'check_asm_loads.py')
+    if not os.path.exists(tool):
+        return
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout.strip(), flush=True)
+    if r.returncode:
+        raise RuntimeError('inline-asm load guard failed:\n' + r.stdout + r.stderr)
 
 
 if __name__ == '__main__':

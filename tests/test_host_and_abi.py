@@ -240,3 +240,31 @@ def test_optimizer_and_training_loop_refuse_the_cpu():
         from neural_ode_features_amd import train as T
         with pytest.raises(SystemExit):
             T.main(['--dataset', 'mnist', '-e', '1', '--run-dir', '/tmp/never_created_run_dir_node'])
+
+
+def test_asm_load_guard_flags_a_register_touched_in_flight(tmp_path):
+    """tools/check_asm_loads.py (run by build.py after a relink): a planted move out of a register whose load has not been waited
+    for is reported; the same stream with the wait in front is clean; lanes of the other side of a divergent if are exempt."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_asm_loads', os.path.join(ROOT, 'tools', 'check_asm_loads.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def stream(body):
+        text = ''
+        for k, n in (('k_w4_gemm128b', 13), ('k_w4_wgrad128b', 14)):
+            text += '_ZN4node%d%sEv:\n%s\ts_endpgm\n.Lfunc_end_%s:\n' % (n, k, body, k)
+        p = tmp_path / 'k.s'
+        p.write_text(text)
+        return mod.check(str(p))
+
+    load = '\tglobal_load_dwordx4 v[8:11], v[4:5], off\n'
+    assert stream(load + '\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v1, v9\n') == []
+    bad = stream(load + '\tv_mov_b32 v1, v9\n\ts_waitcnt vmcnt(0)\n')
+    assert len(bad) == 2 and 'v9' in bad[0]
+    assert len(stream(load + load.replace('v[8:11]', 'v[12:15]') + '\ts_waitcnt vmcnt(1)\n\tv_add_f32 v0, v8, v8\n\tv_add_f32 v0, v12, v0\n')) == 2
+    assert len(stream(load + '\tscratch_store_dword off, v1, off\n\ts_waitcnt vmcnt(0)\n')) == 2
+    other = '\ts_and_saveexec_b64 s[6:7], s[0:1]\n' + load + '\ts_andn2_saveexec_b64 s[6:7], s[6:7]\n' + load + '\ts_or_b64 exec, exec, s[6:7]\n'
+    assert stream(other + '\ts_waitcnt vmcnt(0)\n') == []
+    assert len(stream(other + '\tv_mov_b32 v1, v8\n')) == 2
+    assert len(stream('\tv_mov_b32 v1, v8\n')) == 2         # no load at all: the kernel changed under the guard

@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Build-time guard for the two kernels whose operand requests are inline asm with hand-counted waits (k_w4_gemm128b,
+k_w4_wgrad128b; csrc/kernels_w4.hip): the compiler treats an asm load's '=v' destination as defined at the asm statement, so
+correctness relies on it never reading, copying, moving or overwriting that register while the request is in flight.  This
+script compiles kernels_w4.hip to device assembly and walks both kernels instruction by instruction: every
+`global_load_dwordx4` opens its destination registers, every `s_waitcnt vmcnt(N)` retires all but the N youngest vector-memory
+operations (the walk is linear in program order -- both kernels are straight-line apart from their
+one K loop, whose body begins and ends with nothing in flight), and ANY mention of an open register by another instruction (a use, a v_mov, an overwrite) -- or any scratch
+access -- is reported.  Exit code 1 on a violation.  (Advisor finding, round 3.)
+
+    python tools/check_asm_loads.py            # used by neural-ode-features_amd/build.py after linking
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'neural-ode-features_amd', 'csrc')
+KERNELS = ('k_w4_gemm128b', 'k_w4_wgrad128b')
+VMEM = re.compile(r'^\s*(global_|buffer_|flat_|scratch_)(load|store|atomic)')
+REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check(asm_path):
+    lines = open(asm_path).read().split('\n')
+    bad = []
+    for k in KERNELS:
+        start = next((i for i, ln in enumerate(lines) if re.match(r'^_ZN4node\d+%s' % k, ln)), None)
+        if start is None:
+            bad.append('%s: kernel not found in the assembly' % k)
+            continue
+        inflight = []       # [destination registers or None, line number, other_lanes] of vector-memory operations, oldest first
+        nloads = 0
+        for i in range(start + 1, len(lines)):
+            ln = lines[i].split(';')[0].strip()
+            if ln.startswith('.Lfunc_end'):
+                break
+            if not ln or ln.endswith(':') or ln.startswith('.') or ln.startswith('s_endpgm'):
+                continue
+            if ln.startswith('scratch_'):
+                bad.append('%s: scratch access at line %d: %s' % (k, i + 1, ln))
+            # the else side of a divergent if (`s_xor_b64 exec, exec, saved` / `s_andn2_saveexec_b64`) runs on the lanes the then side did not: what the then
+            # side left in flight is on other lanes until the paths rejoin (`s_or_b64 exec, exec, saved`)
+            if re.match(r's_xor_b64\s+exec,\s*exec,', ln) or ln.startswith('s_andn2_saveexec_b64'):
+                for e in inflight:
+                    e[2] = True
+            elif re.match(r's_or_b64\s+exec,\s*exec,', ln):
+                for e in inflight:
+                    e[2] = False
+            m = re.match(r's_waitcnt.*vmcnt\((\d+)\)', ln)
+            if m:
+                keep = int(m.group(1))
+                inflight = inflight[len(inflight) - keep:] if keep else []
+                continue
+            if ln.startswith('s_waitcnt') and 'vmcnt' not in ln:
+                continue
+            if VMEM.match(ln):
+                ops = ln.split(None, 1)[1] if ' ' in ln else ''
+                if ln.startswith('global_load_dwordx4'):
+                    dest = regs_of(ops.split(',')[0])
+                    src = regs_of(','.join(ops.split(',')[1:]))
+                    nloads += 1
+                else:
+                    dest, src = None, regs_of(ops)
+                hit = [r for d, _, o in inflight if d and not o for r in d if r in src or (dest and r in dest)]
+                if hit:
+                    bad.append('%s: line %d touches v%d while its load is in flight: %s' % (k, i + 1, hit[0], ln))
+                inflight.append([dest, i + 1, False])
+                continue
+            touched = regs_of(ln)
+            hit = [r for d, _, o in inflight if d and not o for r in d if r in touched]
+            if hit:
+                bad.append('%s: line %d touches v%d while its load is in flight: %s' % (k, i + 1, hit[0], ln))
+        if nloads == 0:
+            bad.append('%s: no global_load_dwordx4 found (did the kernel change?)' % k)
+    return bad
+
+
+def main():
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'kw4.s')
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-S', '--cuda-device-only',
+               os.path.join(CSRC, 'kernels_w4.hip'), '-o', out]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        bad = check(out)
+    for b in bad:
+        print('check_asm_loads:', b)
+    print('check_asm_loads: %s' % ('%d violation(s)' % len(bad) if bad else 'ok (%s)' % ', '.join(KERNELS)))
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
