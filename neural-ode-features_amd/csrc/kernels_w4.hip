@@ -423,8 +423,11 @@ struct W4Split { w4_bf16x8 h, m, l; };
 // and level instead of four.  No launch got faster (cfg 2 GEMM 23.2 vs 22.5 us by events, cfg 5 382 vs 383), and the compiler
 // folded the (-1, 0) pair into an inline constant the instruction reads as (0, -1): wrong remainders for every even element,
 // caught by tests/test_gpu_w4.py::test_w4_split_is_exact_on_the_device, which stays.)
+// (the subtraction as ONE v_pk_add_f32 -- written as `x - convert(part)` the compiler emits two v_add_f32: 126 instead of 63
+//  instructions per four K steps of k_w4_gemm64b, whose clock the chip holds down under load: fewer VALU instructions per MFMA is
+//  what raises it, MI355X_MICROARCH.md 'DVFS give-back')
 __device__ __forceinline__ w4_f32x2 w4_minus_part(const w4_f32x2& x, const w4_bf16x2& part) {
-  return x - __builtin_convertvector(part, w4_f32x2);
+  return x + (-__builtin_convertvector(part, w4_f32x2));   // (a two-float fadd is a legal packed operation; the fsub is expanded)
 }
 __device__ __forceinline__ W4Split w4_split8(const float4& p, const float4& q) {
   const w4_f32x2 v[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
@@ -477,15 +480,14 @@ __device__ __forceinline__ void w4_mac6(float16_t& acc, const W4Split& a, const 
 constexpr int W4B_DEPTH = 4;   // K = 16 steps (two g blocks each) in flight
 
 struct W4BStage { float4 a[2][2]; w4_u32x4 b[2][3]; };   // [row block][g of the pair], [column block][part]
-// rot / mask (NODE_TUNE_W4_ROT = 1, measured and NOT kept, round 4): the K steps of a wave's own component in ROTATED order, step
-// (g + rot) & mask.  The idea: every wave walks its operand streams with the same power-of-two strides (512 KB between
-// components, 32 KB between row blocks), so all of an XCD's waves might camp on a few L2 channels.  Measured: 18.2 -> 19.8 us
-// per launch, cfg 2 24 870 -> 24 480 images/s -- the waves that SHARE an operand block (4 column tiles read a V block, 8 row
-// tiles a U block) ask for it at the same time in the lock-step order and are served by one L2 fill; rotated, they are not.
-struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; int rot, mask; };
+// (Measured and removed, round 4: the K steps of a wave's own component in a per-wave ROTATED order against L2-channel camping --
+// every wave walks its streams with the same power-of-two strides.  18.2 -> 19.8 us per launch, cfg 2 24 870 -> 24 480 images/s: the
+// waves that SHARE an operand block ask for it at the same time in the lock-step order and are served by one L2 fill; rotated,
+// they are not.  And there is no camping to cure: pulling every block 1 - 11 KB out of the power-of-two spacing changes nothing
+// (tools/w4_pad.sh, profiles/r04_w4_gemm_pad.txt).)
+struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; };
 template <int NRB>
-__device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2in) {
-  const int g2 = p.mask >= 0 ? ((g2in + p.rot) & p.mask) : g2in;
+__device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2) {
 #pragma unroll
   for (int r = 0; r < NRB; ++r) {
     s.a[r][0] = p.a[r][(size_t)(2 * g2) * 64];
@@ -583,8 +585,32 @@ __device__ __forceinline__ void w4f_run(float16_t (&acc)[2][2], const W4FPtrs& p
 // timing-only ablations (NODE_TUNE_W4_ABLATE, results are wrong): AB bit 2 -- requests without the split / MFMA work (every
 // loaded register is folded into one accumulator element, so the requests and their waits stay); AB bit 8 -- the split /
 // MFMA work on whatever the registers hold, no requests
-template <int D, int NRB, int AB = 0>
-__device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p, int g0, int n) {
+// stamps (timing diagnostics, NODE_TUNE_W4_STAMPS): wall-clock ticks (100 MHz) of lane 0 -- [1] ring requested, [2] first step's operands
+// arrived and multiplied, [3] loop done
+__device__ __forceinline__ void w4_stamp(unsigned long long* st, int k) {
+  if (st != nullptr && (threadIdx.x & 63) == 0) { st[k] = wall_clock64(); st[8 + k] = clock64(); }
+}
+struct W4BCursor { const float4* a[2]; const w4_u32x4* b[2]; };
+template <int NRB>
+__device__ __forceinline__ void w4b_next(W4BStage& s, W4BCursor& cu) {   // the next K = 16 step of the streams
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) {
+    s.a[r][0] = cu.a[r][0];
+    s.a[r][1] = cu.a[r][64];
+    cu.a[r] += 128;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s.b[c][q] = cu.b[c][q * 64];
+    cu.b[c] += 192;
+  }
+}
+struct W4Nothing { __device__ __forceinline__ void operator()() const {} };
+// after_fill: called once the ring's first D steps are requested (k_w4_gemm64b puts the shared component's requests there)
+template <int D, int NRB, int AB = 0, class F = W4Nothing>
+__device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p, int g0, int n, unsigned long long* st = nullptr,
+                                        F after_fill = F()) {
   W4BStage ring[D];
   if (AB & 8) {
     const int lane = threadIdx.x & 63;
@@ -637,15 +663,24 @@ __device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p
     acc[0][0][0] += sink;
     return;
   }
+  // the operand streams as running pointers (one 64-bit add per stream and step; the loads of a step differ by immediates)
+  W4BCursor cu;
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) cu.a[r] = p.a[r] + (size_t)(2 * g0) * 64;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) cu.b[c] = p.b[c] + (size_t)(3 * g0) * 64;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    w4b_load<NRB>(ring[i], p, g0 + i);
+    w4b_next<NRB>(ring[i], cu);
     __builtin_amdgcn_sched_barrier(0);
   }
+  after_fill();
   W4Split cur[2], nxt[2];
+  w4_stamp(st, 1);
 #pragma unroll
   for (int r = 0; r < NRB; ++r) cur[r] = w4_split8(ring[0].a[r][0], ring[0].a[r][1]);
   for (int g = g0; g < g0 + n; g += D) {
+    if (g == g0 + D) w4_stamp(st, 2);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       const W4BStage& ns = ring[(i + 1) % D];          // the step after this one (refilled D - 1 steps ago)
@@ -658,39 +693,52 @@ __device__ __forceinline__ void w4b_run(float16_t (&acc)[2][2], const W4BPtrs& p
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // ... then up to four VALU instructions of the split
       }
       __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
-      w4b_load<NRB>(ring[i], p, g + D + i);
+      w4b_next<NRB>(ring[i], cu);
 #pragma unroll
       for (int r = 0; r < NRB; ++r) cur[r] = nxt[r];
     }
   }
+  w4_stamp(st, 3);
 }
 
 template <int AB>
 __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
-                                                    const Ctrl* ctrl, W4Geom gm, int rot_on) {
+                                                    const Ctrl* ctrl, W4Geom gm, int mode, unsigned long long* stamps) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* st = stamps != nullptr ? stamps + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  w4_stamp(st, 0);
   const int l31 = lane & 31, hi = lane >> 5;
   const int nCT = gm.C >> 6, nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;
   const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
   const int rt = tile / nCT, ct = tile - rt * nCT;
   const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
-  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
-  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
+  // (timing experiments only, NODE_TUNE_W4_PAD = "v,u" with NODE_TUNE_W4_ABLATE >= 16, results wrong: the operand blocks' starts pulled
+  // v / u KB per block out of their power-of-two spacing -- do the streams, which all walk K in the same order, camp on L2 channels?)
+  const int padv = (mode >> 8) & 0xff, padu = (mode >> 16) & 0xff;
+  auto vblk = [&](int comp, int rb) {
+    const size_t b = (size_t)comp * nRB + rb;
+    return reinterpret_cast<const float4*>(V + (b * G8) * 256 - b * padv * 256 + a_off);
+  };
+  auto ublk = [&](int comp, int cb) {
+    const size_t b = (size_t)comp * CB + cb;
+    return reinterpret_cast<const w4_u32x4*>(Ub) + (b * G2) * 192 - b * padu * 64 + lane;
+  };
 
   // The shared component's operands (four K = 16 steps per wave at C = 256: 128 registers -- the kernel runs one wave per
   // SIMD, so the file's other half is free) are requested BEFORE the own component's loop: nothing else would cover their
   // latency behind it (the ablation of DESIGN.md 4.7: the second ring fill cost ~3 of the shared component's 4.7 us).
   constexpr int SH = 4;
   const bool early = !(AB & 1) && !(AB & 2) && !(AB & 8) && (G2 >> 2) == SH;
+  // mode bit 3 (NODE_TUNE_W4_EARLY = 1): ... and BEHIND the ring's first four steps, whose operands the first MFMA waits for (the
+  // texture path takes a CU's requests at 64 B per clock: 32 KB per wave in front of them is ~1 us)
   W4BStage shr[SH];
-  {
+  auto request_shared = [&]() {
     const int scomp = 32 + (j >> 1), srb = 2 * rt + (j & 1);
     W4BPtrs sp;
     sp.a[0] = vblk(scomp, srb); sp.a[1] = sp.a[0];
     sp.b[0] = ublk(scomp, 2 * ct); sp.b[1] = ublk(scomp, 2 * ct + 1);
-    sp.rot = 0; sp.mask = -1;
     if (early) {
 #pragma unroll
       for (int i = 0; i < SH; ++i) {
@@ -699,21 +747,25 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       }
       asm volatile("" ::: "memory");   // (the compiler may not sink these requests to their first use behind the loop)
     }
-  }
+  };
+  const bool behind = (mode & 8) != 0;
+  if (!behind) request_shared();
   // --- this wave's own component: the whole 64 x 64 tile over the whole K range.
-  // rot_on bit 1 (NODE_TUNE_W4_SHAREV, four column tiles only): the four waves of a workgroup take the SAME component and
+  // mode bit 1 (NODE_TUNE_W4_SHAREV, four column tiles only): the four waves of a workgroup take the SAME component and
   // row tile and one column tile each -- they walk the same V blocks in lock-step, so three of their four requests for a
   // block are served by the CU's own L1 / merged in flight -- instead of four components of one tile (nothing shared
   // inside the CU).  The workgroup's place (tile % nCT) then names the component, the wave the column tile.
   {
-    const bool sharev = (rot_on & 2) != 0 && nCT == 4;
-    const int comp = 4 * j + (sharev ? ct : wave);
-    const int oct = sharev ? wave : ct;
+    const bool sharev = (mode & 2) != 0 && nCT == 4;
+    // mode bit 2 (NODE_TUNE_W4_SHAREV = 2; four column tiles, row tiles a multiple of two): a workgroup takes a 128 x 128 tile of
+    // one component, wave (r, c) its 64 x 64 quarter: two waves walk each V block together, two each U block
+    const bool share2 = (mode & 4) != 0 && nCT == 4 && (nRB & 3) == 0;
+    const int comp = 4 * j + (share2 ? (tile & 3) : sharev ? ct : wave);
+    const int oct = share2 ? 2 * ((tile >> 2) & 1) + (wave & 1) : sharev ? wave : ct;
+    const int ort = share2 ? 2 * (tile >> 3) + (wave >> 1) : rt;
     W4BPtrs p;
-    p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
+    p.a[0] = vblk(comp, 2 * ort); p.a[1] = vblk(comp, 2 * ort + 1);
     p.b[0] = ublk(comp, 2 * oct); p.b[1] = ublk(comp, 2 * oct + 1);
-    p.mask = ((rot_on & 1) && (G2 & (G2 - 1)) == 0) ? G2 - 1 : -1;
-    p.rot = (5 * wave + 3 * tile + 7 * j) & (G2 - 1);
     float16_t acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -721,9 +773,9 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
-    w4b_run<W4B_DEPTH, 2, AB>(acc, p, 0, G2);
+    w4b_run<W4B_DEPTH, 2, AB>(acc, p, 0, G2, st, [&]() { if (behind) request_shared(); });
     const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
-    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
+    float* m0 = M + ((size_t)(ort * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
     if (!(AB & 4) || acc[0][0][0] == 123.456f)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -733,6 +785,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       st_wt(o + 8 * sstride, acc[1][0][q]);
       st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q]);
     }
+    w4_stamp(st, 4);
   }
   // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
   if (!(AB & 1)) {
@@ -741,7 +794,6 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     W4BPtrs p;
     p.a[0] = vblk(scomp, rb); p.a[1] = p.a[0];
     p.b[0] = ublk(scomp, 2 * ct); p.b[1] = ublk(scomp, 2 * ct + 1);
-    p.rot = 0; p.mask = -1;
     float16_t acc[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -757,6 +809,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
     } else if (ng % 4 == 0) w4b_run<4, 1, AB>(acc, p, g0, ng);
     else if (ng % 2 == 0) w4b_run<2, 1, AB>(acc, p, g0, ng);
     else w4b_run<1, 1, AB>(acc, p, g0, ng);
+    w4_stamp(st, 5);
     float* red = smem + wave * 2048;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -782,6 +835,224 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       st_wt(mrow + 64, s.z);
       st_wt(mrow + 96, s.w);
     }
+  }
+  if (st != nullptr) {   // (diagnostics: when this wave's stores have drained)
+    w4_stamp(st, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w4_stamp(st, 7);
+  }
+}
+
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm64l (NODE_TUNE_W4_LDS, C = 256, N % 32 == 0): k_w4_gemm64b's products with the own component's operands brought into
+// the CU ONCE.  What bounds k_w4_gemm64b is the bytes its waves load into registers (every operand block aliased onto one
+// 80 KB footprint -- all L2 hits -- it takes 17.3 instead of 18.5 us): 160 KB per wave, 640 KB per CU for the own
+// component.  Here a workgroup takes a 128 x 128 tile of one component (wave (r, c) its 64 x 64 quarter, as NODE_TUNE_W4_SHAREV = 2)
+// and the 320 KB of operands of that tile arrive by LDS-DMA (global_load_lds_dwordx4: no registers, no staging instructions)
+// in a ring of W4L_NS K = 16 steps of 20 KB (V: 4 row blocks x 2 KB fp32; U: 4 column blocks x 3 KB triples), W4L_D steps in
+// flight; the LDS image of a block is in READER-lane order (the permutation sits on the DMA's per-lane source address), so a
+// fragment is one conflict-free ds_read_b128.  One raw s_barrier per step behind a counted s_waitcnt vmcnt (never 0 inside the
+// loop: cdna_hip_programming.md, Pipelining across barriers); a slot is refilled D + 1 steps after its reads were waited for.
+// The shared component (1/9 of the work, no operand shared between waves) keeps k_w4_gemm64b's register path and early requests.
+// ----------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* w4_lds_ptr_t;
+constexpr int W4L_NS = 7, W4L_D = 6, W4L_SLOT = 20 * 1024, W4L_STEPS = 16;
+// one LDS-DMA piece as inline asm: the compiler, which does not count asm memory operations, then neither drains the ring
+// (`s_waitcnt vmcnt(0)`) in front of every fragment read -- with the builtin it does: it cannot tell the reads from the pieces in
+// flight -- nor knows of it: the counted waits of the loop are the only ordering (cdna_hip_programming.md 5.7: M0 is written in the
+// statement that reads it)
+__device__ __forceinline__ void w4l_dma(const unsigned char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void w4l_wait_vm(int n) {   // (n is a compile-time constant after unrolling)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+__global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
+                                                    const Ctrl* ctrl, W4Geom gm, unsigned long long* stamps) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lsm[];   // [W4L_NS][20 KB]; the shared component's reduction in slots 2, 3
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* stp = stamps != nullptr ? stamps + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  w4_stamp(stp, 0);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 6, nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rt = tile / nCT, ct = tile - rt * nCT;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
+
+  // the shared component's operands, requested first (k_w4_gemm64b)
+  constexpr int SH = 4;
+  W4BStage shr[SH];
+  {
+    const int scomp = 32 + (j >> 1), srb = 2 * rt + (j & 1);
+    W4BPtrs sp;
+    sp.a[0] = vblk(scomp, srb); sp.a[1] = sp.a[0];
+    sp.b[0] = ublk(scomp, 2 * ct); sp.b[1] = ublk(scomp, 2 * ct + 1);
+#pragma unroll
+    for (int i = 0; i < SH; ++i) {
+      w4b_load<1>(shr[i], sp, wave * SH + i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::: "memory");
+  }
+
+  // --- own component: the 128 x 128 tile (RT, CT) of component comp; wave (wr, wc) multiplies its 64 x 64 quarter
+  const int comp = 4 * j + (tile & 3), RT = tile >> 3, CT = (tile >> 2) & 1;
+  const int wr = wave >> 1, wc = wave & 1;
+  // the five of a step's twenty 1-KB pieces this wave brings: pieces 0 .. 7 = V (row block p / 2, g block p % 2), 8 .. 19 = U
+  // (column block (p - 8) / 3, part (p - 8) % 3); a piece's source advances by 2 KB (V) / 3 KB (U) per step
+  const unsigned char* src[5];
+  int adv[5], dst[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int p = 5 * wave + i;
+    if (p < 8) {
+      src[i] = reinterpret_cast<const unsigned char*>(vblk(comp, 4 * RT + (p >> 1))) + (p & 1) * 1024;
+      adv[i] = 2048;
+    } else {
+      const int q = p - 8;
+      src[i] = reinterpret_cast<const unsigned char*>(ublk(comp, 4 * CT + q / 3)) + (q % 3) * 1024;
+      adv[i] = 3072;
+    }
+    dst[i] = p * 1024;
+  }
+  const unsigned slot0 = (unsigned)(size_t)(w4_lds_ptr_t)lsm;   // LDS byte address of the ring
+  auto issue = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      w4l_dma(src[i] + (size_t)step * adv[i], slot0 + (unsigned)((step % W4L_NS) * W4L_SLOT + dst[i]));
+  };
+  auto fetch = [&](W4BStage& st, int step) {
+    const unsigned char* slot = lsm + (step % W4L_NS) * W4L_SLOT + lane * 16;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) st.a[r][g] = *reinterpret_cast<const float4*>(slot + ((2 * wr + r) * 2 + g) * 1024);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) st.b[c][q] = *reinterpret_cast<const w4_u32x4*>(slot + 8192 + ((2 * wc + c) * 3 + q) * 1024);
+  };
+  {
+    float16_t acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < W4L_D; ++sp) issue(sp);
+    w4_stamp(stp, 1);
+    W4BStage st[2];
+    w4l_wait_vm(5 * (W4L_D - 1));
+    __builtin_amdgcn_s_barrier();
+    issue(W4L_D);
+    fetch(st[0], 0);
+    W4Split cur[2], nxt[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) cur[r] = w4_split8(st[0].a[r][0], st[0].a[r][1]);
+#pragma unroll
+    for (int g = 0; g < W4L_STEPS; ++g) {
+      if (g == 4) w4_stamp(stp, 2);
+      W4BStage& cs = st[g & 1];
+      W4BStage& ns = st[(g + 1) & 1];
+      if (g + 1 < W4L_STEPS) {
+        const int newest = (g + W4L_D < W4L_STEPS - 1) ? g + W4L_D : W4L_STEPS - 1;   // the youngest step whose pieces are issued
+        w4l_wait_vm(5 * (newest - (g + 1)));            // this wave's pieces of step g + 1 have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads of step g are in registers (the slot may be refilled)
+        __builtin_amdgcn_s_barrier();
+        if (g + 1 + W4L_D < W4L_STEPS) issue(g + 1 + W4L_D);
+        fetch(ns, g + 1);
+      }
+      w4b_mac<2>(acc, cur, cs);
+      if (g + 1 < W4L_STEPS) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) nxt[r] = w4_split8(ns.a[r][0], ns.a[r][1]);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);    // eight MFMAs cover the fragment reads' latency ...
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // ... then one MFMA,
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  //     up to six VALU instructions of the next step's split
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) cur[r] = nxt[r];
+    }
+    w4_stamp(stp, 3);
+    const int ort = 2 * RT + wr, oct = 2 * CT + wc;
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+    float* m0 = M + ((size_t)(ort * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      st_wt(o, acc[0][0][q]);
+      st_wt(o + 36 * 128, acc[0][1][q]);
+      st_wt(o + 8 * sstride, acc[1][0][q]);
+      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q]);
+    }
+    w4_stamp(stp, 4);
+  }
+  // --- half a tile of a shared component (k_w4_gemm64b): rows [32 half, 32 half + 32), K range of wave `wave`
+  {
+    const int scomp = 32 + (j >> 1), rb = 2 * rt + (j & 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
+    W4Split cs[2];
+#pragma unroll
+    for (int i = 0; i < SH; ++i) {
+      cs[0] = w4_split8(shr[i].a[0][0], shr[i].a[0][1]);
+      w4b_mac<1>(acc, cs, shr[i]);
+    }
+    w4_stamp(stp, 5);
+    float* smem = reinterpret_cast<float*>(lsm + 2 * W4L_SLOT);   // (slots 2, 3: steps 9, 10 -- read long ago by every wave)
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + c * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(acc[0][c][4 * r4], acc[0][c][4 * r4 + 1], acc[0][c][4 * r4 + 2], acc[0][c][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk = u >> 8, r4 = (u >> 6) & 3;
+      float4 s = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
+      st_wt(mrow, s.x);
+      st_wt(mrow + 32, s.y);
+      st_wt(mrow + 64, s.z);
+      st_wt(mrow + 96, s.w);
+    }
+  }
+  if (stp != nullptr) {
+    w4_stamp(stp, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w4_stamp(stp, 7);
   }
 }
 
@@ -1063,11 +1334,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
-struct W4Switches { int g64, b16, ablate, small, uf32, rot, sharev; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
-          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_ROT", 0), rd("NODE_TUNE_W4_SHAREV", 1)};
+          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0)};
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1086,7 +1357,14 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   static bool attr[4][MAX_DEVICES] = {};
   const W4Switches sw = w4_switches();
   const int ab = sw.ablate;
-  const int rot_on = (sw.rot ? 1 : 0) | (sw.sharev ? 2 : 0);
+  int mode = (sw.sharev == 1 ? 2 : 0) | (sw.sharev == 2 ? 4 : 0) | (sw.early ? 8 : 0);
+  unsigned long long* stamps = nullptr;   // NODE_TUNE_W4_STAMPS = device address of [grid * 4][16] u64 (tools/w4_stamps.py; diagnostics)
+  { const char* e = getenv("NODE_TUNE_W4_STAMPS"); if (e != nullptr) stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)); }
+  if (ab >= 16) {
+    const char* e = getenv("NODE_TUNE_W4_PAD");
+    int pv = 0, pu = 0;
+    if (e != nullptr && sscanf(e, "%d,%d", &pv, &pu) == 2) mode |= ((pv & 0xff) << 8) | ((pu & 0xff) << 16);
+  }
   static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
@@ -1113,12 +1391,12 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
     }
     if (b16 && Ub != nullptr && ab >= 16) {      // NODE_TUNE_W4_ABLATE = 16 + bits: timing-only ablations of k_w4_gemm64b (results are wrong)
       switch (ab - 16) {
-#define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on); return;
+#define W4B_AB(X) case X: hipLaunchKernelGGL(k_w4_gemm64b<X>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps); return;
         W4B_AB(1) W4B_AB(2) W4B_AB(4) W4B_AB(5) W4B_AB(6) W4B_AB(7) W4B_AB(8) W4B_AB(12) W4B_AB(13) W4B_AB(14) W4B_AB(15) W4B_AB(3) W4B_AB(9) W4B_AB(10) W4B_AB(11)
 #undef W4B_AB
         default: break;
       }
-      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on);
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }
     if (b16 && Ub != nullptr && ab == 0) {
@@ -1134,7 +1412,13 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
         return;
       }
-      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, rot_on);
+      if (sw.lds != 0 && C == 256 && N % 32 == 0) {      // NODE_TUNE_W4_LDS: the own component's operands through an LDS-DMA ring
+        static bool attrl[MAX_DEVICES] = {};
+        allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm64l), attrl);
+        hipLaunchKernelGGL(k_w4_gemm64l, dim3(grid64), dim3(256), (size_t)W4L_NS * W4L_SLOT, s, V, Ub, M, ctrl, gm, stamps);
+        return;
+      }
+      hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }
     if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);

@@ -44,6 +44,26 @@ def _conv_w4(x, w, dgrad):
     return y
 
 
+@pytest.mark.parametrize('switch', ['NODE_TUNE_W4_SHAREV=0', 'NODE_TUNE_W4_SHAREV=2', 'NODE_TUNE_W4_EARLY=1', 'NODE_TUNE_W4_LDS=1'])
+@pytest.mark.parametrize('shape', [(128, 256, 8, 8), (32, 256, 8, 8), (8, 256, 16, 16)])
+def test_w4_gemm_work_assignments_are_bit_identical(shape, switch):
+    """k_w4_gemm64b's alternative assignments of a component's tiles to waves (NODE_TUNE_W4_SHAREV 0 / 1 / 2), the place of the
+    shared component's requests (NODE_TUNE_W4_EARLY) and the LDS-DMA ring variant k_w4_gemm64l (NODE_TUNE_W4_LDS, measured and not
+    the default: DESIGN.md 4.2) multiply the same operands in the same order per output element: the convolution is bit-identical."""
+    N, Cc, H, W = shape
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cc, H, W, generator=gen).cuda()
+    w = ((torch.rand(Cc, Cc + 1, 3, 3, generator=gen) * 2 - 1) / (9 * Cc) ** 0.5).cuda()
+    want = _conv_w4(x, w, 0)
+    key, val = switch.split('=')
+    os.environ[key] = val
+    try:
+        got = _conv_w4(x, w, 0)
+    finally:
+        del os.environ[key]
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize('shape', [(8, 64, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8),
                                    (2, 128, 16, 16), (8, 128, 16, 16), (4, 256, 16, 16), (2, 1024, 16, 16),
                                    (16, 128, 16, 16), (8, 1024, 16, 16)])

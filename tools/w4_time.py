@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_ode_features_amd import _lib
 
+if os.environ.get('NODE_HIP_LIB_AB'):      # A/B of two builds of the library on one box
+    _lib.LIB_PATH = os.environ['NODE_HIP_LIB_AB']
 lib = _lib.load()
 N, Cc, side = (int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else (128, 256, 8)))    # cfg 5: 64,1024,16
 shape = _lib.NodeShape(N, Cc, side, side, 32, 1e-5)
