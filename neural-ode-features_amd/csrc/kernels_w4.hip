@@ -857,7 +857,8 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 // The shared component (1/9 of the work, no operand shared between waves) keeps k_w4_gemm64b's register path and early requests.
 // ----------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* w4_lds_ptr_t;
-constexpr int W4L_NS = 7, W4L_D = 6, W4L_SLOT = 20 * 1024, W4L_STEPS = 16;
+constexpr int W4L_SPS = 2;                          // K steps per ring slot = per barrier
+constexpr int W4L_NS = 4, W4L_D = 3, W4L_STEP = 20 * 1024, W4L_SLOT = W4L_SPS * W4L_STEP, W4L_STEPS = 16, W4L_SLOTS = W4L_STEPS / W4L_SPS;
 // one LDS-DMA piece as inline asm: the compiler, which does not count asm memory operations, then neither drains the ring
 // (`s_waitcnt vmcnt(0)`) in front of every fragment read -- with the builtin it does: it cannot tell the reads from the pieces in
 // flight -- nor knows of it: the counted waits of the loop are the only ordering (cdna_hip_programming.md 5.7: M0 is written in the
@@ -931,13 +932,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V,
     dst[i] = p * 1024;
   }
   const unsigned slot0 = (unsigned)(size_t)(w4_lds_ptr_t)lsm;   // LDS byte address of the ring
-  auto issue = [&](int step) {
+  auto issue = [&](int sl) {                                      // ring slot sl = K steps [SPS sl, SPS sl + SPS)
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-      w4l_dma(src[i] + (size_t)step * adv[i], slot0 + (unsigned)((step % W4L_NS) * W4L_SLOT + dst[i]));
+    for (int k = 0; k < W4L_SPS; ++k) {
+      const int step = sl * W4L_SPS + k;
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        w4l_dma(src[i] + (size_t)step * adv[i], slot0 + (unsigned)((sl % W4L_NS) * W4L_SLOT + k * W4L_STEP + dst[i]));
+    }
   };
   auto fetch = [&](W4BStage& st, int step) {
-    const unsigned char* slot = lsm + (step % W4L_NS) * W4L_SLOT + lane * 16;
+    const unsigned char* slot = lsm + ((step / W4L_SPS) % W4L_NS) * W4L_SLOT + (step % W4L_SPS) * W4L_STEP + lane * 16;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V,
     for (int sp = 0; sp < W4L_D; ++sp) issue(sp);
     w4_stamp(stp, 1);
     W4BStage st[2];
-    w4l_wait_vm(5 * (W4L_D - 1));
+    w4l_wait_vm(5 * W4L_SPS * (W4L_D - 1));
     __builtin_amdgcn_s_barrier();
     issue(W4L_D);
     fetch(st[0], 0);
@@ -972,11 +977,14 @@ __global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V,
       W4BStage& cs = st[g & 1];
       W4BStage& ns = st[(g + 1) & 1];
       if (g + 1 < W4L_STEPS) {
-        const int newest = (g + W4L_D < W4L_STEPS - 1) ? g + W4L_D : W4L_STEPS - 1;   // the youngest step whose pieces are issued
-        w4l_wait_vm(5 * (newest - (g + 1)));            // this wave's pieces of step g + 1 have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads of step g are in registers (the slot may be refilled)
-        __builtin_amdgcn_s_barrier();
-        if (g + 1 + W4L_D < W4L_STEPS) issue(g + 1 + W4L_D);
+        if ((g + 1) % W4L_SPS == 0) {                     // step g + 1 opens ring slot S
+          const int S = (g + 1) / W4L_SPS;
+          const int newest = (S + W4L_D - 1 < W4L_SLOTS - 1) ? S + W4L_D - 1 : W4L_SLOTS - 1;   // the youngest slot whose pieces are issued
+          w4l_wait_vm(5 * W4L_SPS * (newest - S));            // this wave's pieces of slot S have landed
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and its reads of slot S - 1 are in registers (that slot is refilled next)
+          __builtin_amdgcn_s_barrier();
+          if (S + W4L_D < W4L_SLOTS) issue(S + W4L_D);
+        }
         fetch(ns, g + 1);
       }
       w4b_mac<2>(acc, cur, cs);
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V,
       w4b_mac<1>(acc, cs, shr[i]);
     }
     w4_stamp(stp, 5);
-    float* smem = reinterpret_cast<float*>(lsm + 2 * W4L_SLOT);   // (slots 2, 3: steps 9, 10 -- read long ago by every wave)
+    float* smem = reinterpret_cast<float*>(lsm + 1 * W4L_SLOT);   // (ring slot 1, last K steps 10 and 11: read long ago by every wave)
     float* red = smem + wave * 2048;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1055,6 +1063,143 @@ __global__ __launch_bounds__(256) void k_w4_gemm64l(const float* __restrict__ V,
     w4_stamp(stp, 7);
   }
 }
+
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm64k (NODE_TUNE_W4_KSPLIT, C = 256, N % 16 == 0): k_w4_gemm64b's products with TWO waves per SIMD.  The timeline of
+// k_w4_gemm64b (tools/w4_stamps.py): the chip holds ~1.65 GHz in the launch, where the 432 MFMAs of a wave are
+// 8.4 us and the 768 KB a CU's waves request are 7.5 us of its texture path (64 B per clock) -- but with one wave per SIMD the two
+// do not overlap: a wave that stands in a request (the path's queue is full) or in a wait issues no MFMA.  Here every 64 x 64 tile
+// of a component is cut in two K halves, one wave each, so a SIMD holds two waves (<= 256 registers: a ring of two K steps
+// instead of four -- the requests in flight per SIMD stay what they were) and one multiplies while the other stands.
+//   workgroup (512 of them, two per CU) = component 4 j + c4, row tile rt, column tiles 2 p and 2 p + 1: wave 2 t + h = K half h of
+//   tile t (the two tiles walk the same V blocks); the halves meet in LDS: wave h keeps row block h of the tile, hands the other
+//   one over (8 KB), adds its partner's and stores 32 x 64 results.  The four K-sliced components (32 + j / 2): a 32 x 32 piece per
+//   workgroup, four K steps per wave, summed through LDS as in k_w4_gemm64b.  Sums of two K halves: not bit-identical to
+//   k_w4_gemm64b's single chain (same error against fp64).
+// ----------------------------------------------------------------------------
+struct W4KStage { float4 a[2]; w4_u32x4 b[3]; };
+__global__ __launch_bounds__(256, 2) void k_w4_gemm64k(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
+                                                       const Ctrl* ctrl, W4Geom gm, unsigned long long* stamps) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 32 KB: [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* st = stamps != nullptr ? stamps + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+  w4_stamp(st, 0);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
+  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + rb) * G8) * 256 + a_off); };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
+  const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+
+  // the K-sliced component's piece of this workgroup: rows rbs (32), column block cbs (32), K steps [4 wave, 4 wave + 4)
+  const int scomp = 32 + (j >> 1);
+  const int rbs = 2 * (idx >> 3) + (j & 1), cbs = 2 * ((idx >> 1) & 3) + (idx & 1);
+  const int SG = G2 >> 2;                        // its K steps per wave
+  const float4* sa = vblk(scomp, rbs) + (size_t)(2 * wave * SG) * 64;
+  const w4_u32x4* sb = ublk(scomp, cbs) + (size_t)(3 * wave * SG) * 64;
+  auto snext = [&](W4KStage& s) {
+    s.a[0] = sa[0]; s.a[1] = sa[64];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s.b[q] = sb[q * 64];
+    sa += 128; sb += 192;
+  };
+
+  // --- own component: K half h of the 64 x 64 tile (rt, 2 p + t)
+  const int comp = 4 * j + (idx & 3), rt = idx >> 3, t = wave >> 1, h = wave & 1;
+  const int ct = 2 * ((idx >> 2) & 1) + t;
+  W4KStage sring[2];
+  {
+    W4BPtrs p;
+    p.a[0] = vblk(comp, 2 * rt); p.a[1] = vblk(comp, 2 * rt + 1);
+    p.b[0] = ublk(comp, 2 * ct); p.b[1] = ublk(comp, 2 * ct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+    w4b_run<2, 2, 0>(acc, p, h * (G2 >> 1), G2 >> 1, st);
+    // the K-sliced piece's first two steps are requested now: they arrive under the exchange and the stores
+    snext(sring[0]);
+    snext(sring[1]);
+    asm volatile("" ::: "memory");
+    // the halves meet: wave h hands row block 1 - h over and keeps row block h (h is wave-uniform: two straight-line copies, the
+    // accumulators stay in registers)
+    float* mine = smem + wave * 2048;
+    const float* theirs = smem + (wave ^ 1) * 2048;
+    auto give = [&](const float16_t (&g)[2]) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          *reinterpret_cast<float4*>(mine + c * 1024 + (r4 * 64 + lane) * 4) = make_float4(g[c][4 * r4], g[c][4 * r4 + 1], g[c][4 * r4 + 2], g[c][4 * r4 + 3]);
+    };
+    if (h) give(acc[0]); else give(acc[1]);
+    __syncthreads();
+    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31 + (size_t)h * 8 * sstride;
+    auto keep = [&](const float16_t (&k)[2], bool first) {   // first: this wave holds K half 0 (the sum is half 0 + half 1 either way)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float4 o = *reinterpret_cast<const float4*>(theirs + c * 1024 + (r4 * 64 + lane) * 4);
+          float* o0 = m0 + (size_t)(2 * r4) * sstride + c * (36 * 128);
+          st_wt(o0, first ? k[c][4 * r4] + o.x : o.x + k[c][4 * r4]);
+          st_wt(o0 + 32, first ? k[c][4 * r4 + 1] + o.y : o.y + k[c][4 * r4 + 1]);
+          st_wt(o0 + 64, first ? k[c][4 * r4 + 2] + o.z : o.z + k[c][4 * r4 + 2]);
+          st_wt(o0 + 96, first ? k[c][4 * r4 + 3] + o.w : o.w + k[c][4 * r4 + 3]);
+        }
+    };
+    if (h) keep(acc[1], false); else keep(acc[0], true);
+    w4_stamp(st, 4);
+  }
+  // --- the K-sliced component's piece
+  {
+    float16_t acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int g = 0; g < SG; g += 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const W4Split as = w4_split8(sring[i].a[0], sring[i].a[1]);
+        w4_mac6(acc, as, sring[i].b[0], sring[i].b[1], sring[i].b[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 + i < SG) snext(sring[i]);
+      }
+    }
+    w4_stamp(st, 5);
+    __syncthreads();                 // (the exchange's reads of smem are done)
+    float* red = smem + wave * 1024;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+      *reinterpret_cast<float4*>(red + (r4 * 64 + lane) * 4) = make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+    __syncthreads();
+    {
+      const int r4 = wave;
+      float4 s = *reinterpret_cast<const float4*>(smem + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 1024 + (r4 * 64 + lane) * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* mrow = M + ((size_t)(rbs * 8 + 2 * r4 + hi) * (gm.C >> 5) + cbs) * (36 * 128) + (size_t)scomp * 128 + l31;
+      st_wt(mrow, s.x);
+      st_wt(mrow + 32, s.y);
+      st_wt(mrow + 64, s.z);
+      st_wt(mrow + 96, s.w);
+    }
+  }
+  if (st != nullptr) {
+    w4_stamp(st, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w4_stamp(st, 7);
+  }
+}
+
 
 
 // k_w4_gemm64c: k_w4_gemm64b with fp32 filters split in registers (see w4f_run)
@@ -1334,11 +1479,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
-          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0)};
+          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0)};
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1410,6 +1555,10 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         const size_t lds128 = 2 * 24 * 64 * 16;
         allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128b), attr128);
         hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
+        return;
+      }
+      if (sw.ksplit != 0 && C == 256) {   // NODE_TUNE_W4_KSPLIT: two waves per SIMD, a tile's K range in two halves
+        hipLaunchKernelGGL(k_w4_gemm64k, dim3(64 * (N / 16)), dim3(256), 8 * 1024 * sizeof(float), s, V, Ub, M, ctrl, gm, stamps);
         return;
       }
       if (sw.lds != 0 && C == 256 && N % 32 == 0) {      // NODE_TUNE_W4_LDS: the own component's operands through an LDS-DMA ring

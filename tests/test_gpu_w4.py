@@ -64,6 +64,31 @@ def test_w4_gemm_work_assignments_are_bit_identical(shape, switch):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize('shape', [(128, 256, 8, 8), (32, 256, 8, 8), (8, 256, 16, 16)])
+@pytest.mark.parametrize('dgrad', [0, 1])
+def test_w4_gemm_k_halves_variant_matches_fp64(shape, dgrad):
+    """k_w4_gemm64k (NODE_TUNE_W4_KSPLIT, two waves per SIMD, a tile's K range in two halves; measured and not the default,
+    DESIGN.md 4.2): the same part products, summed as two half chains -- same error against fp64, within rounding of the default."""
+    N, Cc, H, W = shape
+    gen = torch.Generator().manual_seed(17 + dgrad)
+    x = torch.randn(N, Cc, H, W, generator=gen).cuda()
+    w = ((torch.rand(Cc, Cc + 1, 3, 3, generator=gen) * 2 - 1) / (9 * Cc) ** 0.5).cuda()
+    want = _conv_w4(x, w, dgrad)
+    os.environ['NODE_TUNE_W4_KSPLIT'] = '1'
+    try:
+        got = _conv_w4(x, w, dgrad)
+    finally:
+        del os.environ['NODE_TUNE_W4_KSPLIT']
+    wd = w[:, 1:].double()
+    ref = F.conv_transpose2d(x.double(), wd, padding=1) if dgrad else F.conv2d(x.double(), wd, padding=1)
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max()) / scale
+    err0 = float((want.double() - ref).abs().max()) / scale
+    diff = float((got - want).abs().max()) / scale
+    print('  k_w4_gemm64k', shape, 'max err / max|y| %.2e (default %.2e), between them %.2e' % (err, err0, diff))
+    assert err < 2e-5 and diff < 5e-6 and not torch.equal(got, want), (err, err0, diff)
+
+
 @pytest.mark.parametrize('shape', [(8, 64, 8, 8), (16, 128, 8, 8), (128, 256, 8, 8),
                                    (2, 128, 16, 16), (8, 128, 16, 16), (4, 256, 16, 16), (2, 1024, 16, 16),
                                    (16, 128, 16, 16), (8, 1024, 16, 16)])
