@@ -263,6 +263,42 @@ def pmc_measure(state, conv_path_env, timeout=(300, 180)):
     return out or None
 
 
+def held_clock_ghz(N, C, side):
+    """The clock the chip holds inside k_w4_gemm64b's K loop: every wave stamps s_memrealtime (100 MHz) and s_memtime (shader
+    clock) around the loop (NODE_TUNE_W4_STAMPS, a diagnostic switch of the launcher).  Median over the waves of
+    one launch behind ten warm-up launches; None where the launch does not take that kernel."""
+    import ctypes as C_
+    import torch
+    from neural_ode_features_amd import _lib
+    if C >= 512 or (N * (4 if side == 16 else 1)) % 16 != 0 or C % 64 != 0:
+        return None
+    lib = _lib.load()
+    shape = _lib.NodeShape(N, C, side, side, 32, 1e-5)
+    x = torch.randn(N, C, side, side, device='cuda')
+    w = torch.randn(C, C + 1, 3, 3, device='cuda') / 48
+    nbytes = lib.node_conv3x3_w4_workspace_bytes(C_.byref(shape))
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device='cuda')
+    base = (ws.data_ptr() + 255) & ~255
+    y = torch.empty_like(x)
+    nn = N * (4 if side == 16 else 1)
+    stamps = torch.zeros((nn // 16) * (C // 64) * 8 * 4, 16, dtype=torch.int64, device='cuda')
+    try:
+        for it in range(11):
+            if it == 10:
+                os.environ['NODE_TUNE_W4_STAMPS'] = hex(stamps.data_ptr())
+            _lib.check(lib.node_conv3x3_w4(C_.byref(shape), w.data_ptr(), 0, x.data_ptr(), y.data_ptr(), base, nbytes,
+                                           torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop('NODE_TUNE_W4_STAMPS', None)
+    raw = stamps.cpu().double()
+    wall = (raw[:, 3] - raw[:, 1]) / 100.0           # us
+    ok = wall > 0
+    if int(ok.sum()) == 0:
+        return None
+    return float(((raw[:, 11] - raw[:, 9])[ok] / wall[ok]).median()) / 1e3
+
+
 def pmc_lookup(pmc, kernel):
     """bytes per launch of the kernel whose name contains `kernel` (the instance with the most bytes), or None"""
     if not pmc:
@@ -595,6 +631,11 @@ def main():
                              'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
                                      'launch time; against the fp32 matrix peak it may exceed 1 -- the products run at the '
                                      'bf16 rate'}
+                clk = held_clock_ghz(cfg['batch'], C, side) if not lds_tiled else None
+                if clk:
+                    mfma_view.update({'held_clock_ghz': clk, 'frac_of_bf16_peak_at_held_clock': issued_bf16 / (MFMA_BF16_PEAK_TFLOPS * clk / 2.4),
+                                      'held_clock_note': 'in-kernel clock over the K loop (s_memtime / s_memrealtime, one stamped launch): the '
+                                                         'chip lowers its clock under this load; the peaks above are priced at 2.4 GHz'})
                 if flops_bf16 / bytes_algo < MFMA_BF16_PEAK_TFLOPS / HBM_PEAK_TBS:
                     roofline.update({
                         'bound': 'hbm', 'kernel': kname,
