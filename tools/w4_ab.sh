@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for envs in "$@"; do
   for rep in 1 2; do
     rm -rf /tmp/wab
-    env $envs rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wab -- python3 $R/tools/w4_time.py 60 128,256,8 > /tmp/wab.log 2>&1 || { echo "$envs failed"; tail -3 /tmp/wab.log; }
+    env $envs rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wab -- python3 $R/tools/w4_time.py ${ITER:-60} 128,256,8 > /tmp/wab.log 2>&1 || { echo "$envs failed"; tail -3 /tmp/wab.log; }
     KS=$(find /tmp/wab -name '*kernel_stats.csv' | head -1)
     python3 - "$KS" "$envs" >> $R/$OUT <<'PY'
 import csv, sys
