@@ -10,7 +10,7 @@ for r in $(seq $ROUNDS); do
     env $e python $R/bench.py --config $CFG --steps 30 --warmup 10 --no-roofline 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('%-44s %9.1f images/s  %.3f ms/step  retries %s' % ('$envs', d['value'], d['ms_per_step'], d['config']['retries']))" >> $R/$OUT
+print('%-44s %9.1f images/s  %.3f ms/step  retries %s  dead steps per step %s  fresh %.0f' % ('$envs', d['value'], d['ms_per_step'], d['config']['retries'], d['config']['dead_steps_per_step'], (d.get('fresh_batches') or {}).get('value', 0)))" >> $R/$OUT
   done
 done
 cat $R/$OUT
