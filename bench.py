@@ -147,9 +147,11 @@ def build_model(device, cfg, method):
 
 
 def train_step(model, opt, x, y, reducer=None):
-    import torch.nn.functional as F
+    # train.py:40-58.  `cross_entropy` is the package's F.cross_entropy (one launch forward; its backward launch also
+    # carries the classifier's Linear layer: csrc/kernels_loss.hip); on CPU tensors (cpu_baseline) it IS F.cross_entropy
+    from neural_ode_features_amd import cross_entropy
     p = model(x)
-    loss = F.cross_entropy(p, y)
+    loss = cross_entropy(p, y)
     nfe_f = model.nfe(reset=True)
     loss.backward()
     nfe_b = model.nfe(reset=True)
@@ -264,39 +266,23 @@ def pmc_measure(state, conv_path_env, timeout=(300, 180)):
 
 
 def held_clock_ghz(N, C, side):
-    """The clock the chip holds inside k_w4_gemm64b's K loop: every wave stamps s_memrealtime (100 MHz) and s_memtime (shader
-    clock) around the loop (NODE_TUNE_W4_STAMPS, a diagnostic switch of the launcher).  Median over the waves of
-    one launch behind ten warm-up launches; None where the launch does not take that kernel."""
-    import ctypes as C_
-    import torch
-    from neural_ode_features_amd import _lib
-    if C >= 512 or (N * (4 if side == 16 else 1)) % 16 != 0 or C % 64 != 0:
+    """The clock the chip holds inside k_w4_gemm64b's K loop (s_memtime / s_memrealtime stamps around the loop).
+    The stamps exist in the DIAGNOSTICS build of the library only (libnode_hip_diag.so): a child process measures it
+    (tools/held_clock.py), started BEFORE this process touches the GPU.  None where the launch does not take that kernel, the
+    diagnostics library is not built, or the child fails."""
+    diag = os.path.join(ROOT, 'neural-ode-features_amd', 'csrc', 'libnode_hip_diag.so')
+    if not os.path.exists(diag) or C >= 512 or (N * (4 if side == 16 else 1)) % 16 != 0 or C % 64 != 0:
         return None
-    lib = _lib.load()
-    shape = _lib.NodeShape(N, C, side, side, 32, 1e-5)
-    x = torch.randn(N, C, side, side, device='cuda')
-    w = torch.randn(C, C + 1, 3, 3, device='cuda') / 48
-    nbytes = lib.node_conv3x3_w4_workspace_bytes(C_.byref(shape))
-    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device='cuda')
-    base = (ws.data_ptr() + 255) & ~255
-    y = torch.empty_like(x)
-    nn = N * (4 if side == 16 else 1)
-    stamps = torch.zeros((nn // 16) * (C // 64) * 8 * 4, 16, dtype=torch.int64, device='cuda')
+    env = dict(os.environ)
+    env['NODE_HIP_DIAG'] = '1'
     try:
-        for it in range(11):
-            if it == 10:
-                os.environ['NODE_TUNE_W4_STAMPS'] = hex(stamps.data_ptr())
-            _lib.check(lib.node_conv3x3_w4(C_.byref(shape), w.data_ptr(), 0, x.data_ptr(), y.data_ptr(), base, nbytes,
-                                           torch.cuda.current_stream().cuda_stream))
-        torch.cuda.synchronize()
-    finally:
-        os.environ.pop('NODE_TUNE_W4_STAMPS', None)
-    raw = stamps.cpu().double()
-    wall = (raw[:, 3] - raw[:, 1]) / 100.0           # us
-    ok = wall > 0
-    if int(ok.sum()) == 0:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'held_clock.py'), '%d,%d,%d' % (N, C, side)], env=env,
+                           capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            return None
+        return json.loads(r.stdout.strip().splitlines()[-1]).get('held_clock_ghz')
+    except Exception:
         return None
-    return float(((raw[:, 11] - raw[:, 9])[ok] / wall[ok]).median()) / 1e3
 
 
 def pmc_lookup(pmc, kernel):
@@ -361,6 +347,9 @@ def main():
         w4_default = os.environ.get('NODE_TUNE_WINO4', '1')
         takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 0.99e-5 and side in (8, 16) and w4_default != '0'
         pmc = pmc_measure(state, {'NODE_TUNE_WINO4': '2' if takes_w4 else '0'})
+    held_clk = None
+    if world == 1 and not args.no_roofline:
+        held_clk = held_clock_ghz(cfg['batch'], cfg['filters'], side)      # (a child process on the diagnostics library)
 
     import torch
     import torch.distributed as dist
@@ -374,10 +363,8 @@ def main():
         raise SystemExit('bench.py: LOCAL_RANK %d but only %d HIP device(s)' % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    # the stem's convolutions are MIOpen's: let it time its algorithms once per geometry (during the warm-up steps)
-    # instead of taking its heuristic pick -- stem forward 0.48 -> 0.46 ms, backward 0.93 -> 0.86 ms per step
-    # (tools/phase_times.py, BENCHMARK=1)
-    torch.backends.cudnn.benchmark = True
+    # (no library setting to tune: the stem, the ODE block, the head and the optimizer step all run on libnode_hip.so's own
+    # kernels -- no MIOpen / hipBLASLt call is left in a training step, profiles/r05_cfg2_steps.txt)
 
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
@@ -597,7 +584,8 @@ def main():
             algo_per_launch = k4['flops'] / k4['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
             issued = 36.0 / (16.0 * 9.0)
             ach = algo_per_launch * issued / (avg_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'k_w4_gemm64 (fp32 MFMA, the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad)',
+            roofline = {'bound': 'mfma', 'kernel': 'k_w4_gemm64 / k_w4_gemm (fp32-MFMA form of the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad: '
+                                                    'batches the bf16-triple kernels do not take, NODE_TUNE_W4_BF16X3=0)',
                         'achieved': ach, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': ach / MFMA_F32_PEAK_TFLOPS, 'traffic': (pmc_lookup(pmc, 'k_w4_gemm') or {}).get('bytes'),
                         'traffic_detail': pmc_lookup(pmc, 'k_w4_gemm'),
@@ -631,7 +619,7 @@ def main():
                              'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
                                      'launch time; against the fp32 matrix peak it may exceed 1 -- the products run at the '
                                      'bf16 rate'}
-                clk = held_clock_ghz(cfg['batch'], C, side) if not lds_tiled else None
+                clk = held_clk if not lds_tiled else None
                 if clk:
                     mfma_view.update({'held_clock_ghz': clk, 'frac_of_bf16_peak_at_held_clock': issued_bf16 / (MFMA_BF16_PEAK_TFLOPS * clk / 2.4),
                                       'held_clock_note': 'in-kernel clock over the K loop (s_memtime / s_memrealtime, one stamped launch): the '

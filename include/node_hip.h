@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define NODE_ABI_VERSION 3
+#define NODE_ABI_VERSION 4
 
 /* method -- the two solver names that reach model.py:367 on the graded configs
  * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
@@ -236,21 +236,61 @@ int node_solve_backprop(const node_shape* shape, const node_params* params,
 int node_head_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
                   const float* scale, float* pooled, float* stats, void* stream);
 
-/* Backward of node_head_fwd: g_pooled [n, c] = dL/dpooled.  Outputs dz [n, c, h, w] and
- * per-sample partials gpart [n, 2, c] of (dL/dgamma, dL/dbeta) -- summed over n by the caller. */
+/* Backward of node_head_fwd: g_pooled [n, c] = dL/dpooled.  Outputs dz [n, c, h, w], the
+ * per-sample partials gpart [n, 2, c] of (dL/dgamma, dL/dbeta) and -- gsum != NULL, a second small
+ * launch -- their sums over n, gsum [2, c] = (dL/dgamma, dL/dbeta). */
 int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
                   const float* scale, const float* stats, const float* g_pooled,
-                  float* dz, float* gpart, void* stream);
+                  float* dz, float* gpart, float* gsum, void* stream);
 
 /* GroupNorm (+ReLU) of the stem's residual blocks -- model.py:284-310 (`relu(norm(x))` in front of every
  * conv; normalization('group') = nn.GroupNorm(min(32,C), C), model.py:268-271), forward and backward.
  * z, out, g_out, dz: [n, c, h, w] (NCHW); stats: [n, groups, 2] (mean, 1/sigma) from the forward;
- * gpart: [n, 2, c] per-sample partials of (dL/dgamma, dL/dbeta), summed over n by the caller.
- * relu != 0: out = relu(GN(z)); relu == 0: out = GN(z).  No workspace; one launch each. */
+ * gpart: [n, 2, c] per-sample partials of (dL/dgamma, dL/dbeta); gsum: NULL, or [2, c] for their sums over n (a second
+ * small launch).  relu != 0: out = relu(GN(z)); relu == 0: out = GN(z).  No workspace; one launch each. */
 int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
                      int relu, float* out, float* stats, void* stream);
 int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
-                     const float* stats, int relu, const float* g_out, float* dz, float* gpart, void* stream);
+                     const float* stats, int relu, const float* g_out, float* dz, float* gpart, float* gsum, void* stream);
+
+/* The classifier's Linear layer and the loss of the training loop as ONE launch each way -- model.py:244-250
+ * (`nn.Linear(in_ch, out)` behind Flatten) and train.py:43 (`F.cross_entropy(p, y)`), plus the per-batch numbers the loop
+ * reads at train.py:44,46 (loss value, correct predictions), left in device memory so that a caller can read them once
+ * per logging interval instead of twice per batch.
+ *   forward : logits[n][o] = sum_c pooled[n][c] weight[o][c] + bias[o]      (pooled == NULL: `logits` are given, not written)
+ *             loss = mean_n | sum_n ( logsumexp_o logits[n] - logits[n][target[n]] )   (target == NULL: Linear alone)
+ *             stat = { loss, #{n : argmax_o logits[n] == target[n]} }                   (optional)
+ *   backward: d_logits = grad_loss * (softmax(logits) - onehot(target)) (/ n for the mean)   -- or `grad_logits` as given;
+ *             d_weight[o][c] = sum_n d_logits[n][o] pooled[n][c], d_bias[o] = sum_n d_logits[n][o],
+ *             d_pooled[n][c] = sum_o d_logits[n][o] weight[o][c]            (pooled == NULL: only `d_logits` is written)
+ * fp32 throughout; class indices are int64 (what PyTorch hands over), every index in [0, classes) (no ignore_index:
+ * an out-of-range target makes the loss NaN); classes <= 1024.  All sums in a fixed order: bit-reproducible.
+ * `scratch`: node_head_loss_scratch_bytes(n) bytes of device memory, ZERO before its first use (the kernel leaves its
+ * arrival counter at zero again), not shared between streams. */
+enum { NODE_REDUCE_MEAN = 0, NODE_REDUCE_SUM = 1 };
+typedef struct node_head_loss {
+  int32_t n, c, classes;
+  int32_t reduction;       /* NODE_REDUCE_MEAN (train.py:43) or NODE_REDUCE_SUM (train.py:93 test loss)            */
+  const float* pooled;     /* [n, c]  what the head's pooling / dropout produced (node_head_fwd), or NULL          */
+  const float* weight;     /* [classes, c]  nn.Linear.weight                                                      */
+  const float* bias;       /* [classes] or NULL                                                                   */
+  const int64_t* target;   /* [n] class indices, or NULL                                                          */
+  float* logits;           /* [n, classes]                                                                        */
+  float* loss;             /* [1]   (written when target != NULL)                                                 */
+  float* stat;             /* [2] or NULL                                                                         */
+  float* scratch;          /* node_head_loss_scratch_bytes(n)   (needed when target != NULL)                      */
+} node_head_loss;
+typedef struct node_head_loss_grad {
+  const float* grad_loss;    /* [1] upstream gradient of the scalar loss (device), NULL = 1                       */
+  const float* grad_logits;  /* [n, classes] given instead of the loss gradient (Linear alone), or NULL          */
+  float* d_logits;           /* [n, classes] or NULL                                                              */
+  float* d_pooled;           /* [n, c]                                                                            */
+  float* d_weight;           /* [classes, c]                                                                      */
+  float* d_bias;             /* [classes] or NULL                                                                 */
+} node_head_loss_grad;
+size_t node_head_loss_scratch_bytes(int n);
+int node_head_loss_fwd(const node_head_loss* head, void* stream);
+int node_head_loss_bwd(const node_head_loss* head, const node_head_loss_grad* grads, void* stream);
 
 /* The optimizer step of the training loop -- train.py:136 (`torch.optim.SGD(params, lr, momentum=0.9, weight_decay=wd)`)
  * stepped at train.py:56-58 -- for ALL parameter tensors of the model in one launch (per 64 tensors):

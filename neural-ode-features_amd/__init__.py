@@ -12,6 +12,7 @@ from .modules import ConcatConv2d, ODEBlock, ODEfunc, normalization  # noqa: F40
 from .odenet import FCClassifier, ODEDownsample, ODEDownsample2, ODENet, ResBlock, StackedODENet  # noqa: F401
 from . import dp, graphs, optim  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
+from .head import cross_entropy, linear, linear_cross_entropy  # noqa: F401
 
 __all__ = ['odeint', 'odeint_adjoint', 'ODEBlock', 'ODEfunc', 'ConcatConv2d', 'ODENet', 'StackedODENet',
            'ODEDownsample', 'ODEDownsample2', 'dp']

@@ -12,8 +12,12 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
+# Diagnostics build (build.py --diag): the product library plus the timing ablations, in-kernel stamps and the
+# measured-and-rejected kernel variants.  Only tools/ and the `-m diag` tests ask for it, by NODE_HIP_DIAG=1 in the
+# environment of their own process; nothing in the package does.
+LIB_DIAG_PATH = os.path.join(HERE, 'csrc', 'libnode_hip_diag.so')
 
-NODE_ABI_VERSION = 3
+NODE_ABI_VERSION = 4
 METHOD_DOPRI5, METHOD_RK4 = 0, 1
 METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
 
@@ -31,6 +35,7 @@ EXPORTS = [
     'node_sgd_step', 'node_profile_begin', 'node_profile_end',
     'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3',
     'node_stem_workspace_bytes', 'node_stem_fwd', 'node_stem_bwd', 'node_stem_conv_workspace_bytes', 'node_stem_conv',
+    'node_head_loss_scratch_bytes', 'node_head_loss_fwd', 'node_head_loss_bwd',
 ]
 
 
@@ -93,6 +98,19 @@ class NodeConvGeom(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ('n', 'cin', 'cout', 'x_h', 'x_w', 'k', 'stride', 'pad')]
 
 
+REDUCE_MEAN, REDUCE_SUM = 0, 1
+
+
+class NodeHeadLoss(C.Structure):
+    _fields_ = [('n', C.c_int32), ('c', C.c_int32), ('classes', C.c_int32), ('reduction', C.c_int32),
+                ('pooled', C.c_void_p), ('weight', C.c_void_p), ('bias', C.c_void_p), ('target', C.c_void_p),
+                ('logits', C.c_void_p), ('loss', C.c_void_p), ('stat', C.c_void_p), ('scratch', C.c_void_p)]
+
+
+class NodeHeadLossGrad(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ('grad_loss', 'grad_logits', 'd_logits', 'd_pooled', 'd_weight', 'd_bias')]
+
+
 class NodeHipError(RuntimeError):
     def __init__(self, code, message):
         self.code = code
@@ -107,11 +125,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_DIAG_PATH if os.environ.get('NODE_HIP_DIAG', '0') not in ('', '0') else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            'libnode_hip.so is not built (%s). Run `python neural-ode-features_amd/build.py` '
-            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            '%s is not built (%s). Run `python neural-ode-features_amd/build.py%s` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.'
+            % (os.path.basename(path), path, ' --diag' if path == LIB_DIAG_PATH else ''))
+    lib = C.CDLL(path)
     vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
     P = C.POINTER
     lib.node_abi_version.restype = i32
@@ -140,11 +160,11 @@ def load():
     lib.node_head_fwd.restype = i32
     lib.node_head_fwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp]
     lib.node_head_bwd.restype = i32
-    lib.node_head_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.node_head_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.node_gn_relu_fwd.restype = i32
     lib.node_gn_relu_fwd.argtypes = [P(NodeShape), vp, vp, vp, i32, vp, vp, vp]
     lib.node_gn_relu_bwd.restype = i32
-    lib.node_gn_relu_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.node_gn_relu_bwd.argtypes = [P(NodeShape), vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.node_sgd_step.restype = i32
     lib.node_sgd_step.argtypes = [P(NodeSgdTensor), i32, f32, f32, f32, f32, vp, vp]
     lib.node_profile_begin.restype = i32
@@ -167,6 +187,12 @@ def load():
     lib.node_stem_conv_workspace_bytes.argtypes = [P(NodeConvGeom)]
     lib.node_stem_conv.restype = i32
     lib.node_stem_conv.argtypes = [P(NodeConvGeom), i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.node_head_loss_scratch_bytes.restype = sz
+    lib.node_head_loss_scratch_bytes.argtypes = [i32]
+    lib.node_head_loss_fwd.restype = i32
+    lib.node_head_loss_fwd.argtypes = [P(NodeHeadLoss), vp]
+    lib.node_head_loss_bwd.restype = i32
+    lib.node_head_loss_bwd.argtypes = [P(NodeHeadLoss), P(NodeHeadLossGrad), vp]
     ver = lib.node_abi_version()
     if ver != NODE_ABI_VERSION:
         raise RuntimeError('libnode_hip ABI %d != binding ABI %d' % (ver, NODE_ABI_VERSION))

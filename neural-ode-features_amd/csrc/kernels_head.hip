@@ -402,6 +402,22 @@ void launch_head_fwd(const node_shape& sh, const float* z, const float* gamma, c
   hipLaunchKernelGGL(k_head_fwd_g, dim3(sh.n), dim3(256), (size_t)sh.c * sizeof(float), s, z, gamma, beta, scale, pooled, stats,
                      sh.c, HW, sh.groups, sh.eps);
 }
+// gsum[j] = sum_n gpart[n][j], j < 2 C: the per-sample (dgamma, dbeta) partials of a backward pass summed over the batch in
+// a fixed order (the caller's `gpart.sum(0)`: an ATen reduction launch + three indexing operators on the host)
+__global__ __launch_bounds__(256) void k_head_gsum(const float* __restrict__ gpart, float* __restrict__ gsum, int N, int W) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < W)
+    for (int n = part; n < N; n += 4) s += gpart[(size_t)n * W + col];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && col < W) gsum[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void launch_head_gsum(const float* gpart, float* gsum, int N, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_head_gsum, dim3((2 * C + 63) / 64), dim3(256), 0, s, gpart, gsum, N, 2 * C);
+}
+
 void launch_head_bwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      const float* stats, const float* gpool, float* dz, float* gpart, hipStream_t s) {
   const int HW = sh.h * sh.w;

@@ -859,6 +859,10 @@ int stem_gn_cb(int HW, int C, int cpg) {
   static int cap = -2;      // NODE_TUNE_STEM_GNCB: upper limit of the channel block (A/B measurements)
   if (cap == -2) { const char* e = getenv("NODE_TUNE_STEM_GNCB"); cap = e ? atoi(e) : -1; }
   while (cap > 0 && cb > cap && cb / 2 >= cpg && cb / 2 >= 8) cb /= 2;
+  // the kernels index channels with `t & (CB - 1)`, run C / CB blocks per sample and CB / cpg whole groups per block:
+  // a block that does not divide C leaves channels unwritten, a group that straddles blocks gets wrong statistics
+  // (filters = 192, 384, ...: cpg = 6, 12).  Such shapes are refused (check_stem_shape) and run the module sequence.
+  if (C % cb != 0 || cb % cpg != 0) return 0;
   return cb;
 }
 void launch_stem_gn_fwd(const SGnArgs& a, hipStream_t s) {

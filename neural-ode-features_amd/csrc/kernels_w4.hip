@@ -517,6 +517,7 @@ __device__ __forceinline__ void w4b_mac(float16_t (&acc)[2][2], const W4Split (&
 // bf16 split of the NEXT step's row operand (v_cvt_pk_bf16_f32 + subtracts: ~44 VALU instructions per row block) is
 // interleaved with the CURRENT step's MFMAs -- one matrix instruction, then a few vector ones -- so that a wave that
 // has its SIMD to itself keeps both pipes busy.
+#ifdef NODE_DIAG
 // --- variant (NODE_TUNE_W4_UF32 = 1): the FILTER operand fp32 as well (the layout k_w4_gemm64 reads), split into its bf16
 // triple in registers like the row operand.  The launch is bound by operand delivery, not by the matrix pipe (ablations,
 // the requests alone take the whole 20 us): fp32 filters are 4 instead of 6 bytes per element -- 8 instead
@@ -582,14 +583,19 @@ __device__ __forceinline__ void w4f_run(float16_t (&acc)[2][2], const W4FPtrs& p
   }
 }
 
+#endif  // NODE_DIAG
 // timing-only ablations (NODE_TUNE_W4_ABLATE, results are wrong): AB bit 2 -- requests without the split / MFMA work (every
 // loaded register is folded into one accumulator element, so the requests and their waits stay); AB bit 8 -- the split /
 // MFMA work on whatever the registers hold, no requests
 // stamps (timing diagnostics, NODE_TUNE_W4_STAMPS): wall-clock ticks (100 MHz) of lane 0 -- [1] ring requested, [2] first step's operands
 // arrived and multiplied, [3] loop done
+#ifdef NODE_DIAG
 __device__ __forceinline__ void w4_stamp(unsigned long long* st, int k) {
   if (st != nullptr && (threadIdx.x & 63) == 0) { st[k] = wall_clock64(); st[8 + k] = clock64(); }
 }
+#else
+__device__ __forceinline__ void w4_stamp(unsigned long long*, int) {}   // (the product library stamps nothing)
+#endif
 struct W4BCursor { const float4* a[2]; const w4_u32x4* b[2]; };
 template <int NRB>
 __device__ __forceinline__ void w4b_next(W4BStage& s, W4BCursor& cu) {   // the next K = 16 step of the streams
@@ -716,7 +722,11 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
   const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;   // lane (row = 4 s + t, k-half hi) inside a V block
   // (timing experiments only, NODE_TUNE_W4_PAD = "v,u" with NODE_TUNE_W4_ABLATE >= 16, results wrong: the operand blocks' starts pulled
   // v / u KB per block out of their power-of-two spacing -- do the streams, which all walk K in the same order, camp on L2 channels?)
+#ifdef NODE_DIAG
   const int padv = (mode >> 8) & 0xff, padu = (mode >> 16) & 0xff;
+#else
+  constexpr int padv = 0, padu = 0;
+#endif
   auto vblk = [&](int comp, int rb) {
     const size_t b = (size_t)comp * nRB + rb;
     return reinterpret_cast<const float4*>(V + (b * G8) * 256 - b * padv * 256 + a_off);
@@ -836,14 +846,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
       st_wt(mrow + 96, s.w);
     }
   }
+#ifdef NODE_DIAG
   if (st != nullptr) {   // (diagnostics: when this wave's stores have drained)
     w4_stamp(st, 6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     w4_stamp(st, 7);
   }
+#endif
 }
 
 
+#ifdef NODE_DIAG   // measured-and-rejected variants: built into libnode_hip_diag.so only (build.py --diag)
 // ----------------------------------------------------------------------------
 // k_w4_gemm64l (NODE_TUNE_W4_LDS, C = 256, N % 32 == 0): k_w4_gemm64b's products with the own component's operands brought into
 // the CU ONCE.  What bounds k_w4_gemm64b is the bytes its waves load into registers (every operand block aliased onto one
@@ -1285,6 +1298,8 @@ __global__ __launch_bounds__(256) void k_w4_gemm64c(const float* __restrict__ V,
 
 
 
+#endif  // NODE_DIAG (measured-and-rejected variants)
+
 // ----------------------------------------------------------------------------
 // k_w4_gemm128b: k_w4_gemm64b's products for LONG reductions (C >= 512: cfg 5's 16x16 states at 1024 filters), as a
 // classic LDS-tiled GEMM.  k_w4_gemm64b gives every wave a component of its own, so the four waves of a workgroup share
@@ -1479,11 +1494,19 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // The A/B switches that select the component-GEMM kernel.  ONE reader for the packer (which filter forms a solve
 // prepares) and the launcher (which kernel reads them), all of them read on every call: a process that changes a
 // switch between solves (the tests do) can never pack for one kernel and launch another.
+// The PRODUCT library (no -DNODE_DIAG) reads only switches under which every result stays correct: which kernel family
+// multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
+// The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
+// kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
 struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit; };
 static W4Switches w4_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+#ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
           rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0)};
+#else
+  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0};
+#endif
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1501,16 +1524,19 @@ bool w4_uses_bf16(int N, int C) {
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {
   static bool attr[4][MAX_DEVICES] = {};
   const W4Switches sw = w4_switches();
-  const int ab = sw.ablate;
   int mode = (sw.sharev == 1 ? 2 : 0) | (sw.sharev == 2 ? 4 : 0) | (sw.early ? 8 : 0);
-  unsigned long long* stamps = nullptr;   // NODE_TUNE_W4_STAMPS = device address of [grid * 4][16] u64 (tools/w4_stamps.py; diagnostics)
+  unsigned long long* stamps = nullptr;
+#ifdef NODE_DIAG
+  const int ab = sw.ablate;
+  // NODE_TUNE_W4_STAMPS = device address of [grid * 4][16] u64 (tools/w4_stamps.py)
   { const char* e = getenv("NODE_TUNE_W4_STAMPS"); if (e != nullptr) stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)); }
   if (ab >= 16) {
     const char* e = getenv("NODE_TUNE_W4_PAD");
     int pv = 0, pu = 0;
     if (e != nullptr && sscanf(e, "%d,%d", &pv, &pu) == 2) mode |= ((pv & 0xff) << 8) | ((pu & 0xff) << 16);
   }
-  static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment (see the kernel)
+#endif
+  static int xm = -1;   // NODE_TUNE_W4_XCD: workgroup -> XCD assignment of k_w4_gemm (see the kernel; results unchanged)
   if (xm < 0) { const char* e = getenv("NODE_TUNE_W4_XCD"); xm = e ? atoi(e) : 0; }
   const W4Geom gm = w4_geom(N, C);
   if (w4_takes_small(sw, N)) {   // NODE_TUNE_W4_SMALL = 0: never the small-batch kernel (A/B measurements)
@@ -1530,6 +1556,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
   if (g64 && N % 16 == 0) {
     const int grid64 = (N / 16) * (C >> 6) * 8;
     const size_t lds64 = 4 * 2048 * sizeof(float);
+#ifdef NODE_DIAG
     if (w4_takes_uf32(sw, N, C) && Ub == nullptr) {
       hipLaunchKernelGGL(k_w4_gemm64c, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
       return;
@@ -1544,7 +1571,8 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
       hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }
-    if (b16 && Ub != nullptr && ab == 0) {
+#endif
+    if (b16 && Ub != nullptr && sw.ablate == 0) {
       // NODE_TUNE_W4_GEMM128 = 0 never / 1 wherever it fits / unset: long reductions (C >= 512)
       const char* g128e = getenv("NODE_TUNE_W4_GEMM128");   // (read on every call, like NODE_TUNE_W4_BF16X3: tests run both kernels)
       const int g128 = g128e ? atoi(g128e) : -1;
@@ -1557,6 +1585,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         hipLaunchKernelGGL(k_w4_gemm128b, dim3(8 * (4 * nT + nT / 2)), dim3(256), lds128, s, V, Ub, M, ctrl, gm);
         return;
       }
+#ifdef NODE_DIAG
       if (sw.ksplit != 0 && C == 256) {   // NODE_TUNE_W4_KSPLIT: two waves per SIMD, a tile's K range in two halves
         hipLaunchKernelGGL(k_w4_gemm64k, dim3(64 * (N / 16)), dim3(256), 8 * 1024 * sizeof(float), s, V, Ub, M, ctrl, gm, stamps);
         return;
@@ -1567,19 +1596,24 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         hipLaunchKernelGGL(k_w4_gemm64l, dim3(grid64), dim3(256), (size_t)W4L_NS * W4L_SLOT, s, V, Ub, M, ctrl, gm, stamps);
         return;
       }
+#endif
       hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }
-    if (ab == 1) hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
-    else if (ab == 2) hipLaunchKernelGGL(k_w4_gemm64<2>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
-    else if (ab == 4) hipLaunchKernelGGL(k_w4_gemm64<4>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
-    else hipLaunchKernelGGL(k_w4_gemm64<0>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
+#ifdef NODE_DIAG
+    if (ab == 1) { hipLaunchKernelGGL(k_w4_gemm64<1>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm); return; }
+    if (ab == 2) { hipLaunchKernelGGL(k_w4_gemm64<2>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm); return; }
+    if (ab == 4) { hipLaunchKernelGGL(k_w4_gemm64<4>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm); return; }
+#endif
+    hipLaunchKernelGGL(k_w4_gemm64<0>, dim3(grid64), dim3(256), lds64, s, V, U, M, ctrl, gm);
     return;
   }
-  if (ab == 1) W4_LAUNCH(1, 1)
-  else if (ab == 2) W4_LAUNCH(2, 2)
-  else if (ab == 4) W4_LAUNCH(4, 3)
-  else W4_LAUNCH(0, 0)
+#ifdef NODE_DIAG
+  if (ab == 1) { W4_LAUNCH(1, 1) return; }
+  if (ab == 2) { W4_LAUNCH(2, 2) return; }
+  if (ab == 4) { W4_LAUNCH(4, 3) return; }
+#endif
+  W4_LAUNCH(0, 0)
 #undef W4_LAUNCH
 }
 

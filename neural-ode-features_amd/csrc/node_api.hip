@@ -157,6 +157,9 @@ static int make_dims(const node_shape* sh, Dims* out) {
       d.csplit = d.HW / 128;
     }
   }
+  if (d.HW > 256 && !d.csplit)   // banded geometry whose tensors pass 2^32 bytes: the 128-row tile holds no whole sample (S = 0)
+    return fail(NODE_ERR_UNSUPPORTED, "H*W = %d with N*H*W*C = %zu elements: the banded convolution addresses at most 2^32 bytes per tensor",
+                d.HW, (size_t)d.N * d.HW * d.C);
   d.S = d.csplit ? 1 : d.BM / d.HW;
   if (d.S > d.N) d.S = d.N;
   while (d.wino != 2 && d.S > 1 && conv_lds_bytes(d, 0) > 150 * 1024) d.S--;
@@ -1616,12 +1619,13 @@ int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma
 }
 
 int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* stats,
-                     int relu, const float* g_out, float* dz, float* gpart, void* stream) {
+                     int relu, const float* g_out, float* dz, float* gpart, float* gsum, void* stream) {
   char why[200];
   const int rc = head_check(shape, why, sizeof(why));
   if (rc != NODE_OK && rc != NODE_ERR_UNSUPPORTED) return fail(rc, "%s", why);
   if (!z || !gamma || !beta || !stats || !g_out || !dz || !gpart) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   launch_gn_relu_bwd(*shape, z, gamma, beta, stats, relu, g_out, dz, gpart, (hipStream_t)stream);
+  if (gsum != nullptr) launch_head_gsum(gpart, gsum, shape->n, shape->c, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_gn_relu_bwd failed: %s", hipGetErrorString(e));
   return NODE_OK;
@@ -1640,12 +1644,13 @@ int node_head_fwd(const node_shape* shape, const float* z, const float* gamma, c
 }
 
 int node_head_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, const float* scale,
-                  const float* stats, const float* g_pooled, float* dz, float* gpart, void* stream) {
+                  const float* stats, const float* g_pooled, float* dz, float* gpart, float* gsum, void* stream) {
   char why[200];
   const int rc = head_check(shape, why, sizeof(why));
   if (rc != NODE_OK) return fail(rc, "%s", why);
   if (!z || !gamma || !beta || !stats || !g_pooled || !dz || !gpart) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   launch_head_bwd(*shape, z, gamma, beta, scale, stats, g_pooled, dz, gpart, (hipStream_t)stream);
+  if (gsum != nullptr) launch_head_gsum(gpart, gsum, shape->n, shape->c, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of node_head_bwd failed: %s", hipGetErrorString(e));
   return NODE_OK;

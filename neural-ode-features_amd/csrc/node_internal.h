@@ -422,6 +422,7 @@ void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_
 struct node_shape;
 namespace node {
 int head_check(const node_shape* sh, char* why, size_t why_len);
+void launch_head_gsum(const float* gpart, float* gsum, int N, int C, hipStream_t s);
 void launch_head_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, const float* scale,
                      float* pooled, float* stats, hipStream_t s);
 void launch_gn_relu_fwd(const node_shape& sh, const float* z, const float* gamma, const float* beta, int relu, float* out,

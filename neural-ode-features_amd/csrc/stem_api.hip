@@ -209,6 +209,13 @@ int check_stem_shape(const node_stem_shape* sh) {
   if (stem_gn_cb((sh->h - 2) * (sh->w - 2), 64, 2) == 0)
     return failf(NODE_ERR_UNSUPPORTED, "the stem's GroupNorm passes hold (sample, 8 channels) blocks in LDS: images up to %d pixels "
                  "behind the first layer (got %d x %d)", 150 * 1024 / 64, sh->h - 2, sh->w - 2);
+  {   // the last block's GroupNorm passes run on `filters` channels in min(32, filters) groups (model.py:268-271)
+    const int cpg = sh->filters / (sh->filters < 32 ? sh->filters : 32);
+    const int h1 = (sh->h - 2 - 1) / 2 + 1, w1 = (sh->w - 2 - 1) / 2 + 1, h2 = (h1 - 1) / 2 + 1, w2 = (w1 - 1) / 2 + 1;
+    if ((sh->filters & (sh->filters - 1)) != 0 || stem_gn_cb(h2 * w2, sh->filters, cpg) == 0)
+      return failf(NODE_ERR_UNSUPPORTED, "the stem's GroupNorm passes take power-of-two filter counts (whole groups per "
+                   "power-of-two channel block); got %d", sh->filters);
+  }
   return NODE_OK;
 }
 

@@ -140,12 +140,21 @@ class FCClassifier(_Wrapped):
                    and (len(body) == 5 or isinstance(body[3], nn.Dropout)))
         if not fusable:
             return self.module(x)
+        pooled = self.pooled(x)
+        last = body[-1]
+        if isinstance(last, nn.Linear):      # one launch (head.linear); `cross_entropy` on its result fuses the two backwards
+            from .head import linear
+            return linear(pooled, last.weight, last.bias)
+        return last(pooled)                  # (feature extraction: the classification layer was replaced, model.py:53)
+
+    def pooled(self, x):
+        """dropout(mean_px relu(GroupNorm(x))): everything in front of the Linear layer, one launch each way."""
         from .head import head_pool
+        body = list(self.module.children())
         gn = body[0]
         drop = body[3] if len(body) == 6 else None
-        pooled = head_pool(x, gn.weight, gn.bias, gn.num_groups, gn.eps,
-                           p=drop.p if drop is not None else 0.0, training=self.training and drop is not None)
-        return body[-1](pooled)
+        return head_pool(x, gn.weight, gn.bias, gn.num_groups, gn.eps,
+                         p=drop.p if drop is not None else 0.0, training=self.training and drop is not None)
 
 
 class ODENet(nn.Module):

@@ -89,6 +89,9 @@ class _StemFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         lib = _lib.load()
         x, *ps = ctx.saved_tensors
+        if ctx.ws is None:
+            raise RuntimeError('the fused stem keeps its activations in a workspace that the first backward releases: '
+                               'a second backward through the same forward (retain_graph=True) is not supported')
         shape = _lib.NodeStemShape(*ctx.shape_args)
         dev = x.device
         grad_out = grad_out.contiguous()
@@ -104,14 +107,19 @@ class _StemFn(torch.autograd.Function):
 
 
 def fusable(seq, x) -> bool:
-    """What the library's stem kernels take (node_stem_fwd): fp32 on a HIP device, in_ch <= 3, filters a multiple of 64,
+    """What the library's stem kernels take (node_stem_fwd): fp32 on a HIP device, in_ch <= 3, filters a power of two >= 64,
     images of up to 2400 pixels behind the first layer (the GroupNorm passes hold a (sample, 8 channels) block in LDS);
     anything else -- the 24- and 32-filter toy nets of the tests, 64x64 inputs -- runs the module sequence."""
     if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 3
             and min(x.shape[2], x.shape[3]) >= 5 and (x.shape[2] - 2) * (x.shape[3] - 2) <= 2400):
         return False
     ps = _params_of(seq)
-    return (ps is not None and ps[-1].shape[0] % 64 == 0 and ps[0].shape[1] == x.shape[1]
+    if x.requires_grad and torch.is_grad_enabled():
+        return False        # the fused backward produces parameter gradients only (saliency / adversarial inputs: module sequence)
+    filters = ps[-1].shape[0] if ps is not None else 0
+    # power-of-two filter counts: the GroupNorm passes keep whole groups inside power-of-two channel blocks (192, 384, ... are
+    # refused by check_stem_shape, csrc/stem_api.hip)
+    return (ps is not None and filters % 64 == 0 and filters & (filters - 1) == 0 and ps[0].shape[1] == x.shape[1]
             and all(p.is_cuda and p.dtype == torch.float32 for p in ps))
 
 

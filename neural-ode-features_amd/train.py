@@ -21,8 +21,9 @@ import shutil
 import sys
 
 import torch
-import torch.nn.functional as F
 from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR, ReduceLROnPlateau
+
+from .head import cross_entropy      # F.cross_entropy (train.py:43,93) on the library's kernels; PyTorch's for CPU tensors
 
 SHAPES = {'mnist': (1, 28, 10), 'cifar10': (3, 32, 10), 'cifar100': (3, 32, 100), 'tiny-imagenet-200': (3, 64, 200)}
 
@@ -58,10 +59,23 @@ class Tally:
         self.hits = self.seen = self.batches = 0
         self.nfe = [0, 0]                      # forward, backward
 
-    def count(self, logits, target, loss_value):
-        self.loss_sum += loss_value
-        self.hits += int((logits.argmax(dim=1) == target).sum())
+    def count(self, logits, target, loss):
+        """train.py:44,46 / :94-96.  The library's loss kernel leaves {loss, correct predictions} of the batch in device
+        memory (`loss.node_stat`): ONE read-back instead of `loss.item()` + an arg-max / compare / sum chain + `.item()`."""
+        stat = getattr(loss, 'node_stat', None)
+        if stat is not None:
+            value, hits = stat.tolist()
+            self.loss_sum += value
+            self.hits += int(round(hits))
+        else:
+            self.loss_sum += loss.item()
+            self.hits += int((logits.argmax(dim=1) == target).sum())
         self.seen += target.shape[0]
+
+    def count_host(self, value, hits, n):
+        self.loss_sum += value
+        self.hits += int(round(hits))
+        self.seen += n
 
 
 def train(data, model, optimizer, args, gen, loop=None):
@@ -75,8 +89,9 @@ def train(data, model, optimizer, args, gen, loop=None):
     tally = Tally()
     if loop is not None:
         def tally_done(results):
-            for logits, target, loss, nf, nb in results:
-                tally.count(logits, target, loss.item())
+            for host, event, n, nf, nb in results:
+                event.synchronize()              # (a batch is handed back one iteration late: its numbers arrived long ago)
+                tally.count_host(float(host[0]), float(host[1]), n)
                 tally.nfe[0] += nf
                 tally.nfe[1] += nb
                 tally.batches += 1
@@ -88,8 +103,8 @@ def train(data, model, optimizer, args, gen, loop=None):
     for images, target in batches(data[0], data[1], args.batch_size, True, gen):
         images, target = images.to(args.device), target.to(args.device)
         logits = model(images)
-        loss = F.cross_entropy(logits, target)
-        tally.count(logits, target, loss.item())
+        loss = cross_entropy(logits, target)
+        tally.count(logits, target, loss)
         tally.nfe[0] += model.nfe(reset=True)
         loss.backward()
         tally.nfe[1] += model.nfe(reset=True)
@@ -111,13 +126,18 @@ def deferred_loop(model, optimizer, args):
 
     def step(images, target):
         logits = model(images)
-        loss = F.cross_entropy(logits, target)
+        loss = cross_entropy(logits, target)
         nf = model.nfe(reset=True)
         loss.backward()
         nb = model.nfe(reset=True)
         optimizer.step()
         optimizer.zero_grad()
-        return logits.detach(), target, loss.detach(), nf, nb
+        # the batch's {loss, correct predictions} travel to pinned host memory behind the step: nothing waits for them
+        host = torch.empty(2, dtype=torch.float32).pin_memory()
+        host.copy_(loss.node_stat, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return host, event, target.shape[0], nf, nb
 
     return integrate.DeferredLoop(integrate.Deferred(args.device), optimizer, step)
 
@@ -131,7 +151,7 @@ def evaluate(data, model, args):
             images, target = images.to(args.device), target.to(args.device)
             logits = model(images)
             tally.nfe[0] += model.nfe(reset=True)
-            tally.count(logits, target, F.cross_entropy(logits, target, reduction='sum').item())
+            tally.count(logits, target, cross_entropy(logits, target, reduction='sum'))
             tally.batches += 1
     return {'test_loss': tally.loss_sum / tally.seen, 'test_acc': tally.hits / tally.seen, 'test_nfe': tally.nfe[0] / tally.batches}
 

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'diag: needs libnode_hip_diag.so (build.py --diag), NODE_HIP_DIAG=1 and a GPU; never part of -m gpu')
 
 
 @pytest.fixture(scope='session')

@@ -155,3 +155,116 @@ def test_stem_and_head_on_gpu_match_the_reference_logits():
     with torch.no_grad():
         got = net(g['x'].cuda())
     assert rel_err(got, g['logits']) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Linear + cross-entropy on the library's kernels (node_head_loss_fwd / _bwd, csrc/kernels_loss.hip)
+# ---------------------------------------------------------------------------------------------------------------
+# (n, in_features, classes): cfg 2 / MNIST / cfg 5 heads, a ragged batch, CIFAR-100 and tiny-imagenet class counts (the lane
+# map changes at 32 and 64 classes), in_features that the channel groups do not divide
+LOSS_SHAPES = [(128, 256, 10), (32, 64, 10), (64, 1024, 10), (7, 64, 10), (1, 256, 10), (33, 96, 100), (16, 256, 200),
+               (5, 20, 3), (130, 64, 33), (9, 256, 64), (4, 64, 1000)]
+
+
+def _loss_case(n, c, o, seed):
+    gen = torch.Generator().manual_seed(seed)
+    pooled = torch.randn(n, c, generator=gen).relu()
+    w = torch.randn(o, c, generator=gen) / c ** 0.5
+    b = 0.1 * torch.randn(o, generator=gen)
+    y = torch.randint(0, o, (n,), generator=gen)
+    return pooled, w, b, y
+
+
+@pytest.mark.parametrize('shape', LOSS_SHAPES, ids=lambda s: 'n%d_c%d_o%d' % s)
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+def test_linear_cross_entropy_matches_oracle(shape, reduction):
+    """The three call shapes -- `linear` then `cross_entropy` (the reference's loop: p = model(x); loss = CE(p, y)), the
+    one-launch `linear_cross_entropy`, and `cross_entropy` on foreign logits -- against oracle.head / torch.autograd on the
+    CPU: logits, loss, the per-batch statistics and every gradient."""
+    import neural_ode_features_amd as nof
+    from oracle.head import linear_cross_entropy as oracle_lce
+    n, c, o = shape
+    pooled, w, b, y = _loss_case(n, c, o, seed=n + c + o)
+    pr, wr, br = (t.clone().requires_grad_(True) for t in (pooled, w, b))
+    want, want_logits = oracle_lce(pr, wr, br, y, reduction)
+    (1.7 * want).backward()
+    hits = float((want_logits.argmax(1) == y).sum())
+    tol = 2e-5
+
+    def check(loss, logits, grads, what):
+        assert rel_err(logits, want_logits) < tol, what
+        assert abs(float(loss) - float(want)) <= tol * max(1.0, abs(float(want))), what
+        stat = loss.node_stat.tolist()
+        assert abs(stat[0] - float(want)) <= tol * max(1.0, abs(float(want))) and stat[1] == hits, (what, stat, hits)
+        for g, r, name in zip(grads, (pr.grad, wr.grad, br.grad), ('d_pooled', 'd_weight', 'd_bias')):
+            assert rel_err(g, r) < 5e-5, (what, name)
+
+    # 1. drop-in call shape: two forward launches, ONE backward launch (the loss node carries the Linear layer)
+    pg, wg, bg = (t.cuda().requires_grad_(True) for t in (pooled, w, b))
+    logits = nof.linear(pg, wg, bg)
+    loss = nof.cross_entropy(logits, y.cuda(), reduction=reduction)
+    assert type(loss.grad_fn).__name__ == '_LinearCrossEntropyBackward'
+    (1.7 * loss).backward()
+    check(loss, logits, (pg.grad, wg.grad, bg.grad), 'linear + cross_entropy')
+    # 2. one forward launch
+    pg, wg, bg = (t.cuda().requires_grad_(True) for t in (pooled, w, b))
+    loss, logits = nof.linear_cross_entropy(pg, wg, bg, y.cuda(), reduction=reduction)
+    (1.7 * loss).backward()
+    check(loss, logits, (pg.grad, wg.grad, bg.grad), 'linear_cross_entropy')
+    # 3. the pieces on their own: Linear's backward from a given dL/dlogits, the loss on logits that came from elsewhere
+    pg, wg, bg = (t.cuda().requires_grad_(True) for t in (pooled, w, b))
+    logits = nof.linear(pg, wg, bg)
+    cot = torch.randn(n, o, generator=torch.Generator().manual_seed(3))
+    logits.backward(cot.cuda())
+    pr2, wr2, br2 = (t.clone().requires_grad_(True) for t in (pooled, w, b))
+    F.linear(pr2, wr2, br2).backward(cot)
+    for g, r in zip((pg.grad, wg.grad, bg.grad), (pr2.grad, wr2.grad, br2.grad)):
+        assert rel_err(g, r) < 5e-5
+    lg = want_logits.detach().cuda().requires_grad_(True)
+    loss = nof.cross_entropy(lg, y.cuda(), reduction=reduction)
+    assert type(loss.grad_fn).__name__ == '_CrossEntropyBackward'
+    loss.backward()
+    lr = want_logits.detach().clone().requires_grad_(True)
+    F.cross_entropy(lr, y, reduction=reduction).backward()
+    assert rel_err(lg.grad, lr.grad) < 5e-5
+
+
+def test_loss_is_bit_reproducible_and_the_scratch_counter_resets():
+    """Fixed summation order, no float atomics: 50 launches give one loss, one set of gradients; the arrival counter of the
+    last-workgroup reduction is left at zero by every launch (a second batch size reuses the same scratch)."""
+    import neural_ode_features_amd as nof
+    pooled, w, b, y = _loss_case(128, 256, 10, seed=1)
+    pg, wg, bg, yg = pooled.cuda(), w.cuda().requires_grad_(True), b.cuda(), y.cuda()
+    first = None
+    for it in range(50):
+        wg.grad = None
+        loss, _ = nof.linear_cross_entropy(pg, wg, bg, yg)
+        loss.backward()
+        got = (float(loss), wg.grad.clone())
+        if first is None:
+            first = got
+        assert got[0] == first[0] and torch.equal(got[1], first[1])
+    p2, w2, b2, y2 = _loss_case(37, 256, 10, seed=2)
+    l2, _ = nof.linear_cross_entropy(p2.cuda(), w2.cuda(), b2.cuda(), y2.cuda())
+    assert abs(float(l2) - float(F.cross_entropy(F.linear(p2, w2, b2), y2))) < 1e-5
+
+
+def test_training_step_runs_no_foreign_kernel_in_the_head():
+    """model(x) -> cross_entropy -> backward of the whole ODENet: PyTorch dispatches no addmm / mm / log_softmax / nll_loss
+    (the head's Linear layer and the loss are the library's launches)."""
+    import neural_ode_features_amd as nof
+    from torch.profiler import ProfilerActivity, profile
+    torch.manual_seed(0)
+    net = nof.ODENet(3, out=10, n_filters=64, downsample='residual', adjoint=True, dropout=0.5).cuda().train()
+    x = torch.randn(8, 3, 32, 32, device='cuda')
+    y = torch.randint(0, 10, (8,), device='cuda')
+    nof.cross_entropy(net(x), y).backward()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        loss = nof.cross_entropy(net(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    bad = [k for k in names if any(s in k.lower() for s in ('addmm', 'aten::mm', 'log_softmax', 'nll_loss', 'aten::linear', 'cross_entropy_loss'))]
+    assert not bad, bad
+    for name, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name

@@ -98,6 +98,35 @@ def test_full_size_free_running_pipeline_vs_oracle_ordinary_parameters(tol):
         assert l2_y < 0.1 and l2_p < 0.1
 
 
+_F64_DEVICE = None
+
+
+def _arbiter_device():
+    """Where the fp64 ARBITER leg of the oracle runs.  The oracle is PyTorch code; its fp64 convolutions on the host are what
+    made the full-size arbiter tests the slowest of the suite (211 s for one case).  Where PyTorch-ROCm can run an fp64
+    conv2d / group_norm forward + backward on the device (its own library path: nothing of this package), the arbiter runs
+    there -- the fp32 oracle leg, the reference-equivalent one, always stays on the CPU.  NODE_TEST_ARBITER=cpu forces the host."""
+    global _F64_DEVICE
+    if _F64_DEVICE is None:
+        _F64_DEVICE = 'cpu'
+        if os.environ.get('NODE_TEST_ARBITER', 'auto') != 'cpu':
+            try:
+                gen = torch.Generator().manual_seed(0)
+                x = torch.randn(2, 8, 8, 8, generator=gen, dtype=torch.float64)
+                w = torch.randn(8, 8, 3, 3, generator=gen, dtype=torch.float64)
+                xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+                yg = F.group_norm(F.conv2d(xg, wg, padding=1), 4)
+                yg.square().sum().backward()
+                xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                yc = F.group_norm(F.conv2d(xc, wc, padding=1), 4)
+                yc.square().sum().backward()
+                if float((yg.detach().cpu() - yc.detach()).abs().max()) < 1e-12 and float((wg.grad.cpu() - wc.grad).abs().max()) < 1e-10:
+                    _F64_DEVICE = 'cuda'
+            except Exception as e:     # no fp64 convolution on this PyTorch-ROCm build: the arbiter stays on the host
+                print('fp64 arbiter stays on the CPU:', type(e).__name__, e)
+    return _F64_DEVICE
+
+
 def _replay_triplet(shape, tol, seed, t_end):
     """Ordinary parameters (ReLUs switch inside the solve) under an fp64 ARBITER.  A free-running HIP solve supplies
     the accepted step sizes (forward and backward); the same discrete scheme is then integrated three times in replay
@@ -131,11 +160,13 @@ def _replay_triplet(shape, tol, seed, t_end):
     # 3. replay by the oracle in fp32 and in fp64
     res = {}
     for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
-        tw = copy.deepcopy(twin).to(dt)
-        yo = y.detach().to(dt).clone().requires_grad_(True)
-        out_o = tdq.odeint_adjoint(tw, yo, t.to(dt), rtol=tol, atol=tol, method='dopri5', options=dict(opts))
-        (out_o * wgt.to(dt)).sum().backward()
-        res[name] = dict(out=out_o.detach(), gy=yo.grad, gp=torch.cat([p.grad.reshape(-1) for p in tw.parameters()]))
+        dev = _arbiter_device() if name == 'f64' else 'cpu'
+        tw = copy.deepcopy(twin).to(dt).to(dev)
+        yo = y.detach().to(dt).to(dev).clone().requires_grad_(True)
+        out_o = tdq.odeint_adjoint(tw, yo, t.to(dt).to(dev), rtol=tol, atol=tol, method='dopri5', options=dict(opts))
+        (out_o * wgt.to(dt).to(dev)).sum().backward()
+        res[name] = dict(out=out_o.detach().cpu(), gy=yo.grad.cpu(), gp=torch.cat([p.grad.reshape(-1) for p in tw.parameters()]).cpu())
+    print('  (fp64 arbiter ran on %s)' % _arbiter_device())
     return hip, res['f32'], res['f64'], free
 
 

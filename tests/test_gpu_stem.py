@@ -154,3 +154,48 @@ def test_stem_runs_no_library_convolution():
     bad = [k for k in names if any(s in k.lower() for s in ('conv', 'miopen', 'group_norm', 'native_group_norm', 'transpose', 'relu'))]
     assert not bad, bad
     assert any('_StemFn' in k for k in names), names
+
+
+def test_stem_filter_counts_the_kernels_refuse_run_the_module_sequence():
+    """filters = 192 (cpg 6): the GroupNorm passes keep whole groups inside power-of-two channel blocks, so the library
+    refuses the shape (check_stem_shape) and the module runs its PyTorch sequence -- output and gradients still match fp64.
+    (Round-4 advisor finding: the fused path took such shapes and left channels 128..191 unwritten.)"""
+    import ctypes as C_
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    for filters in (192, 384):
+        shape = _lib.NodeStemShape(4, 3, 32, 32, filters, 1e-5)
+        assert lib.node_stem_workspace_bytes(C_.byref(shape)) == 0
+    stem, ref = _stem_pair(3, 192, seed=11)
+    stem = stem.cuda()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 32, 32, generator=gen)
+    out = stem(x.cuda())
+    assert type(out.grad_fn).__name__ != '_StemFnBackward'
+    out_ref = ref(x.double())
+    cot = torch.randn(out_ref.shape, generator=gen)
+    out.backward(cot.cuda())
+    out_ref.backward(cot.double())
+    assert float((out.detach().cpu().double() - out_ref.detach()).abs().max() / out_ref.detach().abs().max()) <= 1e-4
+    for (name, p), (_, q) in zip(stem.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.cpu().double() - q.grad).norm() / q.grad.norm()) <= 1e-3, name
+
+
+def test_stem_input_gradient_and_second_backward():
+    """An input that requires a gradient (saliency maps, adversarial examples) takes the module sequence -- the fused node
+    produces parameter gradients only; a second backward through one fused forward raises instead of crashing."""
+    stem, ref = _stem_pair(3, 64, seed=3)
+    stem = stem.cuda()
+    x = torch.randn(2, 3, 32, 32)
+    xg = x.cuda().requires_grad_(True)
+    out = stem(xg)
+    assert type(out.grad_fn).__name__ != '_StemFnBackward'
+    out.sum().backward()
+    xd = x.double().requires_grad_(True)
+    ref(xd).sum().backward()
+    assert float((xg.grad.cpu().double() - xd.grad).abs().max() / xd.grad.abs().max()) <= 1e-3
+    out = stem(x.cuda())
+    assert type(out.grad_fn).__name__ == '_StemFnBackward'
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match='second backward'):
+        out.sum().backward()

@@ -88,12 +88,20 @@ def check(asm_path):
     return bad
 
 
+def build_flags():
+    """The flags the library itself is compiled with (neural-ode-features_amd/build.py: one list, no drift)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('node_amd_build_flags', os.path.join(ROOT, 'neural-ode-features_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.HIPCC, list(mod.FLAGS)
+
+
 def main():
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc, flags = build_flags()
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'kw4.s')
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-S', '--cuda-device-only',
-               os.path.join(CSRC, 'kernels_w4.hip'), '-o', out]
+        cmd = [hipcc] + flags + ['-S', '--cuda-device-only', os.path.join(CSRC, 'kernels_w4.hip'), '-o', out]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         bad = check(out)
     for b in bad:

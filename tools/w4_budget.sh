@@ -7,6 +7,7 @@ OUT=${1:-gpurun_out/w4_budget.txt}
 SHAPE=${2:-128,256,8}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
+export NODE_HIP_DIAG=1    # the ablations live in libnode_hip_diag.so (build.py --diag), not in the product library
 : > $R/$OUT
 for ab in 0 17 18 20 22 24 28 30 21 25; do
   rm -rf /tmp/wb_$ab
@@ -16,7 +17,7 @@ for ab in 0 17 18 20 22 24 28 30 21 25; do
 import csv, sys
 names = {0: 'full kernel', 17: 'no shared component', 18: 'operand requests only (no split / MFMA)', 20: 'no stores',
          22: 'operand requests only, no stores', 24: 'no operand requests (split + MFMA + stores)', 28: 'split + MFMA only (no requests, no stores)',
-         30: 'neither requests, MFMA nor stores: launch + prologue + the LDS reduction', 21: 'no shared component, no stores',
+         30: 'bits 2|4|8: bit 8 wins in w4b_run (kernels_w4.hip) -- split + MFMA only again, i.e. the same as 28, NOT launch + prologue', 21: 'no shared component, no stores',
          25: 'no shared component, no requests'}
 ab = int(sys.argv[2])
 for r in csv.DictReader(open(sys.argv[1])):

@@ -6,6 +6,7 @@ OUT=${1:-gpurun_out/w4_pad.txt}
 SHAPE=${2:-128,256,8}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
+export NODE_HIP_DIAG=1    # the ablations live in libnode_hip_diag.so (build.py --diag), not in the product library
 : > $R/$OUT
 for pad in ${PADS:-0,0 1,0 0,1 1,1 2,3 3,5 5,7 7,11}; do
   for ab in ${ABS:-16 18}; do

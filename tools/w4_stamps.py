@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import sys
 
+os.environ['NODE_HIP_DIAG'] = '1'     # the stamps live in libnode_hip_diag.so (build.py --diag)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_ode_features_amd import _lib
