@@ -346,12 +346,14 @@ class Deferred:
     #     last step: node_step_record.t_prev / dt_used) -- step sizes that come out a few percent smaller on the next batch
     #     then need one step more;
     #   * a count above everything in the history was seen within the last QUIET solves.
+    # Margins: FRAGILE 0.15 / QUIET 16 in round 4; the measured sweep on the cfg-3 bench loop (profiles/r04_deferred_policy_cfg3.txt)
+    # has 0.05 / 8 at +1.3 % images/s with 0 misses in 200 steps, soaked again in round 5 (profiles/r05_deferred_soak_cfg3.txt).
     # Round 3 enqueued last count + 1 until eight exact predictions in a row -- at tol 1e-5 that never happened, and every
     # solve carried one or two dead steps (profiles/r03_r_cfg3_steps.txt: 29 dead component GEMMs per step).
     HIST = int(os.environ.get('NODE_DEFERRED_HIST', 8))
     CALM = 4
-    FRAGILE = float(os.environ.get('NODE_DEFERRED_FRAGILE', 0.15))      # (environment: A/B measurements, tools/deferred_soak.py)
-    QUIET = int(os.environ.get('NODE_DEFERRED_QUIET', 16))
+    FRAGILE = float(os.environ.get('NODE_DEFERRED_FRAGILE', 0.05))      # (environment: A/B measurements, tools/deferred_soak.py)
+    QUIET = int(os.environ.get('NODE_DEFERRED_QUIET', 8))
 
     def __init__(self, device):
         self.device = torch.device(device)

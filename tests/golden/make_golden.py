@@ -31,6 +31,12 @@ name first.  What the fixtures pin:
                           cotangent (round 4: ``python tests/golden/make_golden.py stem``) -- what the library's own stem
                           kernels (csrc/kernels_stem.hip) are held against
 
+  odenet_rk4_f64.pt       reference ``ODENet(1, n_filters=64, downsample='residual', method='rk4', adjoint=True)`` -- the MODEL of
+                          BASELINE.json configs[0] (reproduce.sh:9; MNIST-shaped input, state [n, 64, 7, 7], one rk4 3/8 step) --
+                          trained one step end to end at batch 4, dropout off (round 5: ``python tests/golden/make_golden.py cfg1``):
+                          at 64 filters the library's own stem kernels take the stem (the 8-filter fixtures run the module
+                          sequence), so this is the end-to-end fixture that holds them, the ODE block and the head together
+
 Fixtures are data (tensors / json).  No reference source text is stored.
 """
 import json
@@ -220,6 +226,9 @@ def make_stem(ref):
 
 def main():
     ref = import_reference_model()
+    if 'cfg1' in sys.argv[1:]:         # only the fixture added in round 5
+        make_odenet_e2e(ref, 'odenet_rk4_f64.pt', 'rk4', 1e-3, 1, 64, 28, 4, 1, seed=61)
+        return
     if 'stem' in sys.argv[1:]:         # only the fixture added in round 4
         make_stem(ref)
         return
@@ -244,6 +253,7 @@ def main():
     make_ode_stem_features(ref)
     make_ode2_train(ref)
     make_stem(ref)
+    make_odenet_e2e(ref, 'odenet_rk4_f64.pt', 'rk4', 1e-3, 1, 64, 28, 4, 1, seed=61)
 
 
 if __name__ == '__main__':

@@ -30,9 +30,10 @@ def test_hip_dynamics_match_reference_odefunc_fixture(golden_dir, name):
     assert rel_err(nof.odefunc_forward(f, float(g['t']), g['y'].cuda()), g['f']) < 1e-5
 
 
-@pytest.mark.parametrize('name', ['odenet_rk4.pt', 'odenet_dopri5.pt'])
+@pytest.mark.parametrize('name', ['odenet_rk4.pt', 'odenet_dopri5.pt', 'odenet_rk4_f64.pt'])
 def test_hip_end_to_end_matches_reference_run(golden_dir, name):
-    """Reference ODENet + oracle solver (fixture)  vs  package ODENet + HIP solver."""
+    """Reference ODENet + oracle solver (fixture)  vs  package ODENet + HIP solver.  `odenet_rk4_f64.pt` is the model of
+    BASELINE.json configs[0] (64 filters, MNIST-shaped input, rk4, adjoint): the stem runs on the library's own kernels there."""
     import neural_ode_features_amd as nof
     g = _load(golden_dir, name)
     net = nof.ODENet(g['in_ch'], out=10, n_filters=g['filters'], downsample='residual', method=g['method'],
@@ -59,11 +60,49 @@ def test_hip_end_to_end_matches_reference_run(golden_dir, name):
     # fresh box (tests/test_gpu_head.py): those keep the wider bound.
     from neural_ode_features_amd import stem as stem_mod
     own_stem = isinstance(net.downsample.module, stem_mod.ResidualStem) and stem_mod.fusable(net.downsample.module, g['x'].cuda())
+    assert own_stem == (g['filters'] >= 64)
     for k, v in net.named_parameters():
         ref = g['grads'][k]
         scale = max(float(ref.abs().max()), 1e-4 * gmax)
         bound = 2e-2 if (k.startswith('downsample') and not own_stem) else 5e-3
         assert float((v.grad.detach().cpu() - ref).abs().max()) / scale < bound, k
+
+
+def test_cfg1_exact_shape_training_step_vs_oracle():
+    """BASELINE.json configs[0] at its own size on the HIP path: MNIST-shaped batch [32, 1, 28, 28] ~ U[0, 1), `ODENet(1,
+    n_filters=64, downsample='residual', method='rk4', adjoint=True)` (reproduce.sh:9) -- state [32, 64, 7, 7], one rk4 3/8
+    step forward (NFE-F 4), one backward (NFE-B 5) -- one training step against the same net on the CPU with the oracle
+    standing in for torchdiffeq.  Dropout off: the two devices' generators draw different masks."""
+    import copy
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    torch.manual_seed(23)
+    net = nof.ODENet(1, out=10, n_filters=64, downsample='residual', method='rk4', tol=1e-3, adjoint=True, t1=1, dropout=0)
+    ref = copy.deepcopy(net)
+    ref.odeblock.odeint = tdq.odeint_adjoint
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(32, 1, 28, 28, generator=gen)
+    y = torch.randint(0, 10, (32,), generator=gen)
+    net = net.cuda().train()
+    ref.train()
+    p = net(x.cuda())
+    assert type(net.downsample.module(x.cuda()).grad_fn).__name__ == '_StemFnBackward'     # own stem kernels at 64 filters
+    loss = nof.cross_entropy(p, y.cuda())
+    nfe_f = net.nfe(reset=True)
+    loss.backward()
+    nfe_b = net.nfe(reset=True)
+    pr = ref(x)
+    assert tuple(ref.odeblock.odefunc.norm1.weight.shape) == (64,) and pr.shape == (32, 10)
+    lr = F.cross_entropy(pr, y)
+    rf = ref.nfe(reset=True)
+    lr.backward()
+    rb = ref.nfe(reset=True)
+    assert (nfe_f, nfe_b) == (rf, rb) == (4, 5)
+    assert float((p.detach().cpu() - pr.detach()).abs().max()) <= 1e-4 and abs(float(loss) - float(lr)) < 1e-5
+    gmax = max(float(v.grad.abs().max()) for v in ref.parameters())
+    for (k, v), (_, r) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = max(float(r.grad.abs().max()), 1e-4 * gmax)
+        assert float((v.grad.cpu() - r.grad).abs().max()) / scale < 5e-3, k
 
 
 def test_full_size_cifar_state_forward_and_vjp_vs_oracle():
