@@ -253,6 +253,54 @@ int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma
 int node_gn_relu_bwd(const node_shape* shape, const float* z, const float* gamma, const float* beta,
                      const float* stats, int relu, const float* g_out, float* dz, float* gpart, float* gsum, void* stream);
 
+/* Generic ("flat") solver -- the fallback of SURVEY.md 8b: `torchdiffeq.odeint[_adjoint]` accepts ANY nn.Module as `func`
+ * (model.py:367), and the reference itself offers dynamics the fused kernels do not take (train.py:202 `--norm batch`).
+ * For those the CALLER evaluates the dynamics (PyTorch ops on its stream) and this library does everything else on the
+ * device with the kernels of the fused solves: stage states y + dt sum_j beta_ij k_j, stage times, the Hairer initial
+ * step, the mixed error norm per tensor, accept / reject, the next step size, quartic dense output at the target times,
+ * FSAL commit -- no host decision; the host reads the controller back when it likes (node_flat_status_read).
+ * State: 1..3 flat fp32 tensors (`seg`), each with an end-of-step buffer y1 and seven stage-derivative buffers k[0..6]
+ * owned by the caller, plus -- has_scalar -- one scalar kept inside the controller (the adjoint's time cotangent).
+ * Time is in SOLVER ORIENTATION: increasing; a solve towards smaller t passes tsign = -1, negated times and derivatives
+ * (upstream's convention), and node_flat_stage hands out tsign * time for the caller's function.
+ * dopri5 step:  for s in 0..5: node_flat_stage(s) -> caller evaluates -> stores tsign * f into k[s + 1] (stage 5's state
+ * must be written to the seg's y1 buffers: it IS y1); node_flat_finish_step.  Before the first step: stage NODE_FLAT_F0
+ * (k[0]), then node_flat_initial_step(0), stage NODE_FLAT_PROBE (k[1]), node_flat_initial_step(1) unless first_dt is given.
+ * rk4 (3/8 rule, one step per target interval): stage F0 -> k[0], stages 1..3 -> k[1..3], finish. */
+typedef struct node_flat_seg {
+  float* y;        /* state at the start of the current step (updated in place by the commit)   */
+  float* y1;       /* state at the end of the step                                               */
+  float* k[7];     /* stage derivatives                                                          */
+  size_t n;
+} node_flat_seg;
+typedef struct node_flat_solve {
+  int32_t nseg;          /* 1..3                                                                 */
+  int32_t has_scalar;    /* != 0: augmented (adjoint) solve -- scalar segment, dense output of every segment at the interval's end */
+  node_flat_seg seg[3];
+  float rtol, atol, tsign;
+  int32_t n_targets;     /* output times of the current interval                                 */
+  void* ws;              /* node_flat_workspace_bytes(n_targets) bytes, 256-byte aligned          */
+  size_t ws_bytes;
+} node_flat_solve;
+typedef struct node_flat_status {
+  int32_t done, status, steps, accepted, rejected;
+  double t, dt, first_dt;
+  float scalar;
+} node_flat_status;
+enum { NODE_FLAT_F0 = -1, NODE_FLAT_PROBE = -2 };
+size_t node_flat_workspace_bytes(int n_targets);
+/* new interval starting at t0 (solver orientation) with `targets` (host array, increasing); first_dt = 0: to be chosen
+ * by node_flat_initial_step.  new_solve != 0 also resets the cumulative counters and the scalar segment. */
+int node_flat_begin(const node_flat_solve* f, double t0, const double* targets, double first_dt, int new_solve, void* stream);
+/* y_stage[i] <- stage state of segment i (nothing for NODE_FLAT_F0); *t_stage (device float, nullable) <- tsign * stage time */
+int node_flat_stage(const node_flat_solve* f, int method, int stage, float* const* y_stage, float* t_stage, void* stream);
+/* scalar segment: which = -1 its value, 0..6 a stage derivative; (accumulate ? old : 0) + scale * src[0], src on the device */
+int node_flat_scalar(const node_flat_solve* f, int which, const float* src, float scale, int accumulate, void* stream);
+int node_flat_initial_step(const node_flat_solve* f, int phase, void* stream);
+/* y_out (nullable, forward solves): [n_targets][seg[0].n], row j <- dense output at target j when a step passes it */
+int node_flat_finish_step(const node_flat_solve* f, int method, float* y_out, void* stream);
+int node_flat_status_read(const node_flat_solve* f, node_flat_status* out, void* stream);   /* synchronises the stream */
+
 /* The classifier's Linear layer and the loss of the training loop as ONE launch each way -- model.py:244-250
  * (`nn.Linear(in_ch, out)` behind Flatten) and train.py:43 (`F.cross_entropy(p, y)`), plus the per-batch numbers the loop
  * reads at train.py:44,46 (loss value, correct predictions), left in device memory so that a caller can read them once

@@ -36,6 +36,8 @@ EXPORTS = [
     'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3',
     'node_stem_workspace_bytes', 'node_stem_fwd', 'node_stem_bwd', 'node_stem_conv_workspace_bytes', 'node_stem_conv',
     'node_head_loss_scratch_bytes', 'node_head_loss_fwd', 'node_head_loss_bwd',
+    'node_flat_workspace_bytes', 'node_flat_begin', 'node_flat_stage', 'node_flat_scalar', 'node_flat_initial_step',
+    'node_flat_finish_step', 'node_flat_status_read',
 ]
 
 
@@ -109,6 +111,23 @@ class NodeHeadLoss(C.Structure):
 
 class NodeHeadLossGrad(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ('grad_loss', 'grad_logits', 'd_logits', 'd_pooled', 'd_weight', 'd_bias')]
+
+
+class NodeFlatSeg(C.Structure):
+    _fields_ = [('y', C.c_void_p), ('y1', C.c_void_p), ('k', C.c_void_p * 7), ('n', C.c_size_t)]
+
+
+class NodeFlatSolve(C.Structure):
+    _fields_ = [('nseg', C.c_int32), ('has_scalar', C.c_int32), ('seg', NodeFlatSeg * 3), ('rtol', C.c_float), ('atol', C.c_float),
+                ('tsign', C.c_float), ('n_targets', C.c_int32), ('ws', C.c_void_p), ('ws_bytes', C.c_size_t)]
+
+
+class NodeFlatStatus(C.Structure):
+    _fields_ = [('done', C.c_int32), ('status', C.c_int32), ('steps', C.c_int32), ('accepted', C.c_int32), ('rejected', C.c_int32),
+                ('t', C.c_double), ('dt', C.c_double), ('first_dt', C.c_double), ('scalar', C.c_float)]
+
+
+FLAT_F0, FLAT_PROBE = -1, -2
 
 
 class NodeHipError(RuntimeError):
@@ -193,6 +212,20 @@ def load():
     lib.node_head_loss_fwd.argtypes = [P(NodeHeadLoss), vp]
     lib.node_head_loss_bwd.restype = i32
     lib.node_head_loss_bwd.argtypes = [P(NodeHeadLoss), P(NodeHeadLossGrad), vp]
+    lib.node_flat_workspace_bytes.restype = sz
+    lib.node_flat_workspace_bytes.argtypes = [i32]
+    lib.node_flat_begin.restype = i32
+    lib.node_flat_begin.argtypes = [P(NodeFlatSolve), C.c_double, P(C.c_double), C.c_double, i32, vp]
+    lib.node_flat_stage.restype = i32
+    lib.node_flat_stage.argtypes = [P(NodeFlatSolve), i32, i32, P(C.c_void_p), vp, vp]
+    lib.node_flat_scalar.restype = i32
+    lib.node_flat_scalar.argtypes = [P(NodeFlatSolve), i32, vp, f32, i32, vp]
+    lib.node_flat_initial_step.restype = i32
+    lib.node_flat_initial_step.argtypes = [P(NodeFlatSolve), i32, vp]
+    lib.node_flat_finish_step.restype = i32
+    lib.node_flat_finish_step.argtypes = [P(NodeFlatSolve), i32, vp, vp]
+    lib.node_flat_status_read.restype = i32
+    lib.node_flat_status_read.argtypes = [P(NodeFlatSolve), P(NodeFlatStatus), vp]
     ver = lib.node_abi_version()
     if ver != NODE_ABI_VERSION:
         raise RuntimeError('libnode_hip ABI %d != binding ABI %d' % (ver, NODE_ABI_VERSION))

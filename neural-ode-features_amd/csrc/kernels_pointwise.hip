@@ -733,6 +733,42 @@ void launch_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_emit_outputs, grid, dim3(256), 0, s, a, d);
 }
 
+// The same for a FLAT state (the generic solver, node_flat_*: dynamics evaluated by the caller, no layout): out[j][i]
+__global__ __launch_bounds__(256) void k_emit_flat(EmitArgs a, size_t n) {
+  const Ctrl* c = a.ctrl;
+  const int j0 = c->j0, j1 = c->j1;
+  if (j1 <= j0) return;
+  const float dt = (float)c->dt_used;
+  const float t0f = (float)c->t_prev, t1f = (float)c->t;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (int j = j0; j < j1; ++j) {
+    const float x = ((float)a.targets[j] - t0f) / (t1f - t0f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      float kk[7];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) kk[q] = (q == 1) ? 0.f : a.k[q][i];
+      a.y_out[(size_t)j * n + i] = interp_one(a.y0[i], a.y1[i], kk, dt, x);
+    }
+  }
+}
+void launch_emit_flat(const EmitArgs& a, size_t n, hipStream_t s) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_emit_flat, dim3((unsigned)blocks), dim3(256), 0, s, a, n);
+}
+// the time an evaluation of the caller's dynamics happens at, as a device float (the caller hands it to its function)
+__global__ void k_flat_time(EvalTime et, float* out) { *out = eval_time(et); }
+void launch_flat_time(const EvalTime& et, float* out, hipStream_t s) { hipLaunchKernelGGL(k_flat_time, dim3(1), dim3(1), 0, s, et, out); }
+// the scalar segment of a flat state lives in the controller: which = -1 its value, 0..6 its stage derivatives
+__global__ void k_flat_scalar(Ctrl* c, int which, const float* src, float scale, int accumulate) {
+  const float v = scale * src[0];
+  if (which < 0) c->ts_cur = (accumulate ? c->ts_cur : 0.f) + v;
+  else c->ts_k[which] = (accumulate ? c->ts_k[which] : 0.f) + v;
+}
+void launch_flat_scalar(Ctrl* ctrl, int which, const float* src, float scale, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(k_flat_scalar, dim3(1), dim3(1), 0, s, ctrl, which, src, scale, accumulate);
+}
+
 // Accepted step, interval not finished: y <- y1, k0 <- k6 (FSAL) for every tensor segment.  Augmented solve at the
 // end of its interval: every segment <- dense output at the interval's end time, in place (element-wise).
 __global__ __launch_bounds__(256) void k_commit(CommitArgs a) {

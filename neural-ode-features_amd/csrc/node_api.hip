@@ -1700,6 +1700,197 @@ extern "C" int node_solve_backprop(const node_shape* shape, const node_params* p
   return S.check_launch("node_solve_backprop");
 }
 
+}  // extern "C"
+
+// ----------------------------------------------------------------------------
+// Generic ("flat") solver: the library's device-resident step controller around dynamics that the CALLER evaluates
+// (SURVEY.md 8b "Fallback": model.py:367 accepts any nn.Module; train.py:202 offers norm='batch').  The state is up to
+// three flat fp32 tensors (+ one scalar kept in the controller: the adjoint's time cotangent); the caller owns every
+// buffer, asks for a stage state + stage time, evaluates its function on them (PyTorch ops on the same stream), stores the
+// result in the stage's derivative buffer and calls node_flat_finish_step: error norm, accept / reject, next step
+// size, dense output and FSAL commit are the SAME kernels the fused solves run (k_error_norm, k_step_controller,
+// k_emit_flat, k_commit) -- no decision is taken on the host, which reads the controller back whenever it wants.
+// ----------------------------------------------------------------------------
+namespace {
+struct FlatPlan { Ctrl* ctrl; double* targets; float* partial[3]; size_t bytes; };
+FlatPlan flat_plan(void* base, int n_targets) {
+  FlatPlan f;
+  Bump b(base);
+  f.ctrl = b.take<Ctrl>(1);
+  f.targets = b.take<double>((size_t)(n_targets > 0 ? n_targets : 1));
+  for (int i = 0; i < 3; ++i) f.partial[i] = b.take<float>(ERR_BLOCKS * 2);
+  f.bytes = (b.off + 255) & ~(size_t)255;
+  return f;
+}
+int flat_check(const node_flat_solve* f, FlatPlan* plan) {
+  if (!f) return fail(NODE_ERR_NULL, "node_flat_solve is NULL");
+  if (f->nseg < 1 || f->nseg > 3) return fail(NODE_ERR_ARG, "nseg must be 1..3 (got %d)", f->nseg);
+  if (!f->ws || (((uintptr_t)f->ws) & 255)) return fail(NODE_ERR_ARG, "workspace must be non-NULL and 256-byte aligned");
+  if (f->n_targets < 1 || f->n_targets > STEP_LIST_CAP) return fail(NODE_ERR_ARG, "n_targets must be 1..%d", STEP_LIST_CAP);
+  for (int i = 0; i < f->nseg; ++i) {
+    const node_flat_seg& sg = f->seg[i];
+    if (!sg.y || !sg.y1 || sg.n == 0) return fail(NODE_ERR_NULL, "segment %d: y / y1 is NULL or empty", i);
+    for (int j = 0; j < 7; ++j)
+      if (!sg.k[j]) return fail(NODE_ERR_NULL, "segment %d: stage derivative buffer %d is NULL", i, j);
+    if ((((uintptr_t)sg.y) | ((uintptr_t)sg.y1)) & 15) return fail(NODE_ERR_ARG, "segment %d: buffers must be 16-byte aligned", i);
+  }
+  *plan = flat_plan(f->ws, f->n_targets);
+  if (f->ws_bytes < plan->bytes) return fail(NODE_ERR_WORKSPACE, "workspace too small: %zu < %zu", f->ws_bytes, plan->bytes);
+  return NODE_OK;
+}
+int flat_launch_ok(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(NODE_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return NODE_OK;
+}
+}  // namespace
+
+extern "C" size_t node_flat_workspace_bytes(int n_targets) { return flat_plan(nullptr, n_targets).bytes; }
+
+extern "C" int node_flat_begin(const node_flat_solve* f, double t0, const double* targets, double first_dt, int new_solve, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  if (!targets) return fail(NODE_ERR_NULL, "targets is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  HostStage* hs = nullptr;
+  TRY(get_stage((size_t)f->n_targets + 2 * STEP_LIST_CAP, &hs));
+  // (the staging is reused by the next call of this thread: wait for the copy -- a solve begins once per interval)
+  for (int i = 0; i < f->n_targets; ++i) {
+    if (i > 0 && !(targets[i] > targets[i - 1])) return fail(NODE_ERR_ARG, "targets must increase (solver orientation)");
+    hs->lists[i] = targets[i];
+  }
+  HIP_TRY(hipMemcpyAsync(p.targets, hs->lists, (size_t)f->n_targets * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (new_solve) launch_set_ctrl(p.ctrl, t0, first_dt, 1, st);      // also zeroes the scalar segment
+  else launch_set_interval(p.ctrl, t0, first_dt, st);               // keeps the scalar segment and the cumulative counters
+  return flat_launch_ok("node_flat_begin");
+}
+
+extern "C" int node_flat_stage(const node_flat_solve* f, int method, int stage, float* const* y_stage, float* t_stage, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  hipStream_t st = (hipStream_t)stream;
+  EvalTime et;
+  et.ctrl = p.ctrl; et.tsign = f->tsign; et.mode = TM_STAGE; et.alpha = 0.f;
+  const double* row = nullptr;
+  int ncoef = 0, scale = SC_DT;
+  static const double rk4_rows[3][3] = {{1.0 / 3, 0, 0}, {-1.0 / 3, 1.0, 0}, {1.0, -1.0, 1.0}};
+  static const double rk4_alpha[3] = {1.0 / 3, 2.0 / 3, 1.0};
+  static const double one[1] = {1.0};
+  if (stage == NODE_FLAT_F0) {
+    // f(t, y) at the current point: nothing to combine
+  } else if (stage == NODE_FLAT_PROBE) {
+    row = one; ncoef = 1; scale = SC_H0; et.mode = TM_PROBE;
+  } else if (method == NODE_METHOD_DOPRI5 && stage >= 0 && stage < 6) {
+    row = DP_BETA[stage]; ncoef = stage + 1; et.alpha = (float)DP_ALPHA[stage];
+  } else if (method == NODE_METHOD_RK4 && stage >= 1 && stage <= 3) {
+    row = rk4_rows[stage - 1]; ncoef = stage; et.alpha = (float)rk4_alpha[stage - 1];
+  } else {
+    return fail(NODE_ERR_ARG, "bad (method, stage) = (%d, %d)", method, stage);
+  }
+  if (row != nullptr) {
+    if (!y_stage) return fail(NODE_ERR_NULL, "y_stage is NULL");
+    for (int i = 0; i < f->nseg; ++i) {
+      if (!y_stage[i]) return fail(NODE_ERR_NULL, "y_stage[%d] is NULL", i);
+      float* ks[7];
+      for (int j = 0; j < 7; ++j) ks[j] = f->seg[i].k[j];
+      launch_lincomb(Solver::make_comb(f->seg[i].y, ks, row, ncoef, scale), p.ctrl, y_stage[i], f->seg[i].n, st);
+    }
+  }
+  if (t_stage) launch_flat_time(et, t_stage, st);
+  return flat_launch_ok("node_flat_stage");
+}
+
+extern "C" int node_flat_scalar(const node_flat_solve* f, int which, const float* src, float scale, int accumulate, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  if (!src) return fail(NODE_ERR_NULL, "src is NULL");
+  if (which < -1 || which > 6) return fail(NODE_ERR_ARG, "which must be -1 (value) or 0..6 (stage derivative)");
+  launch_flat_scalar(p.ctrl, which, src, scale, accumulate, (hipStream_t)stream);
+  return flat_launch_ok("node_flat_scalar");
+}
+
+extern "C" int node_flat_initial_step(const node_flat_solve* f, int phase, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  if (phase != 0 && phase != 1) return fail(NODE_ERR_ARG, "phase must be 0 or 1");
+  hipStream_t st = (hipStream_t)stream;
+  InitSeg segs[3];
+  for (int i = 0; i < f->nseg; ++i) segs[i] = {f->seg[i].y, f->seg[i].k[0], f->seg[i].k[1], f->seg[i].n};
+  launch_init_norms(segs, p.partial, f->nseg, f->rtol, f->atol, phase, st);
+  InitCtlArgs ic;
+  memset(&ic, 0, sizeof(ic));
+  ic.ctrl = p.ctrl;
+  for (int i = 0; i < f->nseg; ++i) { ic.partial[i] = p.partial[i]; ic.numel[i] = (double)f->seg[i].n; }
+  ic.nseg = f->nseg; ic.has_scalar = f->has_scalar ? 1 : 0; ic.phase = phase; ic.rtol = f->rtol; ic.atol = f->atol;
+  launch_init_controller(ic, st);
+  return flat_launch_ok("node_flat_initial_step");
+}
+
+extern "C" int node_flat_finish_step(const node_flat_solve* f, int method, float* y_out, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  hipStream_t st = (hipStream_t)stream;
+  const int nseg = f->nseg, aug = f->has_scalar ? 1 : 0;
+  if (method == NODE_METHOD_RK4) {     // y <- y + dt (k0 + 3 k1 + 3 k2 + k3) / 8 on the fixed grid; t advances by dt
+    const double cf[4] = {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8};
+    for (int i = 0; i < nseg; ++i) {
+      float* ks[7];
+      for (int j = 0; j < 7; ++j) ks[j] = f->seg[i].k[j];
+      launch_lincomb(Solver::make_comb(f->seg[i].y, ks, cf, 4, SC_DT), p.ctrl, f->seg[i].y1, f->seg[i].n, st);
+      HIP_TRY(hipMemcpyAsync(f->seg[i].y, f->seg[i].y1, f->seg[i].n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (aug) launch_set_scalar_state(p.ctrl, 0.f, 1, st);
+    return flat_launch_ok("node_flat_finish_step(rk4)");
+  }
+  if (method != NODE_METHOD_DOPRI5) return fail(NODE_ERR_ARG, "unknown method %d", method);
+  ErrSeg es[3];
+  for (int i = 0; i < nseg; ++i) {
+    es[i].y0 = f->seg[i].y; es[i].y1 = f->seg[i].y1; es[i].n = f->seg[i].n; es[i].compute_y1 = 0;   // (y1 = the sixth stage's state)
+    for (int j = 0; j < 7; ++j) es[i].k[j] = f->seg[i].k[j];
+  }
+  launch_error_norm(es, p.partial, nseg, p.ctrl, f->rtol, f->atol, st);
+  StepCtlArgs sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.ctrl = p.ctrl;
+  for (int i = 0; i < nseg; ++i) { sc.partial[i] = p.partial[i]; sc.numel[i] = (double)f->seg[i].n; }
+  sc.nseg = nseg; sc.has_scalar = aug; sc.rtol = f->rtol; sc.atol = f->atol;
+  sc.targets = p.targets; sc.n_targets = f->n_targets; sc.interp_scalar = aug;
+  launch_step_controller(sc, st);
+  if (y_out != nullptr) {
+    EmitArgs ea;
+    ea.ctrl = p.ctrl; ea.targets = p.targets; ea.y0 = f->seg[0].y; ea.y1 = f->seg[0].y1;
+    for (int j = 0; j < 7; ++j) ea.k[j] = f->seg[0].k[j];
+    ea.y_out = y_out;
+    launch_emit_flat(ea, f->seg[0].n, st);
+  }
+  CommitArgs cm;
+  memset(&cm, 0, sizeof(cm));
+  cm.ctrl = p.ctrl; cm.targets = p.targets; cm.nseg = nseg; cm.interp_final = aug;
+  for (int i = 0; i < nseg; ++i) {
+    cm.y[i] = f->seg[i].y; cm.y1[i] = f->seg[i].y1; cm.k0[i] = f->seg[i].k[0]; cm.k6[i] = f->seg[i].k[6]; cm.n[i] = f->seg[i].n;
+    for (int j = 0; j < 7; ++j) cm.k[i][j] = f->seg[i].k[j];
+  }
+  launch_commit(cm, st);
+  return flat_launch_ok("node_flat_finish_step");
+}
+
+extern "C" int node_flat_status_read(const node_flat_solve* f, node_flat_status* out, void* stream) {
+  FlatPlan p;
+  TRY(flat_check(f, &p));
+  if (!out) return fail(NODE_ERR_NULL, "out is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  HostStage* hs = nullptr;
+  TRY(get_stage(16, &hs));
+  HIP_TRY(hipMemcpyAsync(hs->ctrl, p.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const Ctrl& c = *hs->ctrl;
+  out->done = c.done; out->status = c.status; out->steps = c.step_idx; out->accepted = c.n_acc; out->rejected = c.n_rej;
+  out->t = c.t; out->dt = c.dt; out->first_dt = c.first_dt; out->scalar = c.ts_cur;
+  return NODE_OK;
+}
+
+extern "C" {
 int node_gn_relu_fwd(const node_shape* shape, const float* z, const float* gamma, const float* beta, int relu, float* out,
                      float* stats, void* stream) {
   char why[200];

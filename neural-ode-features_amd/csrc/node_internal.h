@@ -298,6 +298,9 @@ struct EmitArgs {
   float* y_out;        // [n_targets][N][C][HW] (NCHW), slot j <-> targets[j]
 };
 void launch_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s);
+void launch_emit_flat(const EmitArgs& a, size_t n, hipStream_t s);       // flat state: out[j][i], no layout change
+void launch_flat_time(const EvalTime& et, float* out, hipStream_t s);
+void launch_flat_scalar(Ctrl* ctrl, int which, const float* src, float scale, int accumulate, hipStream_t s);
 struct CommitArgs {
   const Ctrl* ctrl;
   const double* targets;   // aug: the interval's end time (targets[0]) for the in-place dense output

@@ -4,8 +4,11 @@ library.  Host logic only: argument checking, recognising the conv `ODEfunc`
 (`model.py:326-348`), handing raw device pointers to the C ABI, and wiring the
 adjoint into autograd.  All arithmetic happens in libnode_hip.so.
 
-No CPU path, no pure-PyTorch path: CPU tensors, non-fp32 tensors and dynamics
-that are not the reference's Conv-GroupNorm-ReLU `ODEfunc` raise.
+No CPU path, no path through `oracle/`: CPU tensors and non-fp32 tensors raise.
+Dynamics that are not the reference's Conv-GroupNorm-ReLU `ODEfunc` (any other
+nn.Module, `norm='batch'`) and geometries the fused kernels do not tile run the
+GENERIC solver (generic.py): the caller's function evaluated as PyTorch
+operations, the library's own device-resident step controller around it.
 """
 from __future__ import annotations
 
@@ -141,7 +144,7 @@ def _aligned_ptr(buf: torch.Tensor) -> int:
     return (buf.data_ptr() + 255) & ~255
 
 
-def _check_state(y0: torch.Tensor):
+def _check_state(y0: torch.Tensor, any_rank: bool = False):
     if not torch.is_tensor(y0):
         raise NotImplementedError('tuple states are not supported: the reference passes a single tensor (model.py:367)')
     if not y0.is_cuda:
@@ -149,8 +152,34 @@ def _check_state(y0: torch.Tensor):
                            '(got %s). The CPU restatement lives in oracle/ and is test-only.' % y0.device)
     if y0.dtype != torch.float32:
         raise TypeError('y0 must be float32 (got %s)' % y0.dtype)
-    if y0.dim() != 4:
+    if y0.dim() != 4 and not any_rank:
         raise ValueError('y0 must be [N, C, H, W]')
+
+
+# Foreign dynamics / geometries the fused kernels do not tile: the generic solver (generic.py).  False restores the
+# round-4 behaviour (NotImplementedError / NODE_ERR_UNSUPPORTED) -- tests of the error surface use it.
+GENERIC_FALLBACK = True
+
+
+def _fused_plan(func, y0, method_id, adjoint, n_t):
+    """Recognised(func) when the fused kernels take this (func, state); None -> the generic solver."""
+    try:
+        rec = Recognised(func)
+    except NotImplementedError:
+        if not GENERIC_FALLBACK:
+            raise
+        return None
+    if y0.dim() != 4:
+        if not GENERIC_FALLBACK:
+            raise ValueError('y0 must be [N, C, H, W]')
+        return None
+    if not GENERIC_FALLBACK:
+        return rec
+    n, c, h, w = y0.shape
+    if c != rec.dim:
+        raise ValueError('state has %d channels but the ODEfunc was built for %d' % (c, rec.dim))
+    shape = _lib.NodeShape(n, c, h, w, rec.groups, rec.eps)
+    return rec if _lib.load().node_workspace_bytes(C.byref(shape), method_id, 1 if adjoint else 0, n_t) != 0 else None
 
 
 def _shape_struct(y0: torch.Tensor, rec: Recognised) -> _lib.NodeShape:
@@ -697,16 +726,24 @@ class _HipOdeint(torch.autograd.Function):
 
 
 def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True, last_only=False):
-    _check_state(y0)
+    _check_state(y0, any_rank=GENERIC_FALLBACK)
     if not isinstance(func, nn.Module):
         raise ValueError('func is required to be an instance of nn.Module.')
-    rec = Recognised(func)
     method_id = _method_id(method)
     times = _host_times(t)
     inc = all(b > a for a, b in zip(times[:-1], times[1:]))
     dec = all(b < a for a, b in zip(times[:-1], times[1:]))
     if not (inc or dec):
         raise ValueError('t must be strictly increasing or strictly decreasing')
+    rec = _fused_plan(func, y0, method_id, adjoint, len(times))
+    if rec is None:
+        # any other nn.Module, or a geometry outside the fused kernels' tiling: the caller's function under the library's
+        # device-resident step controller (generic.py).  Replay lists / dt logs are features of the fused solves.
+        if options and any(k in options for k in ('forced_dts', 'forced_dts_bwd', 'record_dt')):
+            raise NotImplementedError('replay / dt-log options are not available on the generic solver')
+        from . import generic
+        out = generic.odeint_generic(func, y0, times, rtol, atol, method_id, options)
+        return out[-1] if last_only else out
     # (grad mode is off inside autograd.Function.forward: whether a gradient will be wanted is decided here)
     wants_grad = torch.is_grad_enabled() and (y0.requires_grad or any(p.requires_grad for p in rec.params))
     return _HipOdeint.apply(func, rec, times, float(rtol), float(atol), method_id, options, adjoint, wants_grad, last_only, y0,

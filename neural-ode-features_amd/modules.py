@@ -24,12 +24,12 @@ from . import integrate
 
 
 def normalization(norm: str = 'group'):
-    """model.py:268-281.  Only 'group' is supported on the accelerated path."""
+    """model.py:268-281.  'group' dynamics run on the fused kernels; 'batch' (model.py:274: BatchNorm2d without running
+    statistics -- it couples the samples of a batch, so no fused kernel takes it) runs the generic solver (generic.py)."""
     if norm == 'group':
         return lambda dim: nn.GroupNorm(min(32, dim), dim)
     if norm == 'batch':
-        raise NotImplementedError("norm='batch' couples samples across the batch and is outside the "
-                                  "accelerated path (SURVEY.md section 2, row 4)")
+        return lambda dim: nn.BatchNorm2d(dim, track_running_stats=False)
     raise NotImplementedError('Normalization layer not implemented: {}'.format(norm))
 
 

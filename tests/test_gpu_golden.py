@@ -206,5 +206,10 @@ def test_errors_surface_as_python_exceptions():
     g, _ = make_func(16, seed=1, device='cuda')
     with pytest.raises(ValueError):
         nof.odeint(g, y, torch.tensor([0.0, 1.0]).cuda())          # channel mismatch
-    with pytest.raises(NodeHipError, match='UNSUPPORTED'):
-        nof.odeint(f, torch.randn(1, 8, 20, 20).cuda(), torch.tensor([0.0, 1.0]).cuda())
+    from neural_ode_features_amd import integrate
+    integrate.GENERIC_FALLBACK = False         # (with the fallback on, this geometry runs the generic solver: test_gpu_generic.py)
+    try:
+        with pytest.raises(NodeHipError, match='UNSUPPORTED'):
+            nof.odeint(f, torch.randn(1, 8, 20, 20).cuda(), torch.tensor([0.0, 1.0]).cuda())
+    finally:
+        integrate.GENERIC_FALLBACK = True

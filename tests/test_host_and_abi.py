@@ -128,9 +128,13 @@ def test_argument_validation_mirrors_torchdiffeq():
         integrate._host_times(torch.tensor([0.0]))
     assert integrate._host_times(torch.tensor([0.0, 0.5, 1.0])) == [0.0, 0.5, 1.0]
     with pytest.raises(NotImplementedError):
-        integrate.Recognised(torch.nn.Linear(3, 3))   # unrecognised dynamics are refused, not emulated
+        integrate.Recognised(torch.nn.Linear(3, 3))   # not the fused kernels' dynamics (they run the generic solver, generic.py)
+    bn = nof.ODEfunc(8, norm='batch')                 # model.py:274: BatchNorm2d without running statistics
+    assert isinstance(bn.norm1, torch.nn.BatchNorm2d) and bn.norm1.track_running_stats is False
     with pytest.raises(NotImplementedError):
-        nof.ODEfunc(8, norm='batch')
+        integrate.Recognised(bn)
+    with pytest.raises(NotImplementedError):
+        nof.ODEfunc(8, norm='layer')
     with pytest.raises(ValueError):
         integrate._odeint_impl(lambda t, y: y, _FakeCuda(), torch.tensor([0.0, 1.0]), 1e-3, 1e-3, None, None)
 

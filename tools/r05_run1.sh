@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05a
 mkdir -p $O
-timeout 1500 python -m pytest tests/ -q -m gpu --durations=30 -x > $O/gpu_tests.log 2>&1
+timeout 1500 python -m pytest tests/ -q -m gpu --durations=30 > $O/gpu_tests.log 2>&1
 echo "pytest rc $?" >> $O/gpu_tests.log
 tail -45 $O/gpu_tests.log
 for side in 1 0; do
