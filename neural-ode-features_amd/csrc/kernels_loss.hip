@@ -34,7 +34,7 @@ struct LossArgs {
   float* logits;            // [N][O]
   float* loss;              // [1]
   float* stat;              // [2] or nullptr
-  float* scratch;           // [2 * nwg] partials + arrival counter
+  float* scratch;           // arrival counter (word 0; a FIXED place: launches of different batch sizes share the scratch), then [2 * nwg] partials from word 4
   int N, C, O;
   int sum_reduction;
   int OL, G, NCH;           // class lanes per group (power of two <= 64), channel groups (64 / OL, or 1), 64-class chunks
@@ -145,11 +145,12 @@ __global__ __launch_bounds__(256) void k_head_loss_fwd(const LossArgs a) {
 #error "k_head_loss_fwd's fence-free hand-off is only valid on gfx950"
 #endif
   const unsigned nwg = gridDim.x;
-  unsigned* counter = reinterpret_cast<unsigned*>(a.scratch + 2 * (size_t)nwg);
+  unsigned* counter = reinterpret_cast<unsigned*>(a.scratch);
+  float* parts = a.scratch + 4;
   if (tid == 0) {
     const float pl = (red[0] + red[2]) + (red[4] + red[6]), ph = (red[1] + red[3]) + (red[5] + red[7]);
-    __hip_atomic_store(a.scratch + 2 * (size_t)blockIdx.x, pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(a.scratch + 2 * (size_t)blockIdx.x + 1, ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(parts + 2 * (size_t)blockIdx.x, pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(parts + 2 * (size_t)blockIdx.x + 1, ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     red[8] = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1 ? 1.f : 0.f;
   }
@@ -157,8 +158,8 @@ __global__ __launch_bounds__(256) void k_head_loss_fwd(const LossArgs a) {
   if (red[8] == 0.f) return;
   float sl = 0.f, sh = 0.f;
   for (unsigned i = tid; i < nwg; i += 256) {
-    sl += __hip_atomic_load(a.scratch + 2 * (size_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh += __hip_atomic_load(a.scratch + 2 * (size_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sl += __hip_atomic_load(parts + 2 * (size_t)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh += __hip_atomic_load(parts + 2 * (size_t)i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   sl = wave_add(sl);
   sh = wave_add(sh);

@@ -270,10 +270,6 @@ struct Plan {
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
   float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
   float *W4Va[2], *W4Z[2], *W4dU;   // F(4x4,3x3)-domain weight gradient (C % 128 == 0): the forward convs' row operands
-  // second set of everything the weight-gradient chain (k_w4_wgrad -> k_theta_finalize) READS, for when that chain runs on the
-  // side stream beside the next evaluation (Solver::side): Va / Z / the GroupNorm passes' partials of evaluation s stay
-  // untouched while evaluation s + 1 writes its own into the other set.  Equal to the first set when the side stream is off.
-  float *W4Va_b[2], *W4Z_b[2], *spart_b[2], *gpart_b[3];
                                     // kept until it runs, Z = A dz A^T of both conv outputs' cotangents, the gradients
   float *act1b, *xh1b, *r1b;   // second set of GroupNorm-1's saved tensors: the pass that ends evaluation s also forms
                                // stage s + 1's conv input, while evaluation s's own set is still being read
@@ -304,13 +300,6 @@ struct Bump {
     return p;
   }
 };
-
-// NODE_TUNE_SIDE = 0: the weight-gradient chain stays on the caller's stream (A/B measurements; read once)
-bool side_stream_wanted() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("NODE_TUNE_SIDE"); v = e ? (atoi(e) != 0) : 1; }
-  return v != 0;
-}
 
 Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   Plan p;
@@ -343,8 +332,6 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
       for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N8, d.C));
       for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N8, d.C));
       p.W4dU = b.take<float>(w4_du_elems(d.C));
-      for (int i = 0; i < 2; ++i) p.W4Va_b[i] = side_stream_wanted() ? b.take<float>(w4_v_elems(d.N8, d.C)) : p.W4Va[i];
-      for (int i = 0; i < 2; ++i) p.W4Z_b[i] = side_stream_wanted() ? b.take<float>(w4_z_elems(d.N8, d.C)) : p.W4Z[i];
     }
     if (adjoint) {
       p.act1b = b.take<float>(d.numel + d.C);
@@ -380,11 +367,6 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.gpart[0] = b.take<float>(grows * 2 * d.C);
     p.gpart[1] = b.take<float>(grows * 2 * d.C);
     p.gpart[2] = b.take<float>(prow * 2 * d.C);
-    const bool second = p.W4dU != nullptr && side_stream_wanted();
-    for (int i = 0; i < 2; ++i) p.spart_b[i] = second ? b.take<float>(prow * 9 * d.C) : p.spart[i];
-    p.gpart_b[0] = second ? b.take<float>(grows * 2 * d.C) : p.gpart[0];
-    p.gpart_b[1] = second ? b.take<float>(grows * 2 * d.C) : p.gpart[1];
-    p.gpart_b[2] = second ? b.take<float>(prow * 2 * d.C) : p.gpart[2];
     p.dots = b.take<float>((size_t)(n_t > 0 ? n_t : 1));
   }
   p.bytes = ((b.off + 255) & ~(size_t)255);
@@ -433,33 +415,6 @@ void remember_steps(const StepGuess& k) {
   g_guess.push_back(k);
 }
 
-// The side stream of a host thread on a device: where an augmented evaluation's weight-gradient chain (k_w4_wgrad, fp32-MFMA
-// bound, 47 us at cfg 2, and k_theta_finalize) runs beside the HBM-bound passes and component GEMMs of the evaluation that
-// follows on the caller's stream.  Host-side objects only (a stream, four events), created at first use and kept; no
-// device memory.  Everything it reads lives in the solve's workspace (second buffer set above); everything it produces
-// is joined back into the caller's stream before a kernel there reads it.
-struct SideStream {
-  int device = -1;
-  hipStream_t s = nullptr;
-  hipEvent_t fork[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-};
-thread_local std::vector<SideStream> g_side;
-SideStream* get_side_stream() {
-  if (!side_stream_wanted()) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  for (auto& x : g_side)
-    if (x.device == dev) return &x;
-  SideStream x;
-  x.device = dev;
-  if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  for (int i = 0; i < 2; ++i)
-    if (hipEventCreateWithFlags(&x.fork[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&x.done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-  g_side.push_back(x);
-  return &g_side.back();
-}
-
 const double DP_ALPHA[6] = {1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0, 1.0};
 const double DP_CMID[7] = {6025192743.0 / 30085553152.0 / 2.0, 0.0, 51252292925.0 / 65400821598.0 / 2.0,
                            -2691868925.0 / 45128329728.0 / 2.0, 187940372067.0 / 1594534317056.0 / 2.0,
@@ -496,19 +451,6 @@ struct Solver {
   }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
-  // side stream for the weight-gradient chain (see SideStream): `wset` = which buffer set the CURRENT augmented evaluation
-  // owns, `pending[x]` = a chain that reads set x was enqueued on the side stream and nobody has waited for it yet
-  SideStream* side = nullptr;
-  int wset = 0;
-  bool pending[2] = {false, false};
-  float* va_of(int i, int set) const { return set ? p.W4Va_b[i] : p.W4Va[i]; }
-  float* z_of(int i, int set) const { return set ? p.W4Z_b[i] : p.W4Z[i]; }
-  float* gpart_of(int i, int set) const { return set ? p.gpart_b[i] : p.gpart[i]; }
-  float* spart_of(int i, int set) const { return set ? p.spart_b[i] : p.spart[i]; }
-  void set_free(int x) {       // the caller's stream may write into set x (or read what its chain produced) from here on
-    if (pending[x]) { (void)hipStreamWaitEvent(st, side->done[x], 0); pending[x] = false; }
-  }
-  void join_side() { set_free(0); set_free(1); }
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
   bool v_ready = false;    // the next evaluation's first pass has run
   int cur = 0;             // which set of GroupNorm-1's saved tensors (act1, xhat-1, 1/sigma-1) the current evaluation owns
@@ -592,15 +534,8 @@ struct Solver {
       for (int i = 0; i < 2; ++i) {
         launch_fill(p.W4Va[i], 0.f, w4_v_elems(d.N8, d.C), st);
         launch_fill(p.W4Z[i], 0.f, w4_z_elems(d.N8, d.C), st);
-        if (p.W4Va_b[i] != p.W4Va[i]) {
-          launch_fill(p.W4Va_b[i], 0.f, w4_v_elems(d.N8, d.C), st);
-          launch_fill(p.W4Z_b[i], 0.f, w4_z_elems(d.N8, d.C), st);
-        }
       }
     }
-    side = (w4_wgrad_on() && p.W4Va_b[0] != p.W4Va[0]) ? get_side_stream() : nullptr;
-    wset = 0;
-    pending[0] = pending[1] = false;
     v_ready = false;
     cur = 0;
     return check_launch("prepare");
@@ -660,11 +595,10 @@ struct Solver {
     return a;
   }
   // tail 1 of a pass: stage combine -> GroupNorm-1 -> ReLU -> V (+ act1, xhat-1, 1/sigma-1 of set `set` when training)
-  // `vset`: the buffer set of the evaluation this combine belongs to (its conv-1 row operand goes there)
-  void w4_tail_combine(W4sArgs& a, const Comb& cy, float* y_out, bool train, int set, int self, int vset = 0) {
+  void w4_tail_combine(W4sArgs& a, const Comb& cy, float* y_out, bool train, int set, int self) {
     a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
     if (train) { a.t.act_nhwc = w4_wgrad_on() ? nullptr : act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
-    a.V = (train && w4_wgrad_on()) ? va_of(0, vset) : p.W4V;
+    a.V = (train && w4_wgrad_on()) ? p.W4Va[0] : p.W4V;
   }
   // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
   // must read or write, once) in the record
@@ -697,26 +631,23 @@ struct Solver {
     if (next != nullptr)   // a combine that reads this evaluation's own derivative anywhere but as its last term cannot merge
       for (int j = 0; j + 1 < next->cy.nk; ++j)
         if (next->cy.k[j] == kY_out || (do_aug && next->cy.k[j] == kA_out)) next = nullptr;
-    const bool wg4 = do_aug && w4_wgrad_on();
-    const bool side_on = wg4 && side != nullptr;
-    const int S = side_on ? wset : 0, Snext = side_on ? wset ^ 1 : 0;     // this evaluation's buffer set, the next one's
     if (!v_ready) {
-      if (side_on) set_free(S);
       W4sArgs a = w4_args();
-      w4_tail_combine(a, cy, y_out, train, cur, 0, S);
+      w4_tail_combine(a, cy, y_out, train, cur, 0);
       w4_pass(0, 1, a);
     }
     v_ready = false;
-    w4_gemm(0, wg4 ? va_of(0, S) : nullptr);
+    const bool wg4 = do_aug && w4_wgrad_on();
+    w4_gemm(0, wg4 ? p.W4Va[0] : nullptr);
     {   // P2
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.bias = prm.conv1_b; a.h.tmapS = p.tmapS[0]; a.h.et = et; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b;
       a.h.osign = 1.f; a.h.relu = 1;
       if (train) { a.h.out_nhwc = wg4 ? nullptr : p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
-      a.V = wg4 ? va_of(1, S) : p.W4V;
+      a.V = wg4 ? p.W4Va[1] : p.W4V;
       w4_pass(1, 0, a);
     }
-    w4_gemm(1, wg4 ? va_of(1, S) : nullptr);
+    w4_gemm(1, wg4 ? p.W4Va[1] : nullptr);
     W4sArgs a3 = w4_args();
     a3.h.M = p.W4M; a3.h.bias = prm.conv2_b; a3.h.tmapS = p.tmapS[1]; a3.h.et = et; a3.h.gamma = prm.norm3_w; a3.h.beta = prm.norm3_b;
     a3.h.osign = et.tsign; a3.h.relu = 0; a3.h.out_s = kY_out;
@@ -733,8 +664,8 @@ struct Solver {
       return check_launch("odefunc forward (F(4x4,3x3))");
     }
     // P3B3: GroupNorm-3, then the adjoint combine through its backward
-    a3.t.comb = *ca; a3.t.csign = csign; a3.t.y_out = a_out; a3.t.gpart = gpart_of(2, S); a3.t.spart = spart_of(1, S);
-    if (wg4) a3.t.z_out = need_theta ? z_of(1, S) : nullptr;
+    a3.t.comb = *ca; a3.t.csign = csign; a3.t.y_out = a_out; a3.t.gpart = p.gpart[2]; a3.t.spart = p.spart[1];
+    if (wg4) a3.t.z_out = need_theta ? p.W4Z[1] : nullptr;
     else a3.t.act_nhwc = p.dz2;
     a3.V = p.W4V;
     w4_pass(1, 2, a3);
@@ -743,8 +674,8 @@ struct Solver {
     {   // PB2
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; a.h.osign = 1.f;
-      a.h.gpart = gpart_of(1, S); a.h.spart = spart_of(0, S);
-      if (wg4) a.h.z_out = need_theta ? z_of(0, S) : nullptr;
+      a.h.gpart = p.gpart[1]; a.h.spart = p.spart[0];
+      if (wg4) a.h.z_out = need_theta ? p.W4Z[0] : nullptr;
       else a.h.out_nhwc = p.dz1;
       a.V = p.W4V;
       w4_pass(2, 0, a);
@@ -752,15 +683,9 @@ struct Solver {
     if (need_theta && wg4) {
       W4WgradArgs wa;
       memset(&wa, 0, sizeof(wa));
-      wa.V1 = va_of(0, S); wa.Z1 = z_of(0, S); wa.V2 = va_of(1, S); wa.Z2 = z_of(1, S); wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
-      hipStream_t ws_ = st;
-      if (side_on) {     // fork: everything the kernel reads has been written by the passes above
-        (void)hipEventRecord(side->fork[0], st);
-        (void)hipStreamWaitEvent(side->s, side->fork[0], 0);
-        ws_ = side->s;
-      }
-      ProfScope ps(1, 2.0 * conv_flops(), ws_);
-      launch_w4_wgrad(wa, ws_);
+      wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
+      ProfScope ps(1, 2.0 * conv_flops(), st);
+      launch_w4_wgrad(wa, st);
     } else if (need_theta) {
       WgradArgs w1;
       memset(&w1, 0, sizeof(w1));
@@ -777,10 +702,9 @@ struct Solver {
     {   // PB1 (+ the next evaluation's combine)
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.gamma = prm.norm1_w; a.h.beta = prm.norm1_b; a.h.xhat_s = xh1_of(cur); a.h.rstd = r1_of(cur);
-      a.h.osign = et.tsign; a.h.out_s = kA_out; a.h.gpart = gpart_of(0, S);
+      a.h.osign = et.tsign; a.h.out_s = kA_out; a.h.gpart = p.gpart[0];
       if (next != nullptr) {
-        if (side_on) set_free(Snext);     // (the chain of the evaluation before this one read that set)
-        w4_tail_combine(a, next->cy, next->y_out, true, cur ^ 1, 0, Snext);
+        w4_tail_combine(a, next->cy, next->y_out, true, cur ^ 1, 0);
         w4_pass(2, 1, a);
         cur ^= 1;
         v_ready = true;
@@ -788,34 +712,18 @@ struct Solver {
         w4_pass(2, 0, a);
       }
     }
-    if (side_on) wset ^= 1;
-    if (!need_theta) {
-      if (side_on && next == nullptr) join_side();     // (a reader of the parameter derivatives may follow)
-      return check_launch("augmented dynamics (F(4x4,3x3))");
-    }
+    if (!need_theta) return check_launch("augmented dynamics (F(4x4,3x3))");
     ThetaFinalizeArgs tf;
     memset(&tf, 0, sizeof(tf));
     tf.dU = wg4 ? p.W4dU : nullptr;
     tf.wpart[0] = p.wpart[0]; tf.wpart[1] = p.wpart[1];
-    tf.spart[0] = spart_of(0, S); tf.spart[1] = spart_of(1, S);
-    tf.gpart[0] = gpart_of(0, S); tf.gpart[1] = gpart_of(1, S); tf.gpart[2] = gpart_of(2, S);
+    tf.spart[0] = p.spart[0]; tf.spart[1] = p.spart[1];
+    tf.gpart[0] = p.gpart[0]; tf.gpart[1] = p.gpart[1]; tf.gpart[2] = p.gpart[2];
     tf.gpart_rows[0] = tf.gpart_rows[1] = tf.gpart_rows[2] = tf.spart_rows = d.N * d.w4q;   // per-sample (per-quadrant) partials from the GroupNorm passes
     tf.wtime[0] = p.wtime[0]; tf.wtime[1] = p.wtime[1]; tf.sred = p.sred;
     tf.et = et; tf.osign = et.tsign; tf.theta_out = kT_out;
     tf.ctrl = p.ctrl; tf.kidx = kidx; tf.write_scalar = kidx >= 0 ? 1 : 0; tf.vjp_t_out = vjp_t_out;
-    if (side_on) {
-      // the finalize reads the last pass's partials: second fork point.  It writes this stage's parameter / time
-      // derivative (KT[kidx], ctrl->ts_k[kidx]) -- read on the caller's stream by the error norm, the commit, the
-      // initial-step norms: whoever enqueues those joins first (an evaluation with no successor joins right here)
-      (void)hipEventRecord(side->fork[1], st);
-      (void)hipStreamWaitEvent(side->s, side->fork[1], 0);
-      launch_theta_finalize(d, tf, side->s);
-      (void)hipEventRecord(side->done[S], side->s);
-      pending[S] = true;
-      if (next == nullptr) join_side();
-    } else {
-      launch_theta_finalize(d, tf, st);
-    }
+    launch_theta_finalize(d, tf, st);
     return check_launch("augmented dynamics (F(4x4,3x3))");
   }
 
@@ -953,7 +861,6 @@ struct Solver {
   int initial_step() {
     const int nseg = aug ? 3 : 1;
     InitSeg segs[3] = {{p.Y, p.KY[0], p.KY[1], d.numel}, {p.A, p.KA[0], p.KA[1], d.numel}, {p.TH, p.KT[0], p.KT[1], d.P}};
-    if (side != nullptr) join_side();
     launch_init_norms(segs, p.partial, nseg, rtol, atol, 0, st);
     InitCtlArgs ic;
     memset(&ic, 0, sizeof(ic));
@@ -1003,7 +910,6 @@ struct Solver {
       es[2].y0 = p.TH; es[2].y1 = p.TH1; es[2].n = d.P; es[2].compute_y1 = 1;
       for (int j = 0; j < 7; ++j) es[2].k[j] = p.KT[j];
     }
-    if (side != nullptr) join_side();
     launch_error_norm(es, p.partial, nseg, p.ctrl, rtol, atol, st);
     StepCtlArgs sc;
     memset(&sc, 0, sizeof(sc));
