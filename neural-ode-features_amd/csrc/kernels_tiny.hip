@@ -1,0 +1,303 @@
+// Latency path: the convolutions of ONE dynamics evaluation of a tiny batch -- the bs = 1 NFE census of the reference
+// (evaluate.py:97-142: every test image solved on its own, model.py:339-348 evaluated ~26 times per image) -- as TWO
+// launches, each a whole 3x3 convolution fused with everything up to the next convolution's input:
+//
+//   k_tiny_conv_gn:   out = [relu] GroupNorm( conv3x3(act) + bias + t * tmap ) * osign
+//
+// Why not the throughput kernels: at bs = 1 the F(4x4,3x3) pipeline reads 9.4 MB of transformed filters per convolution
+// for 19 MFLOP and needs four dependent launches per evaluation (component GEMM, pass, GEMM, pass: 36.7 us per evaluation,
+// profiles/r04_latency_bs1_trace.txt); a kernel boundary costs ~1.5 us, and nothing in an evaluation is large.  Here:
+//   * DIRECT convolution (filters 2.4 MB per conv as fp32; 6.9 MB as packed, column-padded bf16 triples) on the bf16 matrix
+//     pipe at fp32 accuracy -- every operand an exact sum of three bf16 parts, six of the nine part products
+//     (v_mfma_f32_16x16x32_bf16, the split of kernels_w4.hip);
+//   * a workgroup = (sample, GroupNorm group, slice of CS input channels): its 16-column MFMA tile holds the group's <= 16
+//     output channels, so the GroupNorm behind the convolution needs nothing from another group;
+//   * the K slices of a group (C / CS workgroups: 4 at C = 256, 8x8) leave their partial sums in a scratch buffer and count
+//     themselves on a device counter; the LAST one to arrive adds them (fixed order) and runs the epilogue -- bias, the time
+//     channel's border map, GroupNorm statistics over the group, affine, ReLU, store.  One small hand-off (2 - 8 KB per
+//     group) instead of a kernel boundary + a GroupNorm launch;
+//   * the activation slice (padded image x CS channels) is split into its bf16 triples ONCE while it is staged into LDS and
+//     read nine times (taps) as ready MFMA fragments; the filter fragments stream from L2 in fragment order.
+// Forward only (inference solves); any N small enough that the grid stays under a few hundred workgroups.
+#include "node_internal.h"
+
+namespace node {
+
+typedef __bf16 t_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 t_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float t_f32x2 __attribute__((ext_vector_type(2)));
+typedef float t_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned t_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// x = h + m + l exactly (three bf16 parts of an fp32 value), eight values at a time (kernels_w4.hip: w4_split8)
+__device__ __forceinline__ void tiny_split8(const float4& p, const float4& q, t_u32x4& hh, t_u32x4& mm, t_u32x4& ll) {
+  const t_f32x2 v[4] = {{p.x, p.y}, {p.z, p.w}, {q.x, q.y}, {q.z, q.w}};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const t_bf16x2 h = __builtin_convertvector(v[i], t_bf16x2);
+    const t_f32x2 r = v[i] + (-__builtin_convertvector(h, t_f32x2));
+    const t_bf16x2 m = __builtin_convertvector(r, t_bf16x2);
+    const t_f32x2 t = r + (-__builtin_convertvector(m, t_f32x2));
+    const t_bf16x2 l = __builtin_convertvector(t, t_bf16x2);
+    hh[i] = __builtin_bit_cast(unsigned, h);
+    mm[i] = __builtin_bit_cast(unsigned, m);
+    ll[i] = __builtin_bit_cast(unsigned, l);
+  }
+}
+
+__device__ __forceinline__ float tiny_wave_sum(float v) {
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+  return v;
+}
+
+// filters [C][C + 1][3][3] (input channel 0 = time, model.py:321-322) -> bf16 triples in B-fragment order:
+//   wq[(((g KS + ks) 9 + tap) NCH + chunk) 3 + part][lane][8],  lane = 16 kq + col:
+//   element e = W[co = g cpg + col][ci = ks CS + 32 chunk + 8 kq + e][tap]   (zero for col >= cpg)
+__global__ __launch_bounds__(256) void k_tiny_pack(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int cpg,
+                                                   int CS, int total_frags) {
+  const int frag = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (frag >= total_frags) return;
+  const int NCH = CS >> 5, KS = C / CS;
+  int r = frag;
+  const int chunk = r % NCH; r /= NCH;
+  const int tap = r % 9; r /= 9;
+  const int ks = r % KS;
+  const int g = r / KS;
+  const int col = lane & 15, kq = lane >> 4;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = ks * CS + chunk * 32 + kq * 8 + e, co = g * cpg + col;
+    v[e] = col < cpg ? w[((size_t)co * (C + 1) + ci + 1) * 9 + tap] : 0.f;
+  }
+  t_u32x4 hh, mm, ll;
+  tiny_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hh, mm, ll);
+  t_u32x4* dst = reinterpret_cast<t_u32x4*>(wq) + (size_t)frag * 3 * 64 + lane;
+  dst[0] = hh;
+  dst[64] = mm;
+  dst[128] = ll;
+}
+
+struct TinyArgs {
+  const float* act;            // [N][HW][C] NHWC: the convolution's input (post GroupNorm + ReLU)
+  const unsigned short* wq;    // k_tiny_pack
+  const float* bias;           // [C]
+  const float* tmap;           // [HW][C]: sum over the taps inside the image of the time-channel weights
+  EvalTime et;
+  const float* gamma;
+  const float* beta;
+  float* out;                  // [N][HW][C]
+  float* part;                 // [N G][KS][MT 16][16] partial sums (KS > 1)
+  unsigned* counter;           // [N G], zero between launches
+  const Ctrl* ctrl;
+  int N, C, H, W, G, cpg, CS, KS, MT;
+  int relu;
+  float osign, eps;
+};
+
+constexpr int TINY_MAXT = 4;     // pixel tiles per wave: images of up to 256 pixels
+
+// LDS: A [3 parts][PP][CS + 8] bf16 | red [16] floats
+__global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;     // a step enqueued past the end of the interval
+  extern __shared__ __align__(16) unsigned char lsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = a.C, H = a.H, W = a.W, HW = H * W, CS = a.CS, KS = a.KS, MT = a.MT, cpg = a.cpg;
+  const int Wp = W + 2, PP = (H + 2) * Wp, pitch = CS + 8;       // bf16 elements per padded-pixel row of a part plane
+  unsigned short* A = reinterpret_cast<unsigned short*>(lsm);
+  const size_t plane = (size_t)PP * pitch;
+  float* red = reinterpret_cast<float*>(lsm + 3 * plane * sizeof(unsigned short));
+  int r = blockIdx.x;
+  const int ks = r % KS; r /= KS;
+  const int g = r % a.G;
+  const int n = r / a.G;
+
+  // ---- stage the activation slice: padded image x CS channels, split into bf16 triples once
+  {
+    const int q8 = CS >> 3;
+    const float* src = a.act + (size_t)n * HW * C + ks * CS;
+    for (int idx = tid; idx < PP * q8; idx += 256) {
+      const int pp = idx / q8, q = idx - pp * q8;
+      const int yy = pp / Wp - 1, xx = pp % Wp - 1;
+      t_u32x4 hh = {0u, 0u, 0u, 0u}, mm = hh, ll = hh;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)(yy * W + xx) * C + 8 * q);
+        tiny_split8(s4[0], s4[1], hh, mm, ll);
+      }
+      t_u32x4* d = reinterpret_cast<t_u32x4*>(A + (size_t)pp * pitch + 8 * q);
+      d[0] = hh;
+      *reinterpret_cast<t_u32x4*>(A + plane + (size_t)pp * pitch + 8 * q) = mm;
+      *reinterpret_cast<t_u32x4*>(A + 2 * plane + (size_t)pp * pitch + 8 * q) = ll;
+    }
+  }
+  __syncthreads();
+
+  // ---- products: wave w takes the pixel tiles w, w + 4, ...; every wave walks the whole K slice
+  const int col = lane & 15, kq = lane >> 4;
+  t_f32x4 acc[TINY_MAXT];
+  int pbase[TINY_MAXT];      // this lane's A row: padded position (tap 0) of pixel tile * 16 + col ... (col doubles as the row index of A)
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t) {
+    acc[t] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p = (wave + 4 * t) * 16 + col;          // (A fragment: lane holds row = lane & 15)
+    pbase[t] = p < HW ? (p / W) * Wp + (p % W) : -1;
+  }
+  const int NCH = CS >> 5;
+  const t_u32x4* wq = reinterpret_cast<const t_u32x4*>(a.wq) + (size_t)((n * 0 + g) * KS + ks) * 9 * NCH * 3 * 64 + lane;
+  const int ntile = (MT - wave + 3) / 4;               // tiles of this wave
+  for (int tap = 0; tap < 9; ++tap) {
+    const int toff = (tap / 3) * Wp + (tap % 3);
+    for (int ch = 0; ch < NCH; ++ch) {
+      const t_u32x4* wf = wq + (size_t)(tap * NCH + ch) * 3 * 64;
+      const t_bf16x8 Bh = __builtin_bit_cast(t_bf16x8, wf[0]), Bm = __builtin_bit_cast(t_bf16x8, wf[64]), Bl = __builtin_bit_cast(t_bf16x8, wf[128]);
+#pragma unroll
+      for (int t = 0; t < TINY_MAXT; ++t) {
+        if (t < ntile) {
+          // rows of pixels outside the image read the padded position 0 (the top-left halo: zeros)
+          const int pp = pbase[t] >= 0 ? pbase[t] + toff : 0;
+          const unsigned short* ap = A + (size_t)pp * pitch + ch * 32 + kq * 8;
+          const t_bf16x8 Ah = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap));
+          const t_bf16x8 Am = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + plane));
+          const t_bf16x8 Al = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + 2 * plane));
+          t_f32x4 c = acc[t];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);     // smallest products first
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+          acc[t] = c;
+        }
+      }
+    }
+  }
+  // accumulator layout: lane holds column `col` (output channel g cpg + col), rows 4 kq + i of its tile -> pixel (wave + 4 t) 16 + 4 kq + i
+
+  // ---- K slices meet: partial sums -> scratch, the last slice to arrive adds them in slice order
+  const int ng = n * a.G + g;
+  if (KS > 1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_tiny_conv_gn's fence-free hand-off is only valid on gfx950 (see k_theta_finalize)"
+#endif
+    float* mine = a.part + ((size_t)ng * KS + ks) * (MT * 16) * 16;
+#pragma unroll
+    for (int t = 0; t < TINY_MAXT; ++t)
+      if (t < ntile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __hip_atomic_store(mine + (size_t)((wave + 4 * t) * 16 + 4 * kq + i) * 16 + col, acc[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) red[12] = __hip_atomic_fetch_add(a.counter + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(KS - 1) ? 1.f : 0.f;
+    __syncthreads();
+    if (red[12] == 0.f) return;
+    if (tid == 0) __hip_atomic_store(a.counter + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch (stream order)
+    const float* all = a.part + (size_t)ng * KS * (MT * 16) * 16;
+#pragma unroll
+    for (int t = 0; t < TINY_MAXT; ++t)
+      if (t < ntile)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s = 0.f;
+          for (int k = 0; k < KS; ++k)
+            s += __hip_atomic_load(all + ((size_t)k * (MT * 16) + (wave + 4 * t) * 16 + 4 * kq + i) * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[t][i] = s;
+        }
+  }
+
+  // ---- epilogue: + bias + t * tmap, GroupNorm over the group (cpg channels x HW pixels), affine, ReLU, store
+  const bool chan_on = col < cpg;
+  const int c = g * cpg + (chan_on ? col : 0);
+  const float tnow = eval_time(a.et);
+  const float bs = a.bias[c];
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        const bool on = chan_on && p < HW;
+        const float v = on ? acc[t][i] + bs + tnow * a.tmap[(size_t)p * C + c] : 0.f;
+        acc[t][i] = v;
+        sum += v;
+      }
+  const float inv_m = 1.f / (float)(cpg * HW);
+  sum = tiny_wave_sum(sum);
+  __syncthreads();
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * inv_m;
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        if (chan_on && p < HW) { const float dv = acc[t][i] - mean; sq += dv * dv; }
+      }
+  sq = tiny_wave_sum(sq);
+  if (lane == 0) red[4 + wave] = sq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
+  const float gm = a.gamma[c], bt = a.beta[c];
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        if (chan_on && p < HW) {
+          float y = ((acc[t][i] - mean) * rstd) * gm + bt;
+          if (a.relu) y = fmaxf(y, 0.f);
+          a.out[((size_t)n * HW + p) * C + c] = a.osign * y;
+        }
+      }
+}
+
+}  // namespace
+
+// geometry the latency path takes: C a multiple of 32 with whole GroupNorm groups of <= 16 channels inside a 16-column tile,
+// images of up to 256 pixels (16 pixel tiles), a grid that stays small.  Returns CS (input channels per workgroup) or 0.
+int tiny_slice_channels(const Dims& d) {
+  if (d.C % 32 != 0 || d.cpg > 16 || d.HW > 16 * 4 * TINY_MAXT || d.W > 64) return 0;
+  const int CS = (d.HW <= 100 && d.C % 64 == 0) ? 64 : 32;
+  const size_t lds = (size_t)3 * (d.H + 2) * (d.W + 2) * (CS + 8) * 2 + 64;
+  if (lds > 150 * 1024) return 0;
+  if ((long)d.N * d.G * (d.C / CS) > 2048) return 0;
+  return CS;
+}
+size_t tiny_packed_elems(const Dims& d) {       // unsigned shorts of one convolution's packed filters
+  const int CS = tiny_slice_channels(d);
+  if (!CS) return 0;
+  return (size_t)d.G * (d.C / CS) * 9 * (CS / 32) * 3 * 64 * 8;
+}
+size_t tiny_part_elems(const Dims& d) {         // floats of the K-slice partial sums
+  const int CS = tiny_slice_channels(d);
+  if (!CS) return 0;
+  const int MT = (d.HW + 15) / 16;
+  return (size_t)d.N * d.G * (d.C / CS) * MT * 16 * 16;
+}
+void launch_tiny_pack(const Dims& d, const float* w, unsigned short* wq, hipStream_t s) {
+  const int CS = tiny_slice_channels(d);
+  const int frags = d.G * (d.C / CS) * 9 * (CS / 32);
+  hipLaunchKernelGGL(k_tiny_pack, dim3((frags + 3) / 4), dim3(256), 0, s, w, wq, d.C, d.cpg, CS, frags);
+}
+void launch_tiny_conv_gn(const Dims& d, const TinyConvArgs& b, hipStream_t s) {
+  TinyArgs a;
+  a.act = b.act; a.wq = b.wq; a.bias = b.bias; a.tmap = b.tmap; a.et = b.et; a.gamma = b.gamma; a.beta = b.beta; a.out = b.out;
+  a.part = b.part; a.counter = b.counter; a.ctrl = b.ctrl;
+  a.N = d.N; a.C = d.C; a.H = d.H; a.W = d.W; a.G = d.G; a.cpg = d.cpg;
+  a.CS = tiny_slice_channels(d); a.KS = d.C / a.CS; a.MT = (d.HW + 15) / 16;
+  a.relu = b.relu; a.osign = b.osign; a.eps = d.eps;
+  const size_t lds = (size_t)3 * (d.H + 2) * (d.W + 2) * (a.CS + 8) * 2 + 64;
+  static bool attr[MAX_DEVICES] = {};
+  allow_full_lds(reinterpret_cast<const void*>(k_tiny_conv_gn), attr);
+  hipLaunchKernelGGL(k_tiny_conv_gn, dim3(d.N * d.G * a.KS), dim3(256), lds, s, a);
+}
+
+}  // namespace node

@@ -175,6 +175,15 @@ static int make_dims(const node_shape* sh, Dims* out) {
     // buys as soon as the throughput grid has eight workgroups, so only single-digit grids take the small kernel
     d.small = fits && (small_env >= 0 ? small_env != 0 : (long)d.mtiles * d.ntile < 8);
   }
+  {
+    // latency path (kernels_tiny.hip): forward solves of batches of up to ~1000 pixels (bs = 1 .. 16 at 8x8).  NODE_TUNE_TINY =
+    // 0 never / 1 wherever the geometry fits (A/B measurements, tests); results are fp32-exact products either way
+    static int tiny_env = -2;
+    if (tiny_env == -2) { const char* e = getenv("NODE_TUNE_TINY"); tiny_env = e ? atoi(e) : -1; }
+    d.numel = (size_t)d.N * d.C * d.HW;
+    d.tiny = 0;
+    if (tiny_env != 0 && (tiny_env == 1 || (size_t)d.N * d.HW <= 1024)) d.tiny = tiny_slice_channels(d);
+  }
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
   static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels
   if (slab_elems < 0) { const char* e = getenv("NODE_TUNE_SLAB"); slab_elems = e ? atoi(e) : 2048; }
@@ -265,6 +274,9 @@ struct Plan {
   float *act1, *act2;
   float* RAW;               // split-conv / small mode: the conv's raw output, consumed by the GroupNorm pass
   float* wsmall[2];         // small mode: filters packed for k_conv3x3_small
+  unsigned short* wtiny[2]; // latency path (kernels_tiny.hip): filters as column-padded bf16 triples in fragment order
+  float* tpart;             //   K-slice partial sums
+  unsigned* tcount;         //   arrival counters [N G]
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
@@ -322,6 +334,11 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   if (d.csplit || d.small) p.RAW = b.take<float>(d.numel);
   if (d.small && !adjoint)
     for (int i = 0; i < 2; ++i) p.wsmall[i] = b.take<float>((size_t)9 * d.C * d.C);
+  if (d.tiny && !adjoint) {
+    for (int i = 0; i < 2; ++i) p.wtiny[i] = b.take<unsigned short>(tiny_packed_elems(d));
+    p.tpart = b.take<float>(tiny_part_elems(d));
+    p.tcount = b.take<unsigned>((size_t)d.N * d.G);
+  }
   if (d.wino4) {
     p.W4V = b.take<float>(w4_v_elems(d.N8, d.C));
     p.W4M = b.take<float>(w4_v_elems(d.N8, d.C));
@@ -447,8 +464,10 @@ struct Solver {
   // 1e-5: same step sequences, gradients as close to fp64 as the fp32 oracle's -- tests/test_gpu_w4.py).
   bool w4 = false;
   void choose_w4(bool adaptive) {
-    w4 = d.wino4 == 2 || (d.wino4 == 1 && adaptive && rtol >= W4_MIN_TOL && atol >= W4_MIN_TOL);
+    w4 = d.wino4 == 2 || (d.wino4 == 1 && adaptive && rtol >= W4_MIN_TOL && atol >= W4_MIN_TOL && !tiny_mode());
   }
+  // latency path: forward solves of tiny batches run two fused direct-convolution launches per evaluation (kernels_tiny.hip)
+  bool tiny_mode() const { return d.tiny != 0 && !aug && p.wtiny[0] != nullptr; }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
@@ -478,7 +497,7 @@ struct Solver {
   }
 
   // inference solves on grids the throughput tiles cannot spread over the chip (Dims::small)
-  bool small_mode() const { return d.small && !aug && !w4 && p.wsmall[0] != nullptr; }
+  bool small_mode() const { return d.small && !aug && !w4 && p.wsmall[0] != nullptr && !tiny_mode(); }
 
   int prepare() {
     auto pack = d.wino == 2 ? launch_pack_weights_w2 : d.wino ? launch_pack_weights_w : launch_pack_weights;
@@ -505,6 +524,11 @@ struct Solver {
     if (small_mode()) {
       launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
       launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
+    }
+    if (tiny_mode() && !w4) {
+      launch_tiny_pack(d, prm.conv1_w, p.wtiny[0], st);
+      launch_tiny_pack(d, prm.conv2_w, p.wtiny[1], st);
+      launch_fill(reinterpret_cast<float*>(p.tcount), 0.f, (size_t)d.N * d.G, st);     // (0.f is the all-zero word)
     }
     if (w4) {
       W4PackJobs jobs;
@@ -735,6 +759,21 @@ struct Solver {
     ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
     ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
     launch_combine_gn(d, ca, st);
+
+    if (tiny_mode() && !train) {     // latency path: conv + bias + t * tmap + GroupNorm (+ ReLU) per launch
+      TinyConvArgs t1;
+      memset(&t1, 0, sizeof(t1));
+      t1.act = p.act1; t1.wq = p.wtiny[0]; t1.bias = prm.conv1_b; t1.tmap = p.tmap[0]; t1.et = et;
+      t1.gamma = prm.norm2_w; t1.beta = prm.norm2_b; t1.out = p.act2; t1.part = p.tpart; t1.counter = p.tcount; t1.ctrl = p.ctrl;
+      t1.relu = 1; t1.osign = 1.f;
+      { ProfScope ps(0, conv_flops(), st); launch_tiny_conv_gn(d, t1, st); }
+      TinyConvArgs t2 = t1;
+      t2.act = p.act2; t2.wq = p.wtiny[1]; t2.bias = prm.conv2_b; t2.tmap = p.tmap[1];
+      t2.gamma = prm.norm3_w; t2.beta = prm.norm3_b; t2.out = k_out; t2.relu = 0; t2.osign = et.tsign;
+      { ProfScope ps(0, conv_flops(), st); launch_tiny_conv_gn(d, t2, st); }
+      if (count_nfe) nfe += 1;
+      return check_launch("odefunc forward (latency path)");
+    }
 
     ConvArgs c1;
     memset(&c1, 0, sizeof(c1));

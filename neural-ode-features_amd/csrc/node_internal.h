@@ -27,6 +27,8 @@ struct Dims {
   int wino;            // conv kernel: 0 direct, 1 Winograd F(2,3) along the rows (even W), 2 Winograd F(2x2,3x3) (even H, W; 128-pixel tiles)
   int wgrad_wino;      // weight gradient accumulated in the same Winograd domain (k_wgrad_w)
   int wut;          // tiles per unit of the 2-D Winograd wgrad kernel (wgrad_wino == 2)
+  int tiny;         // latency path (kernels_tiny.hip): input channels per workgroup of k_tiny_conv_gn, or 0 -- forward solves of
+                    // batches so small that an evaluation is bound by its dependent launches (bs = 1 census, evaluate.py:97-142)
   int small;        // the throughput tiles give a grid under 32 workgroups: inference solves run k_conv3x3_small (32 px x 32 columns
                     // per workgroup, four-way split K) + a GroupNorm pass instead (latency regime, evaluate.py:97-142)
   int wino4;        // geometry fits the F(4x4,3x3) pipeline (wino4.h): 8x8 images, C % 64 == 0, cpg | 16 -- or 16x16 images,
@@ -419,6 +421,24 @@ struct ThetaFinalizeArgs {
   float* vjp_t_out;        // nullable device float
 };
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s);
+
+// latency path (kernels_tiny.hip): a whole 3x3 convolution + bias + time map + GroupNorm (+ ReLU) of a tiny batch in one launch
+struct TinyConvArgs {
+  const float* act;            // [N][HW][C] NHWC
+  const unsigned short* wq;    // launch_tiny_pack
+  const float* bias; const float* tmap;
+  EvalTime et;
+  const float* gamma; const float* beta;
+  float* out;                  // [N][HW][C] NHWC
+  float* part; unsigned* counter;    // K-slice partial sums, arrival counters [N G] (zero between launches)
+  const Ctrl* ctrl;
+  int relu; float osign;
+};
+int tiny_slice_channels(const Dims& d);
+size_t tiny_packed_elems(const Dims& d);
+size_t tiny_part_elems(const Dims& d);
+void launch_tiny_pack(const Dims& d, const float* w, unsigned short* wq, hipStream_t s);
+void launch_tiny_conv_gn(const Dims& d, const TinyConvArgs& a, hipStream_t s);
 
 // classifier head (kernels_head.hip); node_shape is the public struct of include/node_hip.h
 }  // namespace node
