@@ -96,6 +96,14 @@ struct TinyArgs {
   int N, C, H, W, G, cpg, CS, KS, MT;
   int relu;
   float osign, eps;
+  // the NEXT evaluation's first pass, fused behind the LAST convolution of this one (the group's channels are all it needs):
+  // y_i = comb.y + scale sum_j coef_j k_j (k_self = this launch's output, taken from registers) -> [y_out] -> GroupNorm-1 -> ReLU -> act
+  int nx_on, nx_self;
+  Comb nx;
+  float* nx_y_out;
+  const float* nx_gamma;
+  const float* nx_beta;
+  float* nx_act;
 };
 
 constexpr int TINY_MAXT = 4;     // pixel tiles per wave: images of up to 256 pixels
@@ -145,31 +153,48 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
     const int p = (wave + 4 * t) * 16 + col;          // (A fragment: lane holds row = lane & 15)
     pbase[t] = p < HW ? (p / W) * Wp + (p % W) : -1;
   }
-  const int NCH = CS >> 5;
-  const t_u32x4* wq = reinterpret_cast<const t_u32x4*>(a.wq) + (size_t)((n * 0 + g) * KS + ks) * 9 * NCH * 3 * 64 + lane;
+  const int NCH = CS >> 5, S = 9 * NCH;               // K steps of 32 input channels: (tap, chunk)
+  const t_u32x4* wq = reinterpret_cast<const t_u32x4*>(a.wq) + (size_t)(g * KS + ks) * S * 3 * 64 + lane;
   const int ntile = (MT - wave + 3) / 4;               // tiles of this wave
-  for (int tap = 0; tap < 9; ++tap) {
-    const int toff = (tap / 3) * Wp + (tap % 3);
-    for (int ch = 0; ch < NCH; ++ch) {
-      const t_u32x4* wf = wq + (size_t)(tap * NCH + ch) * 3 * 64;
-      const t_bf16x8 Bh = __builtin_bit_cast(t_bf16x8, wf[0]), Bm = __builtin_bit_cast(t_bf16x8, wf[64]), Bl = __builtin_bit_cast(t_bf16x8, wf[128]);
+  // filter fragments: a ring of RD steps in flight (a step's three parts are 48 B per lane from L2; waiting for each step's
+  // own request in front of its MFMAs cost ~1 us per step)
+  constexpr int RD = 4;
+  t_u32x4 rb[RD][3];
 #pragma unroll
-      for (int t = 0; t < TINY_MAXT; ++t) {
-        if (t < ntile) {
-          // rows of pixels outside the image read the padded position 0 (the top-left halo: zeros)
-          const int pp = pbase[t] >= 0 ? pbase[t] + toff : 0;
-          const unsigned short* ap = A + (size_t)pp * pitch + ch * 32 + kq * 8;
-          const t_bf16x8 Ah = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap));
-          const t_bf16x8 Am = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + plane));
-          const t_bf16x8 Al = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + 2 * plane));
-          t_f32x4 c = acc[t];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);     // smallest products first
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
-          acc[t] = c;
+  for (int i = 0; i < RD; ++i) {
+    const t_u32x4* wf = wq + (size_t)(i < S ? i : 0) * 3 * 64;
+    rb[i][0] = wf[0]; rb[i][1] = wf[64]; rb[i][2] = wf[128];
+  }
+  for (int s0 = 0; s0 < S; s0 += RD) {
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      const int st = s0 + i;
+      if (st < S) {
+        const int tap = st / NCH, ch = st - tap * NCH;
+        const int toff = (tap / 3) * Wp + (tap % 3);
+        const t_bf16x8 Bh = __builtin_bit_cast(t_bf16x8, rb[i][0]), Bm = __builtin_bit_cast(t_bf16x8, rb[i][1]), Bl = __builtin_bit_cast(t_bf16x8, rb[i][2]);
+#pragma unroll
+        for (int t = 0; t < TINY_MAXT; ++t) {
+          if (t < ntile) {
+            // rows of pixels outside the image read the padded position 0 (the top-left halo: zeros)
+            const int pp = pbase[t] >= 0 ? pbase[t] + toff : 0;
+            const unsigned short* ap = A + (size_t)pp * pitch + ch * 32 + kq * 8;
+            const t_bf16x8 Ah = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap));
+            const t_bf16x8 Am = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + plane));
+            const t_bf16x8 Al = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + 2 * plane));
+            t_f32x4 c = acc[t];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);     // smallest products first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+            acc[t] = c;
+          }
+        }
+        if (st + RD < S) {
+          const t_u32x4* wf = wq + (size_t)(st + RD) * 3 * 64;
+          rb[i][0] = wf[0]; rb[i][1] = wf[64]; rb[i][2] = wf[128];
         }
       }
     }
@@ -254,8 +279,61 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
         if (chan_on && p < HW) {
           float y = ((acc[t][i] - mean) * rstd) * gm + bt;
           if (a.relu) y = fmaxf(y, 0.f);
-          a.out[((size_t)n * HW + p) * C + c] = a.osign * y;
+          y *= a.osign;
+          a.out[((size_t)n * HW + p) * C + c] = y;
+          acc[t][i] = y;
         }
+      }
+  if (!a.nx_on) return;
+  // ---- the next evaluation's stage combine -> GroupNorm-1 -> ReLU (k_combine_gn's arithmetic for this group's channels)
+  const float scale = comb_scale(a.nx, a.ctrl);
+  float cf[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) cf[j] = scale * a.nx.coef[j];
+  float sum1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        float v = 0.f;
+        if (chan_on && p < HW) {
+          const size_t idx = ((size_t)n * HW + p) * C + c;
+          float sk = 0.f;
+          for (int j = 0; j < a.nx.nk; ++j) sk += cf[j] * (j == a.nx_self ? acc[t][i] : a.nx.k[j][idx]);
+          v = a.nx.y[idx] + sk;
+          if (a.nx_y_out != nullptr) a.nx_y_out[idx] = v;
+        }
+        acc[t][i] = v;
+        sum1 += v;
+      }
+  sum1 = tiny_wave_sum(sum1);
+  __syncthreads();
+  if (lane == 0) red[wave] = sum1;
+  __syncthreads();
+  const float mean1 = ((red[0] + red[1]) + (red[2] + red[3])) * inv_m;
+  float sq1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        if (chan_on && p < HW) { const float dv = acc[t][i] - mean1; sq1 += dv * dv; }
+      }
+  sq1 = tiny_wave_sum(sq1);
+  if (lane == 0) red[4 + wave] = sq1;
+  __syncthreads();
+  const float rstd1 = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
+  const float g1 = a.nx_gamma[c], b1 = a.nx_beta[c];
+#pragma unroll
+  for (int t = 0; t < TINY_MAXT; ++t)
+    if (t < ntile)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+        if (chan_on && p < HW) a.nx_act[((size_t)n * HW + p) * C + c] = fmaxf(((acc[t][i] - mean1) * rstd1) * g1 + b1, 0.f);
       }
 }
 
@@ -294,6 +372,7 @@ void launch_tiny_conv_gn(const Dims& d, const TinyConvArgs& b, hipStream_t s) {
   a.N = d.N; a.C = d.C; a.H = d.H; a.W = d.W; a.G = d.G; a.cpg = d.cpg;
   a.CS = tiny_slice_channels(d); a.KS = d.C / a.CS; a.MT = (d.HW + 15) / 16;
   a.relu = b.relu; a.osign = b.osign; a.eps = d.eps;
+  a.nx_on = b.nx_on; a.nx_self = b.nx_self; a.nx = b.nx; a.nx_y_out = b.nx_y_out; a.nx_gamma = b.nx_gamma; a.nx_beta = b.nx_beta; a.nx_act = b.nx_act;
   const size_t lds = (size_t)3 * (d.H + 2) * (d.W + 2) * (a.CS + 8) * 2 + 64;
   static bool attr[MAX_DEVICES] = {};
   allow_full_lds(reinterpret_cast<const void*>(k_tiny_conv_gn), attr);

@@ -1498,15 +1498,29 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
 // The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
 // kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit; };
-static W4Switches w4_switches() {
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128; };
+static W4Switches w4_read_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  // NODE_TUNE_W4_GEMM128 / _WGRAD128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512)
 #ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
-          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0)};
+          rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0),
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1)};
 #else
-  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0};
+  return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1)};
 #endif
+}
+// The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
+// launches these kernels), not once per launch: a training step launches ~100 component GEMMs, and eleven getenv scans in
+// front of each were a quarter of a millisecond of host time per step -- on the drop-in path, where the host is what
+// bounds the step, that is throughput.  Tests that flip a switch between two calls still see it.
+static thread_local W4Switches g_w4_sw;
+static thread_local bool g_w4_sw_valid = false;
+void w4_refresh_tuning() { g_w4_sw = w4_read_switches(); g_w4_sw_valid = true; }
+static const W4Switches& w4_switches() {
+  if (!g_w4_sw_valid) w4_refresh_tuning();
+  return g_w4_sw;
 }
 static bool w4_takes_small(const W4Switches& sw, int N) { return sw.small != 0 && N <= 16 && sw.ablate == 0; }   // (ablations time the throughput kernels)
 // fp32 filters, bf16-triple products (k_w4_gemm64c): 8x8 / 16x16 batches of C < 512 (the LDS-tiled kernel of long reductions
@@ -1573,9 +1587,7 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
     }
 #endif
     if (b16 && Ub != nullptr && sw.ablate == 0) {
-      // NODE_TUNE_W4_GEMM128 = 0 never / 1 wherever it fits / unset: long reductions (C >= 512)
-      const char* g128e = getenv("NODE_TUNE_W4_GEMM128");   // (read on every call, like NODE_TUNE_W4_BF16X3: tests run both kernels)
-      const int g128 = g128e ? atoi(g128e) : -1;
+      const int g128 = sw.gemm128;   // 0 never / 1 wherever it fits / -1: long reductions (C >= 512)
       const bool fits = N % 32 == 0 && C % 128 == 0 && (((N / 32) * (C >> 7)) & 1) == 0;
       if (fits && (g128 == 1 || (g128 < 0 && C >= 512))) {
         static bool attr128[MAX_DEVICES] = {};
@@ -1936,8 +1948,7 @@ void launch_w4_wgrad(const W4WgradArgs& a_in, hipStream_t s) {
   // NODE_TUNE_W4_WGRAD128 = 0 never / 1 wherever it fits / unset: long filters (C >= 512), where the fp32 kernel is bound by
   // the matrix pipe (read on every call: tests run both)
   {
-    const char* e = getenv("NODE_TUNE_W4_WGRAD128");
-    const int w128 = e ? atoi(e) : -1;
+    const int w128 = w4_switches().wgrad128;
     const int nT = (a.C >> 7) * (a.C >> 7);
     if (a.V2 != nullptr && a.N % 8 == 0 && a.C % 128 == 0 && (nT & 1) == 0 && (w128 == 1 || (w128 < 0 && a.C >= 512))) {
       hipLaunchKernelGGL(k_w4_wgrad128b, dim3(8 * (8 * nT + nT)), dim3(256), 2 * 24 * 64 * 16, s, a);

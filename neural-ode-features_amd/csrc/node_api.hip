@@ -176,13 +176,13 @@ static int make_dims(const node_shape* sh, Dims* out) {
     d.small = fits && (small_env >= 0 ? small_env != 0 : (long)d.mtiles * d.ntile < 8);
   }
   {
-    // latency path (kernels_tiny.hip): forward solves of batches of up to ~1000 pixels (bs = 1 .. 16 at 8x8).  NODE_TUNE_TINY =
+    // latency path (kernels_tiny.hip): forward solves of batches of up to 256 pixels (bs = 1 .. 4 at 8x8, bs = 1 at 16x16).  NODE_TUNE_TINY =
     // 0 never / 1 wherever the geometry fits (A/B measurements, tests); results are fp32-exact products either way
     static int tiny_env = -2;
     if (tiny_env == -2) { const char* e = getenv("NODE_TUNE_TINY"); tiny_env = e ? atoi(e) : -1; }
     d.numel = (size_t)d.N * d.C * d.HW;
     d.tiny = 0;
-    if (tiny_env != 0 && (tiny_env == 1 || (size_t)d.N * d.HW <= 1024)) d.tiny = tiny_slice_channels(d);
+    if (tiny_env != 0 && (tiny_env == 1 || (size_t)d.N * d.HW <= 256)) d.tiny = tiny_slice_channels(d);
   }
   const int unit = d.cpg / gcd_i(d.cpg, 4) * 4;  // lcm(cpg, 4)
   static int slab_elems = -1;   // elements of one (sample, channel slab) workgroup of the combine / GN kernels
@@ -753,14 +753,18 @@ struct Solver {
 
   int eval_fwd(const Comb& cy, float* y_out, const EvalTime& et, float* k_out, bool train, const NextComb* next = nullptr) {
     if (w4) return eval_w4(cy, y_out, et, k_out, train, nullptr, nullptr, nullptr, nullptr, -1, 0.f, nullptr, false, next);
-    CombineGnArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
-    ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
-    ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
-    launch_combine_gn(d, ca, st);
+    const bool tiny = tiny_mode() && !train;
+    if (!(tiny && v_ready)) {      // (latency path: the previous evaluation's last launch may have formed this conv input already)
+      CombineGnArgs ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.comb = cy; ca.ctrl = p.ctrl; ca.y_out = y_out; ca.act_out = p.act1;
+      ca.xhat_out = train ? p.xh1 : nullptr; ca.rstd_out = train ? p.r1 : nullptr;
+      ca.gamma = prm.norm1_w; ca.beta = prm.norm1_b; ca.relu = 1; ca.osign = 1.f;
+      launch_combine_gn(d, ca, st);
+    }
+    v_ready = false;
 
-    if (tiny_mode() && !train) {     // latency path: conv + bias + t * tmap + GroupNorm (+ ReLU) per launch
+    if (tiny) {     // latency path: conv + bias + t * tmap + GroupNorm (+ ReLU) per launch
       TinyConvArgs t1;
       memset(&t1, 0, sizeof(t1));
       t1.act = p.act1; t1.wq = p.wtiny[0]; t1.bias = prm.conv1_b; t1.tmap = p.tmap[0]; t1.et = et;
@@ -770,6 +774,13 @@ struct Solver {
       TinyConvArgs t2 = t1;
       t2.act = p.act2; t2.wq = p.wtiny[1]; t2.bias = prm.conv2_b; t2.tmap = p.tmap[1];
       t2.gamma = prm.norm3_w; t2.beta = prm.norm3_b; t2.out = k_out; t2.relu = 0; t2.osign = et.tsign;
+      if (next != nullptr) {     // the next evaluation's combine -> GroupNorm-1 -> ReLU rides in this launch
+        t2.nx_on = 1; t2.nx = next->cy; t2.nx_self = -1;
+        for (int j = 0; j < next->cy.nk; ++j)
+          if (next->cy.k[j] == k_out) t2.nx_self = j;
+        t2.nx_y_out = next->y_out; t2.nx_gamma = prm.norm1_w; t2.nx_beta = prm.norm1_b; t2.nx_act = p.act1;
+        v_ready = true;
+      }
       { ProfScope ps(0, conv_flops(), st); launch_tiny_conv_gn(d, t2, st); }
       if (count_nfe) nfe += 1;
       return check_launch("odefunc forward (latency path)");
@@ -879,7 +890,7 @@ struct Solver {
     Comb cy = make_comb(p.Y, p.KY, coef, ncoef, scale_mode);
     NextComb nc;
     const NextComb* next = nullptr;
-    if (w4 && next_coef != nullptr) {
+    if ((w4 || (tiny_mode() && !aug)) && next_coef != nullptr) {
       nc.cy = make_comb(p.Y, p.KY, next_coef, next_ncoef, scale_mode);
       nc.y_out = next_write_new ? p.Y1 : nullptr;
       next = &nc;
@@ -1106,6 +1117,7 @@ size_t node_workspace_bytes(const node_shape* shape, int /*method*/, int adjoint
 
 int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t, const float* y, float* f,
                      void* ws, size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();     // (the NODE_TUNE_W4_* switches: once per call, not per launch)
   if (!y || !f) return fail(NODE_ERR_NULL, "y / f is NULL");
   Solver S;
   TRY(check_common(shape, params, ws, ws_bytes, 0, 2, &S.d, &S.p));
@@ -1130,6 +1142,7 @@ size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape) {
 }
 int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y, void* ws,
                     size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();     // (the NODE_TUNE_W4_* switches: once per call, not per launch)
   if (!shape || !weight || !x || !y || !ws) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   Dims d;
   TRY(make_dims(shape, &d));
@@ -1175,6 +1188,7 @@ int node_w4_split3(const float* x, float* out, size_t n, void* stream) {
 
 int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t, const float* y, const float* cot,
                      float* f, float* vjp_y, float* vjp_t, float* vjp_params, void* ws, size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();     // (the NODE_TUNE_W4_* switches: once per call, not per launch)
   if (!y || !cot || !f || !vjp_y || !vjp_t || !vjp_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   Solver S;
   TRY(check_common(shape, params, ws, ws_bytes, 1, 2, &S.d, &S.p));
@@ -1196,6 +1210,7 @@ int node_odefunc_vjp(const node_shape* shape, const node_params* params, float t
 int node_solve_fwd(const node_shape* shape, const node_params* params, const float* y0, const float* t_pts, int n_t,
                    float rtol, float atol, int method, const node_solve_opts* opts, float* y_out, node_stats* stats,
                    void* ws, size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();
   if (!y0 || !y_out) return fail(NODE_ERR_NULL, "y0 / y_out is NULL");
   if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
   TRY(check_times(t_pts, n_t));
@@ -1296,6 +1311,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
                        const float* t_pts, int n_t, float rtol, float atol, int method, const node_solve_opts* opts,
                        float* grad_y0, float* grad_params, float* grad_t, node_stats* stats, void* ws, size_t ws_bytes,
                        void* stream) {
+  w4_refresh_tuning();
   if (!y_traj || !grad_out || !grad_y0 || !grad_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
   TRY(check_times(t_pts, n_t));
@@ -1463,6 +1479,7 @@ extern "C" size_t node_backprop_workspace_bytes(const node_shape* shape, int met
 extern "C" int node_solve_backprop(const node_shape* shape, const node_params* params, const float* y0, const float* t_pts,
                                    int n_t, const double* step_dt, int n_steps, float rtol, float atol, int method, const float* grad_out,
                                    float* grad_y0, float* grad_params, void* ws, size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();
   if (!y0 || !grad_out || !grad_y0 || !grad_params) return fail(NODE_ERR_NULL, "a required pointer is NULL");
   if (method != NODE_METHOD_DOPRI5 && method != NODE_METHOD_RK4) return fail(NODE_ERR_ARG, "unknown method %d", method);
   TRY(check_times(t_pts, n_t));

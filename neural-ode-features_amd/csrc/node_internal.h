@@ -433,6 +433,9 @@ struct TinyConvArgs {
   float* part; unsigned* counter;    // K-slice partial sums, arrival counters [N G] (zero between launches)
   const Ctrl* ctrl;
   int relu; float osign;
+  // optional: the next evaluation's stage combine -> GroupNorm-1 -> ReLU behind this launch (its last convolution)
+  int nx_on, nx_self;          // nx_self: index of the combine's term that IS this launch's output (taken from registers), or -1
+  Comb nx; float* nx_y_out; const float* nx_gamma; const float* nx_beta; float* nx_act;
 };
 int tiny_slice_channels(const Dims& d);
 size_t tiny_packed_elems(const Dims& d);

@@ -318,6 +318,7 @@ size_t node_stem_workspace_bytes(const node_stem_shape* shape) {
 
 int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* prm, const float* x, float* out, void* ws, size_t ws_bytes,
                   void* stream) {
+  w4_refresh_tuning();     // (NODE_TUNE_W4_*: once per call)
   int rc = check_stem_shape(shape);
   if (rc != NODE_OK) return rc;
   if (!prm || !x || !out || !ws) return failf(NODE_ERR_NULL, "a required pointer is NULL");
@@ -420,6 +421,7 @@ int node_stem_fwd(const node_stem_shape* shape, const node_stem_params* prm, con
 
 int node_stem_bwd(const node_stem_shape* shape, const node_stem_params* prm, const float* x, const float* grad_out,
                   const node_stem_grads* gr, void* ws, size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();     // (NODE_TUNE_W4_*: once per call)
   int rc = check_stem_shape(shape);
   if (rc != NODE_OK) return rc;
   if (!prm || !x || !grad_out || !gr || !ws) return failf(NODE_ERR_NULL, "a required pointer is NULL");
@@ -582,6 +584,7 @@ size_t node_stem_conv_workspace_bytes(const node_conv_geom* g) {
 
 int node_stem_conv(const node_conv_geom* g, int what, const float* x, const float* w, const float* dy, float* result, void* ws,
                    size_t ws_bytes, void* stream) {
+  w4_refresh_tuning();     // (NODE_TUNE_W4_*: once per call)
   int rc = check_geom(g);
   if (rc != NODE_OK) return rc;
   if (!result || !ws || (what != 1 && !x) || (what != 2 && !w) || (what != 0 && !dy)) return failf(NODE_ERR_NULL, "a required pointer is NULL");

@@ -121,6 +121,7 @@ struct W4WgradArgs {
   int sharev;                         // set by launch_w4_wgrad (NODE_TUNE_W4_SHAREV): the waves of a workgroup share one component's V stream
 };
 void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s);
+void w4_refresh_tuning();     // re-read the NODE_TUNE_W4_* switches (once per C-ABI call; kernels_w4.hip)
 __host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C; }
 __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COMPS * C * C; }
 

@@ -14,11 +14,23 @@ from tests.helpers import rel_err
 pytestmark = pytest.mark.gpu
 
 
-def _same_nfe(hip, ref):
-    """Equal counters -- or one accept / reject decision apart (six evaluations in the forward or in the backward solve): two
-    fp32 implementations may land on different sides of an error ratio of 1."""
+def _same_nfe(hip, ref, intervals=1):
+    """Equal counters -- or one accept / reject decision apart per solve (six evaluations; the backward runs one solve per time
+    interval): two fp32 implementations may land on different sides of an error ratio of 1."""
     (hf, hb), (rf, rb) = hip, ref
-    return abs(hf - rf) in (0, 6) and abs((hb - hf) - (rb - rf)) in (0, 6)
+    df, db = abs(hf - rf), abs((hb - hf) - (rb - rf))
+    return df % 6 == 0 and df <= 6 and db % 6 == 0 and db <= 6 * intervals
+
+
+def _grads_close(hip, ref, bound):
+    """Every parameter gradient against the oracle's, each relative to max(its own scale, 1e-4 x the largest gradient of the
+    function): a conv bias in front of a normalisation layer, and a parameter the function never uses, have exactly-zero
+    gradients -- both sides then hold rounding noise only (or None on the HIP side, like upstream's allow_unused)."""
+    gmax = max(float(r.abs().max()) for r in ref)
+    for g, r in zip(hip, ref):
+        g = torch.zeros_like(r) if g is None else g
+        scale = max(float(r.abs().max()), 1e-4 * gmax)
+        assert float((g - r).abs().max()) / scale < bound, (float((g - r).abs().max()), scale)
 
 
 def _both(func, y, tpts, tol, method='dopri5', adjoint=True, weight_seed=7):
@@ -37,7 +49,8 @@ def _both(func, y, tpts, tol, method='dopri5', adjoint=True, weight_seed=7):
         nfe_f = getattr(mod, 'nfe', None)
         (out * wgt.to(dev)).sum().backward()
         nfe_b = getattr(mod, 'nfe', None)
-        res.append(dict(out=out.detach().cpu(), gy=y0.grad.cpu(), gp=[p.grad.cpu() for p in mod.parameters()], nfe=(nfe_f, nfe_b)))
+        res.append(dict(out=out.detach().cpu(), gy=y0.grad.cpu(), gp=[None if p.grad is None else p.grad.cpu() for p in mod.parameters()],
+                        nfe=(nfe_f, nfe_b)))
     return res
 
 
@@ -56,10 +69,9 @@ def test_batchnorm_dynamics_through_odeint_adjoint(tol, tpts):
     hip, ref = _both(func, y, tpts, tol)
     assert torch.equal(hip['out'][0], y)
     assert float((hip['out'] - ref['out']).abs().max()) <= 10 * tol
-    assert _same_nfe(hip['nfe'], ref['nfe']), (hip['nfe'], ref['nfe'])      # same steps tried, same evaluations counted (model.py:340)
+    assert _same_nfe(hip['nfe'], ref['nfe'], len(tpts) - 1), (hip['nfe'], ref['nfe'])      # same steps tried, same evaluations counted (model.py:340)
     assert rel_err(hip['gy'], ref['gy']) < 2e-2
-    for g, r in zip(hip['gp'], ref['gp']):
-        assert rel_err(g, r) < 2e-2
+    _grads_close(hip['gp'], ref['gp'], 2e-2)
 
 
 @pytest.mark.parametrize('shape', [(2, 24, 9, 9), (2, 6, 9, 9), (1, 8, 20, 20), (3, 12, 33, 5)])
@@ -80,8 +92,7 @@ def test_geometries_outside_the_fused_tiling(shape):
         assert float((hip['out'] - ref['out']).abs().max()) <= 10 * tol, (shape, tol)
         assert _same_nfe(hip['nfe'], ref['nfe']), (shape, tol, hip['nfe'], ref['nfe'])
         assert rel_err(hip['gy'], ref['gy']) < 2e-2
-        for g, r in zip(hip['gp'], ref['gp']):
-            assert rel_err(g, r) < 5e-2
+        _grads_close(hip['gp'], ref['gp'], 5e-2)
     hip, ref = _both(func, y, (0.0, 0.5, 1.0), 1e-3, method='rk4')
     assert float((hip['out'] - ref['out']).abs().max()) <= 1e-4
     assert rel_err(hip['gy'], ref['gy']) < 1e-3
@@ -112,13 +123,10 @@ def test_foreign_module_on_a_rank_two_state(tpts):
     for tol in (1e-3, 1e-6):
         hip, ref = _both(func, y, tpts, tol)
         assert float((hip['out'] - ref['out']).abs().max()) <= 10 * tol, tol
-        assert _same_nfe(hip['nfe'], ref['nfe']), (hip['nfe'], ref['nfe'])
+        assert _same_nfe(hip['nfe'], ref['nfe'], len(tpts) - 1), (hip['nfe'], ref['nfe'])
         assert rel_err(hip['gy'], ref['gy']) < max(2e-3, 50 * tol)
-        for g, r in zip(hip['gp'], ref['gp']):
-            if float(r.abs().max()) == 0.0:
-                assert float(g.abs().max()) == 0.0
-            else:
-                assert rel_err(g, r) < max(2e-3, 50 * tol)
+        assert hip['gp'][-1] is None or float(hip['gp'][-1].abs().max()) == 0.0        # `unused`: no gradient, like upstream
+        _grads_close(hip['gp'], ref['gp'], max(2e-3, 50 * tol))
 
 
 def test_plain_odeint_and_the_error_surface():
@@ -141,8 +149,10 @@ def test_plain_odeint_and_the_error_surface():
         nof.odeint(f, y.cuda(), torch.tensor([0.0, 1.0]).cuda(), rtol=1e-9, atol=1e-9, options={'max_num_steps': 2})
     integrate.GENERIC_FALLBACK = False
     try:
+        with pytest.raises(ValueError):
+            nof.odeint(f, y.cuda(), torch.tensor([0.0, 1.0]).cuda())              # rank-2 state
         with pytest.raises(NotImplementedError):
-            nof.odeint(f, y.cuda(), torch.tensor([0.0, 1.0]).cuda())
+            nof.odeint(nn.Conv2d(8, 8, 3, 1, 1).cuda(), torch.randn(1, 8, 4, 4).cuda(), torch.tensor([0.0, 1.0]).cuda())
         g = nof.ODEfunc(8).cuda()
         with pytest.raises(NodeHipError, match='UNSUPPORTED'):
             nof.odeint(g, torch.randn(1, 8, 20, 20).cuda(), torch.tensor([0.0, 1.0]).cuda())
