@@ -107,14 +107,30 @@ struct TinyArgs {
 };
 
 constexpr int TINY_MAXT = 4;     // pixel tiles per wave: images of up to 256 pixels
+constexpr int TINY_MAXKS = 8;    // K slices per group
+constexpr int TINY_STAGE = 6;    // staging items per thread: (H + 2)(W + 2) CS / 8 <= 6 x 256
 
-// LDS: A [3 parts][PP][CS + 8] bf16 | red [16] floats
+// agent-scope (write-through / L1-bypassing) 16-byte accesses for the K-slice hand-off (the 4-byte __hip_atomic_* forms cost one
+// request per value: 128 dependent-looking loads per lane at KS = 8)
+__device__ __forceinline__ void tiny_st16_agent(float* p, const t_f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ t_f32x4 tiny_ld16_agent(const float* p) {
+  t_f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// LDS: A [3 parts][PP][CS + 8] bf16 | red [16] floats.   NCH = CS / 32, TPW = pixel tiles per wave (ceil(MT / 4))
+template <int NCH, int TPW>
 __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   if (a.ctrl != nullptr && a.ctrl->done) return;     // a step enqueued past the end of the interval
   extern __shared__ __align__(16) unsigned char lsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = a.C, H = a.H, W = a.W, HW = H * W, CS = a.CS, KS = a.KS, MT = a.MT, cpg = a.cpg;
-  const int Wp = W + 2, PP = (H + 2) * Wp, pitch = CS + 8;       // bf16 elements per padded-pixel row of a part plane
+  const int C = a.C, H = a.H, W = a.W, HW = H * W, KS = a.KS, cpg = a.cpg;
+  constexpr int CS = 32 * NCH, S = 9 * NCH;                       // input channels per workgroup, K steps (tap, chunk)
+  const int Wp = W + 2, PP = (H + 2) * Wp;
+  constexpr int pitch = CS + 8;                                   // bf16 elements per padded-pixel row of a part plane
   unsigned short* A = reinterpret_cast<unsigned short*>(lsm);
   const size_t plane = (size_t)PP * pitch;
   float* red = reinterpret_cast<float*>(lsm + 3 * plane * sizeof(unsigned short));
@@ -123,41 +139,9 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   const int g = r % a.G;
   const int n = r / a.G;
 
-  // ---- stage the activation slice: padded image x CS channels, split into bf16 triples once
-  {
-    const int q8 = CS >> 3;
-    const float* src = a.act + (size_t)n * HW * C + ks * CS;
-    for (int idx = tid; idx < PP * q8; idx += 256) {
-      const int pp = idx / q8, q = idx - pp * q8;
-      const int yy = pp / Wp - 1, xx = pp % Wp - 1;
-      t_u32x4 hh = {0u, 0u, 0u, 0u}, mm = hh, ll = hh;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)(yy * W + xx) * C + 8 * q);
-        tiny_split8(s4[0], s4[1], hh, mm, ll);
-      }
-      t_u32x4* d = reinterpret_cast<t_u32x4*>(A + (size_t)pp * pitch + 8 * q);
-      d[0] = hh;
-      *reinterpret_cast<t_u32x4*>(A + plane + (size_t)pp * pitch + 8 * q) = mm;
-      *reinterpret_cast<t_u32x4*>(A + 2 * plane + (size_t)pp * pitch + 8 * q) = ll;
-    }
-  }
-  __syncthreads();
-
-  // ---- products: wave w takes the pixel tiles w, w + 4, ...; every wave walks the whole K slice
+  // ---- filter fragments of the first ring turn: requested before anything else (they depend on nothing in LDS)
   const int col = lane & 15, kq = lane >> 4;
-  t_f32x4 acc[TINY_MAXT];
-  int pbase[TINY_MAXT];      // this lane's A row: padded position (tap 0) of pixel tile * 16 + col ... (col doubles as the row index of A)
-#pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t) {
-    acc[t] = t_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int p = (wave + 4 * t) * 16 + col;          // (A fragment: lane holds row = lane & 15)
-    pbase[t] = p < HW ? (p / W) * Wp + (p % W) : -1;
-  }
-  const int NCH = CS >> 5, S = 9 * NCH;               // K steps of 32 input channels: (tap, chunk)
   const t_u32x4* wq = reinterpret_cast<const t_u32x4*>(a.wq) + (size_t)(g * KS + ks) * S * 3 * 64 + lane;
-  const int ntile = (MT - wave + 3) / 4;               // tiles of this wave
-  // filter fragments: a ring of RD steps in flight (a step's three parts are 48 B per lane from L2; waiting for each step's
-  // own request in front of its MFMAs cost ~1 us per step)
   constexpr int RD = 4;
   t_u32x4 rb[RD][3];
 #pragma unroll
@@ -165,38 +149,82 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
     const t_u32x4* wf = wq + (size_t)(i < S ? i : 0) * 3 * 64;
     rb[i][0] = wf[0]; rb[i][1] = wf[64]; rb[i][2] = wf[128];
   }
-  for (int s0 = 0; s0 < S; s0 += RD) {
+
+  // ---- stage the activation slice: padded image x CS channels, split into bf16 triples once.  All of a thread's requests first
+  // (<= TINY_STAGE items of 32 B), then the splits and the LDS writes: one L2 latency instead of one per item
+  {
+    constexpr int q8 = CS >> 3;
+    const float* src = a.act + (size_t)n * HW * C + ks * CS;
+    const int items = PP * q8;
+    float4 ld[TINY_STAGE][2];
 #pragma unroll
-    for (int i = 0; i < RD; ++i) {
-      const int st = s0 + i;
-      if (st < S) {
-        const int tap = st / NCH, ch = st - tap * NCH;
-        const int toff = (tap / 3) * Wp + (tap % 3);
-        const t_bf16x8 Bh = __builtin_bit_cast(t_bf16x8, rb[i][0]), Bm = __builtin_bit_cast(t_bf16x8, rb[i][1]), Bl = __builtin_bit_cast(t_bf16x8, rb[i][2]);
-#pragma unroll
-        for (int t = 0; t < TINY_MAXT; ++t) {
-          if (t < ntile) {
-            // rows of pixels outside the image read the padded position 0 (the top-left halo: zeros)
-            const int pp = pbase[t] >= 0 ? pbase[t] + toff : 0;
-            const unsigned short* ap = A + (size_t)pp * pitch + ch * 32 + kq * 8;
-            const t_bf16x8 Ah = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap));
-            const t_bf16x8 Am = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + plane));
-            const t_bf16x8 Al = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + 2 * plane));
-            t_f32x4 c = acc[t];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);     // smallest products first
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
-            acc[t] = c;
-          }
-        }
-        if (st + RD < S) {
-          const t_u32x4* wf = wq + (size_t)(st + RD) * 3 * 64;
-          rb[i][0] = wf[0]; rb[i][1] = wf[64]; rb[i][2] = wf[128];
-        }
+    for (int it = 0; it < TINY_STAGE; ++it) {
+      const int idx = tid + it * 256;
+      const int pp = idx / q8, q = idx - pp * q8;
+      const int yy = pp / Wp - 1, xx = pp % Wp - 1;
+      ld[it][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ld[it][1] = ld[it][0];
+      if (idx < items && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)(yy * W + xx) * C + 8 * q);
+        ld[it][0] = s4[0];
+        ld[it][1] = s4[1];
       }
+    }
+#pragma unroll
+    for (int it = 0; it < TINY_STAGE; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < items) {
+        const int pp = idx / q8, q = idx - pp * q8;
+        t_u32x4 hh, mm, ll;
+        tiny_split8(ld[it][0], ld[it][1], hh, mm, ll);        // (halo positions: zeros split to zeros)
+        *reinterpret_cast<t_u32x4*>(A + (size_t)pp * pitch + 8 * q) = hh;
+        *reinterpret_cast<t_u32x4*>(A + plane + (size_t)pp * pitch + 8 * q) = mm;
+        *reinterpret_cast<t_u32x4*>(A + 2 * plane + (size_t)pp * pitch + 8 * q) = ll;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- products: wave w takes the pixel tiles w, w + 4, ... (tiles past the image read the zero halo and are masked at the end);
+  // every wave walks the whole K slice.  Straight-line code (S and TPW are compile-time): the compiler counts the waits of the
+  // filter ring exactly
+  t_f32x4 acc[TPW];
+  const unsigned short* abase[TPW];      // this lane's A row (A fragment: lane holds row = lane & 15): padded position of tap 0
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = t_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p = (wave + 4 * t) * 16 + col;
+    const int pb = p < HW ? (p / W) * Wp + (p % W) : -(2 * Wp + 2) - 1;      // (outside: every tap lands on padded position <= 0 ...)
+    abase[t] = A + (size_t)(pb < 0 ? 0 : pb) * pitch + kq * 8;
+  }
+  bool inside[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) inside[t] = (wave + 4 * t) * 16 + col < HW;
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+    const int tap = st / NCH, ch = st - tap * NCH;
+    const int toff = ((tap / 3) * Wp + (tap % 3)) * pitch + ch * 32;
+    const t_bf16x8 Bh = __builtin_bit_cast(t_bf16x8, rb[st % RD][0]), Bm = __builtin_bit_cast(t_bf16x8, rb[st % RD][1]),
+                   Bl = __builtin_bit_cast(t_bf16x8, rb[st % RD][2]);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      // rows of pixels outside the image read the padded position 0 (the top-left halo: zeros)
+      const unsigned short* ap = inside[t] ? abase[t] + toff : A + kq * 8;
+      const t_bf16x8 Ah = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap));
+      const t_bf16x8 Am = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + plane));
+      const t_bf16x8 Al = __builtin_bit_cast(t_bf16x8, *reinterpret_cast<const t_u32x4*>(ap + 2 * plane));
+      t_f32x4 c = acc[t];
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, c, 0, 0, 0);     // smallest products first
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Am, Bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bm, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, c, 0, 0, 0);
+      acc[t] = c;
+    }
+    if (st + RD < S) {
+      const t_u32x4* wf = wq + (size_t)(st + RD) * 3 * 64;
+      rb[st % RD][0] = wf[0]; rb[st % RD][1] = wf[64]; rb[st % RD][2] = wf[128];
     }
   }
   // accumulator layout: lane holds column `col` (output channel g cpg + col), rows 4 kq + i of its tile -> pixel (wave + 4 t) 16 + 4 kq + i
@@ -207,30 +235,32 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "k_tiny_conv_gn's fence-free hand-off is only valid on gfx950 (see k_theta_finalize)"
 #endif
-    float* mine = a.part + ((size_t)ng * KS + ks) * (MT * 16) * 16;
+    // scratch layout [group][slice][tile][lane][4]: a lane's four values of a tile are one 16-byte access
+    const size_t per_slice = (size_t)(4 * TPW) * 64 * 4;
+    float* mine = a.part + ((size_t)ng * KS + ks) * per_slice;
 #pragma unroll
-    for (int t = 0; t < TINY_MAXT; ++t)
-      if (t < ntile)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          __hip_atomic_store(mine + (size_t)((wave + 4 * t) * 16 + 4 * kq + i) * 16 + col, acc[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = 0; t < TPW; ++t) tiny_st16_agent(mine + ((size_t)(wave + 4 * t) * 64 + lane) * 4, acc[t]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) red[12] = __hip_atomic_fetch_add(a.counter + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(KS - 1) ? 1.f : 0.f;
     __syncthreads();
     if (red[12] == 0.f) return;
     if (tid == 0) __hip_atomic_store(a.counter + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch (stream order)
-    const float* all = a.part + (size_t)ng * KS * (MT * 16) * 16;
+    const float* all = a.part + (size_t)ng * KS * per_slice;
+    t_f32x4 got[TINY_MAXKS][TPW];
 #pragma unroll
-    for (int t = 0; t < TINY_MAXT; ++t)
-      if (t < ntile)
+    for (int k = 0; k < TINY_MAXKS; ++k)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float s = 0.f;
-          for (int k = 0; k < KS; ++k)
-            s += __hip_atomic_load(all + ((size_t)k * (MT * 16) + (wave + 4 * t) * 16 + 4 * kq + i) * 16 + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[t][i] = s;
-        }
+      for (int t = 0; t < TPW; ++t)
+        got[k][t] = k < KS ? tiny_ld16_agent(all + (size_t)k * per_slice + ((size_t)(wave + 4 * t) * 64 + lane) * 4) : t_f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      t_f32x4 s4 = got[0][t];
+#pragma unroll
+      for (int k = 1; k < TINY_MAXKS; ++k) s4 += got[k][t];      // (slices past KS hold zeros)
+      acc[t] = s4;
+    }
   }
 
   // ---- epilogue: + bias + t * tmap, GroupNorm over the group (cpg channels x HW pixels), affine, ReLU, store
@@ -240,16 +270,15 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   const float bs = a.bias[c];
   float sum = 0.f;
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        const bool on = chan_on && p < HW;
-        const float v = on ? acc[t][i] + bs + tnow * a.tmap[(size_t)p * C + c] : 0.f;
-        acc[t][i] = v;
-        sum += v;
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      const bool on = chan_on && p < HW;
+      const float v = on ? acc[t][i] + bs + tnow * a.tmap[(size_t)p * C + c] : 0.f;
+      acc[t][i] = v;
+      sum += v;
+    }
   const float inv_m = 1.f / (float)(cpg * HW);
   sum = tiny_wave_sum(sum);
   __syncthreads();
@@ -258,32 +287,30 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * inv_m;
   float sq = 0.f;
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        if (chan_on && p < HW) { const float dv = acc[t][i] - mean; sq += dv * dv; }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      if (chan_on && p < HW) { const float dv = acc[t][i] - mean; sq += dv * dv; }
+    }
   sq = tiny_wave_sum(sq);
   if (lane == 0) red[4 + wave] = sq;
   __syncthreads();
   const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
   const float gm = a.gamma[c], bt = a.beta[c];
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        if (chan_on && p < HW) {
-          float y = ((acc[t][i] - mean) * rstd) * gm + bt;
-          if (a.relu) y = fmaxf(y, 0.f);
-          y *= a.osign;
-          a.out[((size_t)n * HW + p) * C + c] = y;
-          acc[t][i] = y;
-        }
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      if (chan_on && p < HW) {
+        float y = ((acc[t][i] - mean) * rstd) * gm + bt;
+        if (a.relu) y = fmaxf(y, 0.f);
+        y *= a.osign;
+        a.out[((size_t)n * HW + p) * C + c] = y;
+        acc[t][i] = y;
       }
+    }
   if (!a.nx_on) return;
   // ---- the next evaluation's stage combine -> GroupNorm-1 -> ReLU (k_combine_gn's arithmetic for this group's channels)
   const float scale = comb_scale(a.nx, a.ctrl);
@@ -292,22 +319,21 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   for (int j = 0; j < 7; ++j) cf[j] = scale * a.nx.coef[j];
   float sum1 = 0.f;
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        float v = 0.f;
-        if (chan_on && p < HW) {
-          const size_t idx = ((size_t)n * HW + p) * C + c;
-          float sk = 0.f;
-          for (int j = 0; j < a.nx.nk; ++j) sk += cf[j] * (j == a.nx_self ? acc[t][i] : a.nx.k[j][idx]);
-          v = a.nx.y[idx] + sk;
-          if (a.nx_y_out != nullptr) a.nx_y_out[idx] = v;
-        }
-        acc[t][i] = v;
-        sum1 += v;
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      float v = 0.f;
+      if (chan_on && p < HW) {
+        const size_t idx = ((size_t)n * HW + p) * C + c;
+        float sk = 0.f;
+        for (int j = 0; j < a.nx.nk; ++j) sk += cf[j] * (j == a.nx_self ? acc[t][i] : a.nx.k[j][idx]);
+        v = a.nx.y[idx] + sk;
+        if (a.nx_y_out != nullptr) a.nx_y_out[idx] = v;
       }
+      acc[t][i] = v;
+      sum1 += v;
+    }
   sum1 = tiny_wave_sum(sum1);
   __syncthreads();
   if (lane == 0) red[wave] = sum1;
@@ -315,50 +341,55 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   const float mean1 = ((red[0] + red[1]) + (red[2] + red[3])) * inv_m;
   float sq1 = 0.f;
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        if (chan_on && p < HW) { const float dv = acc[t][i] - mean1; sq1 += dv * dv; }
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      if (chan_on && p < HW) { const float dv = acc[t][i] - mean1; sq1 += dv * dv; }
+    }
   sq1 = tiny_wave_sum(sq1);
   if (lane == 0) red[4 + wave] = sq1;
   __syncthreads();
   const float rstd1 = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
   const float g1 = a.nx_gamma[c], b1 = a.nx_beta[c];
 #pragma unroll
-  for (int t = 0; t < TINY_MAXT; ++t)
-    if (t < ntile)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (wave + 4 * t) * 16 + 4 * kq + i;
-        if (chan_on && p < HW) a.nx_act[((size_t)n * HW + p) * C + c] = fmaxf(((acc[t][i] - mean1) * rstd1) * g1 + b1, 0.f);
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      if (chan_on && p < HW) a.nx_act[((size_t)n * HW + p) * C + c] = fmaxf(((acc[t][i] - mean1) * rstd1) * g1 + b1, 0.f);
+    }
 }
 
 }  // namespace
 
 // geometry the latency path takes: C a multiple of 32 with whole GroupNorm groups of <= 16 channels inside a 16-column tile,
-// images of up to 256 pixels (16 pixel tiles), a grid that stays small.  Returns CS (input channels per workgroup) or 0.
+// images of up to 256 pixels (16 pixel tiles), at most TINY_MAXKS channel slices per group, a grid that stays small.
+// Returns CS (input channels per workgroup) or 0.
 int tiny_slice_channels(const Dims& d) {
   if (d.C % 32 != 0 || d.cpg > 16 || d.HW > 16 * 4 * TINY_MAXT || d.W > 64) return 0;
-  const int CS = (d.HW <= 100 && d.C % 64 == 0) ? 64 : 32;
+  int CS = (d.HW <= 100 && d.C % 64 == 0) ? 64 : 32;
+  if (d.C / CS > TINY_MAXKS) CS = 64;
+  if (d.C % CS != 0 || d.C / CS > TINY_MAXKS) return 0;
   const size_t lds = (size_t)3 * (d.H + 2) * (d.W + 2) * (CS + 8) * 2 + 64;
   if (lds > 150 * 1024) return 0;
+  if ((d.H + 2) * (d.W + 2) * (CS / 8) > TINY_STAGE * 256) return 0;
   if ((long)d.N * d.G * (d.C / CS) > 2048) return 0;
   return CS;
+}
+static int tiny_tpw(const Dims& d) {            // pixel tiles per wave: 1, 2 or 4
+  const int MT = (d.HW + 15) / 16, need = (MT + 3) / 4;
+  return need <= 1 ? 1 : need <= 2 ? 2 : 4;
 }
 size_t tiny_packed_elems(const Dims& d) {       // unsigned shorts of one convolution's packed filters
   const int CS = tiny_slice_channels(d);
   if (!CS) return 0;
   return (size_t)d.G * (d.C / CS) * 9 * (CS / 32) * 3 * 64 * 8;
 }
-size_t tiny_part_elems(const Dims& d) {         // floats of the K-slice partial sums
+size_t tiny_part_elems(const Dims& d) {         // floats of the K-slice partial sums: [N G][KS][4 TPW tiles][64 lanes][4]
   const int CS = tiny_slice_channels(d);
   if (!CS) return 0;
-  const int MT = (d.HW + 15) / 16;
-  return (size_t)d.N * d.G * (d.C / CS) * MT * 16 * 16;
+  return (size_t)d.N * d.G * (d.C / CS) * 4 * tiny_tpw(d) * 64 * 4;
 }
 void launch_tiny_pack(const Dims& d, const float* w, unsigned short* wq, hipStream_t s) {
   const int CS = tiny_slice_channels(d);
@@ -374,9 +405,24 @@ void launch_tiny_conv_gn(const Dims& d, const TinyConvArgs& b, hipStream_t s) {
   a.relu = b.relu; a.osign = b.osign; a.eps = d.eps;
   a.nx_on = b.nx_on; a.nx_self = b.nx_self; a.nx = b.nx; a.nx_y_out = b.nx_y_out; a.nx_gamma = b.nx_gamma; a.nx_beta = b.nx_beta; a.nx_act = b.nx_act;
   const size_t lds = (size_t)3 * (d.H + 2) * (d.W + 2) * (a.CS + 8) * 2 + 64;
-  static bool attr[MAX_DEVICES] = {};
-  allow_full_lds(reinterpret_cast<const void*>(k_tiny_conv_gn), attr);
-  hipLaunchKernelGGL(k_tiny_conv_gn, dim3(d.N * d.G * a.KS), dim3(256), lds, s, a);
+  const dim3 grid(d.N * d.G * a.KS);
+  const int tpw = tiny_tpw(d);
+#define TINY_LAUNCH(NCH, TPW)                                                                  \
+  {                                                                                            \
+    static bool attr[MAX_DEVICES] = {};                                                        \
+    allow_full_lds(reinterpret_cast<const void*>(k_tiny_conv_gn<NCH, TPW>), attr);             \
+    hipLaunchKernelGGL((k_tiny_conv_gn<NCH, TPW>), grid, dim3(256), lds, s, a);                \
+    return;                                                                                    \
+  }
+  if (a.CS == 64) {
+    if (tpw == 1) TINY_LAUNCH(2, 1)
+    if (tpw == 2) TINY_LAUNCH(2, 2)
+    TINY_LAUNCH(2, 4)
+  }
+  if (tpw == 1) TINY_LAUNCH(1, 1)
+  if (tpw == 2) TINY_LAUNCH(1, 2)
+  TINY_LAUNCH(1, 4)
+#undef TINY_LAUNCH
 }
 
 }  // namespace node

@@ -856,6 +856,88 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 }
 
 
+// ----------------------------------------------------------------------------
+// k_w4_gemm32b (C = 256, NODE_TUNE_W4_HALF): k_w4_gemm64b's products with HALF-HEIGHT tiles and TWO waves per SIMD.
+// What the counters say about k_w4_gemm64b (profiles/r05_pmc_w4_limiter.txt): the matrix pipe is busy 45 % of a wave's life --
+// ~75 % inside the K loop, idle through a prologue (first operands: L2 latency) and an epilogue (stores, shared component,
+// LDS reduction) that one tile per wave at one wave per SIMD cannot overlap with anything; neither the texture path nor the
+// fabric is saturated.  Here a wave owns a 32 x 64 tile (one row block, two column blocks: 32 + 128 ring registers instead
+// of 64 + 160), the kernel fits 256 registers, and a SIMD holds two waves of two different workgroups: one's prologue and
+// epilogue run under the other's K loop.  Twice the workgroups (N / 8 row tiles x 4 column tiles x 8), each streaming the same
+// filter blocks for half the rows (L1 -> L2 requests of the filter operand double: the texture path has the room).  The
+// shared component 32 + j / 2 is dealt in 32 x 32 blocks (one per workgroup, K range cut over the four waves as before).
+// Every output element is the same sum in the same order as in k_w4_gemm64b: bit-identical.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_w4_gemm32b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
+                                                       const Ctrl* ctrl, W4Geom gm) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nRB = gm.RB, G8 = gm.G8, G2 = G8 >> 1, CB = gm.C >> 5;      // C = 256: four 64-column tiles, eight 32-column blocks
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rb = tile >> 2, ct = tile & 3;                                // 32-row block, the workgroup's place among four
+  const int a_off = (((l31 >> 2) * 8) + hi * 4 + (l31 & 3)) * 4;
+  auto vblk = [&](int comp, int r) { return reinterpret_cast<const float4*>(V + (((size_t)comp * nRB + r) * G8) * 256 + a_off); };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Ub) + (((size_t)comp * CB + cb) * G2) * 192 + lane; };
+  const size_t sstride = (size_t)CB * 36 * 128;   // floats per sample of M
+  {
+    // own component 4 j + ct (the workgroup's place names it, as NODE_TUNE_W4_SHAREV = 1 does in k_w4_gemm64b): the four waves walk
+    // the same V block in lock-step, wave w multiplies it with column tile w
+    const int comp = 4 * j + ct;
+    W4BPtrs p;
+    p.a[0] = vblk(comp, rb); p.a[1] = p.a[0];
+    p.b[0] = ublk(comp, 2 * wave); p.b[1] = ublk(comp, 2 * wave + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
+    w4b_run<W4B_DEPTH, 1>(acc, p, 0, G2);
+    float* m0 = M + ((size_t)(rb * 8 + hi) * CB + 2 * wave) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      st_wt(o, acc[0][0][q]);
+      st_wt(o + 36 * 128, acc[0][1][q]);
+    }
+  }
+  {
+    // a 32 x 32 block of the shared component: rows rb, column block 2 ct + (j & 1); K range [wave G2 / 4, (wave + 1) G2 / 4)
+    const int scomp = 32 + (j >> 1), cb = 2 * ct + (j & 1);
+    const int ng = G2 >> 2, g0 = wave * ng;
+    W4BPtrs p;
+    p.a[0] = vblk(scomp, rb); p.a[1] = p.a[0];
+    p.b[0] = ublk(scomp, cb); p.b[1] = p.b[0];
+    float16_t acc[2][2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc[0][0][q] = 0.f; acc[0][1][q] = 0.f; }
+    // (one column block: the second accumulator of w4b_mac<1> multiplies the same block again and is dropped -- 12 spare MFMAs
+    //  per K step of a phase that is 1 / 9 of the work, for one code path)
+    if (ng % 4 == 0) w4b_run<4, 1>(acc, p, g0, ng);
+    else if (ng % 2 == 0) w4b_run<2, 1>(acc, p, g0, ng);
+    else w4b_run<1, 1>(acc, p, g0, ng);
+    float* red = smem + wave * 1024;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+      *reinterpret_cast<float4*>(red + (r4 * 64 + lane) * 4) =
+          make_float4(acc[0][0][4 * r4], acc[0][0][4 * r4 + 1], acc[0][0][4 * r4 + 2], acc[0][0][4 * r4 + 3]);
+    __syncthreads();
+    const int r4 = wave;      // 256 threads = 4 r4 x 64 lanes
+    float4 sacc = *reinterpret_cast<const float4*>(smem + (r4 * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(smem + w * 1024 + (r4 * 64 + lane) * 4);
+      sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+    }
+    float* mrow = M + ((size_t)(rb * 8 + 2 * r4 + hi) * CB + cb) * (36 * 128) + (size_t)scomp * 128 + l31;
+    st_wt(mrow, sacc.x);
+    st_wt(mrow + 32, sacc.y);
+    st_wt(mrow + 64, sacc.z);
+    st_wt(mrow + 96, sacc.w);
+  }
+}
+
 #ifdef NODE_DIAG   // measured-and-rejected variants: built into libnode_hip_diag.so only (build.py --diag)
 // ----------------------------------------------------------------------------
 // k_w4_gemm64l (NODE_TUNE_W4_LDS, C = 256, N % 32 == 0): k_w4_gemm64b's products with the own component's operands brought into
@@ -1498,17 +1580,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
 // The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
 // kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half; };
 static W4Switches w4_read_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   // NODE_TUNE_W4_GEMM128 / _WGRAD128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512)
 #ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
           rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0),
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0)};
 #else
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0)};
 #endif
 }
 // The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
@@ -1609,6 +1691,10 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         return;
       }
 #endif
+      if (sw.half != 0 && C == 256 && sw.sharev == 1) {    // NODE_TUNE_W4_HALF: half-height tiles, two waves per SIMD (bit-identical)
+        hipLaunchKernelGGL(k_w4_gemm32b, dim3((N / 8) * 4 * 8), dim3(256), 4 * 1024 * sizeof(float), s, V, Ub, M, ctrl, gm);
+        return;
+      }
       hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }
