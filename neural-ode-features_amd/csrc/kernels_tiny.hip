@@ -110,17 +110,6 @@ constexpr int TINY_MAXT = 4;     // pixel tiles per wave: images of up to 256 pi
 constexpr int TINY_MAXKS = 8;    // K slices per group
 constexpr int TINY_STAGE = 6;    // staging items per thread: (H + 2)(W + 2) CS / 8 <= 6 x 256
 
-// agent-scope (write-through / L1-bypassing) 16-byte accesses for the K-slice hand-off (the 4-byte __hip_atomic_* forms cost one
-// request per value: 128 dependent-looking loads per lane at KS = 8)
-__device__ __forceinline__ void tiny_st16_agent(float* p, const t_f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ t_f32x4 tiny_ld16_agent(const float* p) {
-  t_f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-
 // LDS: A [3 parts][PP][CS + 8] bf16 | red [16] floats.   NCH = CS / 32, TPW = pixel tiles per wave (ceil(MT / 4))
 template <int NCH, int TPW>
 __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
@@ -148,6 +137,39 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   for (int i = 0; i < RD; ++i) {
     const t_u32x4* wf = wq + (size_t)(i < S ? i : 0) * 3 * 64;
     rb[i][0] = wf[0]; rb[i][1] = wf[64]; rb[i][2] = wf[128];
+  }
+
+  // ---- everything the epilogue (and the fused next-stage combine) will read, requested NOW: the launch is a chain of dependent
+  // round trips (stage, products, hand-off, epilogue, combine: ~1 us each), and these operands depend on none of them
+  const bool chan_on = col < cpg;
+  const int c = g * cpg + (chan_on ? col : 0);
+  const float bs = a.bias[c], gm = a.gamma[c], bt = a.beta[c];
+  float tm[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+      tm[t][i] = (chan_on && p < HW) ? a.tmap[(size_t)p * C + c] : 0.f;
+    }
+  constexpr bool PRE = TPW <= 2;                 // (four tiles per wave: the registers go to the accumulators and the hand-off)
+  float py[PRE ? TPW : 1][4], pk[PRE ? 7 : 1][PRE ? TPW : 1][4];
+  float g1 = 0.f, b1 = 0.f;
+  if (a.nx_on) {
+    g1 = a.nx_gamma[c]; b1 = a.nx_beta[c];
+    if (PRE) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p = (wave + 4 * t) * 16 + 4 * kq + i;
+          const bool on = chan_on && p < HW;
+          const size_t idx = ((size_t)n * HW + (on ? p : 0)) * C + c;
+          py[t][i] = on ? a.nx.y[idx] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 7; ++j) pk[j][t][i] = (on && j < a.nx.nk && j != a.nx_self) ? a.nx.k[j][idx] : 0.f;
+        }
+    }
   }
 
   // ---- stage the activation slice: padded image x CS channels, split into bf16 triples once.  All of a thread's requests first
@@ -235,11 +257,16 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "k_tiny_conv_gn's fence-free hand-off is only valid on gfx950 (see k_theta_finalize)"
 #endif
-    // scratch layout [group][slice][tile][lane][4]: a lane's four values of a tile are one 16-byte access
+    // scratch layout [group][slice][tile][lane][4].  Agent-scope 4-byte stores / loads through the compiler's own atomics (it
+    // counts their waits; hand-written 16-byte `sc1` asm loads looked cheaper and were WRONG: nothing ties a later register
+    // use to the asm wait, the adds ran before the data had landed)
     const size_t per_slice = (size_t)(4 * TPW) * 64 * 4;
     float* mine = a.part + ((size_t)ng * KS + ks) * per_slice;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) tiny_st16_agent(mine + ((size_t)(wave + 4 * t) * 64 + lane) * 4, acc[t]);
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __hip_atomic_store(mine + ((size_t)(wave + 4 * t) * 64 + lane) * 4 + i, acc[t][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) red[12] = __hip_atomic_fetch_add(a.counter + ng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(KS - 1) ? 1.f : 0.f;
@@ -247,27 +274,27 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
     if (red[12] == 0.f) return;
     if (tid == 0) __hip_atomic_store(a.counter + ng, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch (stream order)
     const float* all = a.part + (size_t)ng * KS * per_slice;
-    t_f32x4 got[TINY_MAXKS][TPW];
-#pragma unroll
-    for (int k = 0; k < TINY_MAXKS; ++k)
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        got[k][t] = k < KS ? tiny_ld16_agent(all + (size_t)k * per_slice + ((size_t)(wave + 4 * t) * 64 + lane) * 4) : t_f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      t_f32x4 s4 = got[0][t];
+      float got[TINY_MAXKS][4];
 #pragma unroll
-      for (int k = 1; k < TINY_MAXKS; ++k) s4 += got[k][t];      // (slices past KS hold zeros)
-      acc[t] = s4;
+      for (int k = 0; k < TINY_MAXKS; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          got[k][i] = k < KS ? __hip_atomic_load(all + (size_t)k * per_slice + ((size_t)(wave + 4 * t) * 64 + lane) * 4 + i, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s1 = got[0][i];
+#pragma unroll
+        for (int k = 1; k < TINY_MAXKS; ++k) s1 += got[k][i];      // (slices past KS hold zeros)
+        acc[t][i] = s1;
+      }
     }
   }
 
   // ---- epilogue: + bias + t * tmap, GroupNorm over the group (cpg channels x HW pixels), affine, ReLU, store
-  const bool chan_on = col < cpg;
-  const int c = g * cpg + (chan_on ? col : 0);
   const float tnow = eval_time(a.et);
-  const float bs = a.bias[c];
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
@@ -275,7 +302,7 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int p = (wave + 4 * t) * 16 + 4 * kq + i;
       const bool on = chan_on && p < HW;
-      const float v = on ? acc[t][i] + bs + tnow * a.tmap[(size_t)p * C + c] : 0.f;
+      const float v = on ? acc[t][i] + bs + tnow * tm[t][i] : 0.f;
       acc[t][i] = v;
       sum += v;
     }
@@ -297,7 +324,6 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   if (lane == 0) red[4 + wave] = sq;
   __syncthreads();
   const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
-  const float gm = a.gamma[c], bt = a.beta[c];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -327,8 +353,15 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
       if (chan_on && p < HW) {
         const size_t idx = ((size_t)n * HW + p) * C + c;
         float sk = 0.f;
-        for (int j = 0; j < a.nx.nk; ++j) sk += cf[j] * (j == a.nx_self ? acc[t][i] : a.nx.k[j][idx]);
-        v = a.nx.y[idx] + sk;
+        if (PRE) {
+#pragma unroll
+          for (int j = 0; j < 7; ++j)
+            if (j < a.nx.nk) sk += cf[j] * (j == a.nx_self ? acc[t][i] : pk[j][PRE ? t : 0][i]);
+          v = py[PRE ? t : 0][i] + sk;
+        } else {
+          for (int j = 0; j < a.nx.nk; ++j) sk += cf[j] * (j == a.nx_self ? acc[t][i] : a.nx.k[j][idx]);
+          v = a.nx.y[idx] + sk;
+        }
         if (a.nx_y_out != nullptr) a.nx_y_out[idx] = v;
       }
       acc[t][i] = v;
@@ -351,7 +384,6 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   if (lane == 0) red[4 + wave] = sq1;
   __syncthreads();
   const float rstd1 = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * inv_m + a.eps);
-  const float g1 = a.nx_gamma[c], b1 = a.nx_beta[c];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll

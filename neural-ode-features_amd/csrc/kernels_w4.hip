@@ -856,6 +856,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 }
 
 
+#ifdef NODE_DIAG   // measured-and-rejected variants (DESIGN.md 4.2): built into libnode_hip_diag.so only (build.py --diag)
 // ----------------------------------------------------------------------------
 // k_w4_gemm32b (C = 256, NODE_TUNE_W4_HALF): k_w4_gemm64b's products with HALF-HEIGHT tiles and TWO waves per SIMD.
 // What the counters say about k_w4_gemm64b (profiles/r05_pmc_w4_limiter.txt): the matrix pipe is busy 45 % of a wave's life --
@@ -867,6 +868,10 @@ __global__ __launch_bounds__(256) void k_w4_gemm64b(const float* __restrict__ V,
 // filter blocks for half the rows (L1 -> L2 requests of the filter operand double: the texture path has the room).  The
 // shared component 32 + j / 2 is dealt in 32 x 32 blocks (one per workgroup, K range cut over the four waves as before).
 // Every output element is the same sum in the same order as in k_w4_gemm64b: bit-identical.
+// MEASURED AND REJECTED (round 5, profiles/r05_w4_half_ab.txt): 24.3 us against 21.1 us by HIP events in the cfg-2 bench loop
+// (24 300 vs 24 880 images/s, cfg 3 18 090 vs 18 560): the second wave's K loop does not hide the first one's prologue --
+// both waves of a SIMD share ONE matrix pipe, so two K loops side by side each run at half rate, and the filter operand's
+// requests double.  Diagnostics library only.
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_w4_gemm32b(const float* __restrict__ V, const unsigned short* __restrict__ Ub, float* __restrict__ M,
                                                        const Ctrl* ctrl, W4Geom gm) {
@@ -938,7 +943,6 @@ __global__ __launch_bounds__(256, 2) void k_w4_gemm32b(const float* __restrict__
   }
 }
 
-#ifdef NODE_DIAG   // measured-and-rejected variants (DESIGN.md 4.2): built into libnode_hip_diag.so only (build.py --diag)
 // ----------------------------------------------------------------------------
 // k_w4_gemm64l (NODE_TUNE_W4_LDS, C = 256, N % 32 == 0): k_w4_gemm64b's products with the own component's operands brought into
 // the CU ONCE.  What bounds k_w4_gemm64b is the bytes its waves load into registers (every operand block aliased onto one
@@ -1590,7 +1594,7 @@ static W4Switches w4_read_switches() {
           rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0)};
 #else
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0};
 #endif
 }
 // The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
@@ -1691,10 +1695,12 @@ void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, 
         return;
       }
 #endif
+#ifdef NODE_DIAG
       if (sw.half != 0 && C == 256 && sw.sharev == 1) {    // NODE_TUNE_W4_HALF: half-height tiles, two waves per SIMD (bit-identical)
         hipLaunchKernelGGL(k_w4_gemm32b, dim3((N / 8) * 4 * 8), dim3(256), 4 * 1024 * sizeof(float), s, V, Ub, M, ctrl, gm);
         return;
       }
+#endif
       hipLaunchKernelGGL(k_w4_gemm64b<0>, dim3(grid64), dim3(256), lds64, s, V, Ub, M, ctrl, gm, mode, stamps);
       return;
     }

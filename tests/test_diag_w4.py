@@ -2,7 +2,7 @@
 `NODE_HIP_DIAG=1 python -m pytest tests/test_diag_w4.py -m diag`): the measured-and-rejected variants of the component GEMM
 that ship in libnode_hip_diag.so, NOT in the product library -- the place of the shared component's requests
 (NODE_TUNE_W4_EARLY), the LDS-DMA ring k_w4_gemm64l (NODE_TUNE_W4_LDS), the K-halves kernel k_w4_gemm64k
-(NODE_TUNE_W4_KSPLIT).  Not part of `-m gpu`: the product's tests never load the diagnostics library."""
+(NODE_TUNE_W4_KSPLIT), the half-height two-waves-per-SIMD kernel k_w4_gemm32b (NODE_TUNE_W4_HALF, round 5).  Not part of `-m gpu`: the product's tests never load the diagnostics library."""
 import ctypes as C
 import os
 
@@ -36,7 +36,7 @@ def _conv_w4(x, w, dgrad):
     return y
 
 
-@pytest.mark.parametrize('switch', ['NODE_TUNE_W4_EARLY=1', 'NODE_TUNE_W4_LDS=1'])
+@pytest.mark.parametrize('switch', ['NODE_TUNE_W4_EARLY=1', 'NODE_TUNE_W4_LDS=1', 'NODE_TUNE_W4_HALF=1'])
 @pytest.mark.parametrize('shape', [(128, 256, 8, 8), (32, 256, 8, 8), (8, 256, 16, 16)])
 def test_w4_gemm_work_assignments_are_bit_identical(shape, switch):
     """k_w4_gemm64b's alternative assignments of a component's tiles to waves (NODE_TUNE_W4_SHAREV 0 / 1 / 2), the place of the

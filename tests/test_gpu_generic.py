@@ -36,7 +36,7 @@ def _grads_close(hip, ref, bound):
 def _both(func, y, tpts, tol, method='dopri5', adjoint=True, weight_seed=7):
     """(HIP-side result, oracle result): outputs, grad_y0, parameter gradients, nfe after forward / backward."""
     import neural_ode_features_amd as nof
-    twin = copy.deepcopy(func)
+    twin = copy.deepcopy(func).cpu()
     f = func.cuda()
     t = torch.tensor(tpts)
     wgt = torch.randn((len(tpts),) + tuple(y.shape), generator=torch.Generator().manual_seed(weight_seed)) / y[0].numel() ** 0.5

@@ -44,12 +44,11 @@ def _conv_w4(x, w, dgrad):
     return y
 
 
-@pytest.mark.parametrize('switch', ['NODE_TUNE_W4_SHAREV=0', 'NODE_TUNE_W4_SHAREV=2', 'NODE_TUNE_W4_HALF=1', 'NODE_TUNE_W4_HALF=0'])
+@pytest.mark.parametrize('switch', ['NODE_TUNE_W4_SHAREV=0', 'NODE_TUNE_W4_SHAREV=2'])
 @pytest.mark.parametrize('shape', [(128, 256, 8, 8), (8, 256, 16, 16)])
 def test_w4_gemm_work_assignments_are_bit_identical(shape, switch):
-    """k_w4_gemm64b's alternative assignments of a component's tiles to waves (NODE_TUNE_W4_SHAREV 0 / 1 / 2) and the half-height,
-    two-waves-per-SIMD form k_w4_gemm32b (NODE_TUNE_W4_HALF) multiply the same operands in the same order per output element: the
-    convolution is bit-identical.  (The measured-and-rejected variants --
+    """k_w4_gemm64b's alternative assignments of a component's tiles to waves (NODE_TUNE_W4_SHAREV 0 / 1 / 2) multiply the same
+    operands in the same order per output element: the convolution is bit-identical.  (The measured-and-rejected variants --
     NODE_TUNE_W4_EARLY, the LDS-DMA ring k_w4_gemm64l, the K-halves kernel k_w4_gemm64k -- live in libnode_hip_diag.so and are
     swept by tests/test_diag_w4.py under `-m diag`.)"""
     N, Cc, H, W = shape

@@ -62,6 +62,29 @@ def test_host_only_entry_points():
         assert len(lib.node_last_error()) > 0
 
 
+def test_new_entry_points_check_their_arguments_without_a_gpu():
+    """ABI 4: the head's Linear + loss launches and the generic (flat) solver refuse NULL / inconsistent arguments with a
+    message before any HIP call; the diagnostics library is a separate file the product binding never loads by itself."""
+    from neural_ode_features_amd import _lib
+    lib = _lib.load()
+    assert lib.node_head_loss_scratch_bytes(128) > 0 and lib.node_head_loss_scratch_bytes(0) == 0
+    assert lib.node_head_loss_fwd(None, None) == -1
+    h = _lib.NodeHeadLoss(128, 256, 10, 0, None, None, None, None, None, None, None, None)
+    assert lib.node_head_loss_fwd(C.byref(h), None) == -1 and b'logits' in lib.node_last_error()
+    h = _lib.NodeHeadLoss(128, 256, 4096, 0, None, None, None, None, 256, None, None, None)
+    assert lib.node_head_loss_fwd(C.byref(h), None) == -3                       # more than 1024 classes
+    h = _lib.NodeHeadLoss(128, 256, 10, 0, None, None, None, None, 256, None, None, None)
+    assert lib.node_head_loss_fwd(C.byref(h), None) == -9                       # neither pooled nor target: nothing to do
+    assert lib.node_head_loss_bwd(C.byref(h), None, None) == -1
+    assert lib.node_flat_workspace_bytes(1) > 0 and lib.node_flat_workspace_bytes(50) > lib.node_flat_workspace_bytes(1)
+    f = _lib.NodeFlatSolve()
+    f.nseg, f.n_targets = 0, 1
+    assert lib.node_flat_finish_step(C.byref(f), 0, None, None) == -9 and b'nseg' in lib.node_last_error()
+    f.nseg = 1
+    assert lib.node_flat_finish_step(C.byref(f), 0, None, None) == -9 and b'workspace' in lib.node_last_error()
+    assert os.path.basename(_lib.LIB_PATH) == 'libnode_hip.so' and os.path.basename(_lib.LIB_DIAG_PATH) == 'libnode_hip_diag.so'
+
+
 def test_error_paths_of_the_c_abi_without_a_gpu():
     """NULL / misaligned / undersized arguments are rejected before any HIP call."""
     from neural_ode_features_amd import _lib
@@ -212,6 +235,12 @@ def test_header_is_plain_c_and_ctypes_layouts_match(tmp_path):
         'node_step_record': (_lib.NodeStepRecord, ['done', 'status', 'steps', 'accepted', 'rejected', 'miss', 't', 'dt', 'first_dt']),
         'node_sgd_tensor': (_lib.NodeSgdTensor, ['param', 'grad', 'momentum_buf', 'n']),
         'node_profile': (_lib.NodeProfile, ['launches', 'total_ms', 'flops']),
+        'node_head_loss': (_lib.NodeHeadLoss, ['n', 'c', 'classes', 'reduction', 'pooled', 'weight', 'bias', 'target', 'logits', 'loss',
+                                               'stat', 'scratch']),
+        'node_head_loss_grad': (_lib.NodeHeadLossGrad, ['grad_loss', 'grad_logits', 'd_logits', 'd_pooled', 'd_weight', 'd_bias']),
+        'node_flat_seg': (_lib.NodeFlatSeg, ['y', 'y1', 'k', 'n']),
+        'node_flat_solve': (_lib.NodeFlatSolve, ['nseg', 'has_scalar', 'seg', 'rtol', 'atol', 'tsign', 'n_targets', 'ws', 'ws_bytes']),
+        'node_flat_status': (_lib.NodeFlatStatus, ['done', 'status', 'steps', 'accepted', 'rejected', 't', 'dt', 'first_dt', 'scalar']),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "node_hip.h"', 'int main(void) {']
     for name, (_, fields) in structs.items():
@@ -272,3 +301,23 @@ def test_asm_load_guard_flags_a_register_touched_in_flight(tmp_path):
     assert stream(other + '\ts_waitcnt vmcnt(0)\n') == []
     assert len(stream(other + '\tv_mov_b32 v1, v8\n')) == 2
     assert len(stream('\tv_mov_b32 v1, v8\n')) == 2         # no load at all: the kernel changed under the guard
+
+
+def test_loss_helpers_route_cpu_tensors_to_pytorch():
+    """`nof.linear` / `nof.cross_entropy` / `nof.linear_cross_entropy` are drop-ins for F.linear / F.cross_entropy: CPU tensors
+    (the CPU baseline of bench.py, the gloo tests) take PyTorch's operators, values and gradients unchanged."""
+    import torch.nn.functional as F
+    import neural_ode_features_amd as nof
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 16, generator=gen, requires_grad=True)
+    w = torch.randn(10, 16, generator=gen, requires_grad=True)
+    b = torch.randn(10, generator=gen, requires_grad=True)
+    y = torch.randint(0, 10, (5,), generator=gen)
+    p = nof.linear(x, w, b)
+    assert torch.equal(p, F.linear(x, w, b))
+    loss = nof.cross_entropy(p, y)
+    assert torch.equal(loss, F.cross_entropy(F.linear(x, w, b), y)) and not hasattr(loss, 'node_stat')
+    loss2, logits = nof.linear_cross_entropy(x, w, b, y, reduction='sum')
+    assert torch.equal(loss2, F.cross_entropy(F.linear(x, w, b), y, reduction='sum')) and torch.equal(logits, p)
+    loss.backward()
+    assert x.grad is not None and w.grad is not None and b.grad is not None
