@@ -20,6 +20,7 @@
 //     read nine times (taps) as ready MFMA fragments; the filter fragments stream from L2 in fragment order.
 // Forward only (inference solves); any N small enough that the grid stays under a few hundred workgroups.
 #include "node_internal.h"
+#include <cstdlib>
 
 namespace node {
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
   // ---- filter fragments of the first ring turn: requested before anything else (they depend on nothing in LDS)
   const int col = lane & 15, kq = lane >> 4;
   const t_u32x4* wq = reinterpret_cast<const t_u32x4*>(a.wq) + (size_t)(g * KS + ks) * S * 3 * 64 + lane;
-  constexpr int RD = 4;
+  constexpr int RD = TPW <= 2 ? 8 : 4;      // K steps of filter fragments in flight (one step is ~100 MFMA cycles at one tile per wave: L2 latency is 3 - 5 of them)
   t_u32x4 rb[RD][3];
 #pragma unroll
   for (int i = 0; i < RD; ++i) {
@@ -400,6 +401,12 @@ __global__ __launch_bounds__(256) void k_tiny_conv_gn(const TinyArgs a) {
 // Returns CS (input channels per workgroup) or 0.
 int tiny_slice_channels(const Dims& d) {
   if (d.C % 32 != 0 || d.cpg > 16 || d.HW > 16 * 4 * TINY_MAXT || d.W > 64) return 0;
+  // measured (profiles/r05_latency_bs1.txt): images of up to 64 pixels win a little (36.7 -> 33.8 us per evaluation at [1,256,8,8]);
+  // at 16x16 the eight-slice hand-off and four tiles per wave lose to the F(4x4,3x3) path (72 vs 39 us), so those keep it
+  // unless NODE_TUNE_TINY=1 forces the latency kernels (tests)
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("NODE_TUNE_TINY"); force = e ? atoi(e) : -1; }
+  if (force != 1 && d.HW > 64) return 0;
   int CS = (d.HW <= 100 && d.C % 64 == 0) ? 64 : 32;
   if (d.C / CS > TINY_MAXKS) CS = 64;
   if (d.C % CS != 0 || d.C / CS > TINY_MAXKS) return 0;

@@ -44,6 +44,8 @@ def _both(func, y, tpts, tol, method='dopri5', adjoint=True, weight_seed=7):
     for mod, dev, solve in ((f, 'cuda', nof.odeint_adjoint if adjoint else nof.odeint), (twin, 'cpu', tdq.odeint_adjoint)):
         if hasattr(mod, 'nfe'):
             mod.nfe = 0
+        for prm in mod.parameters():
+            prm.grad = None
         y0 = y.detach().clone().to(dev).requires_grad_(True)
         out = solve(mod, y0, t.to(dev), rtol=tol, atol=tol, method=method)
         nfe_f = getattr(mod, 'nfe', None)
