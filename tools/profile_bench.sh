@@ -13,8 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline "$@" > $D.log 2>&1 || { tail -20 $D.log; exit 1; }
 cd $R
 grep '"metric"' $D.log > ${OUT}_bench.json || true
-KS=$(find $D -name '*kernel_stats.csv' | head -1)
-KT=$(find $D -name '*kernel_trace.csv' | head -1)
+# (bench.py starts child processes -- the held-clock measurement on the diagnostics library -- and rocprofv3 writes one set of files per
+#  process: the bench's own is the largest)
+KS=$(ls -S $(find $D -name '*kernel_stats.csv') | head -1)
+KT=$(ls -S $(find $D -name '*kernel_trace.csv') | head -1)
 cp $KS ${OUT}_kernel_stats.csv
 # bench runs WARM + settle_steps + STEPS (x timed_region, if a region was measured again) + 2 + STEPS (drop-in region) + 1 + min(STEPS,5) roofline-repeat steps
 REGION=$(python3 -c "import json,sys; print(json.loads(open('${OUT}_bench.json').read().strip().splitlines()[-1])['config'].get('timed_region', 1))")
