@@ -145,6 +145,8 @@ def load():
     if _lib is not None:
         return _lib
     path = LIB_DIAG_PATH if os.environ.get('NODE_HIP_DIAG', '0') not in ('', '0') else LIB_PATH
+    if os.environ.get('NODE_HIP_LIB_AB'):          # tools: A/B of two builds of the library on one box (tools/ab_lib.sh)
+        path = os.environ['NODE_HIP_LIB_AB']
     if not os.path.exists(path):
         raise RuntimeError(
             '%s is not built (%s). Run `python neural-ode-features_amd/build.py%s` '

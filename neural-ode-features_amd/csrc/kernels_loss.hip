@@ -192,29 +192,36 @@ struct LossBwdArgs {
   int NS;                    // samples per LDS chunk
 };
 
-// dl[n][o] of samples [n0, n0 + ns) into LDS (row stride O): one wave per sample at a time
+// dl[n][o] of samples [n0, n0 + ns) into LDS (row stride O).  The chunk's logits (or the given gradient) come in as ONE coalesced
+// copy -- a wave that fetched its samples' rows one after the other paid an L2 round trip per sample (35 us per launch at 128
+// samples: the profile of the first version) -- then every wave turns its rows into gradients in place.
 __device__ __forceinline__ void loss_dl_chunk(const LossBwdArgs& a, float* dl, int n0, int ns, float scale, int write_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, O = a.O;
-  for (int i = wave; i < ns; i += 4) {
-    const int n = n0 + i;
-    const float* lr = a.logits + (size_t)n * O;
-    float* out = dl + (size_t)i * O;
-    if (a.grad_logits != nullptr) {
-      for (int o = lane; o < O; o += 64) out[o] = a.grad_logits[(size_t)n * O + o];
-      continue;
-    }
+  const float* src = (a.grad_logits != nullptr ? a.grad_logits : a.logits) + (size_t)n0 * O;
+  for (int idx = threadIdx.x; idx < ns * O; idx += 256) dl[idx] = src[idx];
+  __syncthreads();
+  if (a.grad_logits != nullptr) return;
+  // this wave's targets (samples wave, wave + 4, ...: <= 128 of them, NS <= 512), one or two per lane, fetched once
+  int tg[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int i = wave + 4 * (lane + 64 * h);
+    tg[h] = i < ns ? (int)a.target[n0 + i] : -1;
+  }
+  for (int i = wave, k = 0; i < ns; i += 4, ++k) {
+    float* row = dl + (size_t)i * O;
     float m = -INFINITY;
-    for (int o = lane; o < O; o += 64) m = fmaxf(m, lr[o]);
+    for (int o = lane; o < O; o += 64) m = fmaxf(m, row[o]);
     m = wave_max(m);
     float se = 0.f;
-    for (int o = lane; o < O; o += 64) se += expf(lr[o] - m);
+    for (int o = lane; o < O; o += 64) se += expf(row[o] - m);
     se = wave_add(se);
     const float inv = 1.f / se;
-    const long long t = a.target[n];
+    const int t = __shfl(k < 64 ? tg[0] : tg[1], k & 63);
     for (int o = lane; o < O; o += 64) {
-      const float v = scale * (expf(lr[o] - m) * inv - (o == t ? 1.f : 0.f));
-      out[o] = v;
-      if (write_out && a.d_logits != nullptr) a.d_logits[(size_t)n * O + o] = v;
+      const float v = scale * (expf(row[o] - m) * inv - (o == t ? 1.f : 0.f));
+      row[o] = v;
+      if (write_out && a.d_logits != nullptr) a.d_logits[(size_t)(n0 + i) * O + o] = v;
     }
   }
 }
