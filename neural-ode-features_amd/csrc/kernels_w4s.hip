@@ -154,7 +154,10 @@ typedef float w4s_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void w4s_st16_wt(float* p, float a, float b, float c, float d) {
 #if NODE_WT_STORES
   const w4s_f4 v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");      // write-through like w4s_st_wt
+  // write-through like w4s_st_wt.  The s_nop is REQUIRED: a VMEM store of more than 64 bits must be followed by a wait state before a
+  // VALU instruction may overwrite its data registers; the compiler's hazard recogniser does that for its own stores but does not
+  // know an asm statement is one (the first cut of this, without it, stored garbage: the next transpose reused the registers)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 #endif

@@ -279,7 +279,9 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, reduction: str = '
     target = target.contiguous()
     src = getattr(logits, _LINEAR_ATTR, None) if torch.is_grad_enabled() else None
     if src is not None:
-        loss, stat, _ = _LinearCrossEntropy.apply(src[0], src[1], src[2], target, _REDUCTIONS[reduction], logits)
+        # (the logits go in DETACHED: as an autograd input of the fused node they would pull `linear`'s own backward into the graph --
+        #  called with a materialised zero gradient: a second, useless launch per step, seen in profiles/r05_cfg2_steps.txt's first cut)
+        loss, stat, _ = _LinearCrossEntropy.apply(src[0], src[1], src[2], target, _REDUCTIONS[reduction], logits.detach())
     else:
         loss, stat = _CrossEntropy.apply(logits, target, _REDUCTIONS[reduction])
     loss.node_stat = stat

@@ -266,5 +266,6 @@ def test_training_step_runs_no_foreign_kernel_in_the_head():
     names = [e.key for e in prof.key_averages()]
     bad = [k for k in names if any(s in k.lower() for s in ('addmm', 'aten::mm', 'log_softmax', 'nll_loss', 'aten::linear', 'cross_entropy_loss'))]
     assert not bad, bad
+    assert not any('_LinearBackward' in k for k in names), names        # the loss node carries the Linear layer: ONE backward launch
     for name, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
