@@ -125,61 +125,6 @@ __device__ __forceinline__ void w4s_gsum2(float& a, float& b, int cpg, W4Wave<Q>
   }
 }
 
-
-// ---- 16-byte forms of the component loads / stores (W4S_VEC).  A lane's element of a component sits next to those of the three other
-// channels of its quad (lanes 4 k .. 4 k + 3: channels c15 & ~3 .. + 3 of one tile) both in M ([4 t][32 c] per component) and in V
-// (... [t][4 e] per 8-channel block): four components of a quad are a 4 x 4 block that one 16-byte access per lane moves, with a
-// 4 x 4 transpose between the lanes of the quad (two butterfly stages, DPP quad_perm) in front of / behind it -- 9 instead of 36
-// vector-memory instructions per thread for 144 more VALU ones.
-#ifndef W4S_VEC
-#define W4S_VEC 1
-#endif
-// x[k] of lane e  <->  x[e] of lane k, within each quad of lanes
-__device__ __forceinline__ void w4s_quad_transpose(float& x0, float& x1, float& x2, float& x3) {
-  const int e = threadIdx.x & 3;
-  {
-    const bool odd = (e & 1) != 0;
-    const float s01 = odd ? x0 : x1, s23 = odd ? x2 : x3;
-    const float r01 = w4s_dpp<0xB1>(s01), r23 = w4s_dpp<0xB1>(s23);      // quad_perm [1,0,3,2]: lane ^ 1
-    if (odd) { x0 = r01; x2 = r23; } else { x1 = r01; x3 = r23; }
-  }
-  {
-    const bool up = (e & 2) != 0;
-    const float s02 = up ? x0 : x2, s13 = up ? x1 : x3;
-    const float r02 = w4s_dpp<0x4E>(s02), r13 = w4s_dpp<0x4E>(s13);      // quad_perm [2,3,0,1]: lane ^ 2
-    if (up) { x0 = r02; x1 = r13; } else { x2 = r02; x3 = r13; }
-  }
-}
-typedef float w4s_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void w4s_st16_wt(float* p, float a, float b, float c, float d) {
-#if NODE_WT_STORES
-  const w4s_f4 v = {a, b, c, d};
-  // write-through like w4s_st_wt.  The s_nop is REQUIRED: a VMEM store of more than 64 bits must be followed by a wait state before a
-  // VALU instruction may overwrite its data registers; the compiler's hazard recogniser does that for its own stores but does not
-  // know an asm statement is one (the first cut of this, without it, stored garbage: the next transpose reused the registers)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-#else
-  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-#endif
-}
-// 36 components of a thread (vals[comp]) -> memory: component `comp` of this lane at `p0 + comp * cstride`, the lane's quad
-// contiguous there (p0 of lane e = quad base + e)
-__device__ __forceinline__ void w4s_store36(const float (&vals)[36], float* __restrict__ p0, size_t cstride) {
-#if W4S_VEC
-  const int e = threadIdx.x & 3;
-  float* qb = p0 - e;
-#pragma unroll
-  for (int m = 0; m < 9; ++m) {
-    float x0 = vals[4 * m], x1 = vals[4 * m + 1], x2 = vals[4 * m + 2], x3 = vals[4 * m + 3];
-    w4s_quad_transpose(x0, x1, x2, x3);
-    w4s_st16_wt(qb + (size_t)(4 * m + e) * cstride, x0, x1, x2, x3);
-  }
-#else
-#pragma unroll
-  for (int q = 0; q < 36; ++q) w4s_st_wt(p0 + (size_t)q * cstride, vals[q]);
-#endif
-}
-
 // A^T x for the points (0, 1, -1, 1/2, -2, inf)   (W4_AT)
 __device__ __forceinline__ void w4s_at6(float m0, float m1, float m2, float m3, float m4, float m5, float& o0, float& o1,
                                         float& o2, float& o3) {
@@ -204,22 +149,8 @@ __device__ __forceinline__ void w4s_bt6(float d0, float d1, float d2, float d3, 
 // Y = A^T M A of the thread's (tile, channel): `mp` points at its element of component 0, components 128 floats apart
 __device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, float y[4][4]) {
   float m[36];
-#if W4S_VEC
-  {
-    const int e = threadIdx.x & 3;
-    const float* qb = mp - e;
-#pragma unroll
-    for (int g4 = 0; g4 < 9; ++g4) {
-      const float4 v = *reinterpret_cast<const float4*>(qb + (4 * g4 + e) * 128);     // component 4 g4 + e, the quad's four channels
-      float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      w4s_quad_transpose(x0, x1, x2, x3);
-      m[4 * g4] = x0; m[4 * g4 + 1] = x1; m[4 * g4 + 2] = x2; m[4 * g4 + 3] = x3;
-    }
-  }
-#else
 #pragma unroll
   for (int q = 0; q < 36; ++q) m[q] = mp[q * 128];
-#endif
   float z[4][6];
 #pragma unroll
   for (int nu = 0; nu < 6; ++nu)
@@ -228,18 +159,30 @@ __device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, 
   for (int i = 0; i < 4; ++i) w4s_at6(z[i][0], z[i][1], z[i][2], z[i][3], z[i][4], z[i][5], y[i][0], y[i][1], y[i][2], y[i][3]);
 }
 
+// (Measured and rejected, round 5 -- review item 3, "16-byte stores for V": the 36 component loads of M and the 36 component stores of
+//  V as NINE 16-byte accesses per lane, a 4 x 4 transpose between the four lanes of a quad (two DPP butterfly stages) behind / in front
+//  of each -- same bytes, a quarter of the vector-memory instructions, +288 VALU per thread; parity green, passes 1.58 -> 1.63 ms
+//  per step, 24 390 -> 24 240 images/s (profiles/r05_pass_vec_ab.txt, commits 69ea3c6 + 5b5dc33).  The counters of the same
+//  profile say why nothing was to win there: the texture path is 25 % busy, the waves wait 48 % of their life -- the launch is one
+//  generation of waves (2 048 of 8 192 slots) that all load, then all compute, then all store; per launch it moves its bytes at
+//  ~90 % of what a streaming copy of the same size reaches once the ~1.5 us of launch ramp are taken out.)
 // V = B^T d B of the 6x6 patch d (the thread's tile + one pixel ring) -> the blocked row operand of the component GEMMs.
 // `vp`: the thread's element of component 0; components `cstride` apart.
 __device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restrict__ vp, size_t cstride) {
   float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
 #pragma unroll
   for (int j = 0; j < 6; ++j) w4s_bt6(d[j][0], d[j][1], d[j][2], d[j][3], d[j][4], d[j][5], w[j][0], w[j][1], w[j][2], w[j][3], w[j][4], w[j][5]);
-  float vals[36];
 #pragma unroll
-  for (int l = 0; l < 6; ++l)      // V[xi][l] = sum_j B^T[xi][j] w[j][l]   (component xi * 6 + l)
-    w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], vals[0 * 6 + l], vals[1 * 6 + l], vals[2 * 6 + l], vals[3 * 6 + l],
-            vals[4 * 6 + l], vals[5 * 6 + l]);
-  w4s_store36(vals, vp, cstride);
+  for (int l = 0; l < 6; ++l) {
+    float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
+    w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
+    w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
+    w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
+    w4s_st_wt(vp + (size_t)(2 * 6 + l) * cstride, v2);
+    w4s_st_wt(vp + (size_t)(3 * 6 + l) * cstride, v3);
+    w4s_st_wt(vp + (size_t)(4 * 6 + l) * cstride, v4);
+    w4s_st_wt(vp + (size_t)(5 * 6 + l) * cstride, v5);
+  }
 }
 // 8x8 image: the ring is nine values held by the three other tiles' lanes of the same wave (zero outside the image)
 __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, float* __restrict__ vp, size_t cstride) {
