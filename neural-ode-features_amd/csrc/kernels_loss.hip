@@ -201,7 +201,27 @@ __device__ __forceinline__ void loss_dl_chunk(const LossBwdArgs& a, float* dl, i
   for (int idx = threadIdx.x; idx < ns * O; idx += 256) dl[idx] = src[idx];
   __syncthreads();
   if (a.grad_logits != nullptr) return;
-  // this wave's targets (samples wave, wave + 4, ...: <= 128 of them, NS <= 512), one or two per lane, fetched once
+  if (O <= 64) {
+    // few classes: ONE LANE per sample walks its row in LDS (no cross-lane reduction at all; the wave-per-sample form below spends
+    // its time in twelve dependent ds_bpermute hops per sample: 40 us per launch at 128 samples x 10 classes)
+    for (int i = threadIdx.x; i < ns; i += 256) {
+      float* row = dl + (size_t)i * O;
+      float m = -INFINITY;
+      for (int o = 0; o < O; ++o) m = fmaxf(m, row[o]);
+      float se = 0.f;
+      for (int o = 0; o < O; ++o) se += expf(row[o] - m);
+      const float inv = 1.f / se;
+      const int t = (int)a.target[n0 + i];
+      for (int o = 0; o < O; ++o) {
+        const float v = scale * (expf(row[o] - m) * inv - (o == t ? 1.f : 0.f));
+        row[o] = v;
+        if (write_out && a.d_logits != nullptr) a.d_logits[(size_t)(n0 + i) * O + o] = v;
+      }
+    }
+    return;
+  }
+  // many classes: a wave per sample, the classes over its lanes; the wave's targets (samples wave, wave + 4, ...: <= 128 of
+  // them, NS <= 512), one or two per lane, fetched once
   int tg[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {

@@ -56,7 +56,7 @@ def _both(func, y, tpts, tol, method='dopri5', adjoint=True, weight_seed=7):
     return res
 
 
-@pytest.mark.parametrize('tol,tpts', [(1e-3, (0.0, 1.0)), (1e-3, (0.0, 0.3, 0.55, 1.0)), (1e-5, (0.0, 1.0))])
+@pytest.mark.parametrize('tol,tpts', [(1e-3, (0.0, 1.0)), (1e-3, (0.0, 0.3, 0.55, 1.0)), (1e-4, (0.0, 1.0))])
 def test_batchnorm_dynamics_through_odeint_adjoint(tol, tpts):
     """The reference's `ODEfunc(dim, norm='batch')` (model.py:274, train.py:202): BatchNorm couples the samples, so no fused
     kernel takes it -- the solve runs the generic path and agrees with the oracle."""

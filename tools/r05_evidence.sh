@@ -1,5 +1,5 @@
 #!/bin/bash
-# final state: whole suite with durations, bench lines cfg 2 / 3 / 5, step profiles, latency
+# round-5 evidence run (what profiles/r05_bench_cfg*.json, r05_cfg*_steps.txt come from): whole suite with durations, bench lines cfg 2 / 3 / 5, step profiles, latency
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05final
 mkdir -p $O gpurun_out/evidence

@@ -1,7 +1,8 @@
 #!/bin/bash
-# A/B of the half-height two-waves-per-SIMD component GEMM (NODE_TUNE_W4_HALF) on the cfg-2 / cfg-3 bench loops + its bit-identity test
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05d
+# (diagnostics library: export NODE_HIP_DIAG=1 first) A/B of the half-height two-waves-per-SIMD component GEMM (NODE_TUNE_W4_HALF) on the cfg-2 / cfg-3 bench loops + its bit-identity test
+cd ${GRAFT_REPO_ROOT:-.}
+export NODE_HIP_DIAG=1     # k_w4_gemm32b lives in libnode_hip_diag.so (build.py --diag)
+O=gpurun_out/w4_half
 mkdir -p $O
 timeout 600 python -m pytest "tests/test_gpu_w4.py::test_w4_gemm_work_assignments_are_bit_identical" tests/test_gpu_parity.py -q -m gpu > $O/tests.log 2>&1; tail -3 $O/tests.log
 for half in 1 0 1 0; do
