@@ -77,14 +77,14 @@ def test_full_size_adjoint_solve_kink_free(tol):
 @pytest.mark.parametrize('tol', [1e-5])
 def test_full_size_free_running_pipeline_vs_oracle_ordinary_parameters(tol):
     """The F(4x4,3x3) pipeline (what a tol >= 1e-5 solve of this shape runs) FREE-RUNNING against the free-running fp32
-    oracle at the full cfg-3 state [128,256,8,8], tol 1e-5, ORDINARY parameters -- no replay, no step sizes borrowed from
+    oracle at the cfg-3 state shape, half its batch ([64,256,8,8]: the CPU oracle's time), tol 1e-5, ORDINARY parameters -- no replay, no step sizes borrowed from
     the run being judged, no other conv path of this package in the comparison.  The advisor's round-3 concern: the
     pipeline's convolution noise (3.2e-6 of max|y|) is the order of the tolerance, and the step controller does not see
     it -- so the accept / reject history itself is the observable: it must equal the oracle's, or differ by one decision
     (which moves both trajectories by O(tol)).  Output within 10 x atol either way; gradients in the robust statistics
     of tests/helpers.py (ReLU masks of pre-activations within rounding of zero differ between any two fp32
     implementations at this size), tight only when the histories are identical."""
-    r = _adjoint_both((128, 256, 8, 8), tol, seed=53, kink_free=False)
+    r = _adjoint_both((64, 256, 8, 8), tol, seed=53, kink_free=False)
     out_err = float((r['out_h'].cpu() - r['out_o']).abs().max())
     print('free-running pipeline vs oracle, tol %g: same history %s, |out - oracle|_max %.3e' % (tol, r['same'], out_err))
     assert out_err <= 10 * tol
@@ -579,16 +579,19 @@ def test_blind_step_enqueue_over_and_under_prediction():
     t = torch.tensor([0.0, 1.0])
     gen = torch.Generator().manual_seed(112)
     base = torch.randn(4, 32, 8, 8, generator=gen)
-    seen = set()
+    seen, oracle = set(), {}
     for scale in (0.05, 30.0, 0.05, 30.0, 30.0, 0.05):
         y = base * scale
-        yo = y.clone().requires_grad_(True)
-        fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
-        out_o = tdq.odeint_adjoint(twin, yo, t, rtol=1e-4, atol=1e-4, method='dopri5', fwd_stats=fs_o, bwd_stats=bs_o)
-        out_o[-1].square().sum().backward()
-        gp_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
-        for p in twin.parameters():
-            p.grad = None
+        if scale not in oracle:       # (the oracle is a pure function of the input: once per distinct input)
+            yo = y.clone().requires_grad_(True)
+            fs_o, bs_o = tdq.SolverStats(), tdq.SolverStats()
+            out_o = tdq.odeint_adjoint(twin, yo, t, rtol=1e-4, atol=1e-4, method='dopri5', fwd_stats=fs_o, bwd_stats=bs_o)
+            out_o[-1].square().sum().backward()
+            gp_o = torch.cat([p.grad.reshape(-1) for p in twin.parameters()])
+            for p in twin.parameters():
+                p.grad = None
+            oracle[scale] = (yo, fs_o, bs_o, out_o.detach(), gp_o)
+        yo, fs_o, bs_o, out_o, gp_o = oracle[scale]
         yh = y.cuda().requires_grad_(True)
         f.nfe = 0
         out_h = nof.odeint_adjoint(f, yh, t.cuda(), rtol=1e-4, atol=1e-4, method='dopri5')

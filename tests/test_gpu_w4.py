@@ -243,7 +243,7 @@ def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
     step counts within one accept / reject decision, output within 10 (atol + rtol |y|), kink-free gradients to 1e-3."""
     import neural_ode_features_amd as nof
     from oracle import torchdiffeq_restated as tdq
-    N, Cc = (16, 64) if side == 8 else (4, 128)     # (16x16 states: four 8x8 quadrants per image, kernels_w4s.hip)
+    N, Cc = (8, 64) if side == 8 else (2, 128)      # (16x16 states: four 8x8 quadrants per image, kernels_w4s.hip)
     assert _engaged(N, Cc, side)
     f, twin = make_func(Cc, seed=2, device='cuda', kink_free=True)
     with torch.no_grad():
@@ -293,7 +293,7 @@ def test_w4_solve_matches_f2_and_oracle_tolerance(tol, gain, side):
             assert rel_err(grads[mode][0], yo.grad) < 1e-3 and rel_err(grads[mode][1], gp_o) < 1e-3
 
 
-@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (2, 128, 16, 16), (3, 256, 16, 16)])
+@pytest.mark.parametrize('shape', [(8, 64, 8, 8), (2, 128, 16, 16), (2, 256, 16, 16)])
 def test_w4_dense_output_many_time_points(shape):
     """evaluate.py:56-94: features at many interior time points from ONE solve (dense output of the accepted steps), here
     through the pipeline's own emit kernel (W4S state -> NCHW slices; 16x16: the quadrant blocking) and with a gradient
@@ -305,8 +305,8 @@ def test_w4_dense_output_many_time_points(shape):
     f, twin = make_func(Cc, seed=4, device='cuda', kink_free=True)
     gen = torch.Generator().manual_seed(31)
     y0 = torch.randn(N, Cc, H, W, generator=gen)
-    t = torch.linspace(0.0, 1.0, 7)
-    wgt = torch.randn(7, N, Cc, H, W, generator=gen)
+    t = torch.linspace(0.0, 1.0, 5)
+    wgt = torch.randn(5, N, Cc, H, W, generator=gen)
     yo = y0.clone().requires_grad_(True)
     out_o = tdq.odeint_adjoint(twin, yo, t, rtol=1e-3, atol=1e-3, method='dopri5')
     (out_o * wgt).sum().backward()
@@ -318,7 +318,7 @@ def test_w4_dense_output_many_time_points(shape):
             (out * wgt.cuda()).sum().backward()
             outs.append(out.detach().cpu())
             gys.append(y.grad.detach().cpu())
-    assert outs[1].shape == (7, N, Cc, H, W)
+    assert outs[1].shape == (5, N, Cc, H, W)
     assert torch.equal(outs[1][0], y0)
     print(shape, 'dense output: vs oracle %.2e, vs F(2x2) %.2e; grad_y0 vs oracle %.2e'
           % (float((outs[1] - out_o.detach()).abs().max()), float((outs[1] - outs[0]).abs().max()), rel_err(gys[1], yo.grad)))
