@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define NODE_ABI_VERSION 4
+#define NODE_ABI_VERSION 5
 
 /* method -- the two solver names that reach model.py:367 on the graded configs
  * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
@@ -161,6 +161,10 @@ size_t node_param_count(const node_shape* shape);
 /* Bytes of caller-provided device workspace needed by the calls below.
  * adjoint != 0 sizes for node_solve_adjoint / node_odefunc_vjp. */
 size_t node_workspace_bytes(const node_shape* shape, int method, int adjoint, int n_t);
+
+/* 1 when a dopri5 forward solve of this shape runs as ONE resident launch on the current device (the bs = 1 census of
+ * evaluate.py:97-142: f0, the initial step, every step with its decision and dense output inside one kernel), else 0. */
+int node_solve_is_resident(const node_shape* shape);
 
 /* f = ODEfunc(t, y)                                     -- model.py:339-348 */
 int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t,

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
 # environment of their own process; nothing in the package does.
 LIB_DIAG_PATH = os.path.join(HERE, 'csrc', 'libnode_hip_diag.so')
 
-NODE_ABI_VERSION = 4
+NODE_ABI_VERSION = 5
 METHOD_DOPRI5, METHOD_RK4 = 0, 1
 METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
 
@@ -28,7 +28,7 @@ ERRORS = {
 }
 
 EXPORTS = [
-    'node_abi_version', 'node_last_error', 'node_param_count', 'node_workspace_bytes',
+    'node_abi_version', 'node_last_error', 'node_param_count', 'node_workspace_bytes', 'node_solve_is_resident',
     'node_odefunc_fwd', 'node_odefunc_vjp', 'node_solve_fwd', 'node_solve_adjoint',
     'node_backprop_workspace_bytes', 'node_solve_backprop',
     'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
@@ -163,6 +163,8 @@ def load():
     lib.node_param_count.argtypes = [P(NodeShape)]
     lib.node_workspace_bytes.restype = sz
     lib.node_workspace_bytes.argtypes = [P(NodeShape), i32, i32, i32]
+    lib.node_solve_is_resident.restype = i32
+    lib.node_solve_is_resident.argtypes = [P(NodeShape)]
     lib.node_odefunc_fwd.restype = i32
     lib.node_odefunc_fwd.argtypes = [P(NodeShape), P(NodeParams), f32, vp, vp, vp, sz, vp]
     lib.node_odefunc_vjp.restype = i32

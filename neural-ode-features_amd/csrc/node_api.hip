@@ -277,6 +277,9 @@ struct Plan {
   unsigned short* wtiny[2]; // latency path (kernels_tiny.hip): filters as column-padded bf16 triples in fragment order
   float* tpart;             //   K-slice partial sums
   unsigned* tcount;         //   arrival counters [N G]
+  float* tpartB;            // resident form (kernels_tiny_solve.hip): the second convolution's partial sums,
+  unsigned* tsync;          //   version flags / arrival counters (zeroed per solve),
+  float* terr;              //   the reducers' partial sums of a step decision
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
@@ -336,8 +339,14 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     for (int i = 0; i < 2; ++i) p.wsmall[i] = b.take<float>((size_t)9 * d.C * d.C);
   if (d.tiny && !adjoint) {
     for (int i = 0; i < 2; ++i) p.wtiny[i] = b.take<unsigned short>(tiny_packed_elems(d));
-    p.tpart = b.take<float>(tiny_part_elems(d));
+    const bool res = tiny_resident_ok(d);
+    p.tpart = b.take<float>(res ? std::max(tiny_part_elems(d), tiny_resident_part_elems(d)) : tiny_part_elems(d));
     p.tcount = b.take<unsigned>((size_t)d.N * d.G);
+    if (res) {
+      p.tpartB = b.take<float>(tiny_resident_part_elems(d));
+      p.tsync = b.take<unsigned>(tiny_resident_sync_words(d));
+      p.terr = b.take<float>(tiny_resident_err_elems(d));
+    }
   }
   if (d.wino4) {
     p.W4V = b.take<float>(w4_v_elems(d.N8, d.C));
@@ -468,6 +477,9 @@ struct Solver {
   }
   // latency path: forward solves of tiny batches run two fused direct-convolution launches per evaluation (kernels_tiny.hip)
   bool tiny_mode() const { return d.tiny != 0 && !aug && p.wtiny[0] != nullptr; }
+  // ... and a free-running or replayed dopri5 forward solve of a state the chip can hold resident is ONE launch (kernels_tiny_solve.hip)
+  bool resident = false;
+  void choose_resident(bool dopri5) { resident = dopri5 && tiny_mode() && !w4 && p.tsync != nullptr && tiny_resident_ok(d); }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
@@ -525,7 +537,11 @@ struct Solver {
       launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
       launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
     }
-    if (tiny_mode() && !w4) {
+    if (tiny_mode() && !w4 && resident) {     // (the whole solve is one launch: its own slicing of the filters, its flags zeroed below)
+      launch_tiny_pack_resident(d, prm.conv1_w, p.wtiny[0], st);
+      launch_tiny_pack_resident(d, prm.conv2_w, p.wtiny[1], st);
+      zr[nz] = reinterpret_cast<float*>(p.tsync); zn[nz++] = tiny_resident_sync_words(d);     // (0.f is the all-zero word)
+    } else if (tiny_mode() && !w4) {
       launch_tiny_pack(d, prm.conv1_w, p.wtiny[0], st);
       launch_tiny_pack(d, prm.conv2_w, p.wtiny[1], st);
       launch_fill(reinterpret_cast<float*>(p.tcount), 0.f, (size_t)d.N * d.G, st);     // (0.f is the all-zero word)
@@ -1115,6 +1131,12 @@ size_t node_workspace_bytes(const node_shape* shape, int /*method*/, int adjoint
   return p.bytes;
 }
 
+int node_solve_is_resident(const node_shape* shape) {
+  Dims d;
+  if (make_dims(shape, &d) != NODE_OK) return 0;
+  return d.tiny != 0 && tiny_resident_ok(d) ? 1 : 0;
+}
+
 int node_odefunc_fwd(const node_shape* shape, const node_params* params, float t, const float* y, float* f,
                      void* ws, size_t ws_bytes, void* stream) {
   w4_refresh_tuning();     // (the NODE_TUNE_W4_* switches: once per call, not per launch)
@@ -1232,8 +1254,9 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   const size_t numel = S.d.numel;
 
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
+  S.choose_resident(method == NODE_METHOD_DOPRI5);
   TRY(S.prepare());
-  S.to_state(y0, S.p.Y);
+  if (!S.resident) S.to_state(y0, S.p.Y);
   HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
 
   if (method == NODE_METHOD_RK4) {
@@ -1270,9 +1293,42 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
   }
   if (forced) TRY(S.upload(S.p.forced, opts->forced_dt, opts->n_forced_dt, hs->lists + n_t));
+  if (S.resident) {
+    // the whole solve -- f0, the initial step, every step with its decision, dense output -- is one launch; it needs as many steps
+    // as it needs (a deferred solve of this kind cannot miss), and the host reads the same record back
+    TinyResidentArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.y0 = y0; ra.y_out = io.y_out;
+    ra.wq[0] = S.p.wtiny[0]; ra.wq[1] = S.p.wtiny[1];
+    ra.bias[0] = params->conv1_b; ra.bias[1] = params->conv2_b;
+    ra.tmap[0] = S.p.tmap[0]; ra.tmap[1] = S.p.tmap[1];
+    ra.gamma[0] = params->norm1_w; ra.gamma[1] = params->norm2_w; ra.gamma[2] = params->norm3_w;
+    ra.beta[0] = params->norm1_b; ra.beta[1] = params->norm2_b; ra.beta[2] = params->norm3_b;
+    ra.act[0] = S.p.act1; ra.act[1] = S.p.act2;
+    ra.part[0] = S.p.tpart; ra.part[1] = S.p.tpartB;
+    ra.sync = S.p.tsync; ra.errpart = S.p.terr; ra.ctrl = S.p.ctrl;
+    ra.targets = S.p.targets; ra.n_targets = io.n_targets;
+    ra.forced = forced ? S.p.forced : nullptr; ra.n_forced = io.n_forced;
+    ra.dt_log = io.log_cap > 0 ? S.p.dtlog : nullptr; ra.dt_log_cap = io.log_cap;
+    ra.t0 = ts[0]; ra.max_steps = max_steps;
+    ra.rtol = rtol; ra.atol = atol; ra.tsign = S.tsign;
+    launch_tiny_solve(S.d, ra, S.st);
+    S.nfe = forced ? 1 : 2;
+    if (blind) {
+      launch_export_record(S.p.ctrl, opts->record, opts->miss_flag, 2147483647, S.st);
+      stt.status = NODE_PENDING;
+      stt.accepted = blind; stt.rejected = 0;
+      stt.nfe = S.nfe + 6 * blind;
+      stt.t_final = ts[1];
+      if (stats) *stats = stt;
+      return S.check_launch("node_solve_fwd(dopri5, resident, deferred)");
+    }
+    TRY(S.readback());
+  } else {
   launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
   if (!forced) TRY(S.initial_step());
+  }
   if (blind) {
     for (int i = 0; i < blind; ++i) TRY(S.enqueue_step(io));
     launch_export_record(S.p.ctrl, opts->record, opts->miss_flag, blind, S.st);
@@ -1285,10 +1341,11 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   }
   StepGuess key = {S.d.N, S.d.C, S.d.H, S.d.W, 0, forced ? 1 : 0, rtol, atol, ts[0], ts[n_t - 1], 0};
   int status = 0;
-  TRY(S.run_steps(io, max_steps, guess_steps(key), &status));
+  if (S.resident) status = S.hctrl->status;
+  else TRY(S.run_steps(io, max_steps, guess_steps(key), &status));
   const Ctrl& h = *S.hctrl;
   key.steps = h.step_idx;
-  if (status == 0) remember_steps(key);
+  if (status == 0 && !S.resident) remember_steps(key);
   stt.status = status;
   stt.accepted = h.n_acc; stt.rejected = h.n_rej;
   stt.nfe = S.nfe + 6 * h.step_idx;     // f0 (+ the initial-step probe) + six stages per step tried (show.py:199)

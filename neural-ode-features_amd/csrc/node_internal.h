@@ -437,6 +437,34 @@ struct TinyConvArgs {
   int nx_on, nx_self;          // nx_self: index of the combine's term that IS this launch's output (taken from registers), or -1
   Comb nx; float* nx_y_out; const float* nx_gamma; const float* nx_beta; float* nx_act;
 };
+// latency path, resident form (kernels_tiny_solve.hip): a whole forward dopri5 solve of a tiny state in one launch
+struct TinyResidentArgs {
+  const float* y0;               // NCHW
+  float* y_out;                  // NCHW [n_targets][N][C][HW]
+  const unsigned short* wq[2];   // launch_tiny_pack_resident
+  const float* bias[2];
+  const float* tmap[2];
+  const float* gamma[3];
+  const float* beta[3];
+  float* act[2];                 // NHWC hand-off buffers
+  float* part[2];                // tiny_resident_part_elems each
+  unsigned* sync;                // tiny_resident_sync_words, zeroed
+  float* errpart;                // tiny_resident_err_elems
+  Ctrl* ctrl;
+  const double* targets; int n_targets;
+  const double* forced; int n_forced;
+  double* dt_log; int dt_log_cap;
+  double t0;
+  long long max_steps;
+  float rtol, atol, tsign;
+};
+bool tiny_resident_ok(const Dims& d);
+size_t tiny_resident_packed_elems(const Dims& d);
+size_t tiny_resident_part_elems(const Dims& d);
+size_t tiny_resident_sync_words(const Dims& d);
+size_t tiny_resident_err_elems(const Dims& d);
+void launch_tiny_pack_resident(const Dims& d, const float* w, unsigned short* wq, hipStream_t s);
+void launch_tiny_solve(const Dims& d, const TinyResidentArgs& a, hipStream_t s);
 int tiny_slice_channels(const Dims& d);
 size_t tiny_packed_elems(const Dims& d);
 size_t tiny_part_elems(const Dims& d);
