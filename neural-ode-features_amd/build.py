@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, 'csrc')
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, 'libnode_hip.so')
 LIB_DIAG = os.path.join(CSRC, 'libnode_hip_diag.so')
-DIAG_SOURCES = ['kernels_w4.hip']       # translation units that hold `#ifdef NODE_DIAG` code
+DIAG_SOURCES = ['kernels_w4.hip', 'kernels_tiny_solve.hip']       # translation units that hold `#ifdef NODE_DIAG` code
 SOURCES = ['kernels_layout.hip', 'kernels_pointwise.hip', 'kernels_conv.hip', 'kernels_wgrad.hip', 'kernels_head.hip', 'kernels_loss.hip', 'kernels_optim.hip', 'kernels_w4.hip', 'kernels_w4s.hip', 'kernels_stem.hip', 'kernels_tiny.hip', 'kernels_tiny_solve.hip', 'stem_api.hip', 'node_api.hip']
 HEADERS = [os.path.join(CSRC, 'node_internal.h'), os.path.join(CSRC, 'wino4.h'), os.path.join(CSRC, 'stem.h'), os.path.join(CSRC, 'step_control.h'), os.path.join(ROOT, 'include', 'node_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

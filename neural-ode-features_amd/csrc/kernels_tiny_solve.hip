@@ -16,9 +16,12 @@
 //     the error norm, dense output and FSAL touch no memory; the step's decision needs ONE all-reducer exchange of a partial
 //     sum per step (two more for the initial step), and every reducer takes the decision redundantly, through the same code
 //     as k_step_controller (step_control.h);
-//   * hand-off idiom: agent-scope relaxed atomics for data and flags, `s_waitcnt vmcnt(0)` + workgroup barrier between a
-//     block's data and its flag (gfx950: k_tiny_conv_gn, k_theta_finalize); every wait is a bounded spin -- a deadline on the
-//     constant 100 MHz clock -- that raises a grid-wide abort word, so the grid drains whatever happens to a neighbour.
+//   * hand-off idiom: every word that crosses workgroups travels as an 8-byte {value, tag} pair (one agent-scope 64-bit store /
+//     load: single-copy atomic), tag = {28-bit nonce of the solve, 4-bit version of the evaluation}: the consumer polls the
+//     DATA and knows each word by its tag -- no flag behind the data, no store acknowledgement before a flag, no counter
+//     (the low-latency protocol of the collective libraries; a hand-off is one store and one load that sees it).  Nothing is
+//     zeroed between solves (stale pairs carry an older nonce); every wait is a bounded spin -- a deadline on the constant
+//     100 MHz clock -- that raises a grid-wide abort word, so the grid drains whatever happens to a neighbour.
 // The grid must be co-resident (one workgroup per CU: N x (C/16) x (C/32) <= CUs; 128 workgroups at [1,256,8,8]).
 #include "node_internal.h"
 #include "step_control.h"
@@ -35,9 +38,7 @@ typedef unsigned s_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr unsigned TS_DONE = 0xFFFFFFFFu;    // flag value: the solve is over (every version number compares below it)
-constexpr unsigned TS_ABORT = 0xFFFFFFFEu;   // poll result: a wait ran into its deadline somewhere in the grid
-constexpr int TS_LINE = 32;                  // words between two flags / counters (one 128-byte line each)
+constexpr unsigned TS_VERS = 15;             // versions cycle 0 .. 14 (a slot is rewritten every evaluation: consecutive versions differ); 15 = the solve is over
 constexpr int TS_PITCH = 40;                 // bf16 elements per padded-pixel row of an LDS part plane (32 channels + 8)
 constexpr long long TS_DEADLINE = 200000000; // 2 s of the 100 MHz constant clock: only a broken grid gets there
 
@@ -51,6 +52,22 @@ __device__ constexpr float TS_BETA[6][6] = {
     {(float)(35.0 / 384), 0.f, (float)(500.0 / 1113), (float)(125.0 / 192), (float)(-2187.0 / 6784), (float)(11.0 / 84)},
 };
 __device__ constexpr float TS_ALPHA[6] = {(float)(1.0 / 5), (float)(3.0 / 10), (float)(4.0 / 5), (float)(8.0 / 9), 1.f, 1.f};
+// row `r` of the tableau and its node as immediates (indexing the arrays with a run-time row is a load from constant memory: two
+// dependent scalar-cache round trips on the critical path of every stage)
+__device__ __forceinline__ void ts_row(int r, float (&b)[6], float& alpha) {
+#define TS_ROW(R)                                                                  \
+  case R:                                                                          \
+    b[0] = TS_BETA[R][0]; b[1] = TS_BETA[R][1]; b[2] = TS_BETA[R][2];              \
+    b[3] = TS_BETA[R][3]; b[4] = TS_BETA[R][4]; b[5] = TS_BETA[R][5];              \
+    alpha = TS_ALPHA[R];                                                           \
+    break;
+  switch (r) {
+    TS_ROW(0) TS_ROW(1) TS_ROW(2) TS_ROW(3) TS_ROW(4)
+    default:
+    TS_ROW(5)
+  }
+#undef TS_ROW
+}
 
 __device__ __forceinline__ void ts_split8(const float* v, s_u32x4& hh, s_u32x4& mm, s_u32x4& ll) {
 #pragma unroll
@@ -67,24 +84,163 @@ __device__ __forceinline__ void ts_split8(const float* v, s_u32x4& hh, s_u32x4& 
   }
 }
 
-__device__ __forceinline__ unsigned ts_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ts_ldf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ts_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ts_stf(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef unsigned long long ts_pair;
+__device__ __forceinline__ void ts_put(ts_pair* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((ts_pair)tag << 32) | (ts_pair)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ ts_pair ts_get(const ts_pair* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ONE thread: wait until *p >= want (TS_DONE included).  Returns the value seen, or TS_ABORT when the grid gave up.
-__device__ __noinline__ unsigned ts_poll(const unsigned* p, unsigned want, unsigned* abort_word) {
-  const long long deadline = wall_clock64() + TS_DEADLINE;
+// A wave collects NV tagged words (those with use[i]); returns 0 when every one carries `tag`, 2 when one carries `tag_done`
+// (the solve is over), 1 when the grid gave up (abort word == nonce, or this wait ran into its deadline).  Wave-uniform.
+template <int NV, bool CHECK_DONE>
+__device__ __forceinline__ int ts_gather(const ts_pair* const (&ptr)[NV], const bool (&use)[NV], unsigned tag, unsigned tag_done,
+                                         float (&out)[NV], unsigned* abort_word, unsigned nonce, int* diag_rounds = nullptr) {
+  long long deadline = 0;
   unsigned it = 0;
   for (;;) {
-    const unsigned v = ts_ld(p);
-    if (v >= want) return v;
-    if ((++it & 31u) == 0) {
-      if (ts_ld(abort_word) != 0u) return TS_ABORT;
-      if (wall_clock64() > deadline) { ts_st(abort_word, 1u); return TS_ABORT; }
+    bool ok = true, dn = false;
+    if (diag_rounds != nullptr && (threadIdx.x & 63) == 0) atomicAdd(diag_rounds, 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ts_pair w = 0;
+      if (use[i]) w = ts_get(ptr[i]);
+      const unsigned t = (unsigned)(w >> 32);
+      if (use[i]) {
+        if (CHECK_DONE && t == tag_done) dn = true;
+        else if (t != tag) ok = false;
+      }
+      out[i] = __uint_as_float((unsigned)w);
+    }
+    if (CHECK_DONE && __any(dn)) return 2;
+    if (__all(ok)) return 0;
+    if ((++it & 15u) == 0) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nonce) return 1;
+      const long long now = wall_clock64();
+      if (deadline == 0) deadline = now + TS_DEADLINE;
+      else if (now > deadline) { __hip_atomic_store(abort_word, nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 1; }
     }
     __builtin_amdgcn_s_sleep(1);
   }
+}
+
+// Gathers read TWO tagged words per request (16 bytes): each 8-byte half validates itself, so a request torn between its halves
+// is harmless, and the number of requests -- what an uncached read costs by (measured: ~100 ns per wave-level request whatever its
+// width) -- halves.  The compiler has no 16-byte atomic load: inline assembly, every request and the wait inside ONE statement (a
+// later use of the results cannot move above the wait).
+#define TS_Q "global_load_dwordx4 "
+__device__ __forceinline__ void ts_load_quads(const ts_pair* const (&p)[4], s_u32x4 (&o)[4]) {
+  asm volatile(TS_Q "%0, %4, off sc1\n\t" TS_Q "%1, %5, off sc1\n\t" TS_Q "%2, %6, off sc1\n\t" TS_Q "%3, %7, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+               : "memory");
+}
+__device__ __forceinline__ void ts_load_quads(const ts_pair* const (&p)[14], s_u32x4 (&o)[14]) {
+  asm volatile(TS_Q "%0, %14, off sc1\n\t" TS_Q "%1, %15, off sc1\n\t" TS_Q "%2, %16, off sc1\n\t" TS_Q "%3, %17, off sc1\n\t"
+               TS_Q "%4, %18, off sc1\n\t" TS_Q "%5, %19, off sc1\n\t" TS_Q "%6, %20, off sc1\n\t" TS_Q "%7, %21, off sc1\n\t"
+               TS_Q "%8, %22, off sc1\n\t" TS_Q "%9, %23, off sc1\n\t" TS_Q "%10, %24, off sc1\n\t" TS_Q "%11, %25, off sc1\n\t"
+               TS_Q "%12, %26, off sc1\n\t" TS_Q "%13, %27, off sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]),
+                 "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]),
+                 "v"(p[11]), "v"(p[12]), "v"(p[13])
+               : "memory");
+}
+#undef TS_Q
+// two tagged words in one 16-byte store (the consumer reads them the same way); the wait state keeps a later VALU write off the
+// data registers while the store still reads them (the compiler's hazard recogniser does not see inline assembly)
+__device__ __forceinline__ void ts_put2(ts_pair* p, float v0, float v1, unsigned tag) {
+  const s_u32x4 w = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
+}
+
+// A wave collects NQ pairs of tagged words (those with use[i]): ts_gather's contract, two words per request.  out[2 i], out[2 i + 1].
+template <int NQ, bool CHECK_DONE>
+__device__ __forceinline__ int ts_gather2(const ts_pair* const (&ptr)[NQ], const bool (&use)[NQ], unsigned tag, unsigned tag_done,
+                                          float (&out)[2 * NQ], unsigned* abort_word, unsigned nonce, int* diag_rounds = nullptr) {
+  long long deadline = 0;
+  unsigned it = 0;
+  for (;;) {
+    bool ok = true, dn = false;
+    if (diag_rounds != nullptr && (threadIdx.x & 63) == 0) atomicAdd(diag_rounds, 1);
+    s_u32x4 w[NQ];
+    ts_load_quads(ptr, w);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      if (use[i]) {
+        if (CHECK_DONE && (w[i][1] == tag_done || w[i][3] == tag_done)) dn = true;
+        else if (w[i][1] != tag || w[i][3] != tag) ok = false;
+      }
+      out[2 * i] = __uint_as_float(w[i][0]);
+      out[2 * i + 1] = __uint_as_float(w[i][2]);
+    }
+    if (CHECK_DONE && __any(dn)) return 2;
+    if (__all(ok)) return 0;
+    if ((++it & 15u) == 0) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nonce) return 1;
+      const long long now = wall_clock64();
+      if (deadline == 0) deadline = now + TS_DEADLINE;
+      else if (now > deadline) { __hip_atomic_store(abort_word, nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 1; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// Before a workgroup asks for a whole block it watches ONE word of it per producer (lane l of wave 0 <-> producer l): a waiting grid
+// that polls whole blocks moves terabytes per second of nothing and delays the very stores it waits for (measured: a hand-off took
+// 3 - 5 us that way).  Same return codes as ts_gather; wave 0 only.
+template <bool CHECK_DONE>
+__device__ __forceinline__ int ts_watch(const ts_pair* word, bool active, unsigned tag, unsigned tag_done, unsigned* abort_word, unsigned nonce) {
+  long long deadline = 0;
+  unsigned it = 0;
+  for (;;) {
+    bool ok = true, dn = false;
+    if (active) {
+      const unsigned t = (unsigned)(ts_get(word) >> 32);
+      if (CHECK_DONE && t == tag_done) dn = true;
+      else if (t != tag) ok = false;
+    }
+    if (CHECK_DONE && __any(dn)) return 2;
+    if (__all(ok)) return 0;
+    if ((++it & 31u) == 0) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nonce) return 1;
+      const long long now = wall_clock64();
+      if (deadline == 0) deadline = now + TS_DEADLINE;
+      else if (now > deadline) { __hip_atomic_store(abort_word, nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return 1; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// sum over the lanes that share a GroupNorm group inside a 16-lane row (cpg = 1, 2, 4, 8, 16 consecutive columns), on the DPP path:
+// quad permutes, then the half-row / row mirrors (values are uniform inside the smaller group by then, so a mirror is the butterfly)
+__device__ __forceinline__ float ts_dpp_add(float v, int ctrl_sel) {
+  const int x = __builtin_bit_cast(int, v);
+  int y;
+  switch (ctrl_sel) {
+    case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); break;     // quad_perm [1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false); break;     // quad_perm [2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); break;    // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); break;   // row_mirror
+  }
+  return v + __builtin_bit_cast(float, y);
+}
+// sum over the four 16-lane rows of a wave, result in every lane.  Inline assembly: handed the same value twice, the builtins'
+// two results are folded into one by the compiler (hipcc 7.2: `v_add_f32 v1, v1, v1` after the swap)
+__device__ __forceinline__ float ts_rows_sum(float x) {
+  float p = x, q = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p), "+v"(q));
+  float r = p + q, t = r;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(r), "+v"(t));
+  return r + t;
+}
+__device__ __forceinline__ float ts_group_sum(float v, int cpg) {
+  if (cpg >= 2) v = ts_dpp_add(v, 0);
+  if (cpg >= 4) v = ts_dpp_add(v, 1);
+  if (cpg >= 8) v = ts_dpp_add(v, 2);
+  if (cpg >= 16) v = ts_dpp_add(v, 3);
+  return v;
 }
 
 struct TinySolveArgs {
@@ -95,10 +251,10 @@ struct TinySolveArgs {
   const float* tmap[2];         // [HW][C]
   const float* gamma[3];
   const float* beta[3];
-  float* act[2];                // NHWC [N][HW][C]: the convolutions' inputs, block by block
-  float* part[2];               // [N GP][KS][4 waves][64 lanes][4] partial sums
-  unsigned* sync;               // zeroed words: flagA | flagB | cnt1 | cnt2 (R lines each) | stepcnt | abort
-  float* errpart;               // [2][R][2]: the reducers' partial sums of a step decision (double-buffered by exchange parity)
+  ts_pair* act[2];              // NHWC [N][HW][C] tagged words: the convolutions' inputs, block by block
+  ts_pair* part[2];             // [N GP][KS][4 elements][4 waves][64 lanes] tagged partial sums
+  ts_pair* errpart;             // [2][R][2]: the reducers' partial sums of a step decision (double-buffered by exchange parity)
+  unsigned* abort_word;         // == nonce: some wait of this solve ran into its deadline
   Ctrl* ctrl;                   // out: the final record (what the host reads back)
   const double* targets; int n_targets;
   const double* forced; int n_forced;
@@ -106,10 +262,12 @@ struct TinySolveArgs {
   double t0;
   long long max_steps;
   float rtol, atol, tsign, eps;
+  unsigned nonce;               // 28 bits, unique per solve of this process (stale words of earlier solves never match)
+  int stamps;                   // diagnostics library: print the in-kernel timeline
   int N, C, H, W, cpg, KS, GP;
 };
 
-// LDS: Wf [2 convs][27 fragments][64 lanes] 16 B | A [3 parts][PP][TS_PITCH] bf16 | floats: red_a[64] red_b[64] bsum[16] | ints [4] | Ctrl
+// LDS: Wf [2 convs][27 fragments][64 lanes] 16 B | A [3 parts][PP][TS_PITCH] bf16 | floats: red_a[256] red_b[256] bsum[16] | ints [4] | Ctrl
 __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   extern __shared__ __align__(16) unsigned char lsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,23 +279,34 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   const size_t plane = (size_t)PP * TS_PITCH;
   float* fl = reinterpret_cast<float*>(lsm + 2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15));
   float* red_a = fl;
-  float* red_b = fl + 64;
-  float* bsum = fl + 128;                          // [0..3], [8..11]: wave partials of two sums
-  int* li = reinterpret_cast<int*>(fl + 144);      // [0] outcome of the last wait
-  Ctrl* lc = reinterpret_cast<Ctrl*>(fl + 148);    // (16-byte aligned: fl is, 148 floats = 592 B)
+  float* red_b = fl + 256;
+  float* bsum = fl + 512;                          // [0..3], [8..11]: wave partials of two sums
+  int* li = reinterpret_cast<int*>(fl + 528);      // [0..3] outcome of the last wait, per wave
+  Ctrl* lc = reinterpret_cast<Ctrl*>(fl + 532);    // (16-byte aligned: fl is, 532 floats = 2128 B)
 
+#ifdef NODE_DIAG
+  // in-kernel timeline (diagnostics library only, NODE_TUNE_TINY_STAMPS=1): workgroups 0 (a reducer) and 1 (a worker) stamp the
+  // constant 100 MHz clock at the phases of their first 48 convolutions and print the differences when the solve is over
+  __shared__ long long stamp[48][8];
+  __shared__ int rounds[4];      // gather rounds (summed over the four waves): activations, partial sums; calls of each
+  if (tid < 4) rounds[tid] = 0;
+#define TS_ROUNDS(k) (a.stamps ? &rounds[k] : nullptr)
+  int stamp_row = 0;
+#define TS_STAMP(k) do { if (a.stamps && blockIdx.x < 2 && tid == 0 && stamp_row < 48) stamp[stamp_row][k] = wall_clock64(); } while (0)
+#define TS_STAMP_NEXT() do { ++stamp_row; } while (0)
+#else
+#define TS_ROUNDS(k) nullptr
+#define TS_STAMP(k) do {} while (0)
+#define TS_STAMP_NEXT() do {} while (0)
+#endif
   int r = blockIdx.x;
   const int ks = r % KS; r /= KS;
   const int gp = r % GP;
   const int n = r / GP;
   const int R = a.N * GP, rid = n * GP + gp;
   const bool is_red = ks == gp % KS;
-  unsigned* flagA = a.sync;
-  unsigned* flagB = a.sync + (size_t)R * TS_LINE;
-  unsigned* cnt1 = a.sync + (size_t)2 * R * TS_LINE;
-  unsigned* cnt2 = a.sync + (size_t)3 * R * TS_LINE;
-  unsigned* stepcnt = a.sync + (size_t)4 * R * TS_LINE;
-  unsigned* abort_word = stepcnt + TS_LINE;
+  const unsigned nonce = a.nonce, tag_done = (nonce << 4) | TS_VERS;
+  auto tag_of = [&](unsigned version) { return (nonce << 4) | (version % TS_VERS); };
 
   // ---- prologue: this workgroup's filter slices of both convolutions -> LDS, for the whole solve
 #pragma unroll
@@ -148,7 +317,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   // zero the activation planes once: the halo stays zero, the interior is rewritten by every staging
   for (int i = tid; i < (int)(3 * plane / 2); i += 256) reinterpret_cast<unsigned*>(A)[i] = 0u;
 
-  // ---- reducer state (meaningful in reducers only; cheap enough to set up everywhere)
+  // ---- reducer state (meaningful in reducers only)
   const int c = gp * 16 + col;
   int pix[4];
   bool on[4];
@@ -179,33 +348,31 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
       lc->dt = a.forced != nullptr ? a.forced[0] : 0.0;
     }
   }
-  if (tid == 0) li[0] = 0;
   __syncthreads();
 
   const float inv_m = 1.f / (float)(cpg * HW);
   const double numel = (double)a.N * C * HW;
 
   // GroupNorm over (cpg channels x HW pixels) of this 16-channel block: v <- [relu](((v - mean) rstd) gamma + beta); masked entries stay 0
+  // a wave's group total stays in registers (DPP inside the 16-lane row, v_permlane16/32_swap across the rows); the four waves meet
+  // in LDS: red_a / red_b [group][wave]
   auto group_norm = [&](float (&v)[4], float gm, float bt, bool relu) {
-    float s = (v[0] + v[1]) + (v[2] + v[3]);
-    for (int m = 1; m < cpg; m <<= 1) s += __shfl_xor(s, m);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    __syncthreads();                       // (the previous use of red_a / red_b is over in every wave)
-    if (kq == 0 && (col & (cpg - 1)) == 0) red_a[wave * 16 + col / cpg] = s;
-    __syncthreads();
     const int grp = col / cpg;
-    const float mean = ((red_a[grp] + red_a[16 + grp]) + (red_a[32 + grp] + red_a[48 + grp])) * inv_m;
+    float s = ts_rows_sum(ts_group_sum((v[0] + v[1]) + (v[2] + v[3]), cpg));
+    __syncthreads();                       // (the previous use of red_a / red_b is over in every wave)
+    if (kq == 0 && (col & (cpg - 1)) == 0) red_a[grp * 4 + wave] = s;
+    __syncthreads();
+    const float4 ta = *reinterpret_cast<const float4*>(red_a + grp * 4);
+    const float mean = ((ta.x + ta.y) + (ta.z + ta.w)) * inv_m;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (on[i]) { const float dv = v[i] - mean; q += dv * dv; }
-    for (int m = 1; m < cpg; m <<= 1) q += __shfl_xor(q, m);
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (kq == 0 && (col & (cpg - 1)) == 0) red_b[wave * 16 + grp] = q;
+    q = ts_rows_sum(ts_group_sum(q, cpg));
+    if (kq == 0 && (col & (cpg - 1)) == 0) red_b[grp * 4 + wave] = q;
     __syncthreads();
-    const float rstd = 1.0f / sqrtf(((red_b[grp] + red_b[16 + grp]) + (red_b[32 + grp] + red_b[48 + grp])) * inv_m + a.eps);
+    const float4 tb = *reinterpret_cast<const float4*>(red_b + grp * 4);
+    const float rstd = 1.0f / sqrtf(((tb.x + tb.y) + (tb.z + tb.w)) * inv_m + a.eps);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float o = ((v[i] - mean) * rstd) * gm + bt;
@@ -213,16 +380,23 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
       v[i] = on[i] ? o : 0.f;
     }
   };
-  // a block of a convolution's input (64 pixels x 16 channels) -> act buffer, then its version flag
-  auto publish = [&](float* act, const float (&v)[4], unsigned* flag, unsigned version) {
+  // a block of a convolution's input (64 pixels x 16 channels) -> tagged words; nobody waits for the stores
+  auto publish = [&](ts_pair* act, const float (&v)[4], unsigned tag) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (on[i]) ts_stf(act + ((size_t)n * HW + pix[i]) * C + c, v[i]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) ts_st(flag + (size_t)rid * TS_LINE, version);
+      if (on[i]) ts_put(act + ((size_t)n * HW + pix[i]) * C + c, v[i], tag);
   };
-  // deterministic sum over the workgroup of two values, result in every thread (bsum[4], bsum[5])
+  // the outcome of a wave-level wait, agreed on by the workgroup: 0 go on, 1 the grid gave up, 2 the solve is over
+  auto agree = [&](int code) -> int {
+    if (lane == 0) li[wave] = code;
+    __syncthreads();
+    const int c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
+    const int any1 = (c0 == 1) | (c1 == 1) | (c2 == 1) | (c3 == 1);
+    const int any2 = (c0 == 2) | (c1 == 2) | (c2 == 2) | (c3 == 2);
+    __syncthreads();                       // (li is free again)
+    return any1 ? 1 : (any2 ? 2 : 0);
+  };
+  // deterministic sum over the workgroup of two values, result in every thread
   auto block_sum2 = [&](float v0, float v1, float& o0, float& o1) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { v0 += __shfl_xor(v0, off); v1 += __shfl_xor(v1, off); }
@@ -236,22 +410,21 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   unsigned xno = 0;
   auto exchange = [&](float p0, float p1, float& tot0, float& tot1) -> bool {
     ++xno;
-    float* mine = a.errpart + ((size_t)(xno & 1u) * R + rid) * 2;
+    const unsigned xtag = tag_of(xno);
+    ts_pair* all = a.errpart + (size_t)(xno & 1u) * R * 2;
     float w0, w1;
     block_sum2(p0, p1, w0, w1);
     if (tid == 0) {
-      ts_stf(mine, w0);
-      ts_stf(mine + 1, w1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(stepcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      li[0] = ts_poll(stepcnt, (unsigned)R * xno, abort_word) == TS_ABORT ? 1 : 0;
+      ts_put(all + 2 * rid, w0, xtag);
+      ts_put(all + 2 * rid + 1, w1, xtag);
     }
-    __syncthreads();
-    if (li[0]) return false;
-    const float* all = a.errpart + (size_t)(xno & 1u) * R * 2;
-    const float q0 = tid < R ? ts_ldf(all + 2 * tid) : 0.f;
-    const float q1 = tid < R ? ts_ldf(all + 2 * tid + 1) : 0.f;
-    block_sum2(q0, q1, tot0, tot1);
+    const int src = tid < R ? tid : 0;
+    const ts_pair* const ptr[2] = {all + 2 * src, all + 2 * src + 1};
+    const bool use[2] = {tid < R, tid < R};
+    float q[2];
+    const int code = agree(ts_gather<2, false>(ptr, use, xtag, 0u, q, a.abort_word, nonce));
+    if (code != 0) return false;
+    block_sum2(q[0], q[1], tot0, tot1);
     return true;
   };
 
@@ -263,49 +436,56 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   if (is_red) {
     float v[4] = {y[0], y[1], y[2], y[3]};
     group_norm(v, g1, e1, true);
-    publish(a.act[0], v, flagA, 1u);
+    publish(a.act[0], v, tag_of(1u));
   }
   bool failed = false;
 
   for (;;) {
     ++ver;
+    const unsigned tag = tag_of(ver);
 #pragma unroll 1
     for (int cv = 0; cv < 2; ++cv) {
-      // ---- worker: wait for the two 16-channel blocks of this slice, stage them as bf16 triples
-      const unsigned* fl_in = cv == 0 ? flagA : flagB;
-      if (tid == 0) {
-        int code = 0;
-        for (int b = 0; b < 2 && code == 0; ++b) {
-          const unsigned got = ts_poll(fl_in + (size_t)(n * GP + 2 * ks + b) * TS_LINE, ver, abort_word);
-          if (got == TS_ABORT) code = 1;
-          else if (got == TS_DONE) code = 2;
-        }
-        li[0] = code;
-      }
-      __syncthreads();
-      if (li[0] != 0) { failed = li[0] == 1; goto finished; }
+      // ---- worker: the two 16-channel blocks of this slice arrive as tagged words; stage them as bf16 triples
+      TS_STAMP(0);
       {
-        const float* src = a.act[cv] + (size_t)n * HW * C + ks * 32;
-        const int items = PP * 4;
+        // wave w takes the pixels 16 w .. 16 w + 15 of the slice, four per request: lane <-> (pixel, channel pair), so a request is
+        // four contiguous 256-byte runs (a first version gave each lane eight consecutive channels: 64 scattered 8-byte reads per
+        // request, 16 x the bytes through the fabric, 2 - 4 us per hand-off)
+        const ts_pair* src = a.act[cv] + (size_t)n * HW * C + ks * 32;
+        const int cp = lane & 15;
+        const ts_pair* ptr[4];
+        bool use[4];
+        int lds_at[4];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int idx = tid + it * 256;
-          const int pp = idx >> 2, q = idx & 3;
-          const int yy = pp / Wp - 1, xx = pp % Wp - 1;
-          if (idx < items && yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const float* s8 = src + (size_t)(yy * W + xx) * C + 8 * q;
-            float f[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = ts_ldf(s8 + e);
-            s_u32x4 hh, mm, ll;
-            ts_split8(f, hh, mm, ll);
-            *reinterpret_cast<s_u32x4*>(A + (size_t)pp * TS_PITCH + 8 * q) = hh;
-            *reinterpret_cast<s_u32x4*>(A + plane + (size_t)pp * TS_PITCH + 8 * q) = mm;
-            *reinterpret_cast<s_u32x4*>(A + 2 * plane + (size_t)pp * TS_PITCH + 8 * q) = ll;
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int p = wave * 16 + 4 * j + (lane >> 4);
+          use[j] = p < HW;
+          ptr[j] = src + (size_t)(use[j] ? p : 0) * C + 2 * cp;
+          lds_at[j] = ((p / W + 1) * Wp + (p % W) + 1) * TS_PITCH + 2 * cp;
         }
+        {   // watch the last word of each of the two blocks (pixel HW - 1, channel 15 of the block) before asking for 8 KB
+          int wcode = 0;
+          if (wave == 0) wcode = ts_watch<true>(src + (size_t)(HW - 1) * C + 16 * (lane & 1) + 15, lane < 2, tag, tag_done, a.abort_word, nonce);
+          wcode = agree(wcode);
+          if (wcode != 0) { failed = wcode == 1; goto finished; }
+          TS_STAMP(1);
+        }
+        float f[8];
+        const int code = agree(ts_gather2<4, true>(ptr, use, tag, tag_done, f, a.abort_word, nonce, TS_ROUNDS(0)));
+        if (code != 0) { failed = code == 1; goto finished; }
+        TS_STAMP(2);
+        s_u32x4 hh, mm, ll;
+        ts_split8(f, hh, mm, ll);       // (pair j = the two channels of pixel j: one 32-bit LDS word per part)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (use[j]) {
+            *reinterpret_cast<unsigned*>(A + lds_at[j]) = hh[j];
+            *reinterpret_cast<unsigned*>(A + plane + lds_at[j]) = mm[j];
+            *reinterpret_cast<unsigned*>(A + 2 * plane + lds_at[j]) = ll[j];
+          }
       }
       __syncthreads();
+      TS_STAMP(3);
       // ---- products: wave = pixel tile, nine K steps (tap x 32 channels), six part products each
       s_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       {
@@ -332,34 +512,54 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
       }
       // accumulator: lane holds output channel c = 16 gp + col, pixels 16 wave + 4 kq + i
 
-      float* part = a.part[cv] + (size_t)rid * KS * 1024;
-      unsigned* cnt = (cv == 0 ? cnt1 : cnt2) + (size_t)rid * TS_LINE;
+      TS_STAMP(4);
+      ts_pair* part = a.part[cv] + (size_t)rid * KS * 1024;
       if (!is_red) {
-        // ---- worker: partial sums to the block's reducer
-        float* mine = part + (size_t)ks * 1024 + (size_t)(wave * 64 + lane) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ts_stf(mine + i, acc[i]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- worker: tagged partial sums to the block's reducer
+        ts_pair* mine = part + (size_t)ks * 1024 + (size_t)(wave * 64 + lane) * 2;       // [slice][half][wave][lane][2]: a request is 1 KB contiguous
+        ts_put2(mine, acc[0], acc[1], tag);
+        ts_put2(mine + 512, acc[2], acc[3], tag);
+        __syncthreads();                   // (the activation planes are free for the next staging)
+        TS_STAMP(5);
+        TS_STAMP_NEXT();
         continue;
       }
       // ---- reducer: the other slices' partial sums, added in slice order
       if (KS > 1) {
-        if (tid == 0) li[0] = ts_poll(cnt, (unsigned)(KS - 1) * ver, abort_word) == TS_ABORT ? 1 : 0;
-        __syncthreads();
-        if (li[0] != 0) { failed = true; goto finished; }
-        float got[8][4];
+        const ts_pair* ptr[14];
+        bool use[14];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 7; ++q) {          // slot q of the seven OTHER slices <-> slice q (q < ks) or q + 1
+          const int sl = q < ks ? q : q + 1;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            got[q][i] = (q < KS && q != ks) ? ts_ldf(part + (size_t)q * 1024 + (size_t)(wave * 64 + lane) * 4 + i) : 0.f;
+          for (int h = 0; h < 2; ++h) {
+            use[2 * q + h] = sl < KS;
+            ptr[2 * q + h] = part + (size_t)(sl < KS ? sl : 0) * 1024 + h * 512 + (size_t)(wave * 64 + lane) * 2;
+          }
+        }
+        {   // watch the last word of each other slice's partial sums (wave 3, lane 63, element 3)
+          int wcode = 0;
+          if (wave == 0) {
+            const int q = lane & 7;
+            wcode = ts_watch<false>(part + (size_t)q * 1024 + 1023, lane < 8 && q < KS && q != ks, tag, 0u, a.abort_word, nonce);
+          }
+          if (agree(wcode) != 0) { failed = true; goto finished; }
+          TS_STAMP(5);
+        }
+        float got[28];
+        const int code = agree(ts_gather2<14, false>(ptr, use, tag, 0u, got, a.abort_word, nonce, TS_ROUNDS(1)));
+        if (code != 0) { failed = true; goto finished; }
+        TS_STAMP(6);
+        // got[4 q + i]: slot q; the sum runs in slice order, this workgroup's own slice in its place (slots past KS: zeros)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float s = 0 == ks ? acc[i] : got[0][i];
+          float s = 0.f;
 #pragma unroll
-          for (int q = 1; q < 8; ++q) s += q == ks ? acc[i] : got[q][i];       // (slices past KS hold zeros)
+          for (int q = 0; q < 7; ++q) {
+            if (q == ks) s += acc[i];
+            s += use[2 * q] ? got[4 * q + i] : 0.f;
+          }
+          if (ks == 7) s += acc[i];
           acc[i] = s;
         }
       }
@@ -369,7 +569,9 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = on[i] ? acc[i] + b1 + tnow * tm1[i] : 0.f;
         group_norm(v, g2, e2, true);
-        publish(a.act[1], v, flagB, ver);
+        publish(a.act[1], v, tag);
+        TS_STAMP(7);
+        TS_STAMP_NEXT();
         continue;
       }
       // conv2 epilogue: + bias + t x time map, GroupNorm-3, orientation -> k[slot]
@@ -386,6 +588,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
       }
 
       // ---- reducer: what follows this evaluation
+      const unsigned next_tag = tag_of(ver + 1);
       bool start_step = false;
       if (phase == PH_F0) {
         if (a.forced != nullptr) {
@@ -418,7 +621,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
           tnow = a.tsign * ((float)lc->t + h0);
           phase = PH_PROBE; slot = 1;
           group_norm(v, g1, e1, true);
-          publish(a.act[0], v, flagA, ver + 1);
+          publish(a.act[0], v, next_tag);
         }
       } else if (phase == PH_PROBE) {
         float s0 = 0.f;
@@ -444,13 +647,15 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
         // the next stage's Butcher combine (the sixth one is y1)
         const float dtf = (float)lc->dt;
         const int nk = stage + 2;
+        float brow[6], alpha_next;
+        ts_row(stage + 1, brow, alpha_next);
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float sk = 0.f;
 #pragma unroll
           for (int j = 0; j < 6; ++j)
-            if (j < nk) sk += (dtf * TS_BETA[stage + 1][j]) * k[j][i];
+            if (j < nk) sk += (dtf * brow[j]) * k[j][i];
           v[i] = on[i] ? y[i] + sk : 0.f;
         }
         ++stage;
@@ -459,9 +664,9 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
           for (int i = 0; i < 4; ++i) y1[i] = v[i];
         }
         slot = stage + 1;
-        tnow = a.tsign * ((float)lc->t + TS_ALPHA[stage] * dtf);
+        tnow = a.tsign * ((float)lc->t + alpha_next * dtf);
         group_norm(v, g1, e1, true);
-        publish(a.act[0], v, flagA, ver + 1);
+        publish(a.act[0], v, next_tag);
       } else {
         // ---- the step's seventh evaluation is in: error norm, decision, dense output, FSAL
         const float dtf = (float)lc->dt;
@@ -519,23 +724,38 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
         phase = PH_STAGE; stage = 0; slot = 1;
         tnow = a.tsign * ((float)lc->t + TS_ALPHA[0] * dtf);
         group_norm(v, g1, e1, true);
-        publish(a.act[0], v, flagA, ver + 1);
+        publish(a.act[0], v, next_tag);
       }
+      TS_STAMP(7);
+      TS_STAMP_NEXT();
     }
   }
 
 finished:
+#ifdef NODE_DIAG
+  if (a.stamps && blockIdx.x < 2 && tid == 0) {
+    printf("wg %d: gather rounds (4 waves): activations %d, partial sums %d over %d convolutions\n", (int)blockIdx.x, rounds[0], rounds[1], stamp_row);
+    for (int i = 0; i < stamp_row && i < 48; ++i) {
+      const long long b = stamp[i][0];
+      if (blockIdx.x == 0)
+        printf("wg 0 conv %2d: top %7lld | +watch %4lld +gather %4lld +stage %4lld +mfma %4lld +watch-parts %4lld +gather-parts %4lld +epilogue %4lld (x10 ns)\n", i,
+               b % 10000000, stamp[i][1] - b, stamp[i][2] - b, stamp[i][3] - b, stamp[i][4] - b, stamp[i][5] - b, stamp[i][6] - b, stamp[i][7] - b);
+      else
+        printf("wg 1 conv %2d: top %7lld | +watch %4lld +gather %4lld +stage %4lld +mfma %4lld +put %4lld (x10 ns)\n", i,
+               b % 10000000, stamp[i][1] - b, stamp[i][2] - b, stamp[i][3] - b, stamp[i][4] - b, stamp[i][5] - b);
+    }
+  }
+#endif
   if (failed) {      // some wait ran into its deadline: the record says so, whoever notices first
     if (tid == 0) { a.ctrl->status = NODE_ERR_HIP; a.ctrl->done = 1; }
-    if (is_red && tid == 0) ts_st(flagA + (size_t)rid * TS_LINE, TS_DONE);
-    return;
+    return;          // (the abort word releases everybody else)
   }
   if (!is_red) return;
   __syncthreads();
-  if (tid == 0) {
-    if (rid == 0) *a.ctrl = *lc;
-    ts_st(flagA + (size_t)rid * TS_LINE, TS_DONE);      // the workers of the next evaluation are waiting on this block: release them
-  }
+  if (rid == 0 && tid == 0) *a.ctrl = *lc;
+  // the workers of the next evaluation are polling this block: tell them the solve is over
+  const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+  publish(a.act[0], zero, tag_done);
 }
 
 }  // namespace
@@ -557,27 +777,36 @@ bool tiny_resident_ok(const Dims& d) {
   }
   const long grid = (long)d.N * (d.C / 16) * (d.C / 32);
   if (grid > cus) return false;
-  if ((size_t)(d.H + 2) * (d.W + 2) * 4 > 512) return false;       // staging: two items per thread
+  if ((size_t)(d.H + 2) * (d.W + 2) > 128) return false;           // (LDS planes of the padded image)
   return true;
 }
 size_t tiny_resident_packed_elems(const Dims& d) { return (size_t)(d.C / 16) * (d.C / 32) * 9 * 3 * 64 * 8; }
-size_t tiny_resident_part_elems(const Dims& d) { return (size_t)d.N * (d.C / 16) * (d.C / 32) * 1024; }
-size_t tiny_resident_sync_words(const Dims& d) { return ((size_t)4 * d.N * (d.C / 16) + 2) * TS_LINE; }
-size_t tiny_resident_err_elems(const Dims& d) { return (size_t)2 * d.N * (d.C / 16) * 2; }
-
+// tagged words (8 bytes each) of the hand-off buffers: two activation buffers | two partial-sum buffers | the decision exchange
+size_t tiny_resident_handoff_words(const Dims& d) {
+  return 2 * d.numel + 2 * (size_t)d.N * (d.C / 16) * (d.C / 32) * 1024 + (size_t)2 * d.N * (d.C / 16) * 2 + 16;
+}
 void launch_tiny_solve(const Dims& d, const TinyResidentArgs& b, hipStream_t s) {
   TinySolveArgs a;
   memset(&a, 0, sizeof(a));
   a.y0 = b.y0; a.y_out = b.y_out;
-  for (int i = 0; i < 2; ++i) { a.wq[i] = b.wq[i]; a.bias[i] = b.bias[i]; a.tmap[i] = b.tmap[i]; a.act[i] = b.act[i]; a.part[i] = b.part[i]; }
+  for (int i = 0; i < 2; ++i) { a.wq[i] = b.wq[i]; a.bias[i] = b.bias[i]; a.tmap[i] = b.tmap[i]; }
+  {
+    ts_pair* w = reinterpret_cast<ts_pair*>(b.handoff);
+    const size_t parts = (size_t)d.N * (d.C / 16) * (d.C / 32) * 1024;
+    a.act[0] = w; a.act[1] = w + d.numel;
+    a.part[0] = w + 2 * d.numel; a.part[1] = a.part[0] + parts;
+    a.errpart = a.part[1] + parts;
+    a.abort_word = reinterpret_cast<unsigned*>(a.errpart + (size_t)2 * d.N * (d.C / 16) * 2);
+  }
+  a.ctrl = b.ctrl; a.nonce = b.nonce;
+  { const char* e = getenv("NODE_TUNE_TINY_STAMPS"); a.stamps = e ? atoi(e) : 0; }
   for (int i = 0; i < 3; ++i) { a.gamma[i] = b.gamma[i]; a.beta[i] = b.beta[i]; }
-  a.sync = b.sync; a.errpart = b.errpart; a.ctrl = b.ctrl;
   a.targets = b.targets; a.n_targets = b.n_targets; a.forced = b.forced; a.n_forced = b.n_forced;
   a.dt_log = b.dt_log; a.dt_log_cap = b.dt_log_cap; a.t0 = b.t0; a.max_steps = b.max_steps;
   a.rtol = b.rtol; a.atol = b.atol; a.tsign = b.tsign; a.eps = d.eps;
   a.N = d.N; a.C = d.C; a.H = d.H; a.W = d.W; a.cpg = d.cpg; a.KS = d.C / 32; a.GP = d.C / 16;
   const size_t plane = (size_t)(d.H + 2) * (d.W + 2) * TS_PITCH;
-  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 148 * sizeof(float) + sizeof(Ctrl) + 64;
+  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 532 * sizeof(float) + sizeof(Ctrl) + 64;
   static bool attr[MAX_DEVICES] = {};
   allow_full_lds(reinterpret_cast<const void*>(k_tiny_solve), attr);
   hipLaunchKernelGGL(k_tiny_solve, dim3(d.N * a.GP * a.KS), dim3(256), lds, s, a);

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -277,9 +278,7 @@ struct Plan {
   unsigned short* wtiny[2]; // latency path (kernels_tiny.hip): filters as column-padded bf16 triples in fragment order
   float* tpart;             //   K-slice partial sums
   unsigned* tcount;         //   arrival counters [N G]
-  float* tpartB;            // resident form (kernels_tiny_solve.hip): the second convolution's partial sums,
-  unsigned* tsync;          //   version flags / arrival counters (zeroed per solve),
-  float* terr;              //   the reducers' partial sums of a step decision
+  void* thand;              // resident form (kernels_tiny_solve.hip): hand-off buffers of tagged words (activations, partial sums, decisions)
   float *W4V, *W4M;         // F(4x4,3x3) pipeline: the current conv's row operand and component products (wino4.h)
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
@@ -339,14 +338,9 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     for (int i = 0; i < 2; ++i) p.wsmall[i] = b.take<float>((size_t)9 * d.C * d.C);
   if (d.tiny && !adjoint) {
     for (int i = 0; i < 2; ++i) p.wtiny[i] = b.take<unsigned short>(tiny_packed_elems(d));
-    const bool res = tiny_resident_ok(d);
-    p.tpart = b.take<float>(res ? std::max(tiny_part_elems(d), tiny_resident_part_elems(d)) : tiny_part_elems(d));
+    p.tpart = b.take<float>(tiny_part_elems(d));
     p.tcount = b.take<unsigned>((size_t)d.N * d.G);
-    if (res) {
-      p.tpartB = b.take<float>(tiny_resident_part_elems(d));
-      p.tsync = b.take<unsigned>(tiny_resident_sync_words(d));
-      p.terr = b.take<float>(tiny_resident_err_elems(d));
-    }
+    if (tiny_resident_ok(d)) p.thand = b.take<unsigned long long>(tiny_resident_handoff_words(d));
   }
   if (d.wino4) {
     p.W4V = b.take<float>(w4_v_elems(d.N8, d.C));
@@ -479,7 +473,7 @@ struct Solver {
   bool tiny_mode() const { return d.tiny != 0 && !aug && p.wtiny[0] != nullptr; }
   // ... and a free-running or replayed dopri5 forward solve of a state the chip can hold resident is ONE launch (kernels_tiny_solve.hip)
   bool resident = false;
-  void choose_resident(bool dopri5) { resident = dopri5 && tiny_mode() && !w4 && p.tsync != nullptr && tiny_resident_ok(d); }
+  void choose_resident(bool dopri5) { resident = dopri5 && tiny_mode() && !w4 && p.thand != nullptr && tiny_resident_ok(d); }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
@@ -537,10 +531,9 @@ struct Solver {
       launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
       launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
     }
-    if (tiny_mode() && !w4 && resident) {     // (the whole solve is one launch: its own slicing of the filters, its flags zeroed below)
+    if (tiny_mode() && !w4 && resident) {     // (the whole solve is one launch: its own slicing of the filters)
       launch_tiny_pack_resident(d, prm.conv1_w, p.wtiny[0], st);
       launch_tiny_pack_resident(d, prm.conv2_w, p.wtiny[1], st);
-      zr[nz] = reinterpret_cast<float*>(p.tsync); zn[nz++] = tiny_resident_sync_words(d);     // (0.f is the all-zero word)
     } else if (tiny_mode() && !w4) {
       launch_tiny_pack(d, prm.conv1_w, p.wtiny[0], st);
       launch_tiny_pack(d, prm.conv2_w, p.wtiny[1], st);
@@ -1304,9 +1297,28 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     ra.tmap[0] = S.p.tmap[0]; ra.tmap[1] = S.p.tmap[1];
     ra.gamma[0] = params->norm1_w; ra.gamma[1] = params->norm2_w; ra.gamma[2] = params->norm3_w;
     ra.beta[0] = params->norm1_b; ra.beta[1] = params->norm2_b; ra.beta[2] = params->norm3_b;
-    ra.act[0] = S.p.act1; ra.act[1] = S.p.act2;
-    ra.part[0] = S.p.tpart; ra.part[1] = S.p.tpartB;
-    ra.sync = S.p.tsync; ra.errpart = S.p.terr; ra.ctrl = S.p.ctrl;
+    ra.handoff = S.p.thand; ra.ctrl = S.p.ctrl;
+    {
+      // every word that crosses workgroups carries {nonce, version}: stale words of any earlier solve of this process never match, so
+      // nothing is zeroed per solve.  The 28-bit nonce starts over every 2^28 solves: a hand-off buffer is zeroed the first time it
+      // is used under a new generation of the counter (and the first time ever: whatever a fresh allocation holds is gone).
+      // Three values are skipped: 0 (zeroed memory) and the two that, with the "solve is over" version, are the 0xFF / 0x7F byte patterns
+      static std::mutex g_mu;
+      static unsigned long long g_count = 0;
+      static std::vector<std::pair<void*, unsigned long long>> g_seen;
+      std::lock_guard<std::mutex> lock(g_mu);
+      unsigned nn;
+      do { nn = (unsigned)(++g_count & 0x0FFFFFFFull); } while (nn == 0u || nn == 0x0FFFFFFFu || nn == 0x07F7F7F7u);
+      const unsigned long long gen = (g_count >> 28) + 1;
+      bool known = false;
+      for (auto& e : g_seen)
+        if (e.first == S.p.thand) { known = e.second == gen; e.second = gen; goto found; }
+      if (g_seen.size() >= 256) g_seen.erase(g_seen.begin());
+      g_seen.emplace_back(S.p.thand, gen);
+    found:
+      if (!known) HIP_TRY(hipMemsetAsync(S.p.thand, 0, tiny_resident_handoff_words(S.d) * 8, S.st));
+      ra.nonce = nn;
+    }
     ra.targets = S.p.targets; ra.n_targets = io.n_targets;
     ra.forced = forced ? S.p.forced : nullptr; ra.n_forced = io.n_forced;
     ra.dt_log = io.log_cap > 0 ? S.p.dtlog : nullptr; ra.dt_log_cap = io.log_cap;

@@ -446,10 +446,8 @@ struct TinyResidentArgs {
   const float* tmap[2];
   const float* gamma[3];
   const float* beta[3];
-  float* act[2];                 // NHWC hand-off buffers
-  float* part[2];                // tiny_resident_part_elems each
-  unsigned* sync;                // tiny_resident_sync_words, zeroed
-  float* errpart;                // tiny_resident_err_elems
+  void* handoff;                 // tiny_resident_handoff_words 8-byte tagged words (never zeroed: see `nonce`)
+  unsigned nonce;                // 28 bits, never repeated by this process within 2^28 solves
   Ctrl* ctrl;
   const double* targets; int n_targets;
   const double* forced; int n_forced;
@@ -460,9 +458,7 @@ struct TinyResidentArgs {
 };
 bool tiny_resident_ok(const Dims& d);
 size_t tiny_resident_packed_elems(const Dims& d);
-size_t tiny_resident_part_elems(const Dims& d);
-size_t tiny_resident_sync_words(const Dims& d);
-size_t tiny_resident_err_elems(const Dims& d);
+size_t tiny_resident_handoff_words(const Dims& d);
 void launch_tiny_pack_resident(const Dims& d, const float* w, unsigned short* wq, hipStream_t s);
 void launch_tiny_solve(const Dims& d, const TinyResidentArgs& a, hipStream_t s);
 int tiny_slice_channels(const Dims& d);
