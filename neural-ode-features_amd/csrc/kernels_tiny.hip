@@ -435,11 +435,6 @@ void launch_tiny_pack(const Dims& d, const float* w, unsigned short* wq, hipStre
   const int frags = d.G * (d.C / CS) * 9 * (CS / 32);
   hipLaunchKernelGGL(k_tiny_pack, dim3((frags + 3) / 4), dim3(256), 0, s, w, wq, d.C, d.cpg, CS, frags);
 }
-// the resident solve (kernels_tiny_solve.hip) slices differently: 16 output channels x 32 input channels per workgroup, no padded columns
-void launch_tiny_pack_resident(const Dims& d, const float* w, unsigned short* wq, hipStream_t s) {
-  const int frags = (d.C / 16) * (d.C / 32) * 9;
-  hipLaunchKernelGGL(k_tiny_pack, dim3((frags + 3) / 4), dim3(256), 0, s, w, wq, d.C, 16, 32, frags);
-}
 void launch_tiny_conv_gn(const Dims& d, const TinyConvArgs& b, hipStream_t s) {
   TinyArgs a;
   a.act = b.act; a.wq = b.wq; a.bias = b.bias; a.tmap = b.tmap; a.et = b.et; a.gamma = b.gamma; a.beta = b.beta; a.out = b.out;

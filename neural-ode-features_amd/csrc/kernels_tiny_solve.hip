@@ -246,17 +246,19 @@ __device__ __forceinline__ float ts_group_sum(float v, int cpg) {
 struct TinySolveArgs {
   const float* y0;              // NCHW [N][C][HW]
   float* y_out;                 // NCHW [n_targets][N][C][HW]: slot j <-> target j
-  const unsigned short* wq[2];  // k_tiny_pack(cpg = 16, CS = 32): [(gp KS + ks) 9 + tap][part][lane][8]
+  float* y_first;               // NCHW [N][C][HW]: the trajectory's slot of t0 (a copy of y0), nullable
+  const float* w[2];            // the convolutions' filters [C][C + 1][3][3] (input channel 0 = time, model.py:321-322), as the model holds them
   const float* bias[2];
-  const float* tmap[2];         // [HW][C]
   const float* gamma[3];
   const float* beta[3];
   ts_pair* act[2];              // NHWC [N][HW][C] tagged words: the convolutions' inputs, block by block
   ts_pair* part[2];             // [N GP][KS][4 elements][4 waves][64 lanes] tagged partial sums
   ts_pair* errpart;             // [2][R][2]: the reducers' partial sums of a step decision (double-buffered by exchange parity)
   unsigned* abort_word;         // == nonce: some wait of this solve ran into its deadline
-  Ctrl* ctrl;                   // out: the final record (what the host reads back)
-  const double* targets; int n_targets;
+  Ctrl* ctrl;                   // out: the final record, in the workspace (what k_export_record reads) ...
+  Ctrl* ctrl_host;              // ... and straight into the caller's pinned host record (visible when the launch has completed)
+  const double* targets; int n_targets;      // device array, or nullptr: the times ride in the arguments (<= 8 of them)
+  double targets_inline[8];
   const double* forced; int n_forced;
   double* dt_log; int dt_log_cap;
   double t0;
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   float* bsum = fl + 512;                          // [0..3], [8..11]: wave partials of two sums
   int* li = reinterpret_cast<int*>(fl + 528);      // [0..3] outcome of the last wait, per wave
   Ctrl* lc = reinterpret_cast<Ctrl*>(fl + 532);    // (16-byte aligned: fl is, 532 floats = 2128 B)
+  double* ltg = reinterpret_cast<double*>(fl + 532 + (sizeof(Ctrl) + 15) / 16 * 4);      // the target times, when they came in the arguments
 
 #ifdef NODE_DIAG
   // in-kernel timeline (diagnostics library only, NODE_TUNE_TINY_STAMPS=1): workgroups 0 (a reducer) and 1 (a worker) stamp the
@@ -308,11 +311,21 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   const unsigned nonce = a.nonce, tag_done = (nonce << 4) | TS_VERS;
   auto tag_of = [&](unsigned version) { return (nonce << 4) | (version % TS_VERS); };
 
-  // ---- prologue: this workgroup's filter slices of both convolutions -> LDS, for the whole solve
+  // ---- prologue: this workgroup's filter slices of both convolutions, straight from the model's fp32 tensors, split into exact bf16
+  // triples in B-fragment order (lane = 16 kq + col holds W[16 gp + col][32 ks + 8 kq .. + 7][tap]) -> LDS, for the whole solve.
+  // Wave w takes the taps w, w + 4, w + 8 (no packing launch, no packed copy in memory)
 #pragma unroll
   for (int cv = 0; cv < 2; ++cv) {
-    const s_u32x4* src = reinterpret_cast<const s_u32x4*>(a.wq[cv]) + (size_t)(gp * KS + ks) * 27 * 64;
-    for (int i = tid; i < 27 * 64; i += 256) Wf[cv * 27 * 64 + i] = src[i];
+    const float* wsrc = a.w[cv] + ((size_t)(gp * 16 + col) * (C + 1) + ks * 32 + kq * 8 + 1) * 9;
+    for (int tap = wave; tap < 9; tap += 4) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = wsrc[e * 9 + tap];
+      s_u32x4 hh, mm, ll;
+      ts_split8(v, hh, mm, ll);
+      s_u32x4* dst = Wf + cv * 27 * 64 + tap * 3 * 64 + lane;
+      dst[0] = hh; dst[64] = mm; dst[128] = ll;
+    }
   }
   // zero the activation planes once: the halo stays zero, the interior is rewritten by every staging
   for (int i = tid; i < (int)(3 * plane / 2); i += 256) reinterpret_cast<unsigned*>(A)[i] = 0u;
@@ -330,13 +343,33 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
     for (int i = 0; i < 4; ++i) k[j][i] = 0.f;
   float tm1[4] = {0.f, 0.f, 0.f, 0.f}, tm2[4] = {0.f, 0.f, 0.f, 0.f};
   float b1 = 0.f, b2 = 0.f, g1 = 0.f, e1 = 0.f, g2 = 0.f, e2 = 0.f, g3 = 0.f, e3 = 0.f;
+  if (tid < 8) ltg[tid] = a.targets_inline[tid];
+  const double* targets = a.targets != nullptr ? a.targets : ltg;
   if (is_red) {
+    // the time channel is constant over the image: its convolution is t x (sum of its taps that fall inside the image) -- the border
+    // map of k_time_prep, here for this lane's channel and four pixels
+    float wt1[9], wt2[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      wt1[tp] = a.w[0][(size_t)c * (C + 1) * 9 + tp];
+      wt2[tp] = a.w[1][(size_t)c * (C + 1) * 9 + tp];
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (on[i]) {
         y[i] = a.y0[((size_t)n * C + c) * HW + pix[i]];
-        tm1[i] = a.tmap[0][(size_t)pix[i] * C + c];
-        tm2[i] = a.tmap[1][(size_t)pix[i] * C + c];
+        if (a.y_first != nullptr) a.y_first[((size_t)n * C + c) * HW + pix[i]] = y[i];
+        const int ph = pix[i] / W, px = pix[i] % W;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int hh2 = ph + kh - 1, ww2 = px + kw - 1;
+            if (hh2 >= 0 && hh2 < H && ww2 >= 0 && ww2 < W) { s1 += wt1[kh * 3 + kw]; s2 += wt2[kh * 3 + kw]; }
+          }
+        tm1[i] = s1;
+        tm2[i] = s2;
       }
     b1 = a.bias[0][c]; b2 = a.bias[1][c];
     g1 = a.gamma[0][c]; e1 = a.beta[0][c];
@@ -687,7 +720,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
           StepCtlArgs sc;
           memset(&sc, 0, sizeof(sc));
           sc.ctrl = lc; sc.numel[0] = numel; sc.nseg = 1; sc.has_scalar = 0; sc.rtol = a.rtol; sc.atol = a.atol;
-          sc.targets = a.targets; sc.n_targets = a.n_targets;
+          sc.targets = targets; sc.n_targets = a.n_targets;
           sc.forced = a.forced; sc.n_forced = a.n_forced;
           sc.dt_log = rid == 0 ? a.dt_log : nullptr; sc.dt_log_cap = a.dt_log_cap;
           float ratios[4] = {(float)((double)tot / numel), 0.f, 0.f, 0.f};
@@ -699,7 +732,7 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
         if (j1 > j0) {
           const float dtu = (float)lc->dt_used, t0f = (float)lc->t_prev, t1f = (float)lc->t;
           for (int j = j0; j < j1; ++j) {
-            const float x = ((float)a.targets[j] - t0f) / (t1f - t0f);
+            const float x = ((float)targets[j] - t0f) / (t1f - t0f);
             float* out = a.y_out + (((size_t)j * a.N + n) * C + c) * HW;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -747,12 +780,18 @@ finished:
   }
 #endif
   if (failed) {      // some wait ran into its deadline: the record says so, whoever notices first
-    if (tid == 0) { a.ctrl->status = NODE_ERR_HIP; a.ctrl->done = 1; }
+    if (tid == 0) {
+      a.ctrl->status = NODE_ERR_HIP; a.ctrl->done = 1;
+      if (a.ctrl_host != nullptr) { a.ctrl_host->status = NODE_ERR_HIP; a.ctrl_host->done = 1; }
+    }
     return;          // (the abort word releases everybody else)
   }
   if (!is_red) return;
   __syncthreads();
-  if (rid == 0 && tid == 0) *a.ctrl = *lc;
+  if (rid == 0 && tid == 0) {
+    *a.ctrl = *lc;
+    if (a.ctrl_host != nullptr) *a.ctrl_host = *lc;
+  }
   // the workers of the next evaluation are polling this block: tell them the solve is over
   const float zero[4] = {0.f, 0.f, 0.f, 0.f};
   publish(a.act[0], zero, tag_done);
@@ -780,7 +819,6 @@ bool tiny_resident_ok(const Dims& d) {
   if ((size_t)(d.H + 2) * (d.W + 2) > 128) return false;           // (LDS planes of the padded image)
   return true;
 }
-size_t tiny_resident_packed_elems(const Dims& d) { return (size_t)(d.C / 16) * (d.C / 32) * 9 * 3 * 64 * 8; }
 // tagged words (8 bytes each) of the hand-off buffers: two activation buffers | two partial-sum buffers | the decision exchange
 size_t tiny_resident_handoff_words(const Dims& d) {
   return 2 * d.numel + 2 * (size_t)d.N * (d.C / 16) * (d.C / 32) * 1024 + (size_t)2 * d.N * (d.C / 16) * 2 + 16;
@@ -789,7 +827,8 @@ void launch_tiny_solve(const Dims& d, const TinyResidentArgs& b, hipStream_t s) 
   TinySolveArgs a;
   memset(&a, 0, sizeof(a));
   a.y0 = b.y0; a.y_out = b.y_out;
-  for (int i = 0; i < 2; ++i) { a.wq[i] = b.wq[i]; a.bias[i] = b.bias[i]; a.tmap[i] = b.tmap[i]; }
+  a.y_first = b.y_first;
+  for (int i = 0; i < 2; ++i) { a.w[i] = b.w[i]; a.bias[i] = b.bias[i]; }
   {
     ts_pair* w = reinterpret_cast<ts_pair*>(b.handoff);
     const size_t parts = (size_t)d.N * (d.C / 16) * (d.C / 32) * 1024;
@@ -798,7 +837,8 @@ void launch_tiny_solve(const Dims& d, const TinyResidentArgs& b, hipStream_t s) 
     a.errpart = a.part[1] + parts;
     a.abort_word = reinterpret_cast<unsigned*>(a.errpart + (size_t)2 * d.N * (d.C / 16) * 2);
   }
-  a.ctrl = b.ctrl; a.nonce = b.nonce;
+  a.ctrl = b.ctrl; a.ctrl_host = b.ctrl_host; a.nonce = b.nonce;
+  for (int i = 0; i < 8; ++i) a.targets_inline[i] = b.targets_inline[i];
   { const char* e = getenv("NODE_TUNE_TINY_STAMPS"); a.stamps = e ? atoi(e) : 0; }
   for (int i = 0; i < 3; ++i) { a.gamma[i] = b.gamma[i]; a.beta[i] = b.beta[i]; }
   a.targets = b.targets; a.n_targets = b.n_targets; a.forced = b.forced; a.n_forced = b.n_forced;
@@ -806,7 +846,7 @@ void launch_tiny_solve(const Dims& d, const TinyResidentArgs& b, hipStream_t s) 
   a.rtol = b.rtol; a.atol = b.atol; a.tsign = b.tsign; a.eps = d.eps;
   a.N = d.N; a.C = d.C; a.H = d.H; a.W = d.W; a.cpg = d.cpg; a.KS = d.C / 32; a.GP = d.C / 16;
   const size_t plane = (size_t)(d.H + 2) * (d.W + 2) * TS_PITCH;
-  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 532 * sizeof(float) + sizeof(Ctrl) + 64;
+  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 532 * sizeof(float) + (sizeof(Ctrl) + 15) / 16 * 16 + 8 * sizeof(double) + 64;
   static bool attr[MAX_DEVICES] = {};
   allow_full_lds(reinterpret_cast<const void*>(k_tiny_solve), attr);
   hipLaunchKernelGGL(k_tiny_solve, dim3(d.N * a.GP * a.KS), dim3(256), lds, s, a);

@@ -531,10 +531,7 @@ struct Solver {
       launch_pack_weights_small(d, prm.conv1_w, p.wsmall[0], st);
       launch_pack_weights_small(d, prm.conv2_w, p.wsmall[1], st);
     }
-    if (tiny_mode() && !w4 && resident) {     // (the whole solve is one launch: its own slicing of the filters)
-      launch_tiny_pack_resident(d, prm.conv1_w, p.wtiny[0], st);
-      launch_tiny_pack_resident(d, prm.conv2_w, p.wtiny[1], st);
-    } else if (tiny_mode() && !w4) {
+    if (tiny_mode() && !w4) {
       launch_tiny_pack(d, prm.conv1_w, p.wtiny[0], st);
       launch_tiny_pack(d, prm.conv2_w, p.wtiny[1], st);
       launch_fill(reinterpret_cast<float*>(p.tcount), 0.f, (size_t)d.N * d.G, st);     // (0.f is the all-zero word)
@@ -1248,9 +1245,11 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
 
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   S.choose_resident(method == NODE_METHOD_DOPRI5);
-  TRY(S.prepare());
-  if (!S.resident) S.to_state(y0, S.p.Y);
-  HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  if (!S.resident) {      // (the resident solve packs its filters, forms its border maps and copies y0 inside its one launch)
+    TRY(S.prepare());
+    S.to_state(y0, S.p.Y);
+    HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  }
 
   if (method == NODE_METHOD_RK4) {
     launch_set_ctrl(S.p.ctrl, ts[0], 0.0, 1, S.st);
@@ -1277,7 +1276,10 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
   // touched by the host after it returns); the outcome goes to the caller's device record
   const int blind = (opts && opts->blind_steps > 0 && opts->record && n_t == 2 && !forced && io.log_cap == 0)
                         ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
-  if (blind) {
+  const bool inline_targets = S.resident && io.n_targets <= 8;      // (the target times ride in the kernel arguments)
+  if (inline_targets) {
+    if (blind) HIP_TRY(hipMemcpyAsync(y_out + numel, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+  } else if (blind) {
     launch_set_target(S.p.targets, ts[1], S.st);
     // a MISSED blind solve never emits its output: leave y0 there, not uninitialised memory (the caller's loss of
     // such a step is then a finite number of a step whose update is skipped anyway)
@@ -1291,13 +1293,12 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     // as it needs (a deferred solve of this kind cannot miss), and the host reads the same record back
     TinyResidentArgs ra;
     memset(&ra, 0, sizeof(ra));
-    ra.y0 = y0; ra.y_out = io.y_out;
-    ra.wq[0] = S.p.wtiny[0]; ra.wq[1] = S.p.wtiny[1];
+    ra.y0 = y0; ra.y_first = y_out; ra.y_out = io.y_out;
+    ra.w[0] = params->conv1_w; ra.w[1] = params->conv2_w;
     ra.bias[0] = params->conv1_b; ra.bias[1] = params->conv2_b;
-    ra.tmap[0] = S.p.tmap[0]; ra.tmap[1] = S.p.tmap[1];
     ra.gamma[0] = params->norm1_w; ra.gamma[1] = params->norm2_w; ra.gamma[2] = params->norm3_w;
     ra.beta[0] = params->norm1_b; ra.beta[1] = params->norm2_b; ra.beta[2] = params->norm3_b;
-    ra.handoff = S.p.thand; ra.ctrl = S.p.ctrl;
+    ra.handoff = S.p.thand; ra.ctrl = S.p.ctrl; ra.ctrl_host = blind ? nullptr : S.hctrl;
     {
       // every word that crosses workgroups carries {nonce, version}: stale words of any earlier solve of this process never match, so
       // nothing is zeroed per solve.  The 28-bit nonce starts over every 2^28 solves: a hand-off buffer is zeroed the first time it
@@ -1319,11 +1320,13 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
       if (!known) HIP_TRY(hipMemsetAsync(S.p.thand, 0, tiny_resident_handoff_words(S.d) * 8, S.st));
       ra.nonce = nn;
     }
-    ra.targets = S.p.targets; ra.n_targets = io.n_targets;
+    ra.targets = inline_targets ? nullptr : S.p.targets; ra.n_targets = io.n_targets;
+    if (inline_targets) for (int j = 0; j < io.n_targets; ++j) ra.targets_inline[j] = ts[j + 1];
     ra.forced = forced ? S.p.forced : nullptr; ra.n_forced = io.n_forced;
     ra.dt_log = io.log_cap > 0 ? S.p.dtlog : nullptr; ra.dt_log_cap = io.log_cap;
     ra.t0 = ts[0]; ra.max_steps = max_steps;
     ra.rtol = rtol; ra.atol = atol; ra.tsign = S.tsign;
+    if (!blind) { S.hctrl->done = 0; S.hctrl->status = NODE_ERR_HIP; }      // (overwritten by the launch: if it never ran, the record says so)
     launch_tiny_solve(S.d, ra, S.st);
     S.nfe = forced ? 1 : 2;
     if (blind) {
@@ -1335,7 +1338,8 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
       if (stats) *stats = stt;
       return S.check_launch("node_solve_fwd(dopri5, resident, deferred)");
     }
-    TRY(S.readback());
+    // the launch wrote the record into the pinned host copy itself: completion of the stream is all the host waits for
+    HIP_TRY(hipStreamSynchronize(S.st));
   } else {
   launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
   TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)

@@ -440,16 +440,18 @@ struct TinyConvArgs {
 // latency path, resident form (kernels_tiny_solve.hip): a whole forward dopri5 solve of a tiny state in one launch
 struct TinyResidentArgs {
   const float* y0;               // NCHW
+  float* y_first;                // NCHW: the trajectory's first slot (<- y0), nullable
   float* y_out;                  // NCHW [n_targets][N][C][HW]
-  const unsigned short* wq[2];   // launch_tiny_pack_resident
+  const float* w[2];             // conv1 / conv2 filters as the model holds them: [C][C + 1][3][3]
   const float* bias[2];
-  const float* tmap[2];
   const float* gamma[3];
   const float* beta[3];
-  void* handoff;                 // tiny_resident_handoff_words 8-byte tagged words (never zeroed: see `nonce`)
+  void* handoff;                 // tiny_resident_handoff_words 8-byte tagged words (never zeroed per solve: see `nonce`)
   unsigned nonce;                // 28 bits, never repeated by this process within 2^28 solves
-  Ctrl* ctrl;
-  const double* targets; int n_targets;
+  Ctrl* ctrl;                    // the record in the workspace
+  Ctrl* ctrl_host;               // the caller's pinned host copy (nullable)
+  const double* targets; int n_targets;      // device array, or nullptr with the times in targets_inline (n_targets <= 8)
+  double targets_inline[8];
   const double* forced; int n_forced;
   double* dt_log; int dt_log_cap;
   double t0;
@@ -457,9 +459,7 @@ struct TinyResidentArgs {
   float rtol, atol, tsign;
 };
 bool tiny_resident_ok(const Dims& d);
-size_t tiny_resident_packed_elems(const Dims& d);
 size_t tiny_resident_handoff_words(const Dims& d);
-void launch_tiny_pack_resident(const Dims& d, const float* w, unsigned short* wq, hipStream_t s);
 void launch_tiny_solve(const Dims& d, const TinyResidentArgs& a, hipStream_t s);
 int tiny_slice_channels(const Dims& d);
 size_t tiny_packed_elems(const Dims& d);
