@@ -269,7 +269,7 @@ struct TinySolveArgs {
   int N, C, H, W, cpg, KS, GP;
 };
 
-// LDS: Wf [2 convs][27 fragments][64 lanes] 16 B | A [3 parts][PP][TS_PITCH] bf16 | floats: red_a[256] red_b[256] bsum[16] | ints [4] | Ctrl
+// LDS: Wf [2 convs][27 fragments][64 lanes] 16 B | A [3 parts][PP][TS_PITCH] bf16 | floats: red_a[256] red_b[256] bsum[16] | ints [12] | Ctrl | target times [8]
 __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   extern __shared__ __align__(16) unsigned char lsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,14 +283,14 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   float* red_a = fl;
   float* red_b = fl + 256;
   float* bsum = fl + 512;                          // [0..3], [8..11]: wave partials of two sums
-  int* li = reinterpret_cast<int*>(fl + 528);      // [0..3] outcome of the last wait, per wave
-  Ctrl* lc = reinterpret_cast<Ctrl*>(fl + 532);    // (16-byte aligned: fl is, 532 floats = 2128 B)
-  double* ltg = reinterpret_cast<double*>(fl + 532 + (sizeof(Ctrl) + 15) / 16 * 4);      // the target times, when they came in the arguments
+  int* li = reinterpret_cast<int*>(fl + 528);      // outcome of a wait, per wave: [0..3] activations, [4..7] partial sums, [8..11] agree()
+  Ctrl* lc = reinterpret_cast<Ctrl*>(fl + 540);    // (16-byte aligned: fl is, 540 floats = 2160 B)
+  double* ltg = reinterpret_cast<double*>(fl + 540 + (sizeof(Ctrl) + 15) / 16 * 4);      // the target times, when they came in the arguments
 
 #ifdef NODE_DIAG
   // in-kernel timeline (diagnostics library only, NODE_TUNE_TINY_STAMPS=1): workgroups 0 (a reducer) and 1 (a worker) stamp the
   // constant 100 MHz clock at the phases of their first 48 convolutions and print the differences when the solve is over
-  __shared__ long long stamp[48][8];
+  __shared__ long long stamp[48][10];
   __shared__ int rounds[4];      // gather rounds (summed over the four waves): activations, partial sums; calls of each
   if (tid < 4) rounds[tid] = 0;
 #define TS_ROUNDS(k) (a.stamps ? &rounds[k] : nullptr)
@@ -392,7 +392,8 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   auto group_norm = [&](float (&v)[4], float gm, float bt, bool relu) {
     const int grp = col / cpg;
     float s = ts_rows_sum(ts_group_sum((v[0] + v[1]) + (v[2] + v[3]), cpg));
-    __syncthreads();                       // (the previous use of red_a / red_b is over in every wave)
+    // (no barrier in front: a wave gets here through the second barrier of the previous call, behind which nobody reads red_a; red_b is
+    //  written behind the first barrier of this call, behind which nobody reads the previous red_b)
     if (kq == 0 && (col & (cpg - 1)) == 0) red_a[grp * 4 + wave] = s;
     __syncthreads();
     const float4 ta = *reinterpret_cast<const float4*>(red_a + grp * 4);
@@ -421,12 +422,12 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
   };
   // the outcome of a wave-level wait, agreed on by the workgroup: 0 go on, 1 the grid gave up, 2 the solve is over
   auto agree = [&](int code) -> int {
-    if (lane == 0) li[wave] = code;
+    if (lane == 0) li[8 + wave] = code;
     __syncthreads();
-    const int c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
+    const int c0 = li[8], c1 = li[9], c2 = li[10], c3 = li[11];
     const int any1 = (c0 == 1) | (c1 == 1) | (c2 == 1) | (c3 == 1);
     const int any2 = (c0 == 2) | (c1 == 2) | (c2 == 2) | (c3 == 2);
-    __syncthreads();                       // (li is free again)
+    __syncthreads();                       // (li[8..11] are free again)
     return any1 ? 1 : (any2 ? 2 : 0);
   };
   // deterministic sum over the workgroup of two values, result in every thread
@@ -496,28 +497,32 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
           ptr[j] = src + (size_t)(use[j] ? p : 0) * C + 2 * cp;
           lds_at[j] = ((p / W + 1) * Wp + (p % W) + 1) * TS_PITCH + 2 * cp;
         }
-        {   // watch the last word of each of the two blocks (pixel HW - 1, channel 15 of the block) before asking for 8 KB
-          int wcode = 0;
-          if (wave == 0) wcode = ts_watch<true>(src + (size_t)(HW - 1) * C + 16 * (lane & 1) + 15, lane < 2, tag, tag_done, a.abort_word, nonce);
-          wcode = agree(wcode);
-          if (wcode != 0) { failed = wcode == 1; goto finished; }
-          TS_STAMP(1);
-        }
+        // each wave waits for ITS pixel tile on its own: it watches the tile's last word in each of the two blocks (two 8-byte polls per
+        // round), then asks for its 4 KB; the outcome meets the other waves' at the barrier the staging needs anyway
+        const int plast = (wave * 16 + 15 < HW ? wave * 16 + 15 : HW - 1);
+        int code = ts_watch<true>(src + (size_t)plast * C + 16 * (lane & 1) + 15, lane < 2 && wave * 16 < HW, tag, tag_done, a.abort_word, nonce);
+        TS_STAMP(1);
         float f[8];
-        const int code = agree(ts_gather2<4, true>(ptr, use, tag, tag_done, f, a.abort_word, nonce, TS_ROUNDS(0)));
-        if (code != 0) { failed = code == 1; goto finished; }
+        if (code == 0) code = ts_gather2<4, true>(ptr, use, tag, tag_done, f, a.abort_word, nonce, TS_ROUNDS(0));
         TS_STAMP(2);
-        s_u32x4 hh, mm, ll;
-        ts_split8(f, hh, mm, ll);       // (pair j = the two channels of pixel j: one 32-bit LDS word per part)
+        if (code == 0) {
+          s_u32x4 hh, mm, ll;
+          ts_split8(f, hh, mm, ll);       // (pair j = the two channels of pixel j: one 32-bit LDS word per part)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (use[j]) {
-            *reinterpret_cast<unsigned*>(A + lds_at[j]) = hh[j];
-            *reinterpret_cast<unsigned*>(A + plane + lds_at[j]) = mm[j];
-            *reinterpret_cast<unsigned*>(A + 2 * plane + lds_at[j]) = ll[j];
-          }
+          for (int j = 0; j < 4; ++j)
+            if (use[j]) {
+              *reinterpret_cast<unsigned*>(A + lds_at[j]) = hh[j];
+              *reinterpret_cast<unsigned*>(A + plane + lds_at[j]) = mm[j];
+              *reinterpret_cast<unsigned*>(A + 2 * plane + lds_at[j]) = ll[j];
+            }
+        }
+        if (lane == 0) li[wave] = code;
       }
       __syncthreads();
+      {
+        const int c0 = li[0], c1 = li[1], c2 = li[2], c3 = li[3];
+        if ((c0 | c1 | c2 | c3) != 0) { failed = c0 == 1 || c1 == 1 || c2 == 1 || c3 == 1; goto finished; }
+      }
       TS_STAMP(3);
       // ---- products: wave = pixel tile, nine K steps (tap x 32 channels), six part products each
       s_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -570,19 +575,19 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
             ptr[2 * q + h] = part + (size_t)(sl < KS ? sl : 0) * 1024 + h * 512 + (size_t)(wave * 64 + lane) * 2;
           }
         }
-        {   // watch the last word of each other slice's partial sums (wave 3, lane 63, element 3)
-          int wcode = 0;
-          if (wave == 0) {
-            const int q = lane & 7;
-            wcode = ts_watch<false>(part + (size_t)q * 1024 + 1023, lane < 8 && q < KS && q != ks, tag, 0u, a.abort_word, nonce);
-          }
-          if (agree(wcode) != 0) { failed = true; goto finished; }
-          TS_STAMP(5);
+        // each wave waits for ITS quarter of the seven other slices: lanes 0 - 7 watch the last word wave `wave` of a slice writes
+        int code;
+        {
+          const int q = lane & 7;
+          code = ts_watch<false>(part + (size_t)q * 1024 + 512 + (size_t)(wave * 64 + 63) * 2 + 1, lane < 8 && q < KS && q != ks, tag, 0u, a.abort_word, nonce);
         }
+        TS_STAMP(5);
         float got[28];
-        const int code = agree(ts_gather2<14, false>(ptr, use, tag, 0u, got, a.abort_word, nonce, TS_ROUNDS(1)));
-        if (code != 0) { failed = true; goto finished; }
+        if (code == 0) code = ts_gather2<14, false>(ptr, use, tag, 0u, got, a.abort_word, nonce, TS_ROUNDS(1));
         TS_STAMP(6);
+        if (lane == 0) li[4 + wave] = code;
+        __syncthreads();
+        if ((li[4] | li[5] | li[6] | li[7]) != 0) { failed = true; goto finished; }
         // got[4 q + i]: slot q; the sum runs in slice order, this workgroup's own slice in its place (slots past KS: zeros)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -601,7 +606,9 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = on[i] ? acc[i] + b1 + tnow * tm1[i] : 0.f;
+        TS_STAMP(8);
         group_norm(v, g2, e2, true);
+        TS_STAMP(9);
         publish(a.act[1], v, tag);
         TS_STAMP(7);
         TS_STAMP_NEXT();
@@ -612,7 +619,9 @@ __global__ __launch_bounds__(256) void k_tiny_solve(const TinySolveArgs a) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = on[i] ? acc[i] + b2 + tnow * tm2[i] : 0.f;
+        TS_STAMP(8);
         group_norm(v, g3, e3, false);
+        TS_STAMP(9);
 #pragma unroll
         for (int j = 0; j < 7; ++j)
           if (j == slot)
@@ -771,8 +780,8 @@ finished:
     for (int i = 0; i < stamp_row && i < 48; ++i) {
       const long long b = stamp[i][0];
       if (blockIdx.x == 0)
-        printf("wg 0 conv %2d: top %7lld | +watch %4lld +gather %4lld +stage %4lld +mfma %4lld +watch-parts %4lld +gather-parts %4lld +epilogue %4lld (x10 ns)\n", i,
-               b % 10000000, stamp[i][1] - b, stamp[i][2] - b, stamp[i][3] - b, stamp[i][4] - b, stamp[i][5] - b, stamp[i][6] - b, stamp[i][7] - b);
+        printf("wg 0 conv %2d: top %7lld | +watch %4lld +gather %4lld +stage %4lld +mfma %4lld +watch-parts %4lld +gather-parts %4lld +sum %4lld +norm %4lld +epilogue %4lld (x10 ns)\n", i,
+               b % 10000000, stamp[i][1] - b, stamp[i][2] - b, stamp[i][3] - b, stamp[i][4] - b, stamp[i][5] - b, stamp[i][6] - b, stamp[i][8] - b, stamp[i][9] - b, stamp[i][7] - b);
       else
         printf("wg 1 conv %2d: top %7lld | +watch %4lld +gather %4lld +stage %4lld +mfma %4lld +put %4lld (x10 ns)\n", i,
                b % 10000000, stamp[i][1] - b, stamp[i][2] - b, stamp[i][3] - b, stamp[i][4] - b, stamp[i][5] - b);
@@ -846,10 +855,12 @@ void launch_tiny_solve(const Dims& d, const TinyResidentArgs& b, hipStream_t s) 
   a.rtol = b.rtol; a.atol = b.atol; a.tsign = b.tsign; a.eps = d.eps;
   a.N = d.N; a.C = d.C; a.H = d.H; a.W = d.W; a.cpg = d.cpg; a.KS = d.C / 32; a.GP = d.C / 16;
   const size_t plane = (size_t)(d.H + 2) * (d.W + 2) * TS_PITCH;
-  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 532 * sizeof(float) + (sizeof(Ctrl) + 15) / 16 * 16 + 8 * sizeof(double) + 64;
+  const size_t lds = (size_t)2 * 27 * 64 * 16 + ((3 * plane * 2 + 15) & ~(size_t)15) + 540 * sizeof(float) + (sizeof(Ctrl) + 15) / 16 * 16 + 8 * sizeof(double) + 64;
   static bool attr[MAX_DEVICES] = {};
   allow_full_lds(reinterpret_cast<const void*>(k_tiny_solve), attr);
-  hipLaunchKernelGGL(k_tiny_solve, dim3(d.N * a.GP * a.KS), dim3(256), lds, s, a);
+  int grid = d.N * a.GP * a.KS;
+  { const char* e = getenv("NODE_TUNE_TINY_RESIDENT"); if (e != nullptr && atoi(e) == 2 && grid > 1) --grid; }    // test hook: a grid that is NOT whole -- every wait must run into its deadline, the grid must drain
+  hipLaunchKernelGGL(k_tiny_solve, dim3(grid), dim3(256), lds, s, a);
 }
 
 }  // namespace node

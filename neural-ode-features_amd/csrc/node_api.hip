@@ -1340,10 +1340,22 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     }
     // the launch wrote the record into the pinned host copy itself: completion of the stream is all the host waits for
     HIP_TRY(hipStreamSynchronize(S.st));
-  } else {
-  launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
-  TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
-  if (!forced) TRY(S.initial_step());
+    if (S.hctrl->status == NODE_ERR_HIP) {
+      // a wait inside the launch ran into its deadline: the grid was not co-resident (other processes' resident grids on this
+      // GPU can leave two launches each waiting for compute units the other holds).  Every workgroup has left; the solve runs
+      // again on the launch-per-convolution path, which needs no co-residency.
+      S.resident = false;
+      S.nfe = 0;
+      TRY(S.prepare());
+      S.to_state(y0, S.p.Y);
+      HIP_TRY(hipMemcpyAsync(y_out, y0, numel * sizeof(float), hipMemcpyDeviceToDevice, S.st));
+      if (inline_targets) TRY(S.upload(S.p.targets, ts.data() + 1, n_t - 1, hs->lists));
+    }
+  }
+  if (!S.resident) {
+    launch_set_ctrl(S.p.ctrl, ts[0], forced ? opts->forced_dt[0] : 0.0, 1, S.st);
+    TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));  // f0 (FSAL seed)
+    if (!forced) TRY(S.initial_step());
   }
   if (blind) {
     for (int i = 0; i < blind; ++i) TRY(S.enqueue_step(io));

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @contextlib.contextmanager
 def resident(on):
     old = os.environ.get('NODE_TUNE_TINY_RESIDENT')
-    os.environ['NODE_TUNE_TINY_RESIDENT'] = '1' if on else '0'
+    os.environ['NODE_TUNE_TINY_RESIDENT'] = str(int(on))
     try:
         yield
     finally:
@@ -177,3 +177,31 @@ def test_resident_solve_through_the_module_interface_and_deferred_record():
     torch.cuda.synchronize()
     assert torch.equal(out, ref) and float(flag) == 0.0
     assert nfe >= 2 + 6 * (st['accepted'] + st['rejected'])
+
+
+def test_a_grid_that_is_not_whole_drains_and_the_solve_falls_back():
+    """The resident solve needs its whole grid on the chip.  NODE_TUNE_TINY_RESIDENT=2 launches it one workgroup short: every
+    wait runs into its deadline (2 s of the constant clock), the grid drains, the C call repeats the solve on the
+    launch-per-convolution path -- same result as that path by itself, no error, and the next solve is resident again."""
+    import time
+    import neural_ode_features_amd as nof
+    shape = (1, 128, 8, 8)
+    f, _ = make_func(shape[1], seed=351, device='cuda')
+    t = torch.tensor([0.0, 0.5, 1.0]).cuda()
+    y = torch.randn(*shape, generator=torch.Generator().manual_seed(352)).cuda()
+    with torch.no_grad():
+        with resident(0):
+            want = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+            stats = dict(f.last_forward_stats)
+        with resident(2):
+            t0 = time.perf_counter()
+            got = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+            torch.cuda.synchronize()
+            waited = time.perf_counter() - t0
+            assert dict(f.last_forward_stats) == stats
+        with resident(1):
+            again = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
+    print('fallback after %.2f s' % waited)
+    assert torch.equal(got, want)
+    assert 1.5 < waited < 10.0
+    assert rel_err(again, want) < 1e-4
