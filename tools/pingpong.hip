@@ -85,7 +85,8 @@ int main() {
   CK(hipMalloc(&data, (size_t)16 * 256 * 8 * 8));
   const int iters = 2000;
   unsigned hx[64];
-  for (int scope = 0; scope < 3; ++scope) {
+  // (workgroup scope, sc0: the polling load keeps hitting its own L1 -- the loop never ends; not run)
+  for (int scope = 0; scope < 3; scope += 2) {
     for (int partner : {1, 8, 4}) {
       CK(hipMemset(flags, 0, 4096)); CK(hipMemset(out, 0, 64));
       if (scope == 0) hipLaunchKernelGGL(k_pingpong<__HIP_MEMORY_SCOPE_AGENT>, dim3(16), dim3(64), 0, 0, flags, 0, partner, iters, out, xcc);
@@ -99,8 +100,8 @@ int main() {
              hx[partner], t * 10.0 / (2.0 * iters), t == 0 ? "  (did not finish)" : "");
     }
   }
-  for (int nprod : {1, 7, 15})
-    for (int wpl : {1, 4, 8}) {
+  for (int nprod : {1, 7})
+    for (int wpl : {1, 4}) {
       CK(hipMemset(data, 0, (size_t)16 * 256 * 8 * 8)); CK(hipMemset(go, 0, 256)); CK(hipMemset(out, 0, 64));
       hipLaunchKernelGGL(k_fanin, dim3(nprod + 1), dim3(256), 0, 0, data, go, nprod, wpl, 500, out);
       CK(hipDeviceSynchronize());
