@@ -907,6 +907,8 @@ struct Solver {
                     p.KY[kout], p.KA[kout], p.KT[kout], kout, -1.f, nullptr, need_theta, next);
   }
 
+  // (measured and not kept, profiles/r05_poll_readback_ab.txt: the record stored into coherent pinned memory by a one-thread launch and
+  //  a host spin on its sequence number instead of copy + synchronise -- 0.884 vs 0.883 of the deferred rate: hipStreamSynchronize spins too)
   int readback() {
     HIP_TRY(hipMemcpyAsync(hctrl, p.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1521,7 +1523,9 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
     if (stats) *stats = stt;
     return S.check_launch("node_solve_adjoint(deferred)");
   }
-  HIP_TRY(hipStreamSynchronize(S.st));
+  // (dopri5: every interval ended with a read-back, behind which nothing of this call is staged on the host -- the launches above are
+  //  ordinary stream work the caller's next launches queue behind, and the host does not wait for them; rk4 has no read-back)
+  if (method == NODE_METHOD_RK4) HIP_TRY(hipStreamSynchronize(S.st));
   stt.nfe = S.nfe + 6 * steps_total;
   stt.t_final = cur_t; stt.last_dt = cur_dt;
   if (stats) *stats = stt;
