@@ -11,7 +11,7 @@
 //     part products each: fp32 accuracy, the split of kernels_w4.hip), the 64 x 16 partial sums go to the block's REDUCER
 //     (the workgroup with ks == gp mod KS), which adds the slices in slice order, applies bias + t x time map + GroupNorm
 //     (+ ReLU) and publishes the block -- workers of the next convolution wait for exactly the two blocks they read
-//     (point-to-point version flags: no grid barrier anywhere in an evaluation);
+//     (point-to-point: no grid barrier anywhere in an evaluation);
 //   * the reducers hold the solver state of their block -- y, y1, k1..k7: 36 registers per lane -- so the Butcher combines,
 //     the error norm, dense output and FSAL touch no memory; the step's decision needs ONE all-reducer exchange of a partial
 //     sum per step (two more for the initial step), and every reducer takes the decision redundantly, through the same code
@@ -22,7 +22,11 @@
 //     (the low-latency protocol of the collective libraries; a hand-off is one store and one load that sees it).  Nothing is
 //     zeroed between solves (stale pairs carry an older nonce); every wait is a bounded spin -- a deadline on the constant
 //     100 MHz clock -- that raises a grid-wide abort word, so the grid drains whatever happens to a neighbour.
-// The grid must be co-resident (one workgroup per CU: N x (C/16) x (C/32) <= CUs; 128 workgroups at [1,256,8,8]).
+//   * one launch and one stream synchronisation per solve: the launch splits the model's fp32 filters itself, forms the time
+//     channel's border maps, copies y0 into the trajectory and writes the record into the caller's pinned host copy.
+// The grid must be co-resident (one workgroup per CU: N x (C/16) x (C/32) <= CUs; 128 workgroups at [1,256,8,8]); a grid that is
+// not runs into its deadline, drains, and node_solve_fwd repeats the solve on kernels_tiny.hip.  Measured: DESIGN.md 4.7,
+// profiles/r05_latency_bs1.txt (18.0 / 15.6 us per evaluation at [1,256,8,8], tol 1e-3 / 1e-5; kernels_tiny.hip 33.9 / 29.7).
 #include "node_internal.h"
 #include "step_control.h"
 #include <cstdlib>
