@@ -22,3 +22,4 @@ except Exception as e:
     print('$f failed', e)
 "; done
 grep -E "k_head_loss|TIMED" $E/cfg2_steps.txt | cut -c1-140
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
