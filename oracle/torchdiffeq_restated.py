@@ -25,7 +25,11 @@ oracle cannot be checked against the reference's own numbers.  It is pinned
 instead by (tests/test_oracle_*.py):
   * exact-rational identities of the Dormand-Prince/Shampine tableau
     (order conditions 1..5 for b, 1..4 for b-hat, mid-point conditions);
-  * closed-form ODEs (y'=-y, y'=Ay, y'=t*y) and scipy cross-checks;
+  * closed-form ODEs (y'=-y, y'=Ay, y'=t*y);
+  * an independent implementation of the same pair, scipy's RK45: tableau, and -- one step of a
+    fixed size from the same state -- propagated solution, FSAL derivative, embedded error estimate
+    and the continuous extension at interior points (the quartic of `_interp_fit_dopri5` IS
+    scipy's dense-output polynomial, to 1e-11);
   * convergence order (h^5 dopri5 fixed-h, h^4 rk4 3/8 rule);
   * the reference's own cost model NFE = 2 + 6*steps (``show.py:199``);
   * adjoint gradients vs autograd through the unrolled solver and vs fp64

@@ -137,6 +137,39 @@ def test_nfe_cost_model_show_py_199():
     assert st.nfe == 4
 
 
+def test_one_step_and_dense_output_vs_scipy_rk45():
+    """An independent implementation of the same pair: scipy's RK45 (Dormand-Prince 5(4), Shampine's dense output).  One
+    step of a fixed size from the same state: the propagated solution, the FSAL derivative, the embedded error estimate
+    (scipy's E is -3/2 of Shampine's weights, see above) and the continuous extension at interior points -- the quartic the
+    restated `_interp_fit_dopri5` builds from (y0, y1, y_mid, f0, f1) must be scipy's polynomial."""
+    rk = pytest.importorskip('scipy.integrate._ivp.rk')
+
+    def f_np(t, y):
+        return np.array([np.sin(3 * t) * y[1] - 0.5 * y[0] ** 2, np.cos(y[0]) + t * y[2], -y[2] * y[1] + 0.3])
+
+    def f_t(t, y):
+        (y,) = y
+        return (torch.stack([torch.sin(3 * t) * y[1] - 0.5 * y[0] ** 2, torch.cos(y[0]) + t * y[2], -y[2] * y[1] + 0.3]),)
+
+    t0, h = 0.2, 0.37
+    y0 = np.array([0.7, -1.1, 0.4])
+    K = np.empty((7, 3))
+    y1_s, f1_s = rk.rk_step(f_np, t0, y0, f_np(t0, y0), h, rk.RK45.A, rk.RK45.B, rk.RK45.C, K)
+    err_s = K.T @ rk.RK45.E * h
+    Q = K.T @ rk.RK45.P
+    y0_t = (torch.tensor(y0, dtype=torch.float64),)
+    f0_t = f_t(torch.tensor(t0, dtype=torch.float64), y0_t)
+    y1_o, f1_o, err_o, k = tdq._runge_kutta_step(f_t, y0_t, f0_t, t0, h)
+    assert np.allclose(y1_o[0].numpy(), y1_s, rtol=1e-13, atol=1e-15)
+    assert np.allclose(f1_o[0].numpy(), f1_s, rtol=1e-13, atol=1e-15)
+    assert np.allclose(err_o[0].numpy(), -2.0 / 3.0 * err_s, rtol=1e-9, atol=1e-16)
+    coef = tdq._interp_fit_dopri5(y0_t, y1_o, k, torch.tensor(h, dtype=torch.float64))
+    for x in (0.0, 0.1, 0.25, 0.5, 0.77, 1.0):
+        got = tdq._interp_evaluate(coef, t0, t0 + h, t0 + x * h)[0].numpy()
+        want = y0 + h * (Q @ np.cumprod(np.full(4, x)))
+        assert np.allclose(got, want, rtol=1e-11, atol=1e-13), (x, got, want)
+
+
 def test_dense_output_against_tight_solve():
     f = lambda t, y: torch.stack([y[1], -y[0]])   # noqa: E731
     y0 = torch.tensor([0.0, 1.0], dtype=torch.float64)
