@@ -29,7 +29,8 @@ instead by (tests/test_oracle_*.py):
   * an independent implementation of the same pair, scipy's RK45: tableau, and -- one step of a
     fixed size from the same state -- propagated solution, FSAL derivative, embedded error estimate
     and the continuous extension at interior points (the quartic of `_interp_fit_dopri5` IS
-    scipy's dense-output polynomial, to 1e-11);
+    scipy's dense-output polynomial, to 1e-11); Hairer's starting step equals scipy's
+    `select_initial_step` (order 4, rms norm) to 1e-12;
   * convergence order (h^5 dopri5 fixed-h, h^4 rk4 3/8 rule);
   * the reference's own cost model NFE = 2 + 6*steps (``show.py:199``);
   * adjoint gradients vs autograd through the unrolled solver and vs fp64

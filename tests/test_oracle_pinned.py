@@ -170,6 +170,28 @@ def test_one_step_and_dense_output_vs_scipy_rk45():
         assert np.allclose(got, want, rtol=1e-11, atol=1e-13), (x, got, want)
 
 
+def test_initial_step_vs_scipy():
+    """Hairer's starting step is the one piece of the step-size logic the 2019 torchdiffeq shares with scipy unchanged
+    (`select_initial_step`, error-estimator order 4, root-mean-square norm): same number from both, on a stiff-ish and on
+    a mild problem, wherever scipy's extra clamps (interval length, max_step) do not bind."""
+    common = pytest.importorskip('scipy.integrate._ivp.common')
+    for scale_y, rate in ((1.0, 3.0), (40.0, 0.05), (1e-3, 200.0)):
+        def f_np(t, y, r=rate):
+            return np.array([-r * y[0] + np.sin(t), r * y[0] * y[1] - y[2], np.cos(3 * t) * y[2] ** 2 + 0.1])
+
+        def f_t(t, y, r=rate):
+            (y,) = y
+            return (torch.stack([-r * y[0] + torch.sin(t), r * y[0] * y[1] - y[2], torch.cos(3 * t) * y[2] ** 2 + 0.1]),)
+
+        y0 = scale_y * np.array([0.9, -0.4, 1.3])
+        for tol in (1e-3, 1e-6):
+            want = common.select_initial_step(f_np, 0.1, y0, 1e9, np.inf, f_np(0.1, y0), 1.0, 4, tol, tol)
+            y0_t = (torch.tensor(y0, dtype=torch.float64),)
+            t0 = torch.tensor(0.1, dtype=torch.float64)
+            got = float(tdq._select_initial_step(f_t, t0, y0_t, 4, tol, tol, f_t(t0, y0_t)))
+            assert abs(got - want) <= 1e-12 * abs(want), (scale_y, rate, tol, got, want)
+
+
 def test_dense_output_against_tight_solve():
     f = lambda t, y: torch.stack([y[1], -y[0]])   # noqa: E731
     y0 = torch.tensor([0.0, 1.0], dtype=torch.float64)
