@@ -205,3 +205,41 @@ def test_a_grid_that_is_not_whole_drains_and_the_solve_falls_back():
     assert torch.equal(got, want)
     assert 1.5 < waited < 10.0
     assert rel_err(again, want) < 1e-4
+
+
+@pytest.mark.parametrize('gain,tol,kink_free', [(1.0, 1e-4, True), (12.0, 1e-6, False)])
+def test_resident_solve_with_rejected_steps_and_many_time_points(gain, tol, kink_free):
+    """13 target times are more than ride in the kernel arguments (> 8: the device array).  The second case is there for the REJECT
+    branch: a stiffer problem (last GroupNorm's weight x 12), ordinary ReLU-kinked parameters and a tolerance of 1e-6 -- the oracle
+    takes 55 steps and rejects two.  At that tolerance fp32 rounding is a visible part of the error estimate, so a few decisions may
+    go the other way in either implementation: step counts within 3, outputs within 2e-5 (1 + max|y|)."""
+    import neural_ode_features_amd as nof
+    from oracle import torchdiffeq_restated as tdq
+    shape = (1, 64, 8, 8)
+    f, twin = make_func(shape[1], seed=361, device='cuda', kink_free=kink_free)
+    with torch.no_grad():
+        f.norm3.weight.mul_(gain)
+        twin.norm3.weight.mul_(gain)
+    y = torch.randn(*shape, generator=torch.Generator().manual_seed(362))
+    t = torch.linspace(0.0, 1.0, 13)
+    fs_o = tdq.SolverStats()
+    with torch.no_grad():
+        ref = tdq.odeint(twin, y, t, rtol=tol, atol=tol, method='dopri5', stats=fs_o)
+        with resident(0):
+            base = nof.odeint(f, y.cuda(), t.cuda(), rtol=tol, atol=tol, method='dopri5')
+            st0 = dict(f.last_forward_stats)
+        with resident(1):
+            f.nfe = 0
+            out = nof.odeint(f, y.cuda(), t.cuda(), rtol=tol, atol=tol, method='dopri5')
+            st = dict(f.last_forward_stats)
+    print('gain', gain, 'tol', tol, 'oracle acc/rej', fs_o.accepted, fs_o.rejected, 'launch path', st0['accepted'], st0['rejected'],
+          'resident', st['accepted'], st['rejected'], 'rel err vs oracle %.2e, vs launch path %.2e' % (rel_err(out, ref), rel_err(out, base)))
+    assert f.nfe == 2 + 6 * (st['accepted'] + st['rejected'])
+    slack = 1 if tol >= 1e-5 else 3
+    assert abs(st['accepted'] - fs_o.accepted) <= slack and abs(st['rejected'] - fs_o.rejected) <= slack
+    big = float(ref.abs().max())
+    assert float((out.cpu() - ref).abs().max()) <= max(10 * tol, 2e-5) * (1 + big)
+    if (st['accepted'], st['rejected']) == (fs_o.accepted, fs_o.rejected) and tol >= 1e-5:
+        assert rel_err(out, ref) < 2e-4
+    if gain > 1.0:
+        assert fs_o.rejected >= 1 and st['rejected'] >= 1, 'this case is here for the reject branch'
