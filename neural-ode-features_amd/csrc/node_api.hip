@@ -448,6 +448,8 @@ const double DP_BETA[6][6] = {
     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
 };
 
+std::atomic<int> g_resident_cooldown{0};     // solves left before the resident latency path is tried again (see Solver::choose_resident)
+
 // ----------------------------------------------------------------------------
 // The solver context: one solve (forward or augmented/adjoint) on one stream
 // ----------------------------------------------------------------------------
@@ -473,7 +475,14 @@ struct Solver {
   bool tiny_mode() const { return d.tiny != 0 && !aug && p.wtiny[0] != nullptr; }
   // ... and a free-running or replayed dopri5 forward solve of a state the chip can hold resident is ONE launch (kernels_tiny_solve.hip)
   bool resident = false;
-  void choose_resident(bool dopri5) { resident = dopri5 && tiny_mode() && !w4 && p.thand != nullptr && tiny_resident_ok(d); }
+  void choose_resident(bool dopri5) {
+    resident = dopri5 && tiny_mode() && !w4 && p.thand != nullptr && tiny_resident_ok(d);
+    // a grid that did not get the whole chip costs its 2 s deadline: after one, the next 64 solves of this process do not try
+    if (resident && g_resident_cooldown.load(std::memory_order_relaxed) > 0) {
+      g_resident_cooldown.fetch_sub(1, std::memory_order_relaxed);
+      resident = false;
+    }
+  }
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
@@ -1347,6 +1356,7 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
       // GPU can leave two launches each waiting for compute units the other holds).  Every workgroup has left; the solve runs
       // again on the launch-per-convolution path, which needs no co-residency.
       S.resident = false;
+      g_resident_cooldown.store(64, std::memory_order_relaxed);
       S.nfe = 0;
       TRY(S.prepare());
       S.to_state(y0, S.p.Y);
