@@ -477,6 +477,11 @@ struct Solver {
   bool resident = false;
   void choose_resident(bool dopri5) {
     resident = dopri5 && tiny_mode() && !w4 && p.thand != nullptr && tiny_resident_ok(d);
+    if (resident) {      // a captured launch would replay its nonce: words of the previous replay would pass for this one's
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+      if (cs != hipStreamCaptureStatusNone) resident = false;
+    }
     // a grid that did not get the whole chip costs its 2 s deadline: after one, the next 64 solves of this process do not try
     if (resident && g_resident_cooldown.load(std::memory_order_relaxed) > 0) {
       g_resident_cooldown.fetch_sub(1, std::memory_order_relaxed);

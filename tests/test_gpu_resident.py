@@ -251,3 +251,45 @@ def test_resident_solve_with_rejected_steps_and_many_time_points(gain, tol, kink
         assert rel_err(out, ref) < 2e-4
     if gain > 1.0:
         assert fs_o.rejected >= 1 and st['rejected'] >= 1, 'this case is here for the reject branch'
+
+
+def test_a_captured_solve_does_not_take_the_resident_grid():
+    """A deferred-completion solve has no host synchronisation in it and can be captured into a hipGraph (tools/exp_graph_solve.py).
+    A captured RESIDENT launch would replay its nonce -- the previous replay's words would pass for this one's -- so under capture the
+    library keeps the launch-per-convolution path: replays on changing inputs equal the eager launch-path results bit for bit."""
+    from neural_ode_features_amd import integrate
+    import neural_ode_features_amd as nof
+    shape = (1, 64, 8, 8)
+    f = nof.ODEfunc(shape[1]).cuda()
+    rec = integrate.Recognised(f)
+    gen = torch.Generator().manual_seed(371)
+    ys = [torch.randn(*shape, generator=gen).cuda() for _ in range(3)]
+    y = ys[0].clone()
+    record = torch.zeros(64, dtype=torch.uint8, device='cuda')
+    flag = torch.zeros(1, device='cuda')
+    times = [0.0, 1.0]
+    with resident(0):
+        wants, steps = [], 1
+        for yi in ys:
+            o, st = integrate.solve_forward(rec, rec.params, yi, times, 1e-3, 1e-3, 0, None)
+            wants.append(o.clone())
+            steps = max(steps, st['accepted'] + st['rejected'])
+
+    def blind():
+        return integrate.solve_forward(rec, rec.params, y, times, 1e-3, 1e-3, 0, None, blind=(steps + 1, record, flag))[0]
+
+    with resident(1):
+        assert _is_resident(shape)
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            blind()
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            static_out = blind()
+        for yi, want in zip(ys, wants):
+            y.copy_(yi)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_out, want) and float(flag) == 0.0
