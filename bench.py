@@ -32,6 +32,8 @@ its enqueued step count costs TIME, not an update: integrate.DeferredLoop keeps 
 batch until its verdict is in and repeats voided batches in order (`config.retries`).
 `fresh_batches` is the same loop on a NEW synthetic batch per step (moving step counts),
 `dropin` the same steps with a read-back per solve (the drop-in odeint / ODEBlock API).
+`latency_bs1` is a side block, not the metric: forward solves of ONE sample of the config's
+state (the reference's bs = 1 NFE census, evaluate.py:97-142), microseconds per evaluation.
 `roofline` is for the dominant kernel -- at the BASELINE configs `k_w4_gemm64b`, the 36
 component GEMMs of a Winograd F(4x4,3x3) convolution on bf16 MFMA at fp32 accuracy
 (exact three-way split, six products), bounded by its bytes through the fabric at
@@ -293,6 +295,44 @@ def pmc_lookup(pmc, kernel):
     return max(hits, key=lambda v: v['bytes']) if hits else None
 
 
+def latency_bs1(cfg, method):
+    """A side block of the line, NOT the metric: the other regime of the same path -- the reference's NFE census solves every test image
+    on its own (evaluate.py:97-142).  Wall time of forward solves of ONE sample of this config's state, host included, per evaluation
+    of the dynamics, at the config's tolerance and at 1e-5.  States the chip can hold resident run as one launch per solve
+    (csrc/kernels_tiny_solve.hip); the others run the throughput kernels."""
+    import torch
+    import neural_ode_features_amd as nof
+    try:
+        C = cfg['filters']
+        side = cfg['image'] // 4
+        torch.manual_seed(1)
+        f = nof.ODEfunc(C).cuda()
+        y = torch.randn(1, C, side, side, device='cuda')
+        t = torch.tensor([0.0, 1.0], device='cuda')
+        rows = []
+        with torch.no_grad():
+            for tol in sorted({float(cfg['tol']), 1e-5}, reverse=True):
+                for _ in range(5):
+                    nof.odeint(f, y, t, rtol=tol, atol=tol, method=method)
+                torch.cuda.synchronize()
+                n = 100
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    nof.odeint(f, y, t, rtol=tol, atol=tol, method=method)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / n
+                st = f.last_forward_stats
+                rows.append({'tol': tol, 'nfe': st['nfe'], 'solve_us': wall * 1e6, 'us_per_evaluation': wall * 1e6 / max(1, st['nfe'])})
+        from neural_ode_features_amd import _lib
+        import ctypes
+        shape = _lib.NodeShape(1, C, side, side, min(32, C), 1e-5)
+        one_launch = bool(_lib.load().node_solve_is_resident(ctypes.byref(shape))) and method == 'dopri5'
+        return {'state': [1, C, side, side], 'solves': rows, 'one_launch_per_solve': one_launch,
+                'note': 'forward solve of ONE sample, wall time over 100 solves back to back (host included) / evaluations of the dynamics'}
+    except Exception as e:      # (a side block never takes the line down)
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -313,6 +353,7 @@ def main():
                          'runs blind without a spare step (integrate.Deferred.settled), so that the timed region is the '
                          'steady state; reported as config.settle_steps')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed region with a read-back per solve')
+    ap.add_argument('--no-latency', action='store_true', help='skip the bs = 1 latency block (evaluate.py:97-142: one image solved on its own)')
     ap.add_argument('--no-fresh', action='store_true', help='skip the timed region on a fresh synthetic batch per step')
     ap.add_argument('--no-deferred', action='store_true',
                     help='every solve ends with a read-back of the device controller (the drop-in default) instead of '
@@ -741,6 +782,8 @@ def main():
             result['dropin'] = dropin
         if roofline is not None:
             result['roofline'] = roofline
+        if world == 1 and not args.no_latency:
+            result['latency_bs1'] = latency_bs1(cfg, args.method)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(init_state, cfg, args.method)
         print(json.dumps(result), flush=True)
