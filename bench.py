@@ -32,6 +32,7 @@ its enqueued step count costs TIME, not an update: integrate.DeferredLoop keeps 
 batch until its verdict is in and repeats voided batches in order (`config.retries`).
 `fresh_batches` is the same loop on a NEW synthetic batch per step (moving step counts),
 `dropin` the same steps with a read-back per solve (the drop-in odeint / ODEBlock API).
+`other_configs` (default run only) holds short side runs of BASELINE configs 3 and 5 on the same box;
 `latency_bs1` is a side block, not the metric: forward solves of ONE sample of the config's
 state (the reference's bs = 1 NFE census, evaluate.py:97-142), microseconds per evaluation.
 `roofline` is for the dominant kernel -- at the BASELINE configs `k_w4_gemm64b`, the 36
@@ -295,6 +296,31 @@ def pmc_lookup(pmc, kernel):
     return max(hits, key=lambda v: v['bytes']) if hits else None
 
 
+def other_configs(args):
+    """Side blocks of the default line, NOT the metric: the other single-GPU BASELINE configs (3: tol 1e-5; 5: three stacked blocks at
+    1024 filters, per-GPU shard) as short runs of this same script in child processes -- so that the record of the default run holds a
+    number for them measured on the same box.  A child that fails or runs past its time leaves an `error` entry."""
+    out = {}
+    for config, extra, limit in ((3, ['--steps', '10', '--warmup', '3'], 240), (5, ['--steps', '4', '--warmup', '2', '--no-dropin'], 300)):
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', str(config), '--method', args.method, '--no-roofline', '--no-cpu-baseline',
+               '--no-fresh', '--no-latency', '--no-other-configs'] + extra
+        env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not lines:
+                out[str(config)] = {'error': 'rc %d: %s' % (r.returncode, r.stderr[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            out[str(config)] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                                'workload': d['config'].get('workload'), 'retries': d['config'].get('retries'),
+                                'dead_steps_per_step': d['config'].get('dead_steps_per_step'),
+                                'dropin': (d.get('dropin') or {}).get('value')}
+        except Exception as e:
+            out[str(config)] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
+
+
 def latency_bs1(cfg, method):
     """A side block of the line, NOT the metric: the other regime of the same path -- the reference's NFE census solves every test image
     on its own (evaluate.py:97-142).  Wall time of forward solves of ONE sample of this config's state, host included, per evaluation
@@ -353,6 +379,8 @@ def main():
                          'runs blind without a spare step (integrate.Deferred.settled), so that the timed region is the '
                          'steady state; reported as config.settle_steps')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second timed region with a read-back per solve')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short side runs of BASELINE configs 3 and 5 that the default (config 2, one GPU) line carries')
     ap.add_argument('--no-latency', action='store_true', help='skip the bs = 1 latency block (evaluate.py:97-142: one image solved on its own)')
     ap.add_argument('--no-fresh', action='store_true', help='skip the timed region on a fresh synthetic batch per step')
     ap.add_argument('--no-deferred', action='store_true',
@@ -391,6 +419,10 @@ def main():
     held_clk = None
     if world == 1 and not args.no_roofline:
         held_clk = held_clock_ghz(cfg['batch'], cfg['filters'], side)      # (a child process on the diagnostics library)
+
+    others = None
+    if world == 1 and args.config == 2 and not args.no_other_configs and args.batch is None and args.filters is None and args.tol is None:
+        others = other_configs(args)      # (child processes, before this one touches the GPU)
 
     import torch
     import torch.distributed as dist
@@ -782,6 +814,8 @@ def main():
             result['dropin'] = dropin
         if roofline is not None:
             result['roofline'] = roofline
+        if others is not None:
+            result['other_configs'] = others
         if world == 1 and not args.no_latency:
             result['latency_bs1'] = latency_bs1(cfg, args.method)
         if world == 1 and not args.no_cpu_baseline:
