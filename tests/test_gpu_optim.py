@@ -150,7 +150,7 @@ def test_bench_one_rank_through_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '6', '--warmup', '3',
-                        '--no-cpu-baseline', '--no-roofline', '--no-dropin'], env=env, capture_output=True, text=True, timeout=800)
+                        '--no-cpu-baseline', '--no-roofline', '--no-dropin', '--no-other-configs', '--no-latency'], env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     print('one rank through RCCL:', d['value'], 'images/s;', d['config']['collectives'], d['config']['solver_completion'])

@@ -10,7 +10,7 @@ mkdir -p "$(dirname "$OUT")"
 D=/tmp/prof_$$
 rm -rf $D
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline "$@" > $D.log 2>&1 || { tail -20 $D.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-other-configs --no-latency "$@" > $D.log 2>&1 || { tail -20 $D.log; exit 1; }
 cd $R
 grep '"metric"' $D.log > ${OUT}_bench.json || true
 # (bench.py starts child processes -- the held-clock measurement on the diagnostics library -- and rocprofv3 writes one set of files per
