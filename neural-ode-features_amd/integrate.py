@@ -74,6 +74,42 @@ class Recognised:
             raise NotImplementedError('ODEfunc.parameters() is not the expected ten tensors in reference order')
 
 
+# Recognised(func) walks the module tree (named_modules, parameters): ~25 us per call, once per solve.  The result is remembered per
+# func OBJECT (weakly) together with the identities it was built from -- the five sub-modules, the two conv layers, the ten parameter
+# objects, the counts of func's own entries -- and rebuilt when any of them is another object (a replaced layer or parameter, a
+# `load_state_dict` keeps the objects and needs nothing).
+_REC_SEEN: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _rec_signature(func):
+    try:      # (straight through the modules' own dicts: nn.Module.__getattr__ costs ~0.4 us per lookup, this runs once per solve)
+        m = func._modules
+        n1, c1, n2, c2, n3 = m['norm1'], m['conv1'], m['norm2'], m['conv2'], m['norm3']
+        l1, l2 = c1._modules['_layer'], c2._modules['_layer']
+        p1, q1, p2, q2, p3 = n1._parameters, l1._parameters, n2._parameters, l2._parameters, n3._parameters
+        return (id(n1), id(c1), id(n2), id(c2), id(n3), id(l1), id(l2),
+                id(p1['weight']), id(p1['bias']), id(q1['weight']), id(q1['bias']), id(p2['weight']), id(p2['bias']),
+                id(q2['weight']), id(q2['bias']), id(p3['weight']), id(p3['bias']), n1.num_groups, n1.eps, len(m), len(func._parameters))
+    except (AttributeError, KeyError):
+        return None
+
+
+def recognised(func: nn.Module) -> Recognised:
+    """Recognised(func), remembered per object; raises NotImplementedError like the constructor."""
+    sig = _rec_signature(func)
+    if sig is not None:
+        try:
+            hit = _REC_SEEN.get(func)
+        except TypeError:       # (an unhashable / non-weakly-referenceable object: no cache)
+            hit, sig = None, None
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+    rec = Recognised(func)
+    if sig is not None:
+        _REC_SEEN[func] = (sig, rec)
+    return rec
+
+
 def _method_id(method) -> int:
     if method is None:
         method = 'dopri5'
@@ -164,7 +200,7 @@ GENERIC_FALLBACK = True
 def _fused_plan(func, y0, method_id, adjoint, n_t):
     """Recognised(func) when the fused kernels take this (func, state); None -> the generic solver."""
     try:
-        rec = Recognised(func)
+        rec = recognised(func)
     except NotImplementedError:
         if not GENERIC_FALLBACK:
             raise

@@ -321,3 +321,30 @@ def test_loss_helpers_route_cpu_tensors_to_pytorch():
     assert torch.equal(loss2, F.cross_entropy(F.linear(x, w, b), y, reduction='sum')) and torch.equal(logits, p)
     loss.backward()
     assert x.grad is not None and w.grad is not None and b.grad is not None
+
+
+def test_recognised_is_remembered_per_object_and_follows_replacements():
+    """`integrate.recognised(func)` skips the module-tree walk of `Recognised(func)` for a func it has seen -- as long as the five
+    sub-modules, the conv layers and the ten parameter OBJECTS are the ones it saw (an optimizer step or `load_state_dict` keeps
+    them; assigning a new layer or parameter does not)."""
+    import torch
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import integrate
+    f = nof.ODEfunc(64)
+    r1 = integrate.recognised(f)
+    assert integrate.recognised(f) is r1
+    f.load_state_dict(f.state_dict())
+    with torch.no_grad():
+        f.norm2.weight.mul_(2.0)
+    assert integrate.recognised(f) is r1 and r1.params[4] is f.norm2.weight
+    f.norm1 = torch.nn.GroupNorm(32, 64)
+    r2 = integrate.recognised(f)
+    assert r2 is not r1 and r2.params[0] is f.norm1.weight
+    f.conv1._layer.weight = torch.nn.Parameter(torch.zeros_like(f.conv1._layer.weight))
+    r3 = integrate.recognised(f)
+    assert r3 is not r2 and r3.params[2] is f.conv1._layer.weight
+    f.extra = torch.nn.Parameter(torch.zeros(1))          # an eleventh parameter: no longer the reference's ODEfunc
+    with pytest.raises(NotImplementedError):
+        integrate.recognised(f)
+    with pytest.raises(NotImplementedError):
+        integrate.recognised(nof.ODEfunc(64, norm='batch'))
