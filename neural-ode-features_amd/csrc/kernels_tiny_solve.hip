@@ -26,7 +26,7 @@
 //     channel's border maps, copies y0 into the trajectory and writes the record into the caller's pinned host copy.
 // The grid must be co-resident (one workgroup per CU: N x (C/16) x (C/32) <= CUs; 128 workgroups at [1,256,8,8]); a grid that is
 // not runs into its deadline, drains, and node_solve_fwd repeats the solve on kernels_tiny.hip.  Measured: DESIGN.md 4.7,
-// profiles/r05_latency_bs1.txt (18.0 / 15.6 us per evaluation at [1,256,8,8], tol 1e-3 / 1e-5; kernels_tiny.hip 33.9 / 29.7).
+// profiles/r05_latency_bs1.txt (17.0 / 15.2 us per evaluation at [1,256,8,8], tol 1e-3 / 1e-5, host included; kernels_tiny.hip 34.3 / 29.7).
 #include "node_internal.h"
 #include "step_control.h"
 #include <cstdlib>
