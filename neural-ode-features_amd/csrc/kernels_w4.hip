@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
   const float* __restrict__ w = jobs.w[blockIdx.y];
   float* __restrict__ U = jobs.u[blockIdx.y];
   unsigned short* __restrict__ Ub = jobs.ub[blockIdx.y];
+  _Float16* __restrict__ Uh = reinterpret_cast<_Float16*>(jobs.uh[blockIdx.y]);
+  const float uscale = Uh != nullptr ? ldexpf(1.f, *jobs.uh_exp[blockIdx.y]) : 1.f;
   const int dgrad = jobs.dgrad[blockIdx.y];
   const int CI = jobs.plain[blockIdx.y] ? C : C + 1, c_off = jobs.plain[blockIdx.y] ? 0 : 1;   // input-channel stride / first data channel
   const int G8 = C >> 3;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
     // consecutive threads write consecutive elements of the layout this launch produces: fp32 [cb][g][hi][col][e], or
     // the bf16 triples [cb][g/2][part][hi][col][g & 1][e] (eight values = one 16-B operand of a lane)
     int e, col, hi, g, cb;
-    if (Ub == nullptr) {
+    if (Ub == nullptr && Uh == nullptr) {
       e = idx & 3; col = (idx >> 2) & 31; hi = (idx >> 7) & 1;
       g = (int)((idx >> 8) % G8); cb = (int)((idx >> 8) / G8);
     } else {
@@ -75,7 +77,14 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
       for (int l = 0; l < 6; ++l) {
         const double v = gt[i][0] * W4_G[l][0] + gt[i][1] * W4_G[l][1] + gt[i][2] * W4_G[l][2];
         const float uf = (float)v;
-        if (Ub == nullptr) {
+        if (Uh != nullptr) {          // "U pairs" (wino4.h): [cb][g2][part][hi][col][gp][e], the parts 512 halves apart
+          const float us = uf * uscale;
+          const _Float16 hh = (_Float16)us;
+          const _Float16 lh = (_Float16)(us - (float)hh);
+          _Float16* o = Uh + (size_t)(i * 6 + l) * total * 2 + ((((size_t)cb * (G8 >> 1) + (g >> 1)) * 2) * 64 + (size_t)(hi * 32 + col)) * 8 + (g & 1) * 4 + e;
+          o[0] = hh;
+          o[512] = lh;
+        } else if (Ub == nullptr) {
           U[(size_t)(i * 6 + l) * total + fidx] = uf;
         } else {
           const unsigned short hb = w4_bf16_rne(uf);
@@ -1387,6 +1396,238 @@ __global__ __launch_bounds__(256) void k_w4_gemm64c(const float* __restrict__ V,
 #endif  // NODE_DIAG (measured-and-rejected variants)
 
 // ----------------------------------------------------------------------------
+// k_w4_scales: the power-of-two scales of a solve's fp16-pair operands (wino4.h, W4Scales) in one launch: block (x, job) adds the
+// maximum of its slice of job's tensor by atomicMax on the fp32 bit pattern (non-negative floats order like unsigned integers);
+// the last block to arrive derives the exponents and zeroes the scratch words for the next launch.
+// ----------------------------------------------------------------------------
+constexpr int W4SC_BLOCKS = 128;
+__global__ __launch_bounds__(256) void k_w4_scales(W4ScaleJobs j) {
+  __shared__ float red[4];
+  const int job = blockIdx.y;
+  const float* p = job < 2 ? j.w[job] : j.gb[job - 2];
+  size_t n = job < 2 ? j.wn : (size_t)j.C;
+  if ((job == 3 || job == 5) && j.vn[(job - 3) >> 1] != 0) n = j.vn[(job - 3) >> 1];
+  float m = 0.f;
+  if (p != nullptr) {
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (n & 3) == 0) {      // 16-B loads, four in flight
+      const float4* q = reinterpret_cast<const float4*>(p);
+      const size_t n4 = n >> 2;
+      for (size_t i = i0; i < n4; i += 4 * step) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i + u * step < n4 ? q[i + u * step] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+      }
+    } else {
+      for (size_t i = i0; i < n; i += step) m = fmaxf(m, fabsf(p[i]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  W4Scales* sc = j.sc;
+  if (m > 0.f) atomicMax(&sc->mx[job], __builtin_bit_cast(unsigned, m));
+  __threadfence();
+  const unsigned ticket = atomicAdd(&sc->arrived, 1u);
+  if (ticket != gridDim.x * gridDim.y - 1) return;
+  __threadfence();
+  float mx[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    mx[q] = __builtin_bit_cast(float, __hip_atomic_load(&sc->mx[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __hip_atomic_store(&sc->mx[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __hip_atomic_store(&sc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // |U| = |G g G^T| <= (28/15)^2 max|w|; ceiling 2^14 (a factor four under fp16's)
+  if (j.w[0] != nullptr) sc->e[W4_E_U1] = w4_scale_exp(3.49f * mx[0], 14);
+  if (j.w[1] != nullptr) sc->e[W4_E_U2] = w4_scale_exp(3.49f * mx[1], 14);
+  // |B^T d B| <= 49 max|d|, d = relu(gamma xhat + beta), |xhat| <= sqrt(m - 1): ceiling 2^15 for the BOUND (what the data reaches is
+  // typically 2^5 under it)
+  const float rm = sqrtf((float)j.gn_m);
+  if (j.gb[0] != nullptr || j.gb[1] != nullptr) sc->e[W4_E_V1] = w4_scale_exp(49.f * (rm * mx[2] + mx[3]), 15);
+  if (j.gb[2] != nullptr || j.gb[3] != nullptr) sc->e[W4_E_V2] = w4_scale_exp(49.f * (rm * mx[4] + mx[5]), 15);
+}
+void launch_w4_scales(const W4ScaleJobs& j, hipStream_t s) {
+  hipLaunchKernelGGL(k_w4_scales, dim3(W4SC_BLOCKS, 6), dim3(256), 0, s, j);
+}
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm64h: k_w4_gemm64b's products on fp16 PAIRS (wino4.h): both operands arrive split -- V pairs written by the GroupNorm
+// pass in front, U pairs by k_w4_pack -- so a K = 16 step of a 32 x 32 block is three v_mfma_f32_32x32x16_f16 (l h, h l, h h) on
+// registers the loads delivered: no conversion, no subtraction, no vector instruction at all between the MFMAs (k_w4_gemm64b: six
+// MFMAs and ~44 VALU instructions per row block and step, the matrix pipe busy 45 % of a wave's life).  Same decomposition, XCD
+// placement and M layout as k_w4_gemm64b: a wave owns a 64 x 64 tile of one component over the whole reduction; eight workgroups
+// share a tile (workgroup j: components 4 j .. 4 j + 3 and half a tile of component 32 + j / 2, K range cut over its waves).
+// The result leaves unscaled: M = acc * 2^-(v_exp + u_exp).
+// ----------------------------------------------------------------------------
+typedef _Float16 w4_f16x8 __attribute__((ext_vector_type(8)));
+struct W4HStage { w4_u32x4 a[2][2], b[2][2]; };    // [row block][part h, l], [column block][part]
+struct W4HCursor { const w4_u32x4* a[2]; const w4_u32x4* b[2]; };
+template <int NRB>
+__device__ __forceinline__ void w4h_next(W4HStage& s, W4HCursor& cu) {   // the next K = 16 step of the streams (2 KB per stream and step)
+#pragma unroll
+  for (int r = 0; r < NRB; ++r) {
+    s.a[r][0] = cu.a[r][0];
+    s.a[r][1] = cu.a[r][64];
+    cu.a[r] += 128;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    s.b[c][0] = cu.b[c][0];
+    s.b[c][1] = cu.b[c][64];
+    cu.b[c] += 128;
+  }
+}
+template <int NRB>
+__device__ __forceinline__ void w4h_mac(float16_t (&acc)[2][2], const W4HStage& s) {
+  w4_f16x8 A[2][2], B[2][2];
+#pragma unroll
+  for (int r = 0; r < NRB; ++r)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) A[r][q] = __builtin_bit_cast(w4_f16x8, s.a[r][q]);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) B[c][q] = __builtin_bit_cast(w4_f16x8, s.b[c][q]);
+#define W4H_P(AP, BQ)                                                                             \
+  _Pragma("unroll") for (int r = 0; r < NRB; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)   \
+      acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[r][AP], B[c][BQ], acc[r][c], 0, 0, 0);
+  W4H_P(1, 0) W4H_P(0, 1) W4H_P(0, 0)   // smallest products first
+#undef W4H_P
+}
+// acc += sum over K = 16 steps [g0, g0 + n) (n a multiple of D): a ring of D stages, each refilled right behind the MFMAs that
+// consumed it (the refills of the last D steps read up to D steps past the range: buffer slack)
+template <int D, int NRB, class F = W4Nothing>
+__device__ __forceinline__ void w4h_run(float16_t (&acc)[2][2], const W4HCursor& start, int n, F after_fill = F()) {
+  W4HStage ring[D];
+  W4HCursor cu = start;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    w4h_next<NRB>(ring[i], cu);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  after_fill();
+  for (int g = 0; g < n; g += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      w4h_mac<NRB>(acc, ring[i]);
+      __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
+      w4h_next<NRB>(ring[i], cu);
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
+                                                    const Ctrl* ctrl, W4Geom gm, int mode, const int* v_exp, const int* u_exp) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 6, nRB = gm.RB, G2 = gm.G8 >> 1, CB = gm.C >> 5;
+  const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
+  const int rt = tile / nCT, ct = tile - rt * nCT;
+  const float inv = ldexpf(1.f, -(*v_exp + *u_exp));
+  const int a_off = ((l31 >> 2) * 8) + hi * 4 + (l31 & 3);   // lane (row = 4 s + t, k-half hi): its 16 B inside a 1 KB part
+  auto vblk = [&](int comp, int rb) { return reinterpret_cast<const w4_u32x4*>(Vh) + (((size_t)comp * nRB + rb) * G2) * 128 + a_off; };
+  auto ublk = [&](int comp, int cb) { return reinterpret_cast<const w4_u32x4*>(Uh) + (((size_t)comp * CB + cb) * G2) * 128 + lane; };
+
+  // the shared component's operands are requested behind the own component's first ring (one wave per SIMD: nothing else would
+  // cover their latency at the end), and multiplied while the own component's stores drain
+  constexpr int SH = 4;
+  const int sng = G2 >> 2;                 // its K steps per wave
+  const bool early = sng == SH;
+  W4HStage shr[SH];
+  const int scomp = 32 + (j >> 1), srb = 2 * rt + (j & 1);
+  W4HCursor scu;
+  scu.a[0] = vblk(scomp, srb) + (size_t)(wave * sng) * 128; scu.a[1] = scu.a[0];
+  scu.b[0] = ublk(scomp, 2 * ct) + (size_t)(wave * sng) * 128; scu.b[1] = ublk(scomp, 2 * ct + 1) + (size_t)(wave * sng) * 128;
+  {
+    // mode bit 1 (NODE_TUNE_W4_SHAREV = 1, four column tiles): the four waves of a workgroup take the SAME component and row tile
+    // and one column tile each (they walk the same V blocks in lock-step); bit 2: a 128 x 128 tile of one component (k_w4_gemm64b)
+    const bool sharev = (mode & 2) != 0 && nCT == 4;
+    const bool share2 = (mode & 4) != 0 && nCT == 4 && (nRB & 3) == 0;
+    const int comp = 4 * j + (share2 ? (tile & 3) : sharev ? ct : wave);
+    const int oct = share2 ? 2 * ((tile >> 2) & 1) + (wave & 1) : sharev ? wave : ct;
+    const int ort = share2 ? 2 * (tile >> 3) + (wave >> 1) : rt;
+    W4HCursor cu;
+    cu.a[0] = vblk(comp, 2 * ort); cu.a[1] = vblk(comp, 2 * ort + 1);
+    cu.b[0] = ublk(comp, 2 * oct); cu.b[1] = ublk(comp, 2 * oct + 1);
+    float16_t acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+    w4h_run<D, 2>(acc, cu, G2, [&]() {
+      if (early) {
+        W4HCursor c2 = scu;
+#pragma unroll
+        for (int i = 0; i < SH; ++i) {
+          w4h_next<1>(shr[i], c2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("" ::: "memory");   // (the compiler may not sink these requests to their first use behind the loop)
+      }
+    });
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
+    float* m0 = M + ((size_t)(ort * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      st_wt(o, acc[0][0][q] * inv);
+      st_wt(o + 36 * 128, acc[0][1][q] * inv);
+      st_wt(o + 8 * sstride, acc[1][0][q] * inv);
+      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q] * inv);
+    }
+  }
+  // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
+  {
+    float16_t acc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[0][c][q] = 0.f;
+    if (early) {
+#pragma unroll
+      for (int i = 0; i < SH; ++i) w4h_mac<1>(acc, shr[i]);
+    } else if (sng % 4 == 0) w4h_run<4, 1>(acc, scu, sng);
+    else if (sng % 2 == 0) w4h_run<2, 1>(acc, scu, sng);
+    else w4h_run<1, 1>(acc, scu, sng);
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + c * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(acc[0][c][4 * r4], acc[0][c][4 * r4 + 1], acc[0][c][4 * r4 + 2], acc[0][c][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk = u >> 8, r4 = (u >> 6) & 3;
+      float4 sm = *reinterpret_cast<const float4*>(smem + blk * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk * 1024 + (r4 * 64 + lane) * 4);
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+      }
+      float* mrow = M + ((size_t)(srb * 8 + 2 * r4 + hi) * (gm.C >> 5) + 2 * ct + blk) * (36 * 128) + (size_t)scomp * 128 + l31;
+      st_wt(mrow, sm.x * inv);
+      st_wt(mrow + 32, sm.y * inv);
+      st_wt(mrow + 64, sm.z * inv);
+      st_wt(mrow + 96, sm.w * inv);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
 // k_w4_gemm128b: k_w4_gemm64b's products for LONG reductions (C >= 512: cfg 5's 16x16 states at 1024 filters), as a
 // classic LDS-tiled GEMM.  k_w4_gemm64b gives every wave a component of its own, so the four waves of a workgroup share
 // nothing and an XCD works on 4.5 components at once: at C = 1024 that is 47 MB of operands against a 4 MB L2, every
@@ -1584,17 +1825,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
 // The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
 // kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half, f16, hdepth; };
 static W4Switches w4_read_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   // NODE_TUNE_W4_GEMM128 / _WGRAD128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512)
 #ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
           rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0),
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0), rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4)};
 #else
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0, rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4)};
 #endif
 }
 // The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
@@ -1619,6 +1860,23 @@ bool w4_uses_bf16(int N, int C) {
   if (w4_takes_small(sw, N)) return false;   // (k_w4_gemm_small reads the fp32 filters)
   if (w4_takes_uf32(sw, N, C)) return false; // (k_w4_gemm64c splits them in registers)
   return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && (sw.ablate == 0 || sw.ablate >= 16);
+}
+
+// NODE_TUNE_W4_F16 = 0: never the fp16-pair operands (the bf16-triple kernels everywhere: A/B measurements, tests); read per call
+bool w4_f16_fits(int N, int C) {
+  const W4Switches sw = w4_switches();
+  return sw.f16 != 0 && sw.ablate == 0 && w4_uses_bf16(N, C) && N % 16 == 0 && C % 64 == 0 && C < 512;
+}
+void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const Ctrl* ctrl, int N, int C, const int* v_exp, const int* u_exp,
+                        hipStream_t s) {
+  const W4Switches sw = w4_switches();
+  const int mode = (sw.sharev == 1 ? 2 : 0) | (sw.sharev == 2 ? 4 : 0);
+  const W4Geom gm = w4_geom(N, C);
+  const int grid64 = (N / 16) * (C >> 6) * 8;
+  const size_t lds64 = 4 * 2048 * sizeof(float);
+  if (sw.hdepth == 8 && (C >> 4) % 8 == 0) hipLaunchKernelGGL(k_w4_gemm64h<8>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
+  else if ((C >> 4) % 4 == 0) hipLaunchKernelGGL(k_w4_gemm64h<4>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
+  else hipLaunchKernelGGL(k_w4_gemm64h<2>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
 }
 
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {

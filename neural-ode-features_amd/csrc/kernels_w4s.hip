@@ -168,7 +168,19 @@ __device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, 
 //  ~90 % of what a streaming copy of the same size reaches once the ~1.5 us of launch ramp are taken out.)
 // V = B^T d B of the 6x6 patch d (the thread's tile + one pixel ring) -> the blocked row operand of the component GEMMs.
 // `vp`: the thread's element of component 0; components `cstride` apart.
-__device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restrict__ vp, size_t cstride) {
+// fp16-pair form (wino4.h, "V pairs"; pscale != 0): the value times pscale as h = fp16(x), l = fp16(x - h); the lane swaps its
+// {h, l} dword with its channel neighbour's (lane ^ 1) and stores {h, h'} (even channel -> part h) or {l', l} (odd -> part l):
+// one dword per lane and component, as in the fp32 form, whole 128-B lines per wave and part
+__device__ __forceinline__ float w4s_pair_word(float x, float pscale, bool odd) {
+  const float xs = x * pscale;
+  const _Float16 h = (_Float16)xs;
+  const _Float16 l = (_Float16)(xs - (float)h);
+  const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  const unsigned out = odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
+  return __builtin_bit_cast(float, out);
+}
+__device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restrict__ vp, size_t cstride, float pscale = 0.f, bool odd = false) {
   float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
 #pragma unroll
   for (int j = 0; j < 6; ++j) w4s_bt6(d[j][0], d[j][1], d[j][2], d[j][3], d[j][4], d[j][5], w[j][0], w[j][1], w[j][2], w[j][3], w[j][4], w[j][5]);
@@ -176,6 +188,10 @@ __device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restri
   for (int l = 0; l < 6; ++l) {
     float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
     w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
+    if (pscale != 0.f) {
+      v0 = w4s_pair_word(v0, pscale, odd); v1 = w4s_pair_word(v1, pscale, odd); v2 = w4s_pair_word(v2, pscale, odd);
+      v3 = w4s_pair_word(v3, pscale, odd); v4 = w4s_pair_word(v4, pscale, odd); v5 = w4s_pair_word(v5, pscale, odd);
+    }
     w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
     w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
     w4s_st_wt(vp + (size_t)(2 * 6 + l) * cstride, v2);
@@ -185,7 +201,8 @@ __device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restri
   }
 }
 // 8x8 image: the ring is nine values held by the three other tiles' lanes of the same wave (zero outside the image)
-__device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, float* __restrict__ vp, size_t cstride) {
+__device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, float* __restrict__ vp, size_t cstride, float pscale = 0.f,
+                                           bool odd = false) {
   float sh[4], sv[4], rh[4], rv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) sh[i] = tx ? a[i][0] : a[i][3];   // my edge column facing the horizontal neighbour
@@ -214,11 +231,12 @@ __device__ __forceinline__ void w4s_emit_v(const float a[4][4], int ty, int tx, 
   d[0][5] = (ty && !tx) ? rc : 0.f;
   d[5][0] = (!ty && tx) ? rc : 0.f;
   d[5][5] = (!ty && !tx) ? rc : 0.f;
-  w4s_store_v(d, vp, cstride);
+  w4s_store_v(d, vp, cstride, pscale, odd);
 }
 // 16x16 image: the workgroup's tiles go through LDS ([wave][pixel][lane]: conflict-free both ways), the ring's twenty
 // values come from up to eight neighbour tiles -- other lanes of this wave or of the other quadrants' waves
-__device__ __forceinline__ void w4s_emit_v16(const float a[4][4], const W4Wave<4>& wv, float* __restrict__ vp, size_t cstride) {
+__device__ __forceinline__ void w4s_emit_v16(const float a[4][4], const W4Wave<4>& wv, float* __restrict__ vp, size_t cstride, float pscale = 0.f,
+                                             bool odd = false) {
   float* mine = wv.tiles + (size_t)wv.w * 1024 + wv.lane;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -248,7 +266,7 @@ __device__ __forceinline__ void w4s_emit_v16(const float a[4][4], const W4Wave<4
       const int base = nb[dy][dx];
       d[r][k] = base >= 0 ? wv.tiles[base + (ii * 4 + jj) * 64] : 0.f;
     }
-  w4s_store_v(d, vp, cstride);
+  w4s_store_v(d, vp, cstride, pscale, odd);
 }
 
 // Z = A dz A^T of the thread's tile (no halo: the transform of a conv OUTPUT's cotangent) for the F(4x4,3x3)-domain
@@ -482,11 +500,18 @@ __device__ __forceinline__ float* w4s_v_ptr(float* V, const W4Wave<Q>& wv, int C
   const int g8 = wv.cb * 2 + (wv.c15 >> 3), hi = (wv.c15 >> 2) & 1, e = wv.c15 & 3;
   return V + ((size_t)((wv.nv >> 3) * (C >> 3) + g8) * 256 + (wv.nv & 7) * 32 + hi * 16 + wv.t * 4 + e);
 }
+// the thread's dword of component 0 in the fp16-pair form: part = channel parity (see w4s_pair_word)
 template <int Q>
-__device__ __forceinline__ void w4s_put_v(const float v[4][4], const W4Wave<Q>& wv, float* V, int C, int Nv) {
-  float* vp = w4s_v_ptr(V, wv, C);
-  if constexpr (Q == 1) w4s_emit_v(v, wv.ty, wv.tx, vp, (size_t)4 * Nv * C);
-  else w4s_emit_v16(v, wv, vp, (size_t)4 * Nv * C);
+__device__ __forceinline__ float* w4s_vh_ptr(float* V, const W4Wave<Q>& wv, int C) {
+  const int gp = wv.c15 >> 3, hi = (wv.c15 >> 2) & 1, e = wv.c15 & 3;
+  return V + ((size_t)(((wv.nv >> 3) * (C >> 4) + wv.cb) * 2 + (e & 1)) * 256 + ((wv.nv & 7) * 8 + hi * 4 + wv.t) * 4 + gp * 2 + (e >> 1));
+}
+template <int Q>
+__device__ __forceinline__ void w4s_put_v(const float v[4][4], const W4Wave<Q>& wv, float* V, int C, int Nv, const int* v_exp = nullptr) {
+  const float pscale = v_exp != nullptr ? ldexpf(1.f, *v_exp) : 0.f;
+  float* vp = v_exp != nullptr ? w4s_vh_ptr(V, wv, C) : w4s_v_ptr(V, wv, C);
+  if constexpr (Q == 1) w4s_emit_v(v, wv.ty, wv.tx, vp, (size_t)4 * Nv * C, pscale, (wv.c15 & 1) != 0);
+  else w4s_emit_v16(v, wv, vp, (size_t)4 * Nv * C, pscale, (wv.c15 & 1) != 0);
 }
 
 // HEAD: 0 none, 1 forward (conv result -> GroupNorm), 2 backward (data gradient -> ReLU mask -> GroupNorm backward)
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_pass(W4sArgs
     }
   }
 
-  if (a.V != nullptr) w4s_put_v(v, wv, a.V, a.C, a.Nv);
+  if (a.V != nullptr) w4s_put_v(v, wv, a.V, a.C, a.Nv, a.v_exp);
 }
 
 // workgroups of the Q = 4 kernels: (sample, NB consecutive 16-channel blocks) x four quadrants, NB = 2 when a GroupNorm
@@ -760,7 +785,8 @@ void launch_w4s_emit_outputs(const Dims& d, const EmitArgs& a, hipStream_t s) {
 // Stand-alone transforms around the GEMM (diagnostics / tests: node_conv3x3_w4): W4S tensor -> V, M -> W4S tensor
 // ----------------------------------------------------------------------------
 template <int Q>
-__global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_input(const float* __restrict__ x, float* __restrict__ V, int C, int Nv) {
+__global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_input(const float* __restrict__ x, float* __restrict__ V, int C, int Nv,
+                                                                          const int* v_exp) {
   __shared__ float s_tiles[Q == 4 ? W4Q_TILES : 1];
   W4Wave<Q> wv;
   w4s_place(wv, C, nullptr, s_tiles);
@@ -771,7 +797,7 @@ __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_input(const 
     const float4 q = w4s_ld4(x, f4 + i * 64);
     v[i][0] = q.x; v[i][1] = q.y; v[i][2] = q.z; v[i][3] = q.w;
   }
-  w4s_put_v(v, wv, V, C, Nv);
+  w4s_put_v(v, wv, V, C, Nv, v_exp);
 }
 template <int Q>
 __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_output(const float* __restrict__ M, float* __restrict__ y, int C) {
@@ -784,11 +810,11 @@ __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_output(const
   for (int i = 0; i < 4; ++i) w4s_st4(y, f4 + i * 64, z[i]);
 }
 // N: samples; Nv: virtual samples (Q N) rounded up to the GEMMs' row block
-void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s) {
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s, const int* v_exp) {
   dim3 grid, block;
   w4s_grid(N, C, 1, Q, grid, block);
-  if (Q == 1) hipLaunchKernelGGL(k_w4s_input<1>, grid, block, 0, s, x_w4s, V, C, Nv);
-  else hipLaunchKernelGGL(k_w4s_input<4>, grid, block, 0, s, x_w4s, V, C, Nv);
+  if (Q == 1) hipLaunchKernelGGL(k_w4s_input<1>, grid, block, 0, s, x_w4s, V, C, Nv, v_exp);
+  else hipLaunchKernelGGL(k_w4s_input<4>, grid, block, 0, s, x_w4s, V, C, Nv, v_exp);
 }
 void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s) {
   dim3 grid, block;

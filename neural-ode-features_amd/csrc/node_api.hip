@@ -283,6 +283,7 @@ struct Plan {
   float* w4u[4];            // its filter operands: forward conv1 / conv2, data gradient conv1 / conv2
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
   float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
+  W4Scales* w4sc;           // power-of-two scales of the fp16-pair operands (wino4.h)
   float *W4Va[2], *W4Z[2], *W4dU;   // F(4x4,3x3)-domain weight gradient (C % 128 == 0): the forward convs' row operands
                                     // kept until it runs, Z = A dz A^T of both conv outputs' cotangents, the gradients
   float *act1b, *xh1b, *r1b;   // second set of GroupNorm-1's saved tensors: the pass that ends evaluation s also forms
@@ -348,6 +349,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4u[i] = b.take<float>(w4_u_elems(d.C));
     for (int i = 0; i < (adjoint ? 4 : 2); ++i) p.w4ub[i] = b.take<unsigned short>(w4_ub_elems(d.C));
     for (int i = 0; i < 2; ++i) p.tmapS[i] = b.take<float>((size_t)d.HW * d.C);
+    p.w4sc = b.take<W4Scales>(1);
     if (adjoint && d.C % 128 == 0) {
       for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N8, d.C));
       for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N8, d.C));
@@ -491,6 +493,7 @@ struct Solver {
   // F(4x4,3x3) passes merged across evaluations (kernels_w4s.hip): the pass that ends evaluation s may already have
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
+  bool w4_f16 = false;     // ... both operands as fp16 pairs (k_w4_gemm64h; wino4.h), decided in prepare()
   bool v_ready = false;    // the next evaluation's first pass has run
   int cur = 0;             // which set of GroupNorm-1's saved tensors (act1, xhat-1, 1/sigma-1) the current evaluation owns
   float* act1_of(int i) const { return i ? p.act1b : p.act1; }
@@ -551,11 +554,30 @@ struct Solver {
       launch_fill(reinterpret_cast<float*>(p.tcount), 0.f, (size_t)d.N * d.G, st);     // (0.f is the all-zero word)
     }
     if (w4) {
+      w4_b16 = w4_uses_bf16(d.N8, d.C);
+      w4_f16 = w4_b16 && !aug && w4_f16_fits(d.N8, d.C);
+      if (w4_f16) { zr[nz] = reinterpret_cast<float*>(p.w4sc); zn[nz++] = sizeof(W4Scales) / sizeof(float); }
+    }
+    // (first: it carries the solve's zero fills, among them the scratch words of k_w4_scales)
+    launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
+                     nz, st);
+    if (w4) {
       W4PackJobs jobs;
       memset(&jobs, 0, sizeof(jobs));
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
-      w4_b16 = w4_uses_bf16(d.N8, d.C);
-      for (int i = 0; i < (aug ? 4 : 2); ++i) { jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr; jobs.dgrad[i] = i >= 2; }
+      if (w4_f16) {       // the scales of the fp16-pair operands: filters from max|w|, forward row operands from the GroupNorm in front
+        W4ScaleJobs sj;
+        memset(&sj, 0, sizeof(sj));
+        sj.w[0] = prm.conv1_w; sj.w[1] = prm.conv2_w; sj.wn = (size_t)d.C * (d.C + 1) * 9;
+        sj.gb[0] = prm.norm1_w; sj.gb[1] = prm.norm1_b; sj.gb[2] = prm.norm2_w; sj.gb[3] = prm.norm2_b;
+        sj.C = d.C; sj.gn_m = d.cpg * d.HW; sj.sc = p.w4sc;
+        launch_w4_scales(sj, st);
+      }
+      for (int i = 0; i < (aug ? 4 : 2); ++i) {
+        jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.dgrad[i] = i >= 2;
+        if (w4_f16) { jobs.uh[i] = reinterpret_cast<unsigned*>(p.w4u[i]); jobs.uh_exp[i] = &p.w4sc->e[(i & 1) ? W4_E_U2 : W4_E_U1]; }
+        else jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr;
+      }
       launch_w4_pack(jobs, aug ? 4 : 2, d.C, st);
     } else if (d.wino == 2) {   // every packing of the solve in one launch
       const float* ws_[4] = {prm.conv1_w, prm.conv2_w, prm.conv1_w, prm.conv2_w};
@@ -570,8 +592,6 @@ struct Solver {
         pack(d, prm.conv2_w, p.wd[1], 1, st);
       }
     }
-    launch_time_prep(d, prm.conv1_w, prm.conv2_w, p.tmap[0], p.tmap[1], aug ? p.wtime[0] : nullptr, aug ? p.wtime[1] : nullptr, zr, zn,
-                     nz, st);
     if (w4) launch_w4s_tmap(p.tmap[0], p.tmap[1], p.tmapS[0], p.tmapS[1], d.C, d.w4q, st);
     if (w4 && aug && d.N * d.w4q != d.N8 && p.W4dU != nullptr) {
       // the weight gradient SUMS over the GEMM rows: the rows of the padding samples (never written by a pass) must be zero
@@ -627,6 +647,11 @@ struct Solver {
   // follows, leaves that conv's row operand in W4V again
   void w4_gemm(int which, const float* V = nullptr) {
     ProfScope ps(2, conv_flops(), st);
+    if (w4_f16) {
+      launch_w4_gemm_f16(reinterpret_cast<const unsigned*>(V ? V : p.W4V), reinterpret_cast<const unsigned*>(p.w4u[which]), p.W4M, p.ctrl, d.N8, d.C,
+                         &p.w4sc->e[(which & 1) ? W4_E_V2 : W4_E_V1], &p.w4sc->e[(which & 1) ? W4_E_U2 : W4_E_U1], st);
+      return;
+    }
     launch_w4_gemm(V ? V : p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N8, d.C, st, w4_b16 ? p.w4ub[which] : nullptr);
   }
   // the weight gradients of an augmented evaluation in the F(4x4,3x3) domain (k_w4_wgrad): needs the forward convs'
@@ -643,6 +668,7 @@ struct Solver {
     a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
     if (train) { a.t.act_nhwc = w4_wgrad_on() ? nullptr : act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
     a.V = (train && w4_wgrad_on()) ? p.W4Va[0] : p.W4V;
+    if (w4_f16) a.v_exp = &p.w4sc->e[W4_E_V1];
   }
   // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
   // must read or write, once) in the record
@@ -689,6 +715,7 @@ struct Solver {
       a.h.osign = 1.f; a.h.relu = 1;
       if (train) { a.h.out_nhwc = wg4 ? nullptr : p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
       a.V = wg4 ? p.W4Va[1] : p.W4V;
+      if (w4_f16) a.v_exp = &p.w4sc->e[W4_E_V2];
       w4_pass(1, 0, a);
     }
     w4_gemm(1, wg4 ? p.W4Va[1] : nullptr);
@@ -1166,7 +1193,7 @@ size_t node_conv3x3_w4_workspace_bytes(const node_shape* shape) {
   const size_t numel = (size_t)shape->n * shape->c * shape->h * shape->w;
   const int nv = (shape->n * (shape->h == 16 ? 4 : 1) + 7) & ~7;
   return (2 * numel + 2 * w4_v_elems(nv, shape->c) + w4_u_elems(shape->c)) * sizeof(float) +
-         w4_ub_elems(shape->c) * sizeof(unsigned short) + 6 * 256;
+         w4_ub_elems(shape->c) * sizeof(unsigned short) + sizeof(W4Scales) + 8 * 256;
 }
 int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, const float* x, float* y, void* ws,
                     size_t ws_bytes, void* stream) {
@@ -1188,14 +1215,25 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   float* M = b.take<float>(w4_v_elems(Nv, d.C));
   float* U = b.take<float>(w4_u_elems(d.C));
   unsigned short* Ub = b.take<unsigned short>(w4_ub_elems(d.C));
+  W4Scales* sc = b.take<W4Scales>(1);
   W4PackJobs jobs;
   memset(&jobs, 0, sizeof(jobs));
   const bool b16 = w4_uses_bf16(Nv, d.C);
-  jobs.w[0] = weight; jobs.u[0] = U; jobs.ub[0] = b16 ? Ub : nullptr; jobs.dgrad[0] = dgrad ? 1 : 0;
+  const bool f16 = w4_f16_fits(Nv, d.C);     // fp16-pair operands (k_w4_gemm64h): the scales from max|w| and max|x|
+  if (f16) {
+    (void)hipMemsetAsync(sc, 0, sizeof(W4Scales), st);
+    W4ScaleJobs sj;
+    memset(&sj, 0, sizeof(sj));
+    sj.w[0] = weight; sj.wn = (size_t)d.C * (d.C + 1) * 9; sj.gb[1] = x; sj.vn[0] = d.numel; sj.C = d.C; sj.gn_m = 1; sj.sc = sc;
+    launch_w4_scales(sj, st);
+  }
+  jobs.w[0] = weight; jobs.u[0] = U; jobs.ub[0] = (b16 && !f16) ? Ub : nullptr; jobs.dgrad[0] = dgrad ? 1 : 0;
+  if (f16) { jobs.uh[0] = reinterpret_cast<unsigned*>(U); jobs.uh_exp[0] = &sc->e[W4_E_U1]; }
   launch_w4_pack(jobs, 1, d.C, st);
   launch_w4s_from_nchw(x, xn, d.N, d.C, Q, st);
-  launch_w4_input(xn, V, d.N, d.C, Q, Nv, st);
-  launch_w4_gemm(V, U, M, nullptr, Nv, d.C, st, b16 ? Ub : nullptr);
+  launch_w4_input(xn, V, d.N, d.C, Q, Nv, st, f16 ? &sc->e[W4_E_V1] : nullptr);
+  if (f16) launch_w4_gemm_f16(reinterpret_cast<const unsigned*>(V), reinterpret_cast<const unsigned*>(U), M, nullptr, Nv, d.C, &sc->e[W4_E_V1], &sc->e[W4_E_U1], st);
+  else launch_w4_gemm(V, U, M, nullptr, Nv, d.C, st, b16 ? Ub : nullptr);
   launch_w4_output(M, yn, d.N, d.C, Q, st);
   launch_w4s_to_nchw(yn, y, d.N, d.C, Q, st);
   hipError_t e = hipGetLastError();

@@ -50,6 +50,49 @@ __host__ __device__ inline W4Geom w4_geom(int N, int C) {
   g.N = N; g.C = C; g.RB = N / 8; g.G8 = C / 8; g.R = 4 * N;
   return g;
 }
+// ----------------------------------------------------------------------------
+// fp16-PAIR operand format of the component GEMMs (round 6; k_w4_gemm64h, k_w4_wgrad64h).
+// An fp32 value x times a power-of-two scale s is held as TWO fp16 numbers, h = fp16(s x) and l = fp16(s x - h): 22 significand
+// bits in the 4 bytes an fp32 takes, and a product of two such operands is THREE v_mfma_f32_32x32x16_f16 (hl, lh, hh; the
+// dropped ll is 2^-22 of the result) with NO vector arithmetic in the loop -- against six bf16 MFMAs plus the in-register
+// three-way split of the bf16-triple form (wino4.h above, k_w4_gemm64b).  fp16's narrow exponent is what the scales are for:
+// an element of magnitude >= 2^-3 after scaling keeps all 22 bits, a smaller one an ABSOLUTE error of 2^-25 (subnormal l; MFMA
+// and the conversions keep fp16 subnormals), 65504 is the ceiling.  tools/f16pair_error.py: at cfg 2's conv shape the convolution
+// error against fp64 is that of the fp32 chain (3.1e-6 of max|y|) for any scale that puts the operand's maximum in [2^3, 2^16).
+//   V pairs  [comp 36][rb][g2 C/16][part 2 (h, l)][s 8][hi 2][t 4][8 halves: (gp 2, e 4)]   channel = 16 g2 + 8 gp + 4 hi + e:
+//            the bytes of the fp32 layout's two g blocks; a GEMM lane's two 16-B loads (h, l: 1 KB apart) are the A operands
+//            of one K = 16 step; a producer lane swaps with its neighbour (one DPP) and stores one dword {h, h'} or {l, l'}
+//   U pairs  [comp 36][cb C/32][g2][part 2][hi 2][col 32][8 halves]                          (k_w4_pack, once per solve)
+// Scales (W4Scales, device memory): powers of two, held as exponents.  Filters: from max|w| (|U| <= 3.49 max|w|).  Forward row
+// operands: from the GroupNorm in front -- |relu(gamma xhat + beta)| <= sqrt(m - 1) max|gamma| + max|beta| over a group of m
+// values, |B^T d B| <= 49 max|d| -- so no data-dependent quantity is needed and no overflow is possible.
+// ----------------------------------------------------------------------------
+struct W4Scales {
+  int e[8];            // scale = 2^e: [0] conv1 filters, [1] conv2 filters, [2] conv1's forward row operand, [3] conv2's, [4] cotangents
+  unsigned mx[8];      // fp32 bit patterns of the maxima the exponents are derived from: |w1|, |w2|, |gamma1|, |beta1|, |gamma2|, |beta2|
+  unsigned arrived;    // k_w4_scales: blocks that have added their maxima
+  unsigned pad[15];
+};
+constexpr int W4_E_U1 = 0, W4_E_U2 = 1, W4_E_V1 = 2, W4_E_V2 = 3, W4_E_G = 4;
+struct W4ScaleJobs {
+  const float* w[2];        // conv weights [C][CI][3][3] (w[1] nullable)
+  size_t wn;                // elements of each
+  const float* gb[4];       // gamma1, beta1, gamma2, beta2 [C] (nullable: exponents 2, 3 are then left alone)
+  size_t vn[2];             // elements of gb[1] / gb[3] when they are not [C] vectors (diagnostics: a whole tensor as "beta"); 0 = C
+  int C, gn_m;              // channels; values per GroupNorm group (cpg x pixels)
+  W4Scales* sc;
+};
+// one launch: maxima by atomics (sc->mx, sc->arrived must be zero), the last block derives the exponents and zeroes them again
+void launch_w4_scales(const W4ScaleJobs& j, hipStream_t s);
+// exponent e with bound * 2^e <= 2^top (bound > 0, finite), clamped to +-60; bound == 0 -> 0
+__host__ __device__ inline int w4_scale_exp(float bound, int top) {
+  if (!(bound > 0.f)) return 0;
+  int ex;
+  (void)frexpf(bound, &ex);          // bound = m 2^ex, m in [0.5, 1)  =>  bound <= 2^ex
+  int e = top - ex;
+  return e > 60 ? 60 : e < -60 ? -60 : e;
+}
+
 constexpr int W4_SLACK = 16 * 256;         // floats behind V and U that k_w4_gemm's operand ring may read (never uses)
 __host__ __device__ inline size_t w4_v_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C + W4_SLACK; }
 __host__ __device__ inline size_t w4_u_elems(int C) { return (size_t)W4_COMPS * C * C + W4_SLACK; }
@@ -98,6 +141,7 @@ struct W4sArgs {
   W4sHead h;
   W4sTail t;
   float* V;               // nullable: blocked input transform of the tensor this pass hands to the next conv
+  const int* v_exp;       // non-null: V leaves as fp16 pairs at scale 2^*v_exp (W4Scales::e; same bytes, layout "V pairs" above)
 };
 // head: 0 none / 1 forward / 2 backward; tail: 0 none / 1 stage combine + GroupNorm-1 + ReLU / 2 adjoint combine + GroupNorm-3 backward
 void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s);
@@ -131,17 +175,22 @@ __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COM
 constexpr float W4_MIN_TOL = 0.99e-5f;
 // per job ONE of u (fp32, k_w4_gemm / k_w4_gemm64) and ub (exact bf16 triples, k_w4_gemm64b) is written: ub when non-null
 // plain[i] != 0: a [C][C][3][3] filter (the stem's conv3x3, model.py:255-258) instead of ConcatConv2d's [C][C + 1][3][3]
-struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; int plain[4]; };
+// uh[i] non-null: the fp16-pair form ("U pairs" above) at scale 2^*uh_exp[i] instead (k_w4_gemm64h)
+struct W4PackJobs { const float* w[4]; float* u[4]; unsigned short* ub[4]; int dgrad[4]; int plain[4]; unsigned* uh[4]; const int* uh_exp[4]; };
 // which form launch_w4_gemm will read for this batch (NODE_TUNE_W4_BF16X3, read on every call)
 bool w4_uses_bf16(int N, int C);
 __host__ __device__ inline size_t w4_ub_elems(int C) { return (size_t)W4_COMPS * C * C * 3 + 8 * 1536; }   // bf16 values (+ ring slack)
 void launch_w4_pack(const W4PackJobs& jobs, int count, int C, hipStream_t s);
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s,
                     const unsigned short* Ub = nullptr);
+// fp16-pair operands (V pairs at 2^*v_exp, U pairs at 2^*u_exp): M = the same fp32 products, unscaled in the epilogue
+bool w4_f16_fits(int N, int C);     // N % 16 == 0, C % 64 == 0, NODE_TUNE_W4_F16 != 0
+void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const Ctrl* ctrl, int N, int C, const int* v_exp, const int* u_exp,
+                        hipStream_t s);
 // diagnostics (node_w4_split3): out[3 i .. 3 i + 2] = the three bf16 parts of x[i] as the GEMM kernels split it; n % 8 == 0
 void launch_w4_split_check(const float* x, float* out, size_t n, hipStream_t s);
 // stand-alone transforms (diagnostics: node_conv3x3_w4; kernels_w4s.hip): W4S tensor -> V, M -> W4S tensor
-void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s);
+void launch_w4_input(const float* x_w4s, float* V, int N, int C, int Q, int Nv, hipStream_t s, const int* v_exp = nullptr);
 void launch_w4_output(const float* M, float* y_w4s, int N, int C, int Q, hipStream_t s);
 // the stem's 8x8 filters -> filters convolution through the pipeline (kernels_w4s.hip, stem_api.hip): transforms that read / write
 // the stem's NHWC tensors (and the caller's NCHW tensors at the stem's boundary) directly
