@@ -2,10 +2,12 @@
 // gfx950 (MI355X / CDNA4) only.  See wino4.h for the data layouts.
 #include "wino4.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace node {
 
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* w4_lds_ptr_t;
 
 // Big once-written, once-read results (M, dU): stored WRITE-THROUGH (agent scope = sc1 on gfx950) so that they leave the
 // XCD's L2 while the kernel still runs instead of as one write-back burst at its end (MI355X_MICROARCH.md, `boundary`:
@@ -84,9 +86,8 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
           _Float16* o = Uh + (size_t)(i * 6 + l) * total * 2 + ((((size_t)cb * (G8 >> 1) + (g >> 1)) * 2) * 64 + (size_t)(hi * 32 + col)) * 8 + (g & 1) * 4 + e;
           o[0] = hh;
           o[512] = lh;
-        } else if (Ub == nullptr) {
-          U[(size_t)(i * 6 + l) * total + fidx] = uf;
-        } else {
+        }
+        if (Ub != nullptr) {          // (an augmented solve prepares both: its first evaluations run the triples, wino4.h)
           const unsigned short hb = w4_bf16_rne(uf);
           const float r1 = uf - w4_bf16_f32(hb);
           const unsigned short mb = w4_bf16_rne(r1);
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void k_w4_pack(W4PackJobs jobs, int C) {
           o[512] = mb;
           o[1024] = lb;
         }
+        if (Ub == nullptr && Uh == nullptr) U[(size_t)(i * 6 + l) * total + fidx] = uf;
       }
   }
 }
@@ -964,7 +966,6 @@ __global__ __launch_bounds__(256, 2) void k_w4_gemm32b(const float* __restrict__
 // loop: cdna_hip_programming.md, Pipelining across barriers); a slot is refilled D + 1 steps after its reads were waited for.
 // The shared component (1/9 of the work, no operand shared between waves) keeps k_w4_gemm64b's register path and early requests.
 // ----------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* w4_lds_ptr_t;
 constexpr int W4L_SPS = 2;                          // K steps per ring slot = per barrier
 constexpr int W4L_NS = 4, W4L_D = 3, W4L_STEP = 20 * 1024, W4L_SLOT = W4L_SPS * W4L_STEP, W4L_STEPS = 16, W4L_SLOTS = W4L_STEPS / W4L_SPS;
 // one LDS-DMA piece as inline asm: the compiler, which does not count asm memory operations, then neither drains the ring
@@ -2290,6 +2291,147 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
         const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
         st_wt(o + (size_t)(8 * (m >> 1) + 4 * (m & 1) + 2 * wr + r) * C + 32 * (2 * wc + c), acc[r][c][q]);
       }
+}
+
+// ----------------------------------------------------------------------------
+// k_w4_wgrad64h: k_w4_wgrad's sums on fp16 PAIRS (wino4.h): dU_c[ci][co] = 2^-(ev + ez) sum_rows V_c[row][ci] Z_c[row][co] with both
+// operands as the GroupNorm passes left them -- V pairs (the forward GEMM's own row operand) and Z pairs in the SAME layout
+// ([comp][rb][g2][part][s][hi][t][8 halves]: rows x 16 channels per 1 KB) -- three v_mfma_f32_32x32x16_f16 per 32 x 32 block and
+// 16 rows: 14.5 GFLOP on the 2.5 PFLOP/s pipe instead of 4.8 GFLOP on the 157 TFLOP/s one.  The reduction runs over ROWS, so an
+// MFMA operand is eight rows of one channel: the [row][channel] images go through LDS as they are (LDS-DMA, 1 KB per wave
+// instruction, no registers) and come out transposed by ds_read_b64_tr_b16 -- a group of 16 lanes reads 4 rows (the four tiles
+// of one sample) x 16 channels and each lane receives its channel's four rows.
+//   workgroup = one 128 ci x 128 co tile of one (layer, component), waves = 64 x 64 quarters; K step = 16 rows = half a row block
+//   (four samples): 8 KB of V + 8 KB of Z per step through a ring of W4WH_NST stages, W4WH_D steps in flight, ONE s_barrier per step
+//   behind a counted s_waitcnt (the DMA pieces are inline asm: the compiler neither drains them in front of every LDS read nor
+//   knows of them -- the counted waits are the only ordering, as in k_w4_gemm64l).  Odd 16-channel blocks sit in the image with
+//   their samples' 128-B slots swapped pairwise (s ^ 1, applied on the DMA's per-lane SOURCE address): the two blocks a 32-lane
+//   half reads then fall on different banks.  (layer, component) pairs are dealt to XCDs nine each, the tiles of a pair together:
+//   its 1 MB of operands stays in that XCD's L2 for the second tile that reads it.  Two workgroups per CU.
+// Needs N % 8 == 0 (whole row blocks), C % 128 == 0.
+// ----------------------------------------------------------------------------
+constexpr int W4WH_NST = 4, W4WH_D = 3, W4WH_STAGE = 16384;
+__device__ __forceinline__ void w4wh_dma(const unsigned char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+struct W4WgradHArgs {
+  const unsigned* V[2]; const unsigned* Z[2];   // per layer (Z[1] / V[1] nullable: one layer)
+  float* dU; const Ctrl* ctrl; int N, C, layers;
+  const int* v_exp[2]; const int* z_exp;
+};
+typedef short w4_s16x4 __attribute__((ext_vector_type(4)));
+typedef short w4_s16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256, 2) void k_w4_wgrad64h(W4WgradHArgs a) {
+  if (a.ctrl != nullptr && a.ctrl->done) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [W4WH_NST][V image 8 KB | Z image 8 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = a.C, nRB = a.N >> 3, G16 = C >> 4, nCT = C >> 7, T = nCT * nCT;
+  const int per_xcd = (36 * a.layers) >> 3;                       // (layer, component) pairs per XCD: 9 or 4.5 -> see the launcher
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const bool by_xcd = ((36 * a.layers) & 7) == 0;                 // (one layer -- the stem's: 36 pairs do not split over 8 XCDs: in order)
+  const int pair = by_xcd ? xcd * per_xcd + slot / T : (int)blockIdx.x / T, tile = by_xcd ? slot % T : (int)blockIdx.x % T;
+  const int layer = pair / 36, comp = pair - layer * 36;
+  const int cit = tile / nCT, cot = tile - cit * nCT;
+  const size_t cbytes = (size_t)nRB * G16 * 2048;                 // bytes per component
+  const unsigned char* Vb = reinterpret_cast<const unsigned char*>(a.V[layer]) + comp * cbytes;
+  const unsigned char* Zb = reinterpret_cast<const unsigned char*>(a.Z[layer]) + comp * cbytes;
+  const float inv = ldexpf(1.f, -(*a.v_exp[layer] + *a.z_exp));
+
+  // --- DMA roles: wave w brings instructions i = 4 w .. 4 w + 3 of a stage: i < 8 the V block g2l = i (lanes 0-31 part h, 32-63
+  // part l), else the Z block g2l = i - 8.  Lane -> its 16-B chunk of the 512-B half part: LDS slot (s', hi, t) <- source (s' ^ odd, hi, t)
+  const unsigned char* src[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = 4 * wave + k, isz = i >> 3, g2l = i & 7;
+    const int part = lane >> 5, sg = lane & 31, ss = (sg >> 3) ^ (g2l & 1), hi = (sg >> 2) & 1, t = sg & 3;
+    const int g2 = (isz ? cot : cit) * 8 + g2l;
+    src[k] = (isz ? Zb : Vb) + ((size_t)g2 * 2 + part) * 1024 + ((ss * 2 + hi) * 4 + t) * 16;
+  }
+  const size_t rb_bytes = (size_t)G16 * 2048;
+  const unsigned lds0 = (unsigned)(size_t)(w4_lds_ptr_t)wsm + (unsigned)(4 * wave) * 1024u;
+  auto issue = [&](int q) {                                       // K step q = (row block q / 2, half q % 2)
+    const size_t off = (size_t)(q >> 1) * rb_bytes + (size_t)(q & 1) * 512;
+    const unsigned dst = lds0 + (unsigned)(q % W4WH_NST) * W4WH_STAGE;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4wh_dma(src[k] + off, dst + (unsigned)k * 1024u);
+  };
+  // --- fragment reads (ds_read_b64_tr_b16): lane = (kh, g2a, m = 4 q4 + p): rows = tiles q4 of samples 2 kh, 2 kh + 1; 8-byte column quad p
+  // = channels 4 p .. 4 p + 3 of its 16-channel block (hi = p & 1, gp = p >> 1); the lane receives channel m of the block
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kh = lane >> 5, g2a = (lane >> 4) & 1, m = lane & 15, q4 = m >> 2, pq = m & 3;
+  const int lane_off = (pq & 1) * 64 + q4 * 16 + (pq >> 1) * 8;
+  const int s_lo = (2 * kh) ^ g2a, s_hi = (2 * kh + 1) ^ g2a;   // LDS slots of the two samples (odd blocks are stored swapped)
+  auto frag = [&](const unsigned char* img, int g2l0, int part) -> w4_f16x8 {
+    const unsigned char* pb = img + ((g2l0 + g2a) * 2 + part) * 512 + lane_off;
+    const w4_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w4_s16x4*)(pb + s_lo * 128));
+    const w4_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w4_s16x4*)(pb + s_hi * 128));
+    const w4_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(w4_f16x8, v);
+  };
+  float16_t acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+
+  const int nK = 2 * nRB;
+#pragma unroll
+  for (int q = 0; q < W4WH_D; ++q)
+    if (q < nK) issue(q);
+  for (int q = 0; q < nK; ++q) {
+    const int ahead = min(q + W4WH_D - 1, nK - 1) - q;          // stages issued behind stage q
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's reads of stage q - 1 are in registers (its slot is refilled next)
+    __builtin_amdgcn_s_barrier();
+    if (q + W4WH_D < nK) issue(q + W4WH_D);
+    const unsigned char* st = wsm + (q % W4WH_NST) * W4WH_STAGE;
+    w4_f16x8 A[2][2], B[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+        A[r][part] = frag(st, 4 * wr + 2 * r, part);
+        B[r][part] = frag(st + 8192, 4 * wc + 2 * r, part);
+      }
+#define W4WH_P(AP, BQ)                                                                       \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)  \
+      acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[r][AP], B[c][BQ], acc[r][c], 0, 0, 0);
+    W4WH_P(1, 0) W4WH_P(0, 1) W4WH_P(0, 0)   // smallest products first
+#undef W4WH_P
+  }
+  // accumulator register q of a lane: row (q & 3) + 8 (q >> 2) + 4 kh = channel ci of the block, column lane & 31 = co
+  float* o = a.dU + ((size_t)layer * 36 + comp) * C * C + (size_t)(cit * 128 + 64 * wr) * C + cot * 128 + 64 * wc + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        st_wt(o + (size_t)(32 * r + row) * C + 32 * c, acc[r][c][q] * inv);
+      }
+}
+bool w4_wgrad_f16_fits(int N, int C) {
+  const W4Switches sw = w4_switches();
+  return sw.f16 != 0 && N % 8 == 0 && C % 128 == 0 && C < 512;
+}
+void launch_w4_wgrad_f16(const unsigned* V1, const unsigned* Z1, const unsigned* V2, const unsigned* Z2, float* dU, const Ctrl* ctrl, int N, int C,
+                         const int* v1_exp, const int* v2_exp, const int* z_exp, hipStream_t s) {
+  static bool attr[MAX_DEVICES] = {};
+  W4WgradHArgs a;
+  memset(&a, 0, sizeof(a));
+  a.V[0] = V1; a.Z[0] = Z1; a.V[1] = V2; a.Z[1] = Z2; a.dU = dU; a.ctrl = ctrl; a.N = N; a.C = C;
+  a.layers = V2 != nullptr ? 2 : 1;
+  a.v_exp[0] = v1_exp; a.v_exp[1] = v2_exp; a.z_exp = z_exp;
+  const int T = (C >> 7) * (C >> 7);
+  allow_full_lds(reinterpret_cast<const void*>(k_w4_wgrad64h), attr);
+  hipLaunchKernelGGL(k_w4_wgrad64h, dim3(36 * a.layers * T), dim3(256), (size_t)W4WH_NST * W4WH_STAGE, s, a);
 }
 
 void launch_w4_wgrad(const W4WgradArgs& a_in, hipStream_t s) {

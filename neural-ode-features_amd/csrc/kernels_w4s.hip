@@ -300,6 +300,39 @@ __device__ __forceinline__ void w4s_emit_z(const float a[4][4], int n, int N, in
   }
 }
 
+// ... as fp16 pairs in V's layout (wino4.h, "V pairs" with co in the place of ci): `zp` = the thread's dword of component 0
+__device__ __forceinline__ void w4s_emit_zh(const float a[4][4], float* __restrict__ zp, size_t cstride, float pscale, bool odd) {
+  float w[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w4s_a6(a[i][0], a[i][1], a[i][2], a[i][3], w[i][0], w[i][1], w[i][2], w[i][3], w[i][4], w[i][5]);
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    float z[6];
+    w4s_a6(w[0][nu], w[1][nu], w[2][nu], w[3][nu], z[0], z[1], z[2], z[3], z[4], z[5]);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) w4s_st_wt(zp + (size_t)(xi * 6 + nu) * cstride, w4s_pair_word(z[xi], pscale, odd));
+  }
+}
+// max|dz| of the wave -> W4Scales::gmax (and `ovf` when the fp16-pair scale 2^*g_exp cannot hold it); see wino4.h
+__device__ __forceinline__ void w4s_record_max(const float v[4][4], W4Scales* sc, const int* g_exp) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(v[i][j]));
+  m = fmaxf(m, w4s_dpp<0xB1>(m));
+  m = fmaxf(m, w4s_dpp<0x4E>(m));
+  m = fmaxf(m, w4s_dpp<0x141>(m));
+  m = fmaxf(m, w4s_dpp<0x140>(m));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    atomicMax(&sc->gmax[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63], __builtin_bit_cast(unsigned, m));
+    // (a non-finite cotangent is not a question of scale: it goes on to the error norm, which stops the solve)
+    if (g_exp != nullptr && m < INFINITY && m * ldexpf(1.f, *g_exp) > W4_G_LIMIT) __hip_atomic_store(&sc->ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // masked column sums of the thread's channel (node_internal.h, masked_colsum_tile): out[tap * ld] for the nine taps.
 // fr / lr / fc / lc: the thread's tile touches the image's first / last row / column.  The sum runs over the wave's four
 // tiles: the whole image (Q = 1) or one quadrant of it (Q = 4: k_theta_finalize adds the quadrants' rows like samples').
@@ -595,7 +628,11 @@ __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_pass(W4sArgs
     }
     if (h.out_nhwc) w4s_store_nhwc(h.out_nhwc, wv, a.C, ho);
     if (h.spart) w4s_colsums(ho, wv, h.spart, a.C);
-    if (h.z_out) w4s_emit_z(ho, wv.nv, a.Nv, a.C, c, t, h.z_out);
+    if (a.gstat != nullptr && (h.z_out != nullptr || (TAIL == 0 && a.V != nullptr))) w4s_record_max(ho, a.gstat, a.z_exp != nullptr ? a.z_exp : (TAIL == 0 ? a.v_exp : nullptr));
+    if (h.z_out) {
+      if (a.z_exp != nullptr) w4s_emit_zh(ho, w4s_vh_ptr(h.z_out, wv, a.C), (size_t)4 * a.Nv * a.C, ldexpf(1.f, *a.z_exp), (wv.c15 & 1) != 0);
+      else w4s_emit_z(ho, wv.nv, a.Nv, a.C, c, t, h.z_out);
+    }
     if (TAIL == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -648,7 +685,11 @@ __global__ __launch_bounds__(Q == 1 ? W4S_THREADS : 512) void k_w4s_pass(W4sArgs
       w4s_gn_bwd(g, hx, a.h.gamma[c], hrstd, cpg, inv_m, 1.f, wv, a.C, tl.gpart, v);
       if (tl.act_nhwc) w4s_store_nhwc(tl.act_nhwc, wv, a.C, v);
       if (tl.spart) w4s_colsums(v, wv, tl.spart, a.C);
-      if (tl.z_out) w4s_emit_z(v, wv.nv, a.Nv, a.C, c, t, tl.z_out);
+      if (a.gstat != nullptr) w4s_record_max(v, a.gstat, a.z_exp != nullptr ? a.z_exp : a.v_exp);
+      if (tl.z_out) {
+        if (a.z_exp != nullptr) w4s_emit_zh(v, w4s_vh_ptr(tl.z_out, wv, a.C), (size_t)4 * a.Nv * a.C, ldexpf(1.f, *a.z_exp), (wv.c15 & 1) != 0);
+        else w4s_emit_z(v, wv.nv, a.Nv, a.C, c, t, tl.z_out);
+      }
     }
   }
 

@@ -494,6 +494,11 @@ struct Solver {
   // formed evaluation s + 1's conv input (Butcher combine -> GroupNorm-1 -> ReLU -> V)
   bool w4_b16 = false;     // the component GEMMs read the filters as exact bf16 triples (k_w4_gemm64b), decided in prepare()
   bool w4_f16 = false;     // ... both operands as fp16 pairs (k_w4_gemm64h; wino4.h), decided in prepare()
+  bool w4_f16_aug = false; // set by the caller before prepare(): an augmented solve may use them (adaptive dopri5 solves: the cotangent-side
+                           // scale follows the data through the step controller)
+  bool g_ready = false;    // the cotangent-side scale is known (behind an interval's first evaluation, launch_w4_gscale)
+  // the format of the evaluation being enqueued: forward solves always pairs; augmented ones once the cotangent scale is known
+  bool f16_now() const { return w4_f16 && (!aug || g_ready); }
   bool v_ready = false;    // the next evaluation's first pass has run
   int cur = 0;             // which set of GroupNorm-1's saved tensors (act1, xhat-1, 1/sigma-1) the current evaluation owns
   float* act1_of(int i) const { return i ? p.act1b : p.act1; }
@@ -555,7 +560,8 @@ struct Solver {
     }
     if (w4) {
       w4_b16 = w4_uses_bf16(d.N8, d.C);
-      w4_f16 = w4_b16 && !aug && w4_f16_fits(d.N8, d.C);
+      w4_f16 = w4_b16 && w4_f16_fits(d.N8, d.C) && (!aug || (w4_f16_aug && w4_wgrad_on() && w4_wgrad_f16_fits(d.N8, d.C)));
+      g_ready = false;
       if (w4_f16) { zr[nz] = reinterpret_cast<float*>(p.w4sc); zn[nz++] = sizeof(W4Scales) / sizeof(float); }
     }
     // (first: it carries the solve's zero fills, among them the scratch words of k_w4_scales)
@@ -576,7 +582,7 @@ struct Solver {
       for (int i = 0; i < (aug ? 4 : 2); ++i) {
         jobs.w[i] = ws_[i]; jobs.u[i] = p.w4u[i]; jobs.dgrad[i] = i >= 2;
         if (w4_f16) { jobs.uh[i] = reinterpret_cast<unsigned*>(p.w4u[i]); jobs.uh_exp[i] = &p.w4sc->e[(i & 1) ? W4_E_U2 : W4_E_U1]; }
-        else jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr;
+        if (!w4_f16 || aug) jobs.ub[i] = w4_b16 ? p.w4ub[i] : nullptr;
       }
       launch_w4_pack(jobs, aug ? 4 : 2, d.C, st);
     } else if (d.wino == 2) {   // every packing of the solve in one launch
@@ -647,9 +653,9 @@ struct Solver {
   // follows, leaves that conv's row operand in W4V again
   void w4_gemm(int which, const float* V = nullptr) {
     ProfScope ps(2, conv_flops(), st);
-    if (w4_f16) {
+    if (f16_now()) {     // which: 0 / 1 forward conv1 / conv2, 2 / 3 their data gradients (row operand = a cotangent)
       launch_w4_gemm_f16(reinterpret_cast<const unsigned*>(V ? V : p.W4V), reinterpret_cast<const unsigned*>(p.w4u[which]), p.W4M, p.ctrl, d.N8, d.C,
-                         &p.w4sc->e[(which & 1) ? W4_E_V2 : W4_E_V1], &p.w4sc->e[(which & 1) ? W4_E_U2 : W4_E_U1], st);
+                         &p.w4sc->e[which >= 2 ? W4_E_G : which ? W4_E_V2 : W4_E_V1], &p.w4sc->e[(which & 1) ? W4_E_U2 : W4_E_U1], st);
       return;
     }
     launch_w4_gemm(V ? V : p.W4V, p.w4u[which], p.W4M, p.ctrl, d.N8, d.C, st, w4_b16 ? p.w4ub[which] : nullptr);
@@ -668,7 +674,7 @@ struct Solver {
     a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
     if (train) { a.t.act_nhwc = w4_wgrad_on() ? nullptr : act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
     a.V = (train && w4_wgrad_on()) ? p.W4Va[0] : p.W4V;
-    if (w4_f16) a.v_exp = &p.w4sc->e[W4_E_V1];
+    if (f16_now()) a.v_exp = &p.w4sc->e[W4_E_V1];
   }
   // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
   // must read or write, once) in the record
@@ -715,7 +721,7 @@ struct Solver {
       a.h.osign = 1.f; a.h.relu = 1;
       if (train) { a.h.out_nhwc = wg4 ? nullptr : p.act2; a.h.xhat_s = p.xh2; a.h.rstd = p.r2; }
       a.V = wg4 ? p.W4Va[1] : p.W4V;
-      if (w4_f16) a.v_exp = &p.w4sc->e[W4_E_V2];
+      if (f16_now()) a.v_exp = &p.w4sc->e[W4_E_V2];
       w4_pass(1, 0, a);
     }
     w4_gemm(1, wg4 ? p.W4Va[1] : nullptr);
@@ -739,6 +745,8 @@ struct Solver {
     if (wg4) a3.t.z_out = need_theta ? p.W4Z[1] : nullptr;
     else a3.t.act_nhwc = p.dz2;
     a3.V = p.W4V;
+    if (w4_f16) a3.gstat = p.w4sc;
+    if (f16_now()) { a3.v_exp = &p.w4sc->e[W4_E_G]; a3.z_exp = &p.w4sc->e[W4_E_G]; }
     w4_pass(1, 2, a3);
     if (count_nfe) nfe += 1;
     w4_gemm(3);   // data gradient of conv2
@@ -749,9 +757,15 @@ struct Solver {
       if (wg4) a.h.z_out = need_theta ? p.W4Z[0] : nullptr;
       else a.h.out_nhwc = p.dz1;
       a.V = p.W4V;
+      if (w4_f16) a.gstat = p.w4sc;
+      if (f16_now()) { a.v_exp = &p.w4sc->e[W4_E_G]; a.z_exp = &p.w4sc->e[W4_E_G]; }
       w4_pass(2, 0, a);
     }
-    if (need_theta && wg4) {
+    if (need_theta && wg4 && f16_now()) {
+      ProfScope ps(1, 2.0 * conv_flops(), st);
+      launch_w4_wgrad_f16(reinterpret_cast<const unsigned*>(p.W4Va[0]), reinterpret_cast<const unsigned*>(p.W4Z[0]), reinterpret_cast<const unsigned*>(p.W4Va[1]),
+                          reinterpret_cast<const unsigned*>(p.W4Z[1]), p.W4dU, p.ctrl, d.N8, d.C, &p.w4sc->e[W4_E_V1], &p.w4sc->e[W4_E_V2], &p.w4sc->e[W4_E_G], st);
+    } else if (need_theta && wg4) {
       W4WgradArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
@@ -1020,6 +1034,7 @@ struct Solver {
     sc.forced = io.n_forced > 0 ? p.forced : nullptr; sc.n_forced = io.n_forced;
     sc.dt_log = io.log_cap > 0 ? p.dtlog : nullptr; sc.dt_log_cap = io.log_cap;
     sc.interp_scalar = aug ? 1 : 0;
+    sc.w4sc = (aug && w4_f16) ? p.w4sc : nullptr;
     launch_step_controller(sc, st);
     if (!aug) {
       EmitArgs ea;
@@ -1477,6 +1492,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
                      method == NODE_METHOD_DOPRI5)
                         ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
+  S.w4_f16_aug = method == NODE_METHOD_DOPRI5;
   TRY(S.prepare());
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
@@ -1519,7 +1535,9 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       launch_set_interval(S.p.ctrl, s0, forced ? opts->forced_dt[0] : 0.0, S.st);
       if (blind) launch_set_target(S.p.targets, s1, S.st);
       else TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
+      S.g_ready = false;      // (fp16-pair operands: the interval's first evaluation runs the triples and records max|dz|, wino4.h)
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
+      if (S.w4_f16) { launch_w4_gscale(S.p.w4sc, S.st); S.g_ready = true; }
       if (gdot) launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], gdot, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
       if (blind) {   // deferred completion (one interval): the record says later whether these were the steps needed

@@ -287,6 +287,7 @@ struct StepCtlArgs {
   double* dt_log;          // device, nullable: dt tried at step k (negative: rejected)
   int dt_log_cap;
   int interp_scalar;       // aug: when the last target is passed, ts_cur <- dense output at that time
+  struct W4Scales* w4sc;   // nullable: the solve's cotangent-side fp16-pair scale follows the data (wino4.h): update it, repeat a step that overflowed
 };
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s);
 

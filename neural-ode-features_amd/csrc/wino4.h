@@ -67,12 +67,48 @@ __host__ __device__ inline W4Geom w4_geom(int N, int C) {
 // operands: from the GroupNorm in front -- |relu(gamma xhat + beta)| <= sqrt(m - 1) max|gamma| + max|beta| over a group of m
 // values, |B^T d B| <= 49 max|d| -- so no data-dependent quantity is needed and no overflow is possible.
 // ----------------------------------------------------------------------------
+// exponent e with bound * 2^e <= 2^top (bound > 0, finite), clamped to +-60; bound == 0 -> 0
+__host__ __device__ inline int w4_scale_exp(float bound, int top) {
+  if (!(bound > 0.f)) return 0;
+  int ex;
+  (void)frexpf(bound, &ex);          // bound = m 2^ex, m in [0.5, 1)  =>  bound <= 2^ex
+  int e = top - ex;
+  return e > 60 ? 60 : e < -60 ? -60 : e;
+}
+
+// COTANGENT-side operands (the data gradients' row operands and Z = A dz A^T of the weight gradient) have no bound a priori:
+// their scale 2^e[W4_E_G] follows the data.  Every pass that forms such a tensor adds max|dz| of its waves to gmax[] (atomicMax
+// on the bit pattern, 64 slots); the step controller (k_step_controller) and k_w4_gscale turn the maximum of the finished step
+// into the next step's exponent, max|dz| 2^e in (2^4, 2^5]: |B^T dz B| <= 49 |dz| and |A dz A^T| <= 225 |dz| then stay under
+// 2^13 -- a cotangent may grow EIGHT-fold from one step to the next before a value could pass fp16's 65504.  A pass that sees
+// max|dz| 2^e > 2^8 raises `ovf`: the controller then REPEATS the step (nothing accepted, dt unchanged, not counted as a step of
+// the solver) at the exponent the recorded maximum asks for.  The first evaluations of an interval (f0, before any maximum is
+// known) run the bf16-triple kernels on fp32 operands and only record.
 struct W4Scales {
   int e[8];            // scale = 2^e: [0] conv1 filters, [1] conv2 filters, [2] conv1's forward row operand, [3] conv2's, [4] cotangents
   unsigned mx[8];      // fp32 bit patterns of the maxima the exponents are derived from: |w1|, |w2|, |gamma1|, |beta1|, |gamma2|, |beta2|
   unsigned arrived;    // k_w4_scales: blocks that have added their maxima
-  unsigned pad[15];
+  unsigned ovf;        // a cotangent-side value left the range of its scale in the current step
+  int n_retry;         // steps repeated for that reason (diagnostics)
+  unsigned pad[13];
+  unsigned gmax[64];   // max|dz| of the current step's passes, fp32 bit patterns (slot = workgroup % 64)
 };
+constexpr int W4_G_TOP = 5;          // max|dz| 2^e <= 2^5
+constexpr float W4_G_LIMIT = 256.f;  // ... and a pass that meets more than 2^8 asks for the step to be repeated
+// ONE thread: the exponent of the cotangent-side operands from the recorded maxima (then cleared); returns whether a pass overflowed
+__device__ inline bool w4_gscale_update(W4Scales* sc) {
+  float g = 0.f;
+  for (int i = 0; i < 64; ++i) {
+    g = fmaxf(g, __builtin_bit_cast(float, __hip_atomic_load(&sc->gmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    __hip_atomic_store(&sc->gmax[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const bool ovf = __hip_atomic_load(&sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  __hip_atomic_store(&sc->ovf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (g > 0.f && g < INFINITY) sc->e[4] = w4_scale_exp(g, W4_G_TOP);
+  if (ovf) sc->n_retry += 1;
+  return ovf;
+}
+void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-thread launch (behind an interval's first evaluation)
 constexpr int W4_E_U1 = 0, W4_E_U2 = 1, W4_E_V1 = 2, W4_E_V2 = 3, W4_E_G = 4;
 struct W4ScaleJobs {
   const float* w[2];        // conv weights [C][CI][3][3] (w[1] nullable)
@@ -84,15 +120,6 @@ struct W4ScaleJobs {
 };
 // one launch: maxima by atomics (sc->mx, sc->arrived must be zero), the last block derives the exponents and zeroes them again
 void launch_w4_scales(const W4ScaleJobs& j, hipStream_t s);
-// exponent e with bound * 2^e <= 2^top (bound > 0, finite), clamped to +-60; bound == 0 -> 0
-__host__ __device__ inline int w4_scale_exp(float bound, int top) {
-  if (!(bound > 0.f)) return 0;
-  int ex;
-  (void)frexpf(bound, &ex);          // bound = m 2^ex, m in [0.5, 1)  =>  bound <= 2^ex
-  int e = top - ex;
-  return e > 60 ? 60 : e < -60 ? -60 : e;
-}
-
 constexpr int W4_SLACK = 16 * 256;         // floats behind V and U that k_w4_gemm's operand ring may read (never uses)
 __host__ __device__ inline size_t w4_v_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C + W4_SLACK; }
 __host__ __device__ inline size_t w4_u_elems(int C) { return (size_t)W4_COMPS * C * C + W4_SLACK; }
@@ -142,6 +169,8 @@ struct W4sArgs {
   W4sTail t;
   float* V;               // nullable: blocked input transform of the tensor this pass hands to the next conv
   const int* v_exp;       // non-null: V leaves as fp16 pairs at scale 2^*v_exp (W4Scales::e; same bytes, layout "V pairs" above)
+  const int* z_exp;       // non-null: z_out (head or tail) leaves as fp16 pairs in V's layout at scale 2^*z_exp
+  W4Scales* gstat;        // non-null: this pass forms a cotangent (dz1 / dz2): record max|dz|, raise ovf past the scale's range
 };
 // head: 0 none / 1 forward / 2 backward; tail: 0 none / 1 stage combine + GroupNorm-1 + ReLU / 2 adjoint combine + GroupNorm-3 backward
 void launch_w4s_pass(int head, int tail, const W4sArgs& a, hipStream_t s);
@@ -165,6 +194,10 @@ struct W4WgradArgs {
   int sharev;                         // set by launch_w4_wgrad (NODE_TUNE_W4_SHAREV): the waves of a workgroup share one component's V stream
 };
 void launch_w4_wgrad(const W4WgradArgs& a, hipStream_t s);
+// fp16-pair operands (k_w4_wgrad64h): V pairs and Z pairs in V's layout; dU as above (unscaled in the epilogue)
+bool w4_wgrad_f16_fits(int N, int C);
+void launch_w4_wgrad_f16(const unsigned* V1, const unsigned* Z1, const unsigned* V2, const unsigned* Z2, float* dU, const Ctrl* ctrl, int N, int C,
+                         const int* v1_exp, const int* v2_exp, const int* z_exp, hipStream_t s);
 void w4_refresh_tuning();     // re-read the NODE_TUNE_W4_* switches (once per C-ABI call; kernels_w4.hip)
 __host__ __device__ inline size_t w4_z_elems(int N, int C) { return (size_t)W4_COMPS * 4 * N * C; }
 __host__ __device__ inline size_t w4_du_elems(int C) { return (size_t)2 * W4_COMPS * C * C; }
