@@ -464,13 +464,14 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
     if (threadIdx.x == 0) ratios[sgi] = (float)((double)tot / a.numel[sgi]);
     __syncthreads();
   }
+  bool w4_ovf = false;
+  if (a.w4sc != nullptr && threadIdx.x < 64) w4_ovf = w4_gscale_update(a.w4sc, threadIdx.x);   // (the first wave, all its lanes)
   if (threadIdx.x != 0) return;
   if (a.w4sc != nullptr) {
-    // fp16-pair operands (wino4.h): the next step's cotangent scale from this step's recorded maximum; a step in which a pass met
-    // a value beyond its scale's range is REPEATED at the new scale -- nothing accepted, t and dt as they were, not a solver step
+    // fp16-pair operands (wino4.h): the next step's cotangent scale from this step's recorded maximum (above); a step in which a pass
+    // met a value beyond its scale's range is REPEATED at the new scale -- nothing accepted, t and dt as they were, not a solver step
     W4Scales* sc = a.w4sc;
-    const bool ovf = w4_gscale_update(sc);
-    if (ovf && sc->pad[0] < 8u) {
+    if (w4_ovf && sc->pad[0] < 8u) {
       sc->pad[0] += 1u;                    // (consecutive repeats: bounded)
       Ctrl* c = a.ctrl;
       c->accept = 0;
@@ -483,8 +484,8 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   }
   step_controller_decide(a, ratios);
 }
-__global__ void k_w4_gscale(W4Scales* sc) { (void)w4_gscale_update(sc); }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(1), 0, s, sc); }
+__global__ __launch_bounds__(64) void k_w4_gscale(W4Scales* sc) { (void)w4_gscale_update(sc, threadIdx.x); }
+void launch_w4_gscale(W4Scales* sc, hipStream_t s) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(64), 0, s, sc); }
 
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);

@@ -1401,16 +1401,27 @@ __global__ __launch_bounds__(256) void k_w4_gemm64c(const float* __restrict__ V,
 // maximum of its slice of job's tensor by atomicMax on the fp32 bit pattern (non-negative floats order like unsigned integers);
 // the last block to arrive derives the exponents and zeroes the scratch words for the next launch.
 // ----------------------------------------------------------------------------
-constexpr int W4SC_BLOCKS = 128;
-__global__ __launch_bounds__(256) void k_w4_scales(W4ScaleJobs j) {
+constexpr int W4SC_BLOCKS = 32;       // per big tensor (every block takes one returning ticket at the end: few blocks, several requests in flight each)
+__global__ __launch_bounds__(256) void k_w4_scales(W4ScaleJobs j, int nbig) {
   __shared__ float red[4];
-  const int job = blockIdx.y;
+  // blocks [0, nbig W4SC_BLOCKS): slices of the big tensors (the conv weights; diagnostics: a whole activation tensor as "beta");
+  // then one block per [C] vector
+  int job, part, parts;
+  if ((int)blockIdx.x < nbig * W4SC_BLOCKS) {
+    const int b = blockIdx.x / W4SC_BLOCKS;
+    part = blockIdx.x - b * W4SC_BLOCKS; parts = W4SC_BLOCKS;
+    job = j.bigjob[b];
+  } else {
+    job = 2 + ((int)blockIdx.x - nbig * W4SC_BLOCKS); part = 0; parts = 1;
+  }
   const float* p = job < 2 ? j.w[job] : j.gb[job - 2];
   size_t n = job < 2 ? j.wn : (size_t)j.C;
-  if ((job == 3 || job == 5) && j.vn[(job - 3) >> 1] != 0) n = j.vn[(job - 3) >> 1];
+  const bool big_vec = (job == 3 || job == 5) && j.vn[(job - 3) >> 1] != 0;
+  if (big_vec) n = j.vn[(job - 3) >> 1];
+  if (parts == 1 && big_vec) p = nullptr;     // (a big "vector" is taken by its sliced blocks)
   float m = 0.f;
   if (p != nullptr) {
-    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    const size_t i0 = (size_t)part * 256 + threadIdx.x, step = (size_t)parts * 256;
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && (n & 3) == 0) {      // 16-B loads, four in flight
       const float4* q = reinterpret_cast<const float4*>(p);
       const size_t n4 = n >> 2;
@@ -1435,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_w4_scales(W4ScaleJobs j) {
   if (m > 0.f) atomicMax(&sc->mx[job], __builtin_bit_cast(unsigned, m));
   __threadfence();
   const unsigned ticket = atomicAdd(&sc->arrived, 1u);
-  if (ticket != gridDim.x * gridDim.y - 1) return;
+  if (ticket != gridDim.x - 1) return;
   __threadfence();
   float mx[6];
 #pragma unroll
@@ -1453,8 +1464,14 @@ __global__ __launch_bounds__(256) void k_w4_scales(W4ScaleJobs j) {
   if (j.gb[0] != nullptr || j.gb[1] != nullptr) sc->e[W4_E_V1] = w4_scale_exp(49.f * (rm * mx[2] + mx[3]), 15);
   if (j.gb[2] != nullptr || j.gb[3] != nullptr) sc->e[W4_E_V2] = w4_scale_exp(49.f * (rm * mx[4] + mx[5]), 15);
 }
-void launch_w4_scales(const W4ScaleJobs& j, hipStream_t s) {
-  hipLaunchKernelGGL(k_w4_scales, dim3(W4SC_BLOCKS, 6), dim3(256), 0, s, j);
+void launch_w4_scales(const W4ScaleJobs& j_in, hipStream_t s) {
+  W4ScaleJobs j = j_in;
+  int nbig = 0;      // the tensors cut over W4SC_BLOCKS blocks: the conv weights, and a "vector" with a length of its own (diagnostics)
+  if (j.w[0] != nullptr) j.bigjob[nbig++] = 0;
+  if (j.w[1] != nullptr) j.bigjob[nbig++] = 1;
+  if (j.vn[0] != 0) j.bigjob[nbig++] = 3;
+  if (j.vn[1] != 0) j.bigjob[nbig++] = 5;
+  hipLaunchKernelGGL(k_w4_scales, dim3(nbig * W4SC_BLOCKS + 4), dim3(256), 0, s, j, nbig);
 }
 
 // ----------------------------------------------------------------------------
@@ -1504,7 +1521,7 @@ __device__ __forceinline__ void w4h_mac(float16_t (&acc)[2][2], const W4HStage& 
 // acc += sum over K = 16 steps [g0, g0 + n) (n a multiple of D): a ring of D stages, each refilled right behind the MFMAs that
 // consumed it (the refills of the last D steps read up to D steps past the range: buffer slack)
 template <int D, int NRB, class F = W4Nothing>
-__device__ __forceinline__ void w4h_run(float16_t (&acc)[2][2], const W4HCursor& start, int n, F after_fill = F()) {
+__device__ __forceinline__ void w4h_run(float16_t (&acc)[2][2], const W4HCursor& start, int n, F after_fill = F(), unsigned long long* st = nullptr) {
   W4HStage ring[D];
   W4HCursor cu = start;
 #pragma unroll
@@ -1513,7 +1530,9 @@ __device__ __forceinline__ void w4h_run(float16_t (&acc)[2][2], const W4HCursor&
     __builtin_amdgcn_sched_barrier(0);
   }
   after_fill();
+  w4_stamp(st, 1);
   for (int g = 0; g < n; g += D) {
+    if (g == D) w4_stamp(st, 2);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       w4h_mac<NRB>(acc, ring[i]);
@@ -1525,10 +1544,12 @@ __device__ __forceinline__ void w4h_run(float16_t (&acc)[2][2], const W4HCursor&
 
 template <int D>
 __global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
-                                                    const Ctrl* ctrl, W4Geom gm, int mode, const int* v_exp, const int* u_exp) {
+                                                    const Ctrl* ctrl, W4Geom gm, int mode, const int* v_exp, const int* u_exp, unsigned long long* stamps) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2 blocks][4 r4][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* st = stamps != nullptr ? stamps + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;   // (diagnostics build only)
+  w4_stamp(st, 0);
   const int l31 = lane & 31, hi = lane >> 5;
   const int nCT = gm.C >> 6, nRB = gm.RB, G2 = gm.G8 >> 1, CB = gm.C >> 5;
   const int j = blockIdx.x & 7, tile = blockIdx.x >> 3;
@@ -1566,7 +1587,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
-    w4h_run<D, 2>(acc, cu, G2, [&]() {
+    auto request_shared = [&]() {
       if (early) {
         W4HCursor c2 = scu;
 #pragma unroll
@@ -1576,16 +1597,53 @@ __global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__
         }
         asm volatile("" ::: "memory");   // (the compiler may not sink these requests to their first use behind the loop)
       }
-    });
+    };
     const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;   // floats per sample of M
     float* m0 = M + ((size_t)(ort * 16 + hi) * (gm.C >> 5) + 2 * oct) * (36 * 128) + (size_t)comp * 128 + l31;
+    if ((mode & 16) != 0 && G2 % D == 0 && G2 >= 2 * D) {
+      // mode bit 4 (NODE_TUNE_W4_HSPLIT, default): the tile as TWO 32-row halves one after the other on ONE operand ring -- the first
+      // half's 16 KB of results drain while the second half's operands stream in (as one 64 x 64 tile every wave of the chip loads, then
+      // every wave stores: 3 us of a 12 us launch in which nothing is read); the column operand is fetched twice (from L2).
+      W4HStage ring[D];
+      W4HCursor cc;
+      cc.a[0] = cu.a[0]; cc.a[1] = cu.a[0]; cc.b[0] = cu.b[0]; cc.b[1] = cu.b[1];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
-      st_wt(o, acc[0][0][q] * inv);
-      st_wt(o + 36 * 128, acc[0][1][q] * inv);
-      st_wt(o + 8 * sstride, acc[1][0][q] * inv);
-      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q] * inv);
+      for (int i = 0; i < D; ++i) {
+        w4h_next<1>(ring[i], cc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      request_shared();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        for (int g = 0; g < G2; g += D) {
+          if (h == 0 && g + D == G2) { cc.a[0] = cu.a[1]; cc.b[0] = cu.b[0]; cc.b[1] = cu.b[1]; }   // this round's refills open the second half
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            w4h_mac<1>(acc, ring[i]);
+            __builtin_amdgcn_sched_barrier(0);   // the refill stays behind the MFMAs that read the old contents
+            w4h_next<1>(ring[i], cc);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32 + (h ? 8 * sstride : 0);
+          st_wt(o, acc[0][0][q] * inv);
+          st_wt(o + 36 * 128, acc[0][1][q] * inv);
+          acc[0][0][q] = 0.f; acc[0][1][q] = 0.f;
+        }
+      }
+    } else {
+      w4h_run<D, 2>(acc, cu, G2, request_shared, st);
+      w4_stamp(st, 3);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+        st_wt(o, acc[0][0][q] * inv);
+        st_wt(o + 36 * 128, acc[0][1][q] * inv);
+        st_wt(o + 8 * sstride, acc[1][0][q] * inv);
+        st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q] * inv);
+      }
+      w4_stamp(st, 4);
     }
   }
   // --- half a tile of a shared component: rows [32 half, 32 half + 32), K range [wave G2/4, (wave+1) G2/4) per wave
@@ -1601,6 +1659,7 @@ __global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__
     } else if (sng % 4 == 0) w4h_run<4, 1>(acc, scu, sng);
     else if (sng % 2 == 0) w4h_run<2, 1>(acc, scu, sng);
     else w4h_run<1, 1>(acc, scu, sng);
+    w4_stamp(st, 5);
     float* red = smem + wave * 2048;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1626,6 +1685,13 @@ __global__ __launch_bounds__(256) void k_w4_gemm64h(const unsigned* __restrict__
       st_wt(mrow + 96, sm.w * inv);
     }
   }
+#ifdef NODE_DIAG
+  if (st != nullptr) {   // (diagnostics: when this wave's stores have drained)
+    w4_stamp(st, 6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    w4_stamp(st, 7);
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -1826,17 +1892,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
 // The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
 // kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half, f16, hdepth; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half, f16, hdepth, hsplit, h128; };
 static W4Switches w4_read_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   // NODE_TUNE_W4_GEMM128 / _WGRAD128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512)
 #ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
           rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0),
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0), rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0), rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1)};
 #else
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0, rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0, rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1)};
 #endif
 }
 // The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
@@ -1863,21 +1929,205 @@ bool w4_uses_bf16(int N, int C) {
   return N % 16 == 0 && sw.g64 != 0 && sw.b16 != 0 && (sw.ablate == 0 || sw.ablate >= 16);
 }
 
+// one 1 KB LDS-DMA piece (lane-linear destination) as inline asm: the compiler neither counts it nor drains it in front of LDS reads
+__device__ __forceinline__ void w4wh_dma(const unsigned char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// ----------------------------------------------------------------------------
+// k_w4_gemm128h: k_w4_gemm64h's products as an LDS-tiled GEMM (the skeleton of k_w4_gemm128b): a workgroup owns a 128 x 128 tile of
+// ONE component, its waves 64 x 64 quarters; per K = 16 step each wave fetches ONE quarter of the tile's operands -- its 32-row block
+// of V pairs and its 32-column block of U pairs, parts h and l: four 16-B requests per lane, already the MFMA fragments -- and
+// the 16 KB of the step go through a two-stage LDS ring (one barrier per step), so a CU takes in 16 KB per step where
+// k_w4_gemm64h's four independent 64 x 64 tiles take 32 KB.  Why: k_w4_gemm64h is bound by the texture path (64 B per clock and CU:
+// tools/w4_stamps.py -- 2.4 us to issue the first ring, then 720 cycles per K step against 384 of matrix work;
+// profiles/r06_pmc_w4h.txt) at short reductions and, like k_w4_gemm64b, by operand re-reads from the Infinity Cache at long ones.
+// Requests as inline asm with hand-placed waits, NSET register sets in flight that are never copied (k_w4_gemm128b).  (Measured and
+// removed, round 6: the same tile with the operands brought by LDS-DMA -- no staging instructions -- 14.1 - 17.9 us against
+// k_w4_gemm64h's 12.8 at cfg 2: a CU's four DMA streams deliver less than its register loads do.)
+// Work: components 0..31 give 32 nT tiles (nT = rows / 128 x C / 128); XCD j takes 4 j .. 4 j + 3 one after the other, and every
+// workgroup adds one EIGHTH of a tile of component 32 + j / 2 (a 32 x 64 block, K range cut over its four waves and summed through
+// LDS, operands straight into registers: k_w4_gemm64h's shared component), so every workgroup does the same work.
+// Needs rows % 128 == 0 (N % 32 == 0), C % 128 == 0, nT even.
+// ----------------------------------------------------------------------------
+struct W4GLoad { w4_u32x4 a0, a1, b0, b1; };
+#define W4G_FETCH(L, PA, PB)                                                                        \
+  {                                                                                                 \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a0) : "v"(PA) : "memory");            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a1) : "v"(PA) : "memory"); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b0) : "v"(PB) : "memory");            \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b1) : "v"(PB) : "memory"); \
+  }
+#define W4G_WAIT(N, L) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((L).a0), "+v"((L).a1), "+v"((L).b0), "+v"((L).b1) : : "memory")
+template <int WPC>
+__global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
+                                                           const Ctrl* ctrl, W4Geom gm, const int* v_exp, const int* u_exp) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) w4_u32x4 gtile[];   // [2 stages][A 4 row blocks x 2 parts | B 4 column blocks x 2 parts][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 7, nRT = gm.R >> 7, nT = nRT * nCT, G2 = gm.G8 >> 1, CB = gm.C >> 5, nRB = gm.RB;
+  const int j = blockIdx.x & 7, i = blockIdx.x >> 3;            // XCD, slot: 4 nT slots per XCD
+  const int comp = 4 * j + i / nT, tile = i % nT;
+  const int RT = tile / nCT, CT = tile - RT * nCT;
+  const float inv = ldexpf(1.f, -(*v_exp + *u_exp));
+  const int a_off = ((l31 >> 2) * 8) + hi * 4 + (l31 & 3);      // lane (row = 4 s + t, k-half hi): its 16 B inside a 1 KB part of V
+  // --- the shared component's piece: component 32 + j / 2; the pair of XCDs holds 8 nT workgroups = nT tiles x 8 pieces (4 row blocks x 2 column halves)
+  const int sidx = (j & 1) * 4 * nT + i;
+  const int stile = sidx >> 3, spiece = sidx & 7;
+  const int scomp = 32 + (j >> 1);
+  const int srb = 4 * (stile / nCT) + (spiece >> 1);             // its 32-row block
+  const int scb = 4 * (stile % nCT) + 2 * (spiece & 1);          // the first of its two 32-column blocks
+  const int sng = G2 >> 2;                                       // K steps per wave
+  W4HCursor scu;
+  scu.a[0] = reinterpret_cast<const w4_u32x4*>(Vh) + (((size_t)scomp * nRB + srb) * G2 + (size_t)wave * sng) * 128 + a_off; scu.a[1] = scu.a[0];
+  scu.b[0] = reinterpret_cast<const w4_u32x4*>(Uh) + (((size_t)scomp * CB + scb) * G2 + (size_t)wave * sng) * 128 + lane;
+  scu.b[1] = reinterpret_cast<const w4_u32x4*>(Uh) + (((size_t)scomp * CB + scb + 1) * G2 + (size_t)wave * sng) * 128 + lane;
+
+  // this lane's requests of step g2: V at pa + g2 * 2 KB (+ 1 KB: part l), U at pb + g2 * 2 KB (+ 1 KB)
+  const char* pa = reinterpret_cast<const char*>(reinterpret_cast<const w4_u32x4*>(Vh) + (((size_t)comp * nRB + 4 * RT + wave) * G2) * 128 + a_off);
+  const char* pb = reinterpret_cast<const char*>(reinterpret_cast<const w4_u32x4*>(Uh) + (((size_t)comp * CB + 4 * CT + wave) * G2) * 128 + lane);
+  auto blk = [&](int stage, int kind, int b, int part) { return gtile + (((stage * 2 + kind) * 4 + b) * 2 + part) * 64 + lane; };
+#define W4G_STASH(L, STAGE)                   \
+  {                                           \
+    *blk(STAGE, 0, wave, 0) = (L).a0;         \
+    *blk(STAGE, 0, wave, 1) = (L).a1;         \
+    *blk(STAGE, 1, wave, 0) = (L).b0;         \
+    *blk(STAGE, 1, wave, 1) = (L).b1;         \
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  float16_t acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+
+  // FOUR register sets, never copied: at the top of step k (k % 4 == 0) l1 holds step k + 1, l2 k + 2, l3 k + 3, l0 is free for
+  // k + 4 -- three steps of cover (reads past the reduction's end land in the buffers' slack: W4_SLACK)
+  W4GLoad l0, l1, l2, l3;
+  W4G_FETCH(l0, pa, pb)
+  W4G_FETCH(l1, pa + 2048, pb + 2048)
+  W4G_FETCH(l2, pa + 4096, pb + 4096)
+  W4G_FETCH(l3, pa + 6144, pb + 6144)
+  W4G_WAIT(12, l0);
+  W4G_STASH(l0, 0)
+  pa += 4 * 2048; pb += 4 * 2048;            // -> step 4
+  __syncthreads();
+#define W4G_STEP(ST, LNEXT, LFREE)                                                                                \
+  {                                                                                                               \
+    W4HStage f_;                                                                                                  \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                 \
+      f_.a[r][q] = *blk(ST, 0, 2 * wr + r, q);                                                                    \
+      f_.b[r][q] = *blk(ST, 1, 2 * wc + r, q);                                                                    \
+    }                                                                                                             \
+    W4G_FETCH(LFREE, pa, pb) /* the set whose step was stashed a step ago: step k + 4 */                          \
+    pa += 2048; pb += 2048;                                                                                       \
+    w4h_mac<2>(acc, f_);                                                                                          \
+    W4G_WAIT(12, LNEXT); /* the oldest four of the sixteen in flight: step k + 1 */                               \
+    W4G_STASH(LNEXT, (ST) ^ 1) /* -> the other stage (everybody left it at the last barrier) */                   \
+    __syncthreads();                                                                                              \
+  }
+  for (int k = 0; k < G2; k += 4) {   // (G2 = C / 16 is a multiple of 4: C % 128 == 0 gives 8)
+    W4G_STEP(0, l1, l0)
+    W4G_STEP(1, l2, l1)
+    W4G_STEP(0, l3, l2)
+    W4G_STEP(1, l0, l3)
+  }
+  W4G_WAIT(0, l0);                    // nothing may still be landing in registers the epilogue reuses
+  W4G_WAIT(0, l1);
+  W4G_WAIT(0, l2);
+  W4G_WAIT(0, l3);
+#undef W4G_STEP
+#undef W4G_STASH
+  {
+    const int rt = 2 * RT + wr, ct = 2 * CT + wc;                // this wave's 64 x 64 quarter
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;       // floats per sample of M
+    float* m0 = M + ((size_t)(rt * 16 + hi) * (gm.C >> 5) + 2 * ct) * (36 * 128) + (size_t)comp * 128 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* o = m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32;
+      st_wt(o, acc[0][0][q] * inv);
+      st_wt(o + 36 * 128, acc[0][1][q] * inv);
+      st_wt(o + 8 * sstride, acc[1][0][q] * inv);
+      st_wt(o + 8 * sstride + 36 * 128, acc[1][1][q] * inv);
+    }
+  }
+  // --- the shared piece: rows srb (32), column blocks scb, scb + 1; K range [wave sng, (wave + 1) sng) per wave
+  {
+    float16_t sa[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sa[0][c][q] = 0.f;
+    if (sng % 4 == 0) w4h_run<4, 1>(sa, scu, sng);
+    else if (sng % 2 == 0) w4h_run<2, 1>(sa, scu, sng);
+    else w4h_run<1, 1>(sa, scu, sng);
+    float* smem = reinterpret_cast<float*>(gtile);               // (everybody left the ring at the loop's last barrier)
+    float* red = smem + wave * 2048;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *reinterpret_cast<float4*>(red + c * 1024 + (r4 * 64 + lane) * 4) =
+            make_float4(sa[0][c][4 * r4], sa[0][c][4 * r4 + 1], sa[0][c][4 * r4 + 2], sa[0][c][4 * r4 + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int u = tid + it * 256;
+      const int blk2 = u >> 8, r4 = (u >> 6) & 3;
+      float4 sm = *reinterpret_cast<const float4*>(smem + blk2 * 1024 + (r4 * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(smem + w * 2048 + blk2 * 1024 + (r4 * 64 + lane) * 4);
+        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+      }
+      float* mrow = M + ((size_t)(srb * 8 + 2 * r4 + hi) * (gm.C >> 5) + scb + blk2) * (36 * 128) + (size_t)scomp * 128 + l31;
+      st_wt(mrow, sm.x * inv);
+      st_wt(mrow + 32, sm.y * inv);
+      st_wt(mrow + 64, sm.z * inv);
+      st_wt(mrow + 96, sm.w * inv);
+    }
+  }
+}
+#undef W4G_FETCH
+#undef W4G_WAIT
+
 // NODE_TUNE_W4_F16 = 0: never the fp16-pair operands (the bf16-triple kernels everywhere: A/B measurements, tests); read per call
 bool w4_f16_fits(int N, int C) {
   const W4Switches sw = w4_switches();
-  return sw.f16 != 0 && sw.ablate == 0 && w4_uses_bf16(N, C) && N % 16 == 0 && C % 64 == 0 && C < 512;
+  if (!(sw.f16 != 0 && sw.ablate == 0 && w4_uses_bf16(N, C) && N % 16 == 0 && C % 64 == 0)) return false;
+  if (C < 512) return true;
+  return sw.h128 != 0 && N % 32 == 0 && C % 128 == 0 && (((N / 32) * (C >> 7)) & 1) == 0;    // long reductions: the LDS-tiled kernel only
 }
 void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const Ctrl* ctrl, int N, int C, const int* v_exp, const int* u_exp,
                         hipStream_t s) {
   const W4Switches sw = w4_switches();
-  const int mode = (sw.sharev == 1 ? 2 : 0) | (sw.sharev == 2 ? 4 : 0);
+  const int mode = (sw.sharev == 1 ? 2 : 0) | (sw.sharev == 2 ? 4 : 0) | (sw.hsplit ? 16 : 0);
   const W4Geom gm = w4_geom(N, C);
+  {
+    // NODE_TUNE_W4_H128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512) -- the LDS-tiled kernel (at cfg 2 it takes
+    // 14.4 us against k_w4_gemm64h's 12.7: profiles/r06_w4h_kernels.txt)
+    const int nT = (N / 32) * (C >> 7);
+    if ((sw.h128 == 1 || (sw.h128 < 0 && C >= 512)) && N % 32 == 0 && C % 128 == 0 && (nT & 1) == 0) {
+      const size_t lds = 2 * 16 * 64 * 16;      // two stages of sixteen 1 KB blocks
+      if (C >= 512) hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
+      else hipLaunchKernelGGL(k_w4_gemm128h<1>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
+      return;
+    }
+  }
   const int grid64 = (N / 16) * (C >> 6) * 8;
   const size_t lds64 = 4 * 2048 * sizeof(float);
-  if (sw.hdepth == 8 && (C >> 4) % 8 == 0) hipLaunchKernelGGL(k_w4_gemm64h<8>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
-  else if ((C >> 4) % 4 == 0) hipLaunchKernelGGL(k_w4_gemm64h<4>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
-  else hipLaunchKernelGGL(k_w4_gemm64h<2>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp);
+  unsigned long long* stamps = nullptr;
+#ifdef NODE_DIAG
+  { const char* e = getenv("NODE_TUNE_W4_STAMPS"); if (e != nullptr) stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)); }
+#endif
+  if (sw.hdepth == 8 && (C >> 4) % 8 == 0) hipLaunchKernelGGL(k_w4_gemm64h<8>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp, stamps);
+  else if ((C >> 4) % 4 == 0) hipLaunchKernelGGL(k_w4_gemm64h<4>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp, stamps);
+  else hipLaunchKernelGGL(k_w4_gemm64h<2>, dim3(grid64), dim3(256), lds64, s, Vh, Uh, M, ctrl, gm, mode, v_exp, u_exp, stamps);
 }
 
 void launch_w4_gemm(const float* V, const float* U, float* M, const Ctrl* ctrl, int N, int C, hipStream_t s, const unsigned short* Ub) {
@@ -2311,11 +2561,6 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad128b(W4WgradArgs a) {
 // Needs N % 8 == 0 (whole row blocks), C % 128 == 0.
 // ----------------------------------------------------------------------------
 constexpr int W4WH_NST = 4, W4WH_D = 3, W4WH_STAGE = 16384;
-__device__ __forceinline__ void w4wh_dma(const unsigned char* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 struct W4WgradHArgs {
   const unsigned* V[2]; const unsigned* Z[2];   // per layer (Z[1] / V[1] nullable: one layer)
   float* dU; const Ctrl* ctrl; int N, C, layers;
@@ -2419,7 +2664,7 @@ __global__ __launch_bounds__(256, 2) void k_w4_wgrad64h(W4WgradHArgs a) {
 }
 bool w4_wgrad_f16_fits(int N, int C) {
   const W4Switches sw = w4_switches();
-  return sw.f16 != 0 && N % 8 == 0 && C % 128 == 0 && C < 512;
+  return sw.f16 != 0 && N % 8 == 0 && C % 128 == 0;
 }
 void launch_w4_wgrad_f16(const unsigned* V1, const unsigned* Z1, const unsigned* V2, const unsigned* Z2, float* dU, const Ctrl* ctrl, int N, int C,
                          const int* v1_exp, const int* v2_exp, const int* z_exp, hipStream_t s) {

@@ -168,17 +168,27 @@ __device__ __forceinline__ void w4s_out_transform(const float* __restrict__ mp, 
 //  ~90 % of what a streaming copy of the same size reaches once the ~1.5 us of launch ramp are taken out.)
 // V = B^T d B of the 6x6 patch d (the thread's tile + one pixel ring) -> the blocked row operand of the component GEMMs.
 // `vp`: the thread's element of component 0; components `cstride` apart.
-// fp16-pair form (wino4.h, "V pairs"; pscale != 0): the value times pscale as h = fp16(x), l = fp16(x - h); the lane swaps its
-// {h, l} dword with its channel neighbour's (lane ^ 1) and stores {h, h'} (even channel -> part h) or {l', l} (odd -> part l):
-// one dword per lane and component, as in the fp32 form, whole 128-B lines per wave and part
-__device__ __forceinline__ float w4s_pair_word(float x, float pscale, bool odd) {
-  const float xs = x * pscale;
-  const _Float16 h = (_Float16)xs;
-  const _Float16 l = (_Float16)(xs - (float)h);
-  const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-  const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-  const unsigned out = odd ? ((other >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (other << 16));
-  return __builtin_bit_cast(float, out);
+// fp16-pair form (wino4.h, "V pairs"; pscale != 0): the value times pscale as h = fp16(x), l = fp16(x - h); the lane exchanges with
+// its channel neighbour (lane ^ 1) and stores {h, h'} (even channel -> part h) or {l', l} (odd -> part l): one dword per lane and
+// component, as in the fp32 form, whole 128-B lines per wave and part
+// (two values at a time: v_cvt_pk_f16_f32 converts a pair, ONE DPP exchange moves the dword the neighbour needs -- {h, h} of the odd
+//  lane's two values to the even lane, {l, l} the other way -- and one v_perm_b32 per value with a lane-dependent selector puts the
+//  halves in channel order: ~5.5 instead of ~10 vector instructions per value on passes that wait for them before they store)
+typedef _Float16 w4s_h2 __attribute__((ext_vector_type(2)));
+typedef float w4s_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void w4s_pair_words2(float& x0, float& x1, float pscale, bool odd) {
+  const w4s_f2 xs = {x0 * pscale, x1 * pscale};
+  const w4s_h2 h = __builtin_convertvector(xs, w4s_h2);
+  const w4s_f2 hf = __builtin_convertvector(h, w4s_f2);
+  const w4s_f2 r = {xs.x - hf.x, xs.y - hf.y};
+  const w4s_h2 l = __builtin_convertvector(r, w4s_h2);
+  const unsigned H = __builtin_bit_cast(unsigned, h), L = __builtin_bit_cast(unsigned, l);
+  const unsigned keep = odd ? L : H, send = odd ? H : L;
+  const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]: lane ^ 1
+  // v_perm_b32: bytes 0-3 = `keep`, 4-7 = `got`; even lane {keep.lo, got.lo} / {keep.hi, got.hi}, odd lane {got.lo, keep.lo} / {got.hi, keep.hi}
+  const unsigned sel0 = odd ? 0x01000504u : 0x05040100u, sel1 = odd ? 0x03020706u : 0x07060302u;
+  x0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(got, keep, sel0));
+  x1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(got, keep, sel1));
 }
 __device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restrict__ vp, size_t cstride, float pscale = 0.f, bool odd = false) {
   float w[6][6];   // w[j][l] = sum_k B^T[l][k] d[j][k]
@@ -189,8 +199,9 @@ __device__ __forceinline__ void w4s_store_v(const float d[6][6], float* __restri
     float v0, v1, v2, v3, v4, v5;   // V[xi][l] = sum_j B^T[xi][j] w[j][l]
     w4s_bt6(w[0][l], w[1][l], w[2][l], w[3][l], w[4][l], w[5][l], v0, v1, v2, v3, v4, v5);
     if (pscale != 0.f) {
-      v0 = w4s_pair_word(v0, pscale, odd); v1 = w4s_pair_word(v1, pscale, odd); v2 = w4s_pair_word(v2, pscale, odd);
-      v3 = w4s_pair_word(v3, pscale, odd); v4 = w4s_pair_word(v4, pscale, odd); v5 = w4s_pair_word(v5, pscale, odd);
+      w4s_pair_words2(v0, v1, pscale, odd);
+      w4s_pair_words2(v2, v3, pscale, odd);
+      w4s_pair_words2(v4, v5, pscale, odd);
     }
     w4s_st_wt(vp + (size_t)(0 * 6 + l) * cstride, v0);
     w4s_st_wt(vp + (size_t)(1 * 6 + l) * cstride, v1);
@@ -309,8 +320,11 @@ __device__ __forceinline__ void w4s_emit_zh(const float a[4][4], float* __restri
   for (int nu = 0; nu < 6; ++nu) {
     float z[6];
     w4s_a6(w[0][nu], w[1][nu], w[2][nu], w[3][nu], z[0], z[1], z[2], z[3], z[4], z[5]);
+    w4s_pair_words2(z[0], z[1], pscale, odd);
+    w4s_pair_words2(z[2], z[3], pscale, odd);
+    w4s_pair_words2(z[4], z[5], pscale, odd);
 #pragma unroll
-    for (int xi = 0; xi < 6; ++xi) w4s_st_wt(zp + (size_t)(xi * 6 + nu) * cstride, w4s_pair_word(z[xi], pscale, odd));
+    for (int xi = 0; xi < 6; ++xi) w4s_st_wt(zp + (size_t)(xi * 6 + nu) * cstride, z[xi]);
   }
 }
 // max|dz| of the wave -> W4Scales::gmax (and `ovf` when the fp16-pair scale 2^*g_exp cannot hold it); see wino4.h

@@ -95,20 +95,21 @@ struct W4Scales {
 };
 constexpr int W4_G_TOP = 5;          // max|dz| 2^e <= 2^5
 constexpr float W4_G_LIMIT = 256.f;  // ... and a pass that meets more than 2^8 asks for the step to be repeated
-// ONE thread: the exponent of the cotangent-side operands from the recorded maxima (then cleared); returns whether a pass overflowed
-__device__ inline bool w4_gscale_update(W4Scales* sc) {
-  float g = 0.f;
-  for (int i = 0; i < 64; ++i) {
-    g = fmaxf(g, __builtin_bit_cast(float, __hip_atomic_load(&sc->gmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-    __hip_atomic_store(&sc->gmax[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The FIRST WAVE of a workgroup (all 64 lanes; `lane` = threadIdx.x): the exponent of the cotangent-side operands from the recorded
+// maxima (then cleared); every lane returns whether a pass overflowed.  (One thread walking the 64 slots cost 11 us.)
+__device__ inline bool w4_gscale_update(W4Scales* sc, int lane) {
+  float g = __builtin_bit_cast(float, __hip_atomic_load(&sc->gmax[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const bool ovf = __hip_atomic_load(&sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // (every lane reads it before lane 0 clears it)
+  __hip_atomic_store(&sc->gmax[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o, 64));
+  if (lane == 0) {
+    __hip_atomic_store(&sc->ovf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g > 0.f && g < INFINITY) sc->e[4] = w4_scale_exp(g, W4_G_TOP);
+    if (ovf) sc->n_retry += 1;
   }
-  const bool ovf = __hip_atomic_load(&sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-  __hip_atomic_store(&sc->ovf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (g > 0.f && g < INFINITY) sc->e[4] = w4_scale_exp(g, W4_G_TOP);
-  if (ovf) sc->n_retry += 1;
   return ovf;
 }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-thread launch (behind an interval's first evaluation)
+void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-wave launch (behind an interval's first evaluation)
 constexpr int W4_E_U1 = 0, W4_E_U2 = 1, W4_E_V1 = 2, W4_E_V2 = 3, W4_E_G = 4;
 struct W4ScaleJobs {
   const float* w[2];        // conv weights [C][CI][3][3] (w[1] nullable)
@@ -117,6 +118,7 @@ struct W4ScaleJobs {
   size_t vn[2];             // elements of gb[1] / gb[3] when they are not [C] vectors (diagnostics: a whole tensor as "beta"); 0 = C
   int C, gn_m;              // channels; values per GroupNorm group (cpg x pixels)
   W4Scales* sc;
+  int bigjob[4];            // (filled by launch_w4_scales)
 };
 // one launch: maxima by atomics (sc->mx, sc->arrived must be zero), the last block derives the exponents and zeroes them again
 void launch_w4_scales(const W4ScaleJobs& j, hipStream_t s);

@@ -53,7 +53,7 @@ for _ in range(REP):
         acc[k] += torch.tensor([v.min(), v.quantile(0.5), v.mean(), v.quantile(0.95), v.max()], dtype=torch.float64)
 acc /= REP
 clk /= REP
-print('k_w4_gemm64b at %s, %d waves, mean of %d launches; us since the first wave started' % ((N, Cc, side), grid * 4, REP))
+print('component GEMM at %s, %d waves, mean of %d launches; us since the first wave started' % ((N, Cc, side), grid * 4, REP))
 print('%-26s %8s %8s %8s %8s %8s' % ('stamp', 'min', 'median', 'mean', 'p95', 'max'))
 for k in range(8):
     print('%-26s %8.2f %8.2f %8.2f %8.2f %8.2f' % ((names[k],) + tuple(acc[k].tolist())))
