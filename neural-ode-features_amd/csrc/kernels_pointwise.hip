@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
     __syncthreads();
   }
   bool w4_ovf = false;
-  if (a.w4sc != nullptr && threadIdx.x < 64) w4_ovf = w4_gscale_update(a.w4sc, threadIdx.x);   // (the first wave, all its lanes)
+  if (a.w4sc != nullptr) w4_ovf = w4_gscale_update(a.w4sc, threadIdx.x, red);   // (all 256 threads)
   if (threadIdx.x != 0) return;
   if (a.w4sc != nullptr) {
     // fp16-pair operands (wino4.h): the next step's cotangent scale from this step's recorded maximum (above); a step in which a pass
@@ -484,8 +484,11 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   }
   step_controller_decide(a, ratios);
 }
-__global__ __launch_bounds__(64) void k_w4_gscale(W4Scales* sc) { (void)w4_gscale_update(sc, threadIdx.x); }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(64), 0, s, sc); }
+__global__ __launch_bounds__(256) void k_w4_gscale(W4Scales* sc) {
+  __shared__ float red[4];
+  (void)w4_gscale_update(sc, threadIdx.x, red);
+}
+void launch_w4_gscale(W4Scales* sc, hipStream_t s) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(256), 0, s, sc); }
 
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);

@@ -1940,7 +1940,7 @@ __device__ __forceinline__ void w4wh_dma(const unsigned char* gsrc, unsigned lds
 // k_w4_gemm128h: k_w4_gemm64h's products as an LDS-tiled GEMM (the skeleton of k_w4_gemm128b): a workgroup owns a 128 x 128 tile of
 // ONE component, its waves 64 x 64 quarters; per K = 16 step each wave fetches ONE quarter of the tile's operands -- its 32-row block
 // of V pairs and its 32-column block of U pairs, parts h and l: four 16-B requests per lane, already the MFMA fragments -- and
-// the 16 KB of the step go through a two-stage LDS ring (one barrier per step), so a CU takes in 16 KB per step where
+// the 16 KB of the step go through a four-stage LDS ring (one barrier per step), so a CU takes in 16 KB per step where
 // k_w4_gemm64h's four independent 64 x 64 tiles take 32 KB.  Why: k_w4_gemm64h is bound by the texture path (64 B per clock and CU:
 // tools/w4_stamps.py -- 2.4 us to issue the first ring, then 720 cycles per K step against 384 of matrix work;
 // profiles/r06_pmc_w4h.txt) at short reductions and, like k_w4_gemm64b, by operand re-reads from the Infinity Cache at long ones.
@@ -1965,7 +1965,7 @@ template <int WPC>
 __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
                                                            const Ctrl* ctrl, W4Geom gm, const int* v_exp, const int* u_exp) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
-  extern __shared__ __attribute__((aligned(16))) w4_u32x4 gtile[];   // [2 stages][A 4 row blocks x 2 parts | B 4 column blocks x 2 parts][64 lanes]
+  extern __shared__ __attribute__((aligned(16))) w4_u32x4 gtile[];   // [4 stages][A 4 row blocks x 2 parts | B 4 column blocks x 2 parts][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int nCT = gm.C >> 7, nRT = gm.R >> 7, nT = nRT * nCT, G2 = gm.G8 >> 1, CB = gm.C >> 5, nRB = gm.RB;
@@ -2006,41 +2006,52 @@ __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __rest
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
 
-  // FOUR register sets, never copied: at the top of step k (k % 4 == 0) l1 holds step k + 1, l2 k + 2, l3 k + 3, l0 is free for
-  // k + 4 -- three steps of cover (reads past the reduction's end land in the buffers' slack: W4_SLACK)
+  // FOUR register sets, never copied (step s travels in set s % 4), FOUR LDS stages (step s sits in stage s % 4), TWO fragment sets:
+  // step k multiplies fragments read from LDS a step earlier while step k + 1's travel LDS -> registers, stashes step k + 2 (requested
+  // four steps ago) and requests step k + 6 -- one barrier per step, nothing a wave waits for was issued less than a step ago.
+  // (Reads past the reduction's end land in the buffers' slack: W4_SLACK.)
   W4GLoad l0, l1, l2, l3;
+  W4HStage fA, fB;
   W4G_FETCH(l0, pa, pb)
   W4G_FETCH(l1, pa + 2048, pb + 2048)
   W4G_FETCH(l2, pa + 4096, pb + 4096)
   W4G_FETCH(l3, pa + 6144, pb + 6144)
   W4G_WAIT(12, l0);
   W4G_STASH(l0, 0)
-  pa += 4 * 2048; pb += 4 * 2048;            // -> step 4
+  W4G_FETCH(l0, pa + 8192, pb + 8192)
+  W4G_WAIT(12, l1);
+  W4G_STASH(l1, 1)
+  W4G_FETCH(l1, pa + 10240, pb + 10240)
+  pa += 6 * 2048; pb += 6 * 2048;            // -> step 6
   __syncthreads();
-#define W4G_STEP(ST, LNEXT, LFREE)                                                                                \
-  {                                                                                                               \
-    W4HStage f_;                                                                                                  \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                 \
-      f_.a[r][q] = *blk(ST, 0, 2 * wr + r, q);                                                                    \
-      f_.b[r][q] = *blk(ST, 1, 2 * wc + r, q);                                                                    \
-    }                                                                                                             \
-    W4G_FETCH(LFREE, pa, pb) /* the set whose step was stashed a step ago: step k + 4 */                          \
-    pa += 2048; pb += 2048;                                                                                       \
-    w4h_mac<2>(acc, f_);                                                                                          \
-    W4G_WAIT(12, LNEXT); /* the oldest four of the sixteen in flight: step k + 1 */                               \
-    W4G_STASH(LNEXT, (ST) ^ 1) /* -> the other stage (everybody left it at the last barrier) */                   \
-    __syncthreads();                                                                                              \
+#define W4G_FRAGS(F, ST)                                                                          \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
+    (F).a[r][q] = *blk(ST, 0, 2 * wr + r, q);                                                     \
+    (F).b[r][q] = *blk(ST, 1, 2 * wc + r, q);                                                     \
+  }
+  W4G_FRAGS(fA, 0)
+  // step k: FCUR = fragments of step k, FNEXT <- stage (k + 1) % 4, LSET = set (k + 2) % 4 -> stage (k + 2) % 4, then refilled with step k + 6
+#define W4G_STEP(FCUR, FNEXT, STN, LSET, STS)                                                     \
+  {                                                                                               \
+    W4G_FRAGS(FNEXT, STN)                                                                         \
+    w4h_mac<2>(acc, FCUR);                                                                        \
+    W4G_WAIT(12, LSET);                                                                           \
+    W4G_STASH(LSET, STS)                                                                          \
+    W4G_FETCH(LSET, pa, pb)                                                                       \
+    pa += 2048; pb += 2048;                                                                       \
+    __syncthreads();                                                                              \
   }
   for (int k = 0; k < G2; k += 4) {   // (G2 = C / 16 is a multiple of 4: C % 128 == 0 gives 8)
-    W4G_STEP(0, l1, l0)
-    W4G_STEP(1, l2, l1)
-    W4G_STEP(0, l3, l2)
-    W4G_STEP(1, l0, l3)
+    W4G_STEP(fA, fB, 1, l2, 2)
+    W4G_STEP(fB, fA, 2, l3, 3)
+    W4G_STEP(fA, fB, 3, l0, 0)
+    W4G_STEP(fB, fA, 0, l1, 1)
   }
   W4G_WAIT(0, l0);                    // nothing may still be landing in registers the epilogue reuses
   W4G_WAIT(0, l1);
   W4G_WAIT(0, l2);
   W4G_WAIT(0, l3);
+#undef W4G_FRAGS
 #undef W4G_STEP
 #undef W4G_STASH
   {
@@ -2113,7 +2124,10 @@ void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const 
     // 14.4 us against k_w4_gemm64h's 12.7: profiles/r06_w4h_kernels.txt)
     const int nT = (N / 32) * (C >> 7);
     if ((sw.h128 == 1 || (sw.h128 < 0 && C >= 512)) && N % 32 == 0 && C % 128 == 0 && (nT & 1) == 0) {
-      const size_t lds = 2 * 16 * 64 * 16;      // two stages of sixteen 1 KB blocks
+      const size_t lds = 4 * 16 * 64 * 16;      // four stages of sixteen 1 KB blocks
+      static bool attr1[MAX_DEVICES] = {}, attr2[MAX_DEVICES] = {};
+      allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<1>), attr1);
+      allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<2>), attr2);
       if (C >= 512) hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
       else hipLaunchKernelGGL(k_w4_gemm128h<1>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
       return;

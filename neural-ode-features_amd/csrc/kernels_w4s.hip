@@ -341,7 +341,7 @@ __device__ __forceinline__ void w4s_record_max(const float v[4][4], W4Scales* sc
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) {
-    atomicMax(&sc->gmax[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63], __builtin_bit_cast(unsigned, m));
+    atomicMax(&sc->gmax[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (W4_GSLOTS - 1)], __builtin_bit_cast(unsigned, m));
     // (a non-finite cotangent is not a question of scale: it goes on to the error norm, which stops the solve)
     if (g_exp != nullptr && m < INFINITY && m * ldexpf(1.f, *g_exp) > W4_G_LIMIT) __hip_atomic_store(&sc->ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

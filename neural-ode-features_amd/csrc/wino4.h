@@ -78,7 +78,7 @@ __host__ __device__ inline int w4_scale_exp(float bound, int top) {
 
 // COTANGENT-side operands (the data gradients' row operands and Z = A dz A^T of the weight gradient) have no bound a priori:
 // their scale 2^e[W4_E_G] follows the data.  Every pass that forms such a tensor adds max|dz| of its waves to gmax[] (atomicMax
-// on the bit pattern, 64 slots); the step controller (k_step_controller) and k_w4_gscale turn the maximum of the finished step
+// on the bit pattern, one slot per wave); the step controller (k_step_controller) and k_w4_gscale turn the maximum of the finished step
 // into the next step's exponent, max|dz| 2^e in (2^4, 2^5]: |B^T dz B| <= 49 |dz| and |A dz A^T| <= 225 |dz| then stay under
 // 2^13 -- a cotangent may grow EIGHT-fold from one step to the next before a value could pass fp16's 65504.  A pass that sees
 // max|dz| 2^e > 2^8 raises `ovf`: the controller then REPEATS the step (nothing accepted, dt unchanged, not counted as a step of
@@ -91,25 +91,34 @@ struct W4Scales {
   unsigned ovf;        // a cotangent-side value left the range of its scale in the current step
   int n_retry;         // steps repeated for that reason (diagnostics)
   unsigned pad[13];
-  unsigned gmax[64];   // max|dz| of the current step's passes, fp32 bit patterns (slot = workgroup % 64)
+  unsigned gmax[2048]; // max|dz| of the current step's passes, fp32 bit patterns (slot = wave of the pass % 2048: a slot is hit by one wave
+                       // per pass at cfg 2 -- 32 waves per slot serialised their atomics for ~2.5 us behind every pass that records)
 };
+constexpr int W4_GSLOTS = 2048;
 constexpr int W4_G_TOP = 5;          // max|dz| 2^e <= 2^5
 constexpr float W4_G_LIMIT = 256.f;  // ... and a pass that meets more than 2^8 asks for the step to be repeated
-// The FIRST WAVE of a workgroup (all 64 lanes; `lane` = threadIdx.x): the exponent of the cotangent-side operands from the recorded
-// maxima (then cleared); every lane returns whether a pass overflowed.  (One thread walking the 64 slots cost 11 us.)
-__device__ inline bool w4_gscale_update(W4Scales* sc, int lane) {
-  float g = __builtin_bit_cast(float, __hip_atomic_load(&sc->gmax[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  const bool ovf = __hip_atomic_load(&sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;   // (every lane reads it before lane 0 clears it)
-  __hip_atomic_store(&sc->gmax[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// A whole workgroup of 256 threads (`red`: 4 floats of LDS): the exponent of the cotangent-side operands from the recorded maxima
+// (then cleared); every thread returns whether a pass overflowed.
+__device__ inline bool w4_gscale_update(W4Scales* sc, int tid, float* red) {
+  const bool ovf = __hip_atomic_load(&sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  float g = 0.f;
+#pragma unroll
+  for (int i = 0; i < W4_GSLOTS / 256; ++i) {
+    g = fmaxf(g, __builtin_bit_cast(float, __hip_atomic_load(&sc->gmax[i * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    __hip_atomic_store(&sc->gmax[i * 256 + tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o, 64));
-  if (lane == 0) {
+  if ((tid & 63) == 0) red[tid >> 6] = g;
+  __syncthreads();                    // (also: every thread has read `ovf` before thread 0 clears it)
+  if (tid == 0) {
+    g = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __hip_atomic_store(&sc->ovf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (g > 0.f && g < INFINITY) sc->e[4] = w4_scale_exp(g, W4_G_TOP);
     if (ovf) sc->n_retry += 1;
   }
   return ovf;
 }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-wave launch (behind an interval's first evaluation)
+void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-workgroup launch (behind an interval's first evaluation)
 constexpr int W4_E_U1 = 0, W4_E_U2 = 1, W4_E_V1 = 2, W4_E_V2 = 3, W4_E_G = 4;
 struct W4ScaleJobs {
   const float* w[2];        // conv weights [C][CI][3][3] (w[1] nullable)

@@ -26,7 +26,7 @@ def conv(x, w, dgrad=0):
 
 
 worst = 0.0
-for shape in ((128, 256, 8, 8), (16, 64, 8, 8), (4, 256, 16, 16), (16, 128, 8, 8)):
+for shape in ((128, 256, 8, 8), (16, 64, 8, 8), (4, 256, 16, 16), (16, 128, 8, 8), (8, 1024, 16, 16), (32, 512, 8, 8)):
     for xs, wsc in ((1.0, 1.0), (1e-4, 1.0), (1e3, 1.0), (1.0, 1e-3), (1.0, 30.0), (3e-7, 1e-2)):
         for dgrad in (0, 1):
             N, Cc, H, W = shape
