@@ -35,12 +35,12 @@ batch until its verdict is in and repeats voided batches in order (`config.retri
 `other_configs` (default run only) holds short side runs of BASELINE configs 3 and 5 on the same box;
 `latency_bs1` is a side block, not the metric: forward solves of ONE sample of the config's
 state (the reference's bs = 1 NFE census, evaluate.py:97-142), microseconds per evaluation.
-`roofline` is for the dominant kernel -- at the BASELINE configs `k_w4_gemm64b`, the 36
-component GEMMs of a Winograd F(4x4,3x3) convolution on bf16 MFMA at fp32 accuracy
-(exact three-way split, six products), bounded by its bytes through the fabric at
-C = 256 (`bound: hbm`, achieved = algorithmic bytes per launch / mean launch duration
-from HIP events recorded by the library on the launch stream) and by the matrix pipe
-at C = 1024 (`k_w4_gemm128b`, `bound: mfma`); `roofline.hbm` prices the HBM-bound
+`roofline` is for the dominant kernel -- at the BASELINE configs `k_w4_gemm64h`, the 36
+component GEMMs of a Winograd F(4x4,3x3) convolution on fp16 MFMA at fp32 accuracy
+(both operands as scaled fp16 pairs, three products), bounded by its bytes through the
+fabric at C = 256 (`bound: hbm`, achieved = algorithmic bytes per launch / mean launch
+duration from HIP events recorded by the library on the launch stream) and by the matrix
+pipe at C = 1024 (`k_w4_gemm128h`, `bound: mfma`); `roofline.hbm` prices the HBM-bound
 GroupNorm / transform passes, `roofline.wgrad` the weight gradient.  `cpu_baseline` is
 the oracle (CPU restatement of the torchdiffeq path driving PyTorch-CPU conv /
 group_norm) on this box's host cores.
@@ -218,9 +218,9 @@ def cpu_baseline(state_dict, cfg, method, min_seconds=12.0, max_seconds=30.0):
                       % (done, bs, nf, nb, dt)}
 
 
-def pmc_measure(state, conv_path_env, timeout=(300, 180)):
-    """HBM bytes per launch of every library kernel of an augmented dynamics evaluation at this workload's state shape,
-    MEASURED in this run: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no
+def pmc_measure(state, conv_path_env, timeout=(300, 180), tol=1e-3):
+    """HBM bytes per launch of every library kernel of an adaptive solve (forward + adjoint, the config's tolerance) at this
+    workload's state shape, MEASURED in this run: two child processes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no
     trace domain, the program itself behind `--`) over tools/prof_eval.py, started BEFORE this process touches the GPU.
     FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (wide coalesced reads are tallied at half
     their bytes); WRITE_SIZE also counts evictions of the previous kernel's dirty lines.  Returns {kernel name: bytes}
@@ -239,7 +239,7 @@ def pmc_measure(state, conv_path_env, timeout=(300, 180)):
     for ci, counter in enumerate(('FETCH_SIZE', 'WRITE_SIZE')):   # (the first child may pay the cold `import torch` of a fresh box)
         d = tempfile.mkdtemp(prefix='node_pmc_', dir='/tmp')
         cmd = [rocprof, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
-               os.path.join(ROOT, 'tools', 'prof_eval.py'), '--shape', ','.join(str(v) for v in state), '--iters', '4']
+               os.path.join(ROOT, 'tools', 'prof_eval.py'), '--shape', ','.join(str(v) for v in state), '--iters', '2', '--solve', repr(float(tol))]
         try:
             r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=timeout[ci])
             if r.returncode != 0:
@@ -301,8 +301,8 @@ def other_configs(args):
     1024 filters, per-GPU shard) as short runs of this same script in child processes -- so that the record of the default run holds a
     number for them measured on the same box.  A child that fails or runs past its time leaves an `error` entry."""
     out = {}
-    for config, extra, limit in ((3, ['--steps', '10', '--warmup', '3'], 240), (5, ['--steps', '4', '--warmup', '2', '--no-dropin'], 300)):
-        cmd = [sys.executable, os.path.abspath(__file__), '--config', str(config), '--method', args.method, '--no-roofline', '--no-cpu-baseline',
+    for config, extra, limit in ((3, ['--steps', '10', '--warmup', '3'], 300), (5, ['--steps', '4', '--warmup', '2', '--no-dropin'], 420)):
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', str(config), '--method', args.method, '--no-cpu-baseline',
                '--no-fresh', '--no-latency', '--no-other-configs'] + extra
         env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
         try:
@@ -312,10 +312,13 @@ def other_configs(args):
                 out[str(config)] = {'error': 'rc %d: %s' % (r.returncode, r.stderr[-300:])}
                 continue
             d = json.loads(lines[-1])
+            rf = d.get('roofline') or {}
             out[str(config)] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
                                 'workload': d['config'].get('workload'), 'retries': d['config'].get('retries'),
                                 'dead_steps_per_step': d['config'].get('dead_steps_per_step'),
-                                'dropin': (d.get('dropin') or {}).get('value')}
+                                'dropin': (d.get('dropin') or {}).get('value'),
+                                'roofline': {k: rf.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us',
+                                                                    'launches', 'bytes_per_launch', 'flops_per_launch')} if rf else None}
         except Exception as e:
             out[str(config)] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
@@ -415,7 +418,8 @@ def main():
         # forced, so the children run with the conv path the timed solves will take.
         w4_default = os.environ.get('NODE_TUNE_WINO4', '1')
         takes_w4 = args.method == 'dopri5' and cfg['tol'] >= 0.99e-5 and side in (8, 16) and w4_default != '0'
-        pmc = pmc_measure(state, {'NODE_TUNE_WINO4': '2' if takes_w4 else '0'})
+        # (the children run whole solves at the config's tolerance: the adaptive-solve kernels -- fp16-pair GEMMs, weight gradient -- are in)
+        pmc = pmc_measure(state, {} if takes_w4 else {'NODE_TUNE_WINO4': '0'}, tol=cfg['tol'])
     held_clk = None
     if world == 1 and not args.no_roofline:
         held_clk = held_clock_ghz(cfg['batch'], cfg['filters'], side)      # (a child process on the diagnostics library)
@@ -678,20 +682,37 @@ def main():
                 # 279 FLOP/B sits left of the bf16 ridge (2500 TFLOP/s / 8 TB/s = 312 FLOP/B) -> HBM; at cfg 5
                 # (C = 1024) 464 GFLOP over 528 MB = 878 FLOP/B -> the matrix pipe.  The other view is reported next to it.
                 C, Nn = cfg['filters'], cfg['batch'] * quads
-                bytes_algo = 36.0 * 4 * Nn * C * 4 * 2 + 36.0 * C * C * 6
+                # round 6: both operands as fp16 PAIRS (x 2^e = h + l, 22 significand bits in the 4 bytes of an fp32; three
+                # part products hl, lh, hh per fp32 product, no vector arithmetic in the loop: k_w4_gemm64h / k_w4_gemm128h) --
+                # every launch of an adaptive solve but the few of each interval's first augmented evaluation (bf16 triples)
+                f16 = (os.environ.get('NODE_TUNE_W4_F16', '1') != '0' and Nn % 16 == 0 and C % 64 == 0 and
+                       (C < 512 or (Nn % 32 == 0 and C % 128 == 0 and ((Nn // 32) * (C // 128)) % 2 == 0)))
+                nprod = 3.0 if f16 else 6.0
+                bytes_algo = 36.0 * 4 * Nn * C * 4 * 2 + 36.0 * C * C * (4 if f16 else 6)
                 tbs = bytes_algo / (avg_ms * 1e-3) / 1e12
-                flops_bf16 = algo_per_launch * issued * 6.0
+                flops_bf16 = algo_per_launch * issued * nprod
                 issued_bf16 = flops_bf16 / (avg_ms * 1e-3) / 1e12
                 lds_tiled = C >= 512 and Nn % 32 == 0 and C % 128 == 0 and os.environ.get('NODE_TUNE_W4_GEMM128', '1') != '0'
-                kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
-                         'at fp32 accuracy: exact three-way bf16 split of both operands, six products%s)'
-                         % (('k_w4_gemm128b', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
-                            else ('k_w4_gemm64b', '')))
+                if f16:
+                    kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on fp16 MFMA at fp32 accuracy: both operands '
+                             'as scaled fp16 pairs h + l, three products%s)'
+                             % (('k_w4_gemm128h', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
+                                else ('k_w4_gemm64h', '')))
+                    gem_pmc = 'k_w4_gemm128h' if lds_tiled else 'k_w4_gemm64h'
+                else:
+                    kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
+                             'at fp32 accuracy: exact three-way bf16 split of both operands, six products%s)'
+                             % (('k_w4_gemm128b', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
+                                else ('k_w4_gemm64b', '')))
+                    gem_pmc = 'k_w4_gemm128b' if lds_tiled else 'k_w4_gemm64b'
+                roofline['traffic'] = (pmc_lookup(pmc, gem_pmc) or {}).get('bytes')
+                roofline['traffic_detail'] = pmc_lookup(pmc, gem_pmc)
                 mfma_view = {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
                              'fp32_equivalent_tflops': ach, 'vs_fp32_matrix_peak': ach / MFMA_F32_PEAK_TFLOPS,
-                             'note': 'fp32_equivalent = the component products the fp32 MFMA kernel would issue, over this '
-                                     'launch time; against the fp32 matrix peak it may exceed 1 -- the products run at the '
-                                     'bf16 rate'}
+                             'part_products_per_fp32_product': nprod,
+                             'note': 'issued = 16-bit MFMA FLOPs (fp16 and bf16 forms run at the same rate); fp32_equivalent = the '
+                                     'component products the fp32 MFMA kernel would issue, over this launch time; against the fp32 '
+                                     'matrix peak it may exceed 1 -- the products run at the 16-bit rate'}
                 clk = held_clk if not lds_tiled else None
                 if clk:
                     mfma_view.update({'held_clock_ghz': clk, 'frac_of_bf16_peak_at_held_clock': issued_bf16 / (MFMA_BF16_PEAK_TFLOPS * clk / 2.4),
@@ -702,17 +723,18 @@ def main():
                         'bound': 'hbm', 'kernel': kname,
                         'achieved': tbs, 'peak': HBM_PEAK_TBS, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS,
                         'bytes_per_launch': bytes_algo, 'mfma': mfma_view,
-                        'note': 'achieved = algorithmic bytes per launch (row operand fp32 + filter bf16 triples + products fp32) '
-                                '/ mean launch duration (HIP events); `traffic` = the bytes counted by rocprofv3 PMC in this run'})
+                        'note': 'achieved = algorithmic bytes per launch (row operand + filters as %s + products fp32) '
+                                '/ mean launch duration (HIP events, all component-GEMM launches of the repeated steps); `traffic` = the '
+                                'bytes counted by rocprofv3 PMC in this run' % ('fp16 pairs' if f16 else 'fp32 / bf16 triples')})
                 else:
                     roofline.update({
                         'bound': 'mfma', 'kernel': kname,
                         'achieved': issued_bf16, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
                         'flops_per_launch': flops_bf16, 'bytes_per_launch': bytes_algo, 'mfma': mfma_view,
                         'hbm_side': {'achieved': tbs, 'unit': 'TB/s', 'frac': tbs / HBM_PEAK_TBS},
-                        'note': 'achieved = bf16 MFMA FLOPs issued per launch (six part products per fp32 product, 0.25 of the '
-                                'direct-convolution FLOPs each) / mean launch duration (HIP events) over the dense bf16 matrix '
-                                'peak; %.0f FLOP/B sits right of the bf16 ridge' % (flops_bf16 / bytes_algo)})
+                        'note': 'achieved = 16-bit MFMA FLOPs issued per launch (%d part products per fp32 product, 0.25 of the '
+                                'direct-convolution FLOPs each) / mean launch duration (HIP events) over the dense bf16 / fp16 matrix '
+                                'peak; %.0f FLOP/B sits right of the ridge' % (int(nprod), flops_bf16 / bytes_algo)})
         elif k['launches'] > 0:
             avg_ms = k['total_ms'] / k['launches']
             algo_per_launch = k['flops'] / k['launches']      # direct 3x3 conv: 2*9*C^2*N*H*W
@@ -744,7 +766,17 @@ def main():
                 wissued, wname = 36.0 / 144.0, 'k_w4_wgrad (F(4x4,3x3) domain, both conv layers per launch, no split-K slabs)'
             roofline['wgrad'] = {'kernel': wname, 'achieved': walgo * wissued, 'frac': walgo * wissued / MFMA_F32_PEAK_TFLOPS,
                                  'algorithmic': walgo, 'avg_launch_us': wavg * 1e3, 'launches': w['launches']}
-            if wname.startswith('k_w4_wgrad') and cfg['filters'] >= 512 and os.environ.get('NODE_TUNE_W4_WGRAD128', '1') != '0':
+            quads_w = 4 if side == 16 else 1
+            if (wname.startswith('k_w4_wgrad') and os.environ.get('NODE_TUNE_W4_F16', '1') != '0' and (cfg['batch'] * quads_w) % 16 == 0 and
+                    args.method == 'dopri5'):
+                # round 6: V pairs x Z pairs, three fp16 MFMA products per fp32 product (k_w4_wgrad64h), every launch of an adaptive
+                # solve but the one of each interval's first evaluation
+                roofline['wgrad'].update({
+                    'kernel': 'k_w4_wgrad64h (F(4x4,3x3) domain, both conv layers per launch, fp16 pairs, LDS-DMA ring + transposed LDS reads)',
+                    'achieved': walgo * wissued * 3.0, 'frac': walgo * wissued * 3.0 / MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s of fp16 MFMA issued',
+                    'fp32_equivalent_tflops': walgo * wissued,
+                    'traffic': (pmc_lookup(pmc, 'k_w4_wgrad64h') or {}).get('bytes')})
+            elif wname.startswith('k_w4_wgrad') and cfg['filters'] >= 512 and os.environ.get('NODE_TUNE_W4_WGRAD128', '1') != '0':
                 # long filters: the same sums on bf16 triples, LDS-tiled (k_w4_wgrad128b): six bf16 MFMA products per fp32 product
                 roofline['wgrad'].update({
                     'kernel': 'k_w4_wgrad128b (F(4x4,3x3) domain, both conv layers per launch, bf16 MFMA at fp32 accuracy, LDS-tiled)',
@@ -789,6 +821,9 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
+            'dtype_note': 'fp32 tensors end to end; the 3x3 convolutions run as Winograd F(4x4,3x3) with every fp32 operand of the component '
+                          'GEMMs held as a scaled fp16 pair h + l (22 significand bits, 3 MFMA products per fp32 product): fp32-accuracy '
+                          'emulation on the 16-bit matrix pipe, 3e-6 of max|y| per convolution against fp64 (the fp32 chain: 3e-6)',
             'data': 'synthetic',
             'config': {
                 'workload': '%s, bs=%d per GPU, SGD step (BASELINE.json configs[%d])' % (cfg['name'], cfg['batch'], args.config - 1),

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define NODE_ABI_VERSION 5
+#define NODE_ABI_VERSION 6
 
 /* method -- the two solver names that reach model.py:367 on the graded configs
  * (`'dopri5'` train.py:219 default; `'rk4'` BASELINE.json configs[0]). */
@@ -192,6 +192,14 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
  * their fp32 operands on the device, element by element: out[3 i + p] = part p of x[i], widened to float.
  * x: n floats, out: 3 n floats (device); n a positive multiple of 8. */
 int node_w4_split3(const float* x, float* out, size_t n, void* stream);
+
+/* Diagnostics (tests; ABI 6): what the last node_solve_adjoint of the process did with the fp16-PAIR operand format of the
+ * F(4x4,3x3) pipeline (csrc/wino4.h): out[0] = 1 when the solve used it, out[1] = steps the device controller REPEATED because a
+ * cotangent left the range of its power-of-two scale (such a step is not a solver step: it appears in no statistic), out[2] = the
+ * cotangent exponent at the end, out[3] = 0.  Filled only by solves that ran with NODE_TUNE_W4_STATS=1 in the environment (two
+ * words more in the final read-back); -1 in out[1] otherwise.  NODE_TUNE_W4_GSKEW=k (diagnostics) starts every interval with the
+ * cotangent exponent k too high, so that its first step overflows and is repeated. */
+int node_w4_pair_stats(int32_t* out4);
 
 /* torchdiffeq.odeint(ODEfunc, y0, t, rtol, atol, method)  -- model.py:367
  * t_pts: host array of n_t strictly monotonic times; y_out: [n_t, n, c, h, w]

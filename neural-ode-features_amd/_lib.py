@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, 'csrc', 'libnode_hip.so')
 # environment of their own process; nothing in the package does.
 LIB_DIAG_PATH = os.path.join(HERE, 'csrc', 'libnode_hip_diag.so')
 
-NODE_ABI_VERSION = 5
+NODE_ABI_VERSION = 6
 METHOD_DOPRI5, METHOD_RK4 = 0, 1
 METHODS = {'dopri5': METHOD_DOPRI5, 'rk4': METHOD_RK4}
 
@@ -33,7 +33,7 @@ EXPORTS = [
     'node_backprop_workspace_bytes', 'node_solve_backprop',
     'node_head_fwd', 'node_head_bwd', 'node_gn_relu_fwd', 'node_gn_relu_bwd',
     'node_sgd_step', 'node_profile_begin', 'node_profile_end',
-    'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3',
+    'node_conv3x3_w4_workspace_bytes', 'node_conv3x3_w4', 'node_w4_split3', 'node_w4_pair_stats',
     'node_stem_workspace_bytes', 'node_stem_fwd', 'node_stem_bwd', 'node_stem_conv_workspace_bytes', 'node_stem_conv',
     'node_head_loss_scratch_bytes', 'node_head_loss_fwd', 'node_head_loss_bwd',
     'node_flat_workspace_bytes', 'node_flat_begin', 'node_flat_stage', 'node_flat_scalar', 'node_flat_initial_step',
@@ -196,6 +196,8 @@ def load():
     lib.node_profile_end.argtypes = [P(NodeProfile)]
     lib.node_conv3x3_w4_workspace_bytes.restype = sz
     lib.node_conv3x3_w4_workspace_bytes.argtypes = [P(NodeShape)]
+    lib.node_w4_pair_stats.restype = i32
+    lib.node_w4_pair_stats.argtypes = [P(C.c_int32)]
     lib.node_conv3x3_w4.restype = i32
     lib.node_conv3x3_w4.argtypes = [P(NodeShape), vp, i32, vp, vp, vp, sz, vp]
     lib.node_w4_split3.restype = i32

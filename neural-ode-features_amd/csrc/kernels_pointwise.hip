@@ -484,11 +484,12 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   }
   step_controller_decide(a, ratios);
 }
-__global__ __launch_bounds__(256) void k_w4_gscale(W4Scales* sc) {
+__global__ __launch_bounds__(256) void k_w4_gscale(W4Scales* sc, int skew) {
   __shared__ float red[4];
   (void)w4_gscale_update(sc, threadIdx.x, red);
+  if (threadIdx.x == 0 && skew != 0) sc->e[W4_E_G] += skew;
 }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(256), 0, s, sc); }
+void launch_w4_gscale(W4Scales* sc, hipStream_t s, int skew) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(256), 0, s, sc, skew); }
 
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);

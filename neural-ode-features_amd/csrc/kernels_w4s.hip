@@ -333,7 +333,10 @@ __device__ __forceinline__ void w4s_record_max(const float v[4][4], W4Scales* sc
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(v[i][j]));
+    for (int j = 0; j < 4; ++j) {
+      const float av = fabsf(v[i][j]);
+      m = av < INFINITY ? fmaxf(m, av) : m;      // (finite values only: behind an overflow the rest of the step computes on infinities,
+    }                                            //  and the maximum must stay the one the repeated step is scaled by)
   m = fmaxf(m, w4s_dpp<0xB1>(m));
   m = fmaxf(m, w4s_dpp<0x4E>(m));
   m = fmaxf(m, w4s_dpp<0x141>(m));

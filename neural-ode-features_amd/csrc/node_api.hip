@@ -450,6 +450,7 @@ const double DP_BETA[6][6] = {
     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
 };
 
+int g_w4_pair_stats[4] = {0, -1, 0, 0};   // node_w4_pair_stats (diagnostics; process-wide: a backward pass runs on autograd's thread)
 std::atomic<int> g_resident_cooldown{0};     // solves left before the resident latency path is tried again (see Solver::choose_resident)
 
 // ----------------------------------------------------------------------------
@@ -1256,6 +1257,12 @@ int node_conv3x3_w4(const node_shape* shape, const float* weight, int dgrad, con
   return NODE_OK;
 }
 
+int node_w4_pair_stats(int32_t* out4) {
+  if (!out4) return fail(NODE_ERR_NULL, "out4 is NULL");
+  for (int i = 0; i < 4; ++i) out4[i] = g_w4_pair_stats[i];
+  return NODE_OK;
+}
+
 // Diagnostics: the exact three-way bf16 split the component GEMMs apply to their fp32 row operands (k_w4_gemm64b and its
 // siblings), element by element: out[3 i + p] = part p of x[i] as a float.
 int node_w4_split3(const float* x, float* out, size_t n, void* stream) {
@@ -1494,6 +1501,11 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   S.w4_f16_aug = method == NODE_METHOD_DOPRI5;
   TRY(S.prepare());
+  int w4_gskew = 0;           // diagnostics (include/node_hip.h, node_w4_pair_stats)
+  bool w4_stats = false;
+  { const char* e = getenv("NODE_TUNE_W4_GSKEW"); if (e != nullptr) w4_gskew = atoi(e); }
+  { const char* e = getenv("NODE_TUNE_W4_STATS"); w4_stats = e != nullptr && atoi(e) != 0; }
+  g_w4_pair_stats[0] = S.w4_f16 ? 1 : 0; g_w4_pair_stats[1] = -1; g_w4_pair_stats[2] = 0; g_w4_pair_stats[3] = 0;
   launch_set_ctrl(S.p.ctrl, 0.0, 0.0, 1, S.st);  // also zeroes the scalar segment (adj_time = 0)
   launch_fill(S.p.TH, 0.f, S.d.P, S.st);         // adj_params = 0
   // grad_last_only: `grad_out` is the last slice alone, every other slice of dL/dy_out is zero (node_solve_opts)
@@ -1537,7 +1549,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
       else TRY(S.upload(S.p.targets, &s1, 1, hs->lists + (n_t - 1 - i) % n_t));
       S.g_ready = false;      // (fp16-pair operands: the interval's first evaluation runs the triples and records max|dz|, wino4.h)
       TRY(S.eval_sys(0, nullptr, 0, SC_ABS, S.et_stage(0.0), false));
-      if (S.w4_f16) { launch_w4_gscale(S.p.w4sc, S.st); S.g_ready = true; }
+      if (S.w4_f16) { launch_w4_gscale(S.p.w4sc, S.st, w4_gskew); S.g_ready = true; }
       if (gdot) launch_dot_sub_scalar(S.p.ctrl, S.p.KY[0], gdot, numel, S.tsign, S.p.partial[0], dots_i, S.st);
       if (!forced) TRY(S.initial_step());
       if (blind) {   // deferred completion (one interval): the record says later whether these were the steps needed
@@ -1597,6 +1609,13 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
   // (dopri5: every interval ended with a read-back, behind which nothing of this call is staged on the host -- the launches above are
   //  ordinary stream work the caller's next launches queue behind, and the host does not wait for them; rk4 has no read-back)
   if (method == NODE_METHOD_RK4) HIP_TRY(hipStreamSynchronize(S.st));
+  if (w4_stats && S.w4_f16) {   // (diagnostics: two words of the scale block; the read-back above left the stream idle)
+    W4Scales hsc;
+    HIP_TRY(hipMemcpyAsync(&hsc, S.p.w4sc, offsetof(W4Scales, pad), hipMemcpyDeviceToHost, S.st));
+    HIP_TRY(hipStreamSynchronize(S.st));
+    g_w4_pair_stats[1] = hsc.n_retry;
+    g_w4_pair_stats[2] = hsc.e[W4_E_G];
+  }
   stt.nfe = S.nfe + 6 * steps_total;
   stt.t_final = cur_t; stt.last_dt = cur_dt;
   if (stats) *stats = stt;

@@ -118,7 +118,7 @@ __device__ inline bool w4_gscale_update(W4Scales* sc, int tid, float* red) {
   }
   return ovf;
 }
-void launch_w4_gscale(W4Scales* sc, hipStream_t s);      // the same as a one-workgroup launch (behind an interval's first evaluation)
+void launch_w4_gscale(W4Scales* sc, hipStream_t s, int skew = 0);   // skew (diagnostics): the exponent lands `skew` too high      // the same as a one-workgroup launch (behind an interval's first evaluation)
 constexpr int W4_E_U1 = 0, W4_E_U2 = 1, W4_E_V1 = 2, W4_E_V2 = 3, W4_E_G = 4;
 struct W4ScaleJobs {
   const float* w[2];        // conv weights [C][CI][3][3] (w[1] nullable)

@@ -69,7 +69,7 @@ def test_full_size_adjoint_solve_kink_free(tol):
     print('full-size kink-free adjoint: grad_y rel', e_y, 'grad_theta rel', e_p, 'same history', r['same'])
     if r['same']:
         assert rel_err(r['out_h'], r['out_o']) < 2e-4
-        assert e_y < 1e-3 and e_p < 1e-3
+        assert e_y < 2e-4 and e_p < 2e-4          # (measured, round 6: 2.2e-6 / 2.1e-6 at tol 1e-3, 1.5e-5 / 3.4e-5 at 1e-5)
     else:       # an accept/reject flip moves both trajectories by O(tol)
         assert e_y < 5e-2 and e_p < 5e-2
 
@@ -127,7 +127,7 @@ def _arbiter_device():
     return _F64_DEVICE
 
 
-def _replay_triplet(shape, tol, seed, t_end):
+def _replay_triplet(shape, tol, seed, t_end, with_f32=True):
     """Ordinary parameters (ReLUs switch inside the solve) under an fp64 ARBITER.  A free-running HIP solve supplies
     the accepted step sizes (forward and backward); the same discrete scheme is then integrated three times in replay
     mode: HIP (fp32), oracle fp32, oracle fp64.  Returns the three gradient sets."""
@@ -159,7 +159,7 @@ def _replay_triplet(shape, tol, seed, t_end):
     hip = dict(out=out_h.detach().cpu(), gy=yh.grad.cpu(), gp=torch.cat([p.grad.reshape(-1) for p in f.parameters()]).cpu())
     # 3. replay by the oracle in fp32 and in fp64
     res = {}
-    for name, dt in (('f32', torch.float32), ('f64', torch.float64)):
+    for name, dt in ((('f32', torch.float32),) if with_f32 else ()) + (('f64', torch.float64),):
         dev = _arbiter_device() if name == 'f64' else 'cpu'
         tw = copy.deepcopy(twin).to(dt).to(dev)
         yo = y.detach().to(dt).to(dev).clone().requires_grad_(True)
@@ -167,7 +167,7 @@ def _replay_triplet(shape, tol, seed, t_end):
         (out_o * wgt.to(dt).to(dev)).sum().backward()
         res[name] = dict(out=out_o.detach().cpu(), gy=yo.grad.cpu(), gp=torch.cat([p.grad.reshape(-1) for p in tw.parameters()]).cpu())
     print('  (fp64 arbiter ran on %s)' % _arbiter_device())
-    return hip, res['f32'], res['f64'], free
+    return hip, res.get('f32'), res['f64'], free
 
 
 @contextlib.contextmanager
@@ -217,7 +217,8 @@ def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end, batch):
     # max 1.8e-3.  At tol 1e-3 (3 + 7 steps) the pipeline's median is 7e-4 of a gradient ten times larger.  So the median
     # is held under 1e-3 -- a wrong scale, mask rule or missing term anywhere would sit orders above -- and the relative
     # L2 distances above and below carry the parity claim.
-    assert float(per.median()) <= max(10 * tol, 1e-3)
+    # round 6 (fp16-pair operands): measured median 3.8e-4 at tol 1e-3 (batch 128), 1.9e-4 at tol 1e-5 (batch 64): three times that
+    assert float(per.median()) <= {1e-3: 1.2e-3, 1e-5: 6e-4}[tol]
     C = 256
     sizes = [C, C, C * (C + 1) * 9, C, C, C, C * (C + 1) * 9, C, C, C]
     off = 0
@@ -227,6 +228,34 @@ def test_full_size_adjoint_solve_w4_fp64_arbiter(tol, t_end, batch):
         eh, ea = float((h - r).norm() / r.norm()), float((a - r).norm() / r.norm())
         print('  theta tensor %d: relative L2 distance to fp64: HIP %.3e | fp32 oracle %.3e' % (i, eh, ea))
         assert eh <= 3.0 * ea + 1e-4, i
+    assert rel_err(free['gy'], hip['gy']) < 1e-4 and rel_err(free['gp'], hip['gp']) < 1e-4
+
+
+def test_full_batch_tol_1e5_ordinary_parameters_against_the_fp64_arbiter():
+    """configs[2] at its FULL batch [128,256,8,8], tol 1e-5, ORDINARY parameters (round-5 review: this case ran at half batch because
+    of the CPU fp32 oracle leg): the HIP replay against the fp64 arbiter alone, which runs on the device.  The fp32 oracle's own
+    distance to fp64 on this problem is measured by the half-batch test above (relative L2 5.9e-5 for grad_y0, 5e-5 .. 1.3e-4 per
+    parameter tensor); the pipeline must sit in that class here: output within 10 x atol, relative L2 of every gradient tensor
+    <= 5e-4, per-sample max-norm median <= 6e-4 (measured at batch 64: 8.3e-5, 5e-5 .. 1.3e-4, 1.9e-4)."""
+    if _arbiter_device() != 'cuda':
+        pytest.skip('no fp64 convolution on the device: the full batch on the host takes minutes')
+    tol = 1e-5
+    with _wino4(1):
+        hip, _, o64, free = _replay_triplet((128, 256, 8, 8), tol, seed=52, t_end=1.0, with_f32=False)
+    assert float((hip['out'][-1].double() - o64['out'][-1]).abs().max()) <= 10 * tol
+    l2 = float((hip['gy'].double() - o64['gy']).norm() / o64['gy'].norm())
+    per = (hip['gy'].double() - o64['gy']).abs().flatten(1).amax(dim=1) / o64['gy'].abs().max()
+    print('full batch, tol 1e-5: grad_y0 relative L2 to fp64 %.3e; per-sample max-norm median %.3e max %.3e' % (l2, float(per.median()), float(per.max())))
+    assert l2 <= 5e-4 and float(per.median()) <= 6e-4
+    C = 256
+    sizes = [C, C, C * (C + 1) * 9, C, C, C, C * (C + 1) * 9, C, C, C]
+    off = 0
+    for i, n in enumerate(sizes):
+        h, r = hip['gp'][off:off + n].double(), o64['gp'][off:off + n]
+        off += n
+        eh = float((h - r).norm() / r.norm())
+        print('  theta tensor %d: relative L2 distance to fp64 %.3e' % (i, eh))
+        assert eh <= 5e-4, i
     assert rel_err(free['gy'], hip['gy']) < 1e-4 and rel_err(free['gp'], hip['gp']) < 1e-4
 
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.node_abi_version() == _lib.NODE_ABI_VERSION == 5
+    assert lib.node_abi_version() == _lib.NODE_ABI_VERSION == 6
     m = re.search(r'#define NODE_ABI_VERSION (\d+)', header)
     assert int(m.group(1)) == _lib.NODE_ABI_VERSION
 

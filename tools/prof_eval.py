@@ -22,6 +22,9 @@ def main():
     ap.add_argument('--shape', default='128,256,8,8')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--fwd-only', action='store_true')
+    ap.add_argument('--solve', type=float, default=0.0, metavar='TOL',
+                    help='whole adaptive solves (forward + adjoint, dopri5 at this tolerance) instead of single evaluations: the kernels a '
+                         'training step launches, fp16-pair component GEMMs and weight gradient included')
     args = ap.parse_args()
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import integrate
@@ -31,7 +34,15 @@ def main():
     y = torch.randn(N, C, H, W, device='cuda')
     cot = torch.randn(N, C, H, W, device='cuda')
 
+    tt = torch.tensor([0.0, 1.0], device='cuda')
+    wgt = torch.randn(N, C, H, W, device='cuda') / (C * H * W) ** 0.5
+
     def once():
+        if args.solve > 0.0:
+            yy = y.clone().requires_grad_(True)
+            out = nof.odeint_adjoint(f, yy, tt, rtol=args.solve, atol=args.solve, method='dopri5')[-1]
+            (out * wgt).sum().backward()
+            return out
         if args.fwd_only:
             return nof.odefunc_forward(f, 0.3, y)
         return nof.odefunc_vjp(f, 0.3, y, cot)
