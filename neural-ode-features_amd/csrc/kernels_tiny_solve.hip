@@ -29,6 +29,7 @@
 // profiles/r05_latency_bs1.txt (17.0 / 15.2 us per evaluation at [1,256,8,8], tol 1e-3 / 1e-5, host included; kernels_tiny.hip 34.3 / 29.7).
 #include "node_internal.h"
 #include "step_control.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -44,7 +45,7 @@ namespace {
 
 constexpr unsigned TS_VERS = 15;             // versions cycle 0 .. 14 (a slot is rewritten every evaluation: consecutive versions differ); 15 = the solve is over
 constexpr int TS_PITCH = 40;                 // bf16 elements per padded-pixel row of an LDS part plane (32 channels + 8)
-constexpr long long TS_DEADLINE = 200000000; // 2 s of the 100 MHz constant clock: only a broken grid gets there
+constexpr long long TS_DEADLINE = 25000000;  // 0.25 s of the 100 MHz constant clock (a solve takes ~1 ms): only a grid that is not whole gets there
 
 // Butcher rows as the host path builds them: (float) of the double coefficient (Solver::make_comb), scaled by (float) dt at use
 __device__ constexpr float TS_BETA[6][6] = {
@@ -820,12 +821,20 @@ bool tiny_resident_ok(const Dims& d) {
   if (e != nullptr && atoi(e) == 0) return false;
   if (d.C % 32 != 0 || d.C > 256 || d.HW > 64 || d.W > 62) return false;
   if (d.cpg < 1 || d.cpg > 16 || (d.cpg & (d.cpg - 1)) != 0) return false;
-  static int cus = -1;
-  if (cus < 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
-    else cus = prop.multiProcessorCount;
+  // compute units of the CURRENT device (cached per device: a process may drive several), one workgroup each -- the kernel's LDS
+  // leaves room for exactly one per CU, which hipOccupancyMaxActiveBlocksPerMultiprocessor confirms once per device.  (Other streams
+  // and processes can still hold CUs when the launch arrives: that is what the bounded waits and the fallback are for.)
+  static std::atomic<int> cus_of[MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return false; }
+  int cus = cus_of[dev].load(std::memory_order_relaxed);
+  if (cus == 0) {
+    int n = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = -1; }
+    if (n > 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_tiny_solve), 256, 64 * 1024) != hipSuccess ||
+                  per_cu < 1)) { (void)hipGetLastError(); n = -1; }
+    cus = n > 0 ? n : -1;
+    cus_of[dev].store(cus, std::memory_order_relaxed);
   }
   const long grid = (long)d.N * (d.C / 16) * (d.C / 32);
   if (grid > cus) return false;

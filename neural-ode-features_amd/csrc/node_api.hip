@@ -451,6 +451,8 @@ const double DP_BETA[6][6] = {
 };
 
 int g_w4_pair_stats[4] = {0, -1, 0, 0};   // node_w4_pair_stats (diagnostics; process-wide: a backward pass runs on autograd's thread)
+thread_local Ctrl* g_blind_resident_ctrl = nullptr;   // pinned: where a DEFERRED resident solve leaves its record for this library itself --
+                                                       // the caller reads the device record; a later call of this thread arms the cooldown from this one
 std::atomic<int> g_resident_cooldown{0};     // solves left before the resident latency path is tried again (see Solver::choose_resident)
 
 // ----------------------------------------------------------------------------
@@ -480,6 +482,11 @@ struct Solver {
   bool resident = false;
   void choose_resident(bool dopri5) {
     resident = dopri5 && tiny_mode() && !w4 && p.thand != nullptr && tiny_resident_ok(d);
+    if (g_blind_resident_ctrl != nullptr && g_blind_resident_ctrl->status == NODE_ERR_HIP) {
+      // an earlier DEFERRED resident solve of this thread ran into its deadline (nobody read its record on this side): same cooldown
+      g_blind_resident_ctrl->status = 0;
+      g_resident_cooldown.store(64, std::memory_order_relaxed);
+    }
     if (resident) {      // a captured launch would replay its nonce: words of the previous replay would pass for this one's
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
@@ -1374,7 +1381,11 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
     ra.bias[0] = params->conv1_b; ra.bias[1] = params->conv2_b;
     ra.gamma[0] = params->norm1_w; ra.gamma[1] = params->norm2_w; ra.gamma[2] = params->norm3_w;
     ra.beta[0] = params->norm1_b; ra.beta[1] = params->norm2_b; ra.beta[2] = params->norm3_b;
-    ra.handoff = S.p.thand; ra.ctrl = S.p.ctrl; ra.ctrl_host = blind ? nullptr : S.hctrl;
+    if (blind && g_blind_resident_ctrl == nullptr) {
+      if (hipHostMalloc((void**)&g_blind_resident_ctrl, sizeof(Ctrl), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); g_blind_resident_ctrl = nullptr; }
+      else memset(g_blind_resident_ctrl, 0, sizeof(Ctrl));
+    }
+    ra.handoff = S.p.thand; ra.ctrl = S.p.ctrl; ra.ctrl_host = blind ? g_blind_resident_ctrl : S.hctrl;
     {
       // every word that crosses workgroups carries {nonce, version}: stale words of any earlier solve of this process never match, so
       // nothing is zeroed per solve.  The 28-bit nonce starts over every 2^28 solves: a hand-off buffer is zeroed the first time it

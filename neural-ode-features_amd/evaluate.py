@@ -1,12 +1,18 @@
 #!/usr/bin/env python
-"""The two evaluations of the reference that drive the ODE block hardest, on the HIP backend
-(`/root/reference/evaluate.py:24-142`; the second-heaviest user of the path):
+"""The evaluations of the reference that drive the ODE block, on the HIP backend
+(`/root/reference/evaluate.py:24-305`; the second-heaviest user of the path):
 
   features   `model.to_features_extractor()`, `odeblock.t1 = [0, .05, ..., 1]`, `odeblock.tol` swept: one dense-output
              solve per batch and tolerance, the head's pooling per time slice  -> features [tols, T, N, C]
              (evaluate.py:24-94; written as .npz -- h5py is not in this image)
   nfe        batch size 1, `tol x t1` sweep, `model.nfe(reset=True)` per image -> nfe.csv.gz with the reference's
              columns y_true, y_pred, nfe, t1, tol (evaluate.py:97-142): the latency regime
+  tradeoff   `tol x t1` sweep at the run's batch size, `odeblock.t1` / `.tol` mutated between forwards: test loss, accuracy and
+             mean NFE per batch -> tradeoff.csv with the reference's columns t1, test_loss, test_acc, test_nfe, test_tol
+             (evaluate.py:145-204)
+  accuracy   ONE dense-output solve per batch and tolerance at t1 = [.05, ..., 1] (`return_last_only = False`; the ODE stem of an
+             `ode2` run alike, `apply_conv = True`): loss and accuracy of the classifier at EVERY time slice -> `results` (csv)
+             with the reference's columns t1, test_loss, test_acc, test_nfe, test_tol (evaluate.py:207-305)
 
 Runs on a run directory written by `neural_ode_features_amd.train` (or any `{'params', 'model'}` checkpoint with the
 reference's state_dict keys).  Test data: `--data file.pt` (`x_test`, `y_test`) or the synthetic set of that run.
@@ -93,9 +99,91 @@ def nfe(args):
     return out
 
 
+def _test_batches(xte, yte, bs, device):
+    for i in range(0, xte.shape[0], bs):
+        yield xte[i:i + bs].to(device), yte[i:i + bs].to(device)
+
+
+def tradeoff(args):
+    """evaluate.py:145-204: accuracy / NFE trade-off over `tol x t1`, the live block mutated between forwards."""
+    import pandas as pd
+    import torch.nn.functional as F
+    model, p, xte, yte = load_run(args.run)
+    if args.limit:
+        xte, yte = xte[:args.limit], yte[:args.limit]
+    model = model.to(args.device).eval()
+    rows = []
+    with torch.no_grad():
+        for tol, t1 in itertools.product(args.tol, args.t1):
+            model.odeblock.t1 = t1
+            model.odeblock.tol = tol
+            model.nfe(reset=True)
+            n_correct = n_processed = n_batches = nfe_forward = 0
+            loss = None
+            for x, y in _test_batches(xte, yte, p.batch_size, args.device):
+                pr = model(x)
+                nfe_forward += model.nfe(reset=True)
+                loss = F.cross_entropy(pr, y)
+                n_correct += int((y == pr.argmax(dim=1)).sum())
+                n_processed += y.shape[0]
+                n_batches += 1
+            # (the reference reports the LAST batch's mean loss over the images processed so far, evaluate.py:181: kept as it is)
+            rows.append({'t1': t1, 'test_loss': float(loss) / n_processed, 'test_acc': n_correct / n_processed,
+                         'test_nfe': nfe_forward / n_batches, 'test_tol': tol})
+    out = os.path.join(args.run, 'tradeoff.csv')
+    df = pd.DataFrame(rows)
+    df.to_csv(out, index=False)
+    print(df)
+    return out
+
+
+def accuracy(args):
+    """evaluate.py:207-305: the classifier's loss / accuracy at every time slice of ONE dense-output solve per batch."""
+    import pandas as pd
+    import torch.nn.functional as F
+    model, p, xte, yte = load_run(args.run)
+    if args.limit:
+        xte, yte = xte[:args.limit], yte[:args.limit]
+    model = model.to(args.device).eval()
+    t1 = torch.arange(0, 1.05, .05) if args.t1 is None or len(args.t1) < 2 else torch.tensor([0.0] + [t for t in args.t1 if t > 0])
+    model.odeblock.t1 = t1[1:].tolist()           # 0 is implicit (evaluate.py:231)
+    model.odeblock.return_last_only = False
+    if p.downsample == 'ode2':
+        model.downsample.odeblock.t1 = t1[1:].tolist()
+        model.downsample.odeblock.return_last_only = False
+        model.downsample.odeblock.apply_conv = True
+        t1 = torch.cat((t1, t1))
+    T = len(t1)
+    frames = []
+    with torch.no_grad():
+        for tol in args.tol:
+            model.odeblock.tol = tol
+            if 'ode' in p.downsample:
+                model.downsample.odeblock.tol = tol
+            model.nfe(reset=True)
+            n_correct, tot_losses = torch.zeros(T), torch.zeros(T)
+            n_processed = n_batches = nfe_forward = 0
+            for x, y in _test_batches(xte, yte, p.batch_size, args.device):
+                pr = model(x)                                      # timestamps (T) x batch (N) x classes (C)
+                nfe_forward += model.nfe(reset=True)
+                losses = F.cross_entropy(pr.permute(1, 2, 0), y.unsqueeze(1).expand(-1, T), reduction='none')      # N x T
+                tot_losses += losses.sum(0).cpu()
+                n_correct += (y.unsqueeze(0).expand(T, -1) == pr.argmax(dim=-1)).sum(-1).float().cpu()
+                n_processed += y.shape[0]
+                n_batches += 1
+            frames.append(pd.DataFrame({'t1': t1.numpy(), 'test_loss': (tot_losses / n_processed).numpy(),
+                                        'test_acc': (n_correct / n_processed).numpy(), 'test_nfe': [nfe_forward / n_batches] * T,
+                                        'test_tol': [tol] * T}))
+    out = os.path.join(args.run, 'results')
+    df = pd.concat(frames, ignore_index=True)
+    df.to_csv(out, index=False)
+    print(df)
+    return out
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description='features / nfe evaluations of the reference on the HIP backend')
-    ap.add_argument('mode', choices=('features', 'nfe'))
+    ap = argparse.ArgumentParser(description='features / nfe / tradeoff / accuracy evaluations of the reference on the HIP backend')
+    ap.add_argument('mode', choices=('features', 'nfe', 'tradeoff', 'accuracy'))
     ap.add_argument('run')
     ap.add_argument('--t1', type=float, nargs='+', default=np.arange(0, 1.05, .05).tolist())      # evaluate.py:424
     ap.add_argument('--tol', type=float, nargs='+', default=[1e-3, 1e-2, 1e-1, 1e0, 1e1, 1e2])      # evaluate.py:423
@@ -104,7 +192,7 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit('neural_ode_features_amd.evaluate needs a HIP device: the ODE block has no CPU path')
     args.device = torch.device('cuda')
-    return {'features': features, 'nfe': nfe}[args.mode](args)
+    return {'features': features, 'nfe': nfe, 'tradeoff': tradeoff, 'accuracy': accuracy}[args.mode](args)
 
 
 if __name__ == '__main__':

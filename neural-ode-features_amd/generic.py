@@ -13,6 +13,12 @@ Nothing here imports `oracle/`; CPU and non-fp32 tensors still raise (integrate.
 
 Algorithm = the fused path's: dopri5 with torchdiffeq's 2019 controller, rk4 3/8 rule on the `t` grid,
 continuous adjoint on the augmented state (y, a, adj_t, adj_params) with one `torch.autograd.grad` per evaluation.
+
+`func` must be PURE in the sense upstream's solvers assume as well: the solver enqueues as many steps as the previous solve of the
+same problem took before it reads the controller back, so steps past the end of the interval still CALL `func` (on stage states that are
+then discarded; only `func.nfe` is corrected afterwards).  Modules with side effects -- BatchNorm running statistics, dropout RNG,
+counters, hooks -- see those extra calls; `BatchNorm2d(track_running_stats=False)`, what the reference's `norm='batch'` is
+(model.py:268-271), has none.
 """
 from __future__ import annotations
 

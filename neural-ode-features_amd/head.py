@@ -183,7 +183,9 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
         return F.linear(x, weight, bias)
     out = _Linear.apply(x, weight, bias)
     if torch.is_grad_enabled() and out.requires_grad:
-        setattr(out, _LINEAR_ATTR, (x, weight, bias))
+        # (with the version of the result: an in-place edit of the logits between `linear` and `cross_entropy` -- `logits.div_(T)`,
+        #  `masked_fill_` -- must take the ordinary autograd edge, not the fused backward that assumes logits = x W^T + b)
+        setattr(out, _LINEAR_ATTR, (x, weight, bias, out._version))
     return out
 
 
@@ -278,6 +280,8 @@ def cross_entropy(logits: torch.Tensor, target: torch.Tensor, reduction: str = '
         return F.cross_entropy(logits, target, reduction=reduction)
     target = target.contiguous()
     src = getattr(logits, _LINEAR_ATTR, None) if torch.is_grad_enabled() else None
+    if src is not None and (logits._version != src[3] or logits._backward_hooks or logits.retains_grad):
+        src = None      # edited in place since `linear`, or somebody wants to see its gradient: the plain edge through `_Linear`
     if src is not None:
         # (the logits go in DETACHED: as an autograd input of the fused node they would pull `linear`'s own backward into the graph --
         #  called with a materialised zero gradient: a second, useless launch per step, seen in profiles/r05_cfg2_steps.txt's first cut)

@@ -134,7 +134,11 @@ def deferred_loop(model, optimizer, args):
         optimizer.zero_grad()
         # the batch's {loss, correct predictions} travel to pinned host memory behind the step: nothing waits for them
         host = torch.empty(2, dtype=torch.float32).pin_memory()
-        host.copy_(loss.node_stat, non_blocking=True)
+        stat = getattr(loss, 'node_stat', None)
+        if stat is None:      # (`cross_entropy` went to PyTorch: > 1024 classes, class-probability targets, non-fp32 logits)
+            with torch.no_grad():
+                stat = torch.stack([loss.detach().float(), (logits.argmax(dim=1) == target).sum().float()])
+        host.copy_(stat, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         return host, event, target.shape[0], nf, nb

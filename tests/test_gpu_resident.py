@@ -181,7 +181,7 @@ def test_resident_solve_through_the_module_interface_and_deferred_record():
 
 def test_a_grid_that_is_not_whole_drains_and_the_solve_falls_back():
     """The resident solve needs its whole grid on the chip.  NODE_TUNE_TINY_RESIDENT=2 launches it one workgroup short: every
-    wait runs into its deadline (2 s of the constant clock), the grid drains, the C call repeats the solve on the
+    wait runs into its deadline (0.25 s of the constant clock), the grid drains, the C call repeats the solve on the
     launch-per-convolution path -- same result as that path by itself, no error; the process then leaves the resident grid alone for
     its next 64 solves and takes it again after them."""
     import time
@@ -211,7 +211,7 @@ def test_a_grid_that_is_not_whole_drains_and_the_solve_falls_back():
             back = nof.odeint(f, y, t, rtol=1e-3, atol=1e-3)
     print('fallback after %.2f s; the 64 solves behind it %.3f s' % (waited, cooled))
     assert torch.equal(got, want)
-    assert 1.5 < waited < 10.0 and cooled < 1.0
+    assert 0.2 < waited < 5.0 and cooled < 1.0
     assert rel_err(back, want) < 1e-4 and not torch.equal(back, want)      # (the two paths round differently: equal bits would mean the same path)
 
 

@@ -94,3 +94,20 @@ def test_features_and_nfe_evaluations_on_a_trained_run(tmp_path):
     assert list(df.columns) == ['y_true', 'y_pred', 'nfe', 't1', 'tol'] and len(df) == 2 * 2 * 6   # evaluate.py:121-140
     assert ((df.nfe - 2) % 6 == 0).all() and (df.nfe >= 8).all()                         # show.py:199: NFE = 2 + 6 steps
     assert df[df.tol == 1e-1].nfe.mean() <= df[df.tol == 1e-3].nfe.mean()
+    # evaluate.py:145-204: tol x t1 trade-off at the run's batch size, the live block mutated between forwards
+    out = E.main(['tradeoff', run, '--t1', '0.5', '1', '--tol', '1e-3', '1e-1', '--limit', '64'])
+    df = pd.read_csv(out)
+    assert list(df.columns) == ['t1', 'test_loss', 'test_acc', 'test_nfe', 'test_tol'] and len(df) == 4
+    assert ((df.test_nfe - 2) % 6 == 0).all() and (df.test_acc >= 0).all() and (df.test_acc <= 1).all()
+    assert float(df[(df.test_tol == 1e-1)].test_nfe.mean()) <= float(df[(df.test_tol == 1e-3)].test_nfe.mean())
+    # evaluate.py:207-305: loss / accuracy of the classifier at every time slice of ONE dense-output solve per batch and tolerance
+    out = E.main(['accuracy', run, '--tol', '1e-3', '1e-1', '--limit', '64'])
+    df = pd.read_csv(out)
+    assert list(df.columns) == ['t1', 'test_loss', 'test_acc', 'test_nfe', 'test_tol'] and len(df) == 2 * 21      # t1 = 0, .05, ..., 1
+    assert np.allclose(df.t1.values[:21], np.arange(0, 1.05, .05), atol=1e-6)
+    a, b = df[df.test_tol == 1e-3], df[df.test_tol == 1e-1]
+    assert abs(float(a.test_loss.values[0]) - float(b.test_loss.values[0])) < 1e-6        # the slice at t = 0 is the stem's output: no solve in it
+    assert np.abs(a.test_loss.values - b.test_loss.values).max() < 0.2                     # ... and the two tolerances agree roughly everywhere
+    # the slice at t1 = 1 of the dense-output solve is what the trade-off run computed at t1 = 1, tol 1e-3 (same solve, same end point)
+    tr = pd.read_csv(os.path.join(run, 'tradeoff.csv'))
+    assert abs(float(a.test_acc.values[-1]) - float(tr[(tr.t1 == 1.0) & (tr.test_tol == 1e-3)].test_acc.values[0])) < 1e-6
