@@ -285,7 +285,8 @@ def test_asm_load_guard_flags_a_register_touched_in_flight(tmp_path):
 
     def stream(body):
         text = ''
-        for k, n in (('k_w4_gemm128b', 13), ('k_w4_wgrad128b', 14)):
+        for k in mod.KERNELS:
+            n = len(k)
             text += '_ZN4node%d%sEv:\n%s\ts_endpgm\n.Lfunc_end_%s:\n' % (n, k, body, k)
         p = tmp_path / 'k.s'
         p.write_text(text)
@@ -294,13 +295,14 @@ def test_asm_load_guard_flags_a_register_touched_in_flight(tmp_path):
     load = '\tglobal_load_dwordx4 v[8:11], v[4:5], off\n'
     assert stream(load + '\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v1, v9\n') == []
     bad = stream(load + '\tv_mov_b32 v1, v9\n\ts_waitcnt vmcnt(0)\n')
-    assert len(bad) == 2 and 'v9' in bad[0]
-    assert len(stream(load + load.replace('v[8:11]', 'v[12:15]') + '\ts_waitcnt vmcnt(1)\n\tv_add_f32 v0, v8, v8\n\tv_add_f32 v0, v12, v0\n')) == 2
-    assert len(stream(load + '\tscratch_store_dword off, v1, off\n\ts_waitcnt vmcnt(0)\n')) == 2
+    nk = len(mod.KERNELS)
+    assert len(bad) == nk and 'v9' in bad[0]
+    assert len(stream(load + load.replace('v[8:11]', 'v[12:15]') + '\ts_waitcnt vmcnt(1)\n\tv_add_f32 v0, v8, v8\n\tv_add_f32 v0, v12, v0\n')) == nk
+    assert len(stream(load + '\tscratch_store_dword off, v1, off\n\ts_waitcnt vmcnt(0)\n')) == nk
     other = '\ts_and_saveexec_b64 s[6:7], s[0:1]\n' + load + '\ts_andn2_saveexec_b64 s[6:7], s[6:7]\n' + load + '\ts_or_b64 exec, exec, s[6:7]\n'
     assert stream(other + '\ts_waitcnt vmcnt(0)\n') == []
-    assert len(stream(other + '\tv_mov_b32 v1, v8\n')) == 2
-    assert len(stream('\tv_mov_b32 v1, v8\n')) == 2         # no load at all: the kernel changed under the guard
+    assert len(stream(other + '\tv_mov_b32 v1, v8\n')) == nk
+    assert len(stream('\tv_mov_b32 v1, v8\n')) == nk         # no load at all: the kernel changed under the guard
 
 
 def test_loss_helpers_route_cpu_tensors_to_pytorch():
