@@ -284,6 +284,8 @@ struct Plan {
   unsigned short* w4ub[4];  // the same as exact bf16 triples (k_w4_gemm64b)
   float* tmapS[2];          // the border maps in the W4S blocking (kernels_w4s.hip)
   W4Scales* w4sc;           // power-of-two scales of the fp16-pair operands (wino4.h)
+  float* W4Va0b;            // second copy of W4Va[0]: the pass that ends an evaluation writes the NEXT one's conv-1 operand while this
+                            // evaluation's weight gradient may still read its own (side stream, Solver::wgrad_side)
   float *W4Va[2], *W4Z[2], *W4dU;   // F(4x4,3x3)-domain weight gradient (C % 128 == 0): the forward convs' row operands
                                     // kept until it runs, Z = A dz A^T of both conv outputs' cotangents, the gradients
   float *act1b, *xh1b, *r1b;   // second set of GroupNorm-1's saved tensors: the pass that ends evaluation s also forms
@@ -352,6 +354,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
     p.w4sc = b.take<W4Scales>(1);
     if (adjoint && d.C % 128 == 0) {
       for (int i = 0; i < 2; ++i) p.W4Va[i] = b.take<float>(w4_v_elems(d.N8, d.C));
+      p.W4Va0b = b.take<float>(w4_v_elems(d.N8, d.C));
       for (int i = 0; i < 2; ++i) p.W4Z[i] = b.take<float>(w4_z_elems(d.N8, d.C));
       p.W4dU = b.take<float>(w4_du_elems(d.C));
     }
@@ -450,6 +453,34 @@ const double DP_BETA[6][6] = {
     {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84},
 };
 
+// A second stream for the weight gradient of an augmented evaluation (Solver::wgrad_side): one per host thread and device, created at
+// first use and kept (stream creation costs milliseconds).
+struct SideStream {
+  int dev = -1;
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+thread_local SideStream g_side;
+static bool get_side(SideStream** out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (g_side.s != nullptr && g_side.dev != dev) {
+    (void)hipEventDestroy(g_side.fork); (void)hipEventDestroy(g_side.join); (void)hipStreamDestroy(g_side.s);
+    g_side = SideStream();
+  }
+  if (g_side.s == nullptr) {
+    if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g_side = SideStream();
+      return false;
+    }
+    g_side.dev = dev;
+  }
+  *out = &g_side;
+  return true;
+}
 int g_w4_pair_stats[4] = {0, -1, 0, 0};   // node_w4_pair_stats (diagnostics; process-wide: a backward pass runs on autograd's thread)
 thread_local Ctrl* g_blind_resident_ctrl = nullptr;   // pinned: where a DEFERRED resident solve leaves its record for this library itself --
                                                        // the caller reads the device record; a later call of this thread arms the cooldown from this one
@@ -504,6 +535,12 @@ struct Solver {
   bool w4_f16 = false;     // ... both operands as fp16 pairs (k_w4_gemm64h; wino4.h), decided in prepare()
   bool w4_f16_aug = false; // set by the caller before prepare(): an augmented solve may use them (adaptive dopri5 solves: the cotangent-side
                            // scale follows the data through the step controller)
+  // The fp16-pair weight gradient (k_w4_wgrad64h: two small workgroups per CU, <= 128 registers) on a SIDE stream beside the data
+  // gradient of conv 1 and the pass behind it (k_w4_gemm64h: one 332-register wave per SIMD, which leaves it room): forked behind the
+  // pass that wrote Z1, joined in front of k_theta_finalize.  NODE_TUNE_W4_WGRAD_SIDE = 0 / 1 (read per solve in prepare()).
+  SideStream* side = nullptr;
+  bool side_pending = false;
+  float* va0_of(int set) const { return (set && p.W4Va0b != nullptr) ? p.W4Va0b : p.W4Va[0]; }
   bool g_ready = false;    // the cotangent-side scale is known (behind an interval's first evaluation, launch_w4_gscale)
   // the format of the evaluation being enqueued: forward solves always pairs; augmented ones once the cotangent scale is known
   bool f16_now() const { return w4_f16 && (!aug || g_ready); }
@@ -570,6 +607,11 @@ struct Solver {
       w4_b16 = w4_uses_bf16(d.N8, d.C);
       w4_f16 = w4_b16 && w4_f16_fits(d.N8, d.C) && (!aug || (w4_f16_aug && w4_wgrad_on() && w4_wgrad_f16_fits(d.N8, d.C)));
       g_ready = false;
+      side = nullptr; side_pending = false;
+      if (w4_f16 && aug) {
+        const char* e = getenv("NODE_TUNE_W4_WGRAD_SIDE");
+        if ((e ? atoi(e) : 0) != 0 && !get_side(&side)) side = nullptr;
+      }
       if (w4_f16) { zr[nz] = reinterpret_cast<float*>(p.w4sc); zn[nz++] = sizeof(W4Scales) / sizeof(float); }
     }
     // (first: it carries the solve's zero fills, among them the scratch words of k_w4_scales)
@@ -613,6 +655,7 @@ struct Solver {
         launch_fill(p.W4Va[i], 0.f, w4_v_elems(d.N8, d.C), st);
         launch_fill(p.W4Z[i], 0.f, w4_z_elems(d.N8, d.C), st);
       }
+      launch_fill(p.W4Va0b, 0.f, w4_v_elems(d.N8, d.C), st);
     }
     v_ready = false;
     cur = 0;
@@ -681,7 +724,7 @@ struct Solver {
   void w4_tail_combine(W4sArgs& a, const Comb& cy, float* y_out, bool train, int set, int self) {
     a.t.comb = cy; a.t.self = self; a.t.y_out = y_out; a.t.gamma = prm.norm1_w; a.t.beta = prm.norm1_b;
     if (train) { a.t.act_nhwc = w4_wgrad_on() ? nullptr : act1_of(set); a.t.xhat_s = xh1_of(set); a.t.rstd = r1_of(set); }
-    a.V = (train && w4_wgrad_on()) ? p.W4Va[0] : p.W4V;
+    a.V = (train && w4_wgrad_on()) ? va0_of(set) : p.W4V;
     if (f16_now()) a.v_exp = &p.w4sc->e[W4_E_V1];
   }
   // launch one pass; under node_profile_begin() with HIP events around it and its algorithmic bytes (every tensor it
@@ -722,7 +765,7 @@ struct Solver {
     }
     v_ready = false;
     const bool wg4 = do_aug && w4_wgrad_on();
-    w4_gemm(0, wg4 ? p.W4Va[0] : nullptr);
+    w4_gemm(0, wg4 ? va0_of(cur) : nullptr);
     {   // P2
       W4sArgs a = w4_args();
       a.h.M = p.W4M; a.h.bias = prm.conv1_b; a.h.tmapS = p.tmapS[0]; a.h.et = et; a.h.gamma = prm.norm2_w; a.h.beta = prm.norm2_b;
@@ -770,13 +813,22 @@ struct Solver {
       w4_pass(2, 0, a);
     }
     if (need_theta && wg4 && f16_now()) {
-      ProfScope ps(1, 2.0 * conv_flops(), st);
-      launch_w4_wgrad_f16(reinterpret_cast<const unsigned*>(p.W4Va[0]), reinterpret_cast<const unsigned*>(p.W4Z[0]), reinterpret_cast<const unsigned*>(p.W4Va[1]),
-                          reinterpret_cast<const unsigned*>(p.W4Z[1]), p.W4dU, p.ctrl, d.N8, d.C, &p.w4sc->e[W4_E_V1], &p.w4sc->e[W4_E_V2], &p.w4sc->e[W4_E_G], st);
+      hipStream_t ws = st;
+      if (side != nullptr) {        // fork: the weight gradient runs beside the data gradient of conv 1 and its pass
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(side->s, side->fork, 0);
+        ws = side->s;
+      }
+      {
+        ProfScope ps(1, 2.0 * conv_flops(), ws);
+        launch_w4_wgrad_f16(reinterpret_cast<const unsigned*>(va0_of(cur)), reinterpret_cast<const unsigned*>(p.W4Z[0]), reinterpret_cast<const unsigned*>(p.W4Va[1]),
+                            reinterpret_cast<const unsigned*>(p.W4Z[1]), p.W4dU, p.ctrl, d.N8, d.C, &p.w4sc->e[W4_E_V1], &p.w4sc->e[W4_E_V2], &p.w4sc->e[W4_E_G], ws);
+      }
+      if (side != nullptr) { (void)hipEventRecord(side->join, side->s); side_pending = true; }
     } else if (need_theta && wg4) {
       W4WgradArgs wa;
       memset(&wa, 0, sizeof(wa));
-      wa.V1 = p.W4Va[0]; wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
+      wa.V1 = va0_of(cur); wa.Z1 = p.W4Z[0]; wa.V2 = p.W4Va[1]; wa.Z2 = p.W4Z[1]; wa.dU = p.W4dU; wa.ctrl = p.ctrl; wa.N = d.N8; wa.C = d.C;
       ProfScope ps(1, 2.0 * conv_flops(), st);
       launch_w4_wgrad(wa, st);
     } else if (need_theta) {
@@ -806,6 +858,7 @@ struct Solver {
       }
     }
     if (!need_theta) return check_launch("augmented dynamics (F(4x4,3x3))");
+    if (side_pending) { (void)hipStreamWaitEvent(st, side->join, 0); side_pending = false; }      // join: dU is complete
     ThetaFinalizeArgs tf;
     memset(&tf, 0, sizeof(tf));
     tf.dU = wg4 ? p.W4dU : nullptr;
