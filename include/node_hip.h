@@ -134,6 +134,19 @@ typedef struct node_solve_opts {
    * with return_last_only, model.py:368-369), so dL/dy_out is zero in every other slice: `grad_out` then points to
    * that ONE slice [n, c, h, w] and the zero slices are neither materialised by the caller nor read here. */
   int32_t grad_last_only;
+  /* GLOBAL-NORM mode of a data-parallel solve (ABI 6; dopri5; SURVEY.md 8e, collective 2): every rank integrates its shard of the
+   * batch, and the sums the step controller decides from -- sum (err / tol)^2 of every state segment, the sums of Hairer's
+   * initial step -- are added over the ranks before each decision, so that ALL RANKS TAKE IDENTICAL STEPS (no straggler, and for
+   * the sharded segments y and adj_y exactly the mixed norm of the unsharded batch).  The library packs its local sums into
+   * `norm_buf` (device, >= 8 floats) on the stream and calls `norm_reduce(ctx, norm_buf, 8, stream)`, which must leave the SUM
+   * over the `norm_world` ranks in the buffer, enqueued on (or ordered behind) that stream; the next launch reads it.  Called from
+   * inside node_solve_fwd / node_solve_adjoint on the calling thread: twice per interval for the initial step, once per step.
+   * The segments every rank holds as its own partial (adj_params, adj_t) enter with the mean of the ranks' ratios; the fp16-pair
+   * "repeat this step" flag of any rank repeats the step on all.  NULL: local norms (upstream behaviour per process). */
+  void (*norm_reduce)(void* ctx, float* norm_buf, int32_t n, void* stream);
+  void* norm_reduce_ctx;
+  float* norm_buf;
+  int32_t norm_world;
 } node_solve_opts;
 
 /* Per-kernel-class timing collected with HIP events on the caller's stream

@@ -69,7 +69,11 @@ class NodeStepRecord(C.Structure):
 class NodeSolveOpts(C.Structure):
     _fields_ = [('max_num_steps', C.c_int32), ('n_forced_dt', C.c_int32), ('forced_dt', C.POINTER(C.c_double)),
                 ('record_dt', C.c_int32), ('dt_log', C.POINTER(C.c_double)), ('n_dt_log', C.POINTER(C.c_int32)),
-                ('blind_steps', C.c_int32), ('record', C.c_void_p), ('miss_flag', C.c_void_p), ('grad_last_only', C.c_int32)]
+                ('blind_steps', C.c_int32), ('record', C.c_void_p), ('miss_flag', C.c_void_p), ('grad_last_only', C.c_int32),
+                ('norm_reduce', C.c_void_p), ('norm_reduce_ctx', C.c_void_p), ('norm_buf', C.c_void_p), ('norm_world', C.c_int32)]
+
+
+NORM_REDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 
 NODE_PENDING = 1

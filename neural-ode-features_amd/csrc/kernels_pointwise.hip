@@ -460,12 +460,17 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
     return;
   }
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    if (a.gbuf != nullptr) {      // global-norm mode: the sums of all ranks (k_norm_pack + the caller's all-reduce)
+      if (threadIdx.x == 0) ratios[sgi] = (float)((double)a.gbuf[sgi] / (a.numel[sgi] * (double)a.gworld));
+      continue;
+    }
     const float tot = reduce_partials_512(a.partial[sgi], red);
     if (threadIdx.x == 0) ratios[sgi] = (float)((double)tot / a.numel[sgi]);
     __syncthreads();
   }
   bool w4_ovf = false;
   if (a.w4sc != nullptr) w4_ovf = w4_gscale_update(a.w4sc, threadIdx.x, red);   // (all 256 threads)
+  if (a.gbuf != nullptr && a.gbuf[4] > 0.f) w4_ovf = true;                      // (some rank's cotangent left its scale: all repeat)
   if (threadIdx.x != 0) return;
   if (a.w4sc != nullptr) {
     // fp16-pair operands (wino4.h): the next step's cotangent scale from this step's recorded maximum (above); a step in which a pass
@@ -530,9 +535,64 @@ void launch_init_norms(const InitSeg* segs, float* const* partial, int nseg, flo
   hipLaunchKernelGGL(k_init_norms, dim3(ERR_BLOCKS, nseg), dim3(256), 0, s, a, rtol, atol, phase);
 }
 
+// global-norm mode: this rank's sums of the coming decision -> gbuf[8] (see NormPackArgs; the caller's hook adds the ranks')
+__global__ __launch_bounds__(256) void k_norm_pack(NormPackArgs a) {
+  __shared__ float red[4];
+  const Ctrl* c = a.ctrl;
+  float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    const float* p = a.partial[sgi];
+    if (a.mode == 0) {
+      out[sgi] = reduce_partials_512(p, red);
+    } else {
+      float v0 = p[threadIdx.x * 2] + p[(threadIdx.x + 256) * 2];
+      float v1 = p[threadIdx.x * 2 + 1] + p[(threadIdx.x + 256) * 2 + 1];
+      v0 = block_sum_256(v0, red);
+      v1 = block_sum_256(v1, red);
+      if (a.mode == 1) { out[2 * sgi] = v0; out[2 * sgi + 1] = v1; }
+      else out[sgi] = v0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  if (a.has_scalar) {
+    if (a.mode == 0) {        // the scalar segment's squared error ratio, as step_controller_decide forms it
+      const float dtf = (float)c->dt;
+      float e = (dtf * c_CERR[0]) * c->ts_k[0];
+      float s = (dtf * c_CSOL[0]) * c->ts_k[0];
+#pragma unroll
+      for (int j = 2; j < 7; ++j) { e += (dtf * c_CERR[j]) * c->ts_k[j]; if (j < 6) s += (dtf * c_CSOL[j]) * c->ts_k[j]; }
+      const float y1 = c->ts_cur + s;
+      const float r = e / (a.atol + a.rtol * fmaxf(fabsf(c->ts_cur), fabsf(y1)));
+      out[3] = r * r;
+    } else {
+      const float sc = a.atol + fabsf(c->ts_cur) * a.rtol;
+      if (a.mode == 1) { const float d0 = c->ts_cur / sc, d1 = c->ts_k[0] / sc; out[6] = d0 * d0; out[7] = d1 * d1; }
+      else { const float d2 = (c->ts_k[1] - c->ts_k[0]) / sc; out[3] = d2 * d2; }
+    }
+  }
+  if (a.mode == 0 && a.w4sc != nullptr && __hip_atomic_load(&a.w4sc->ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) out[4] = 1.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a.gbuf[i] = out[i];
+}
+void launch_norm_pack(const NormPackArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_norm_pack, dim3(1), dim3(256), 0, s, a); }
+
 __global__ __launch_bounds__(256) void k_init_controller(InitCtlArgs a) {
   __shared__ float red[4];
   __shared__ float sums[3][2];
+  if (a.gbuf != nullptr) {      // global-norm mode: the sums of all ranks; the counts are the ranks' together
+    if (threadIdx.x == 0) {
+      float gs[3][2];
+      InitCtlArgs b = a;
+      for (int sgi = 0; sgi < a.nseg; ++sgi) {
+        gs[sgi][0] = a.phase == 0 ? a.gbuf[2 * sgi] : a.gbuf[sgi];
+        gs[sgi][1] = a.phase == 0 ? a.gbuf[2 * sgi + 1] : 0.f;
+        b.numel[sgi] = a.numel[sgi] * (double)a.gworld;
+      }
+      init_controller_decide(b, gs);
+    }
+    return;
+  }
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
     const float* p = a.partial[sgi];
     float v0 = p[threadIdx.x * 2] + p[(threadIdx.x + 256) * 2];

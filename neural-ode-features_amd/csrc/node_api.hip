@@ -558,6 +558,26 @@ struct Solver {
     else launch_nhwc_to_nchw(d, src, nchw, st);
   }
   struct NextComb { Comb cy; float* y_out; };
+  // global-norm mode of a data-parallel solve (node_solve_opts::norm_reduce): the caller's hook adds the ranks' sums before each decision
+  void (*nr_fn)(void*, float*, int32_t, void*) = nullptr;
+  void* nr_ctx = nullptr;
+  float* nr_buf = nullptr;
+  float nr_world = 1.f;
+  void take_norm_hook(const node_solve_opts* o) {
+    if (o != nullptr && o->norm_reduce != nullptr && o->norm_buf != nullptr && o->norm_world >= 1) {
+      nr_fn = o->norm_reduce; nr_ctx = o->norm_reduce_ctx; nr_buf = o->norm_buf; nr_world = (float)o->norm_world;
+    }
+  }
+  // this rank's sums of the coming decision -> nr_buf, summed over the ranks by the hook (both enqueued on the solve's stream)
+  void norm_exchange(int mode, int nseg) {
+    NormPackArgs np;
+    memset(&np, 0, sizeof(np));
+    np.ctrl = p.ctrl; np.partial[0] = p.partial[0]; np.partial[1] = p.partial[1]; np.partial[2] = p.partial[2];
+    np.nseg = nseg; np.has_scalar = aug ? 1 : 0; np.mode = mode; np.rtol = rtol; np.atol = atol;
+    np.w4sc = (aug && w4_f16) ? p.w4sc : nullptr; np.gbuf = nr_buf;
+    launch_norm_pack(np, st);
+    nr_fn(nr_ctx, nr_buf, 8, (void*)st);
+  }
   bool count_nfe = true;   // off while steps are enqueued blind: those evaluations are counted from the device's step counter
   Ctrl* hctrl = nullptr;
 
@@ -1041,11 +1061,13 @@ struct Solver {
     ic.ctrl = p.ctrl;
     for (int i = 0; i < nseg; ++i) { ic.partial[i] = p.partial[i]; ic.numel[i] = (double)segs[i].n; }
     ic.nseg = nseg; ic.has_scalar = aug ? 1 : 0; ic.phase = 0; ic.rtol = rtol; ic.atol = atol;
+    if (nr_fn != nullptr) { norm_exchange(1, nseg); ic.gbuf = nr_buf; ic.gworld = nr_world; }
     launch_init_controller(ic, st);
     const double one[1] = {1.0};
     TRY(eval_sys(1, one, 1, SC_H0, et_probe(), false));
     launch_init_norms(segs, p.partial, nseg, rtol, atol, 1, st);
     ic.phase = 1;
+    if (nr_fn != nullptr) norm_exchange(2, nseg);
     launch_init_controller(ic, st);
     return check_launch("initial step");
   }
@@ -1096,6 +1118,7 @@ struct Solver {
     sc.dt_log = io.log_cap > 0 ? p.dtlog : nullptr; sc.dt_log_cap = io.log_cap;
     sc.interp_scalar = aug ? 1 : 0;
     sc.w4sc = (aug && w4_f16) ? p.w4sc : nullptr;
+    if (nr_fn != nullptr) { norm_exchange(0, nseg); sc.gbuf = nr_buf; sc.gworld = nr_world; }
     launch_step_controller(sc, st);
     if (!aug) {
       EmitArgs ea;
@@ -1381,6 +1404,8 @@ int node_solve_fwd(const node_shape* shape, const node_params* params, const flo
 
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   S.choose_resident(method == NODE_METHOD_DOPRI5);
+  if (method == NODE_METHOD_DOPRI5) S.take_norm_hook(opts);
+  if (S.nr_fn != nullptr) S.resident = false;      // (global-norm mode: the host's hook sits between the launches of a step)
   if (!S.resident) {      // (the resident solve packs its filters, forms its border maps and copies y0 inside its one launch)
     TRY(S.prepare());
     S.to_state(y0, S.p.Y);
@@ -1564,6 +1589,7 @@ int node_solve_adjoint(const node_shape* shape, const node_params* params, const
                         ? (opts->blind_steps < max_steps ? opts->blind_steps : (int)max_steps) : 0;
   S.choose_w4(method == NODE_METHOD_DOPRI5);   // (a replay of recorded steps runs the numerics of the solve it replays)
   S.w4_f16_aug = method == NODE_METHOD_DOPRI5;
+  if (method == NODE_METHOD_DOPRI5) S.take_norm_hook(opts);
   TRY(S.prepare());
   int w4_gskew = 0;           // diagnostics (include/node_hip.h, node_w4_pair_stats)
   bool w4_stats = false;

@@ -288,7 +288,20 @@ struct StepCtlArgs {
   int dt_log_cap;
   int interp_scalar;       // aug: when the last target is passed, ts_cur <- dense output at that time
   struct W4Scales* w4sc;   // nullable: the solve's cotangent-side fp16-pair scale follows the data (wino4.h): update it, repeat a step that overflowed
+  const float* gbuf;       // nullable: GLOBAL-NORM mode (include/node_hip.h): [0 .. nseg) sums of (err / tol)^2 over all ranks, [3] the sum of
+  float gworld;            // the ranks' scalar-segment ratios, [4] > 0: some rank asks for the step to be repeated; gworld = ranks
 };
+// global-norm mode: this rank's sums -> gbuf (k_norm_pack), all-reduced by the caller's hook before the controller reads them
+struct NormPackArgs {
+  const Ctrl* ctrl;
+  const float* partial[3];
+  int nseg, has_scalar;
+  int mode;                // 0: step (partial = [ERR_BLOCKS]); 1 / 2: initial step phase 0 / 1 (partial = [ERR_BLOCKS][2])
+  float rtol, atol;
+  const struct W4Scales* w4sc;
+  float* gbuf;             // [8]
+};
+void launch_norm_pack(const NormPackArgs& a, hipStream_t s);
 void launch_step_controller(const StepCtlArgs& a, hipStream_t s);
 
 // After the controller, on the device (no host decision):
@@ -330,6 +343,8 @@ struct InitCtlArgs {
   double numel[3];
   int nseg, has_scalar, phase;
   float rtol, atol;
+  const float* gbuf;       // nullable: global-norm mode -- phase 0: [2 seg], [2 seg + 1] the segment's two sums, [6], [7] the scalar segment's
+  float gworld;            // squares; phase 1: [seg], [3]; all summed over the ranks
 };
 void launch_init_controller(const InitCtlArgs& a, hipStream_t s);
 void launch_set_ctrl(Ctrl* ctrl, double t, double dt, int reset_counters, hipStream_t s);

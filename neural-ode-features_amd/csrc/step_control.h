@@ -32,7 +32,7 @@ __device__ inline void step_controller_decide(const StepCtlArgs& a, float* ratio
     for (int j = 2; j < 7; ++j) { e += (dtf * c_CERR[j]) * c->ts_k[j]; if (j < 6) s += (dtf * c_CSOL[j]) * c->ts_k[j]; }
     const float y1 = c->ts_cur + s;
     const float r = e / (a.atol + a.rtol * fmaxf(fabsf(c->ts_cur), fabsf(y1)));
-    ratios[nr++] = r * r;
+    ratios[nr++] = a.gbuf != nullptr ? a.gbuf[3] / a.gworld : r * r;     // (global-norm mode: the mean of the ranks' ratios, k_norm_pack)
     c->ts_new = y1;
   }
   bool accept = true, nan = false;
@@ -126,7 +126,8 @@ __device__ inline void init_controller_decide(const InitCtlArgs& a, const float 
     }
     if (a.has_scalar) {
       const float sc = a.atol + fabsf(c->ts_cur) * a.rtol;
-      const float d0 = fabsf(c->ts_cur / sc), d1 = fabsf(c->ts_k[0] / sc);
+      float d0 = fabsf(c->ts_cur / sc), d1 = fabsf(c->ts_k[0] / sc);
+      if (a.gbuf != nullptr) { d0 = sqrtf(a.gbuf[6] / a.gworld); d1 = sqrtf(a.gbuf[7] / a.gworld); }   // (root mean square over the ranks)
       d0max = fmaxf(d0max, d0);
       d1max = fmaxf(d1max, d1);
       qmax = fmaxf(qmax, d0 / d1);
@@ -146,7 +147,7 @@ __device__ inline void init_controller_decide(const InitCtlArgs& a, const float 
     }
     if (a.has_scalar) {
       const float sc = a.atol + fabsf(c->ts_cur) * a.rtol;
-      d2max = fmaxf(d2max, fabsf((c->ts_k[1] - c->ts_k[0]) / sc) / h0);
+      d2max = fmaxf(d2max, (a.gbuf != nullptr ? sqrtf(a.gbuf[3] / a.gworld) : fabsf((c->ts_k[1] - c->ts_k[0]) / sc)) / h0);
     }
     float h1;
     if (c->d1 <= 1e-15f && d2max <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);

@@ -26,6 +26,11 @@ connected 8-GPU xGMI node each all-reduce is per-link bound; the ODE bucket
     reducer.finish()                          # wait (and average, unless the optimizer folds 1/world in)
     optimizer.step(); optimizer.zero_grad()
 
+GLOBAL-NORM mode (opt-in, SURVEY.md 8e collective 2): `enable_global_norm(model)` makes every ODE block of the model add, over the
+ranks, the sums each step decision is taken from (one 32-byte all-reduce per step, two per initial step) -- all ranks then take
+IDENTICAL steps (no straggler rank holding the gradient all-reduce up) and the sharded state segments are controlled by exactly the
+mixed norm of the unsharded batch, which is what a single process at the global batch size does (`train.py:40-58` at bs = 1024).
+
 One backward per `finish()`; micro-batches that accumulate (`train.py:56-58`) run
 under `with reducer.accumulate():` for all but the last backward.
 """
@@ -37,6 +42,18 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 from torch import nn
+
+
+def enable_global_norm(model: nn.Module, process_group=True) -> int:
+    """Switch every ODE block of `model` (the package's `ODEBlock`: anything with a `global_norm` attribute and an `odefunc`) to
+    GLOBAL-NORM solves over `process_group` (True = the default group; None / False switches the mode off again).  Returns the
+    number of blocks touched.  The C side: `node_solve_opts::norm_reduce` (include/node_hip.h)."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, 'global_norm') and hasattr(m, 'odefunc'):
+            m.global_norm = process_group if process_group else None
+            n += 1
+    return n
 
 
 def shard_batch(x: torch.Tensor, rank: int, world: int) -> torch.Tensor:

@@ -239,17 +239,52 @@ def _params_struct(params: List[torch.Tensor], device) -> Tuple[_lib.NodeParams,
     return _lib.NodeParams(*ptrs), keep
 
 
-def _opts_struct(options: Optional[dict], key: str, blind: Optional[tuple] = None, grad_last_only: bool = False):
+def _global_norm_group(options: Optional[dict]):
+    """The process group of a GLOBAL-NORM solve (`options['global_norm']`: True = the default group, or a group), or None:
+    no option, torch.distributed not initialised, or a world of one."""
+    g = (options or {}).get('global_norm')
+    if g is None or g is False:
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = None if g is True else g
+    return (group,) if dist.get_world_size(group) > 1 else None
+
+
+def _plain(options: Optional[dict]) -> bool:
+    """no option that deferred completion cannot serve (replay lists, dt logs, step limits); `global_norm` can ride along"""
+    return not options or all(k == 'global_norm' for k in options)
+
+
+def _opts_struct(options: Optional[dict], key: str, blind: Optional[tuple] = None, grad_last_only: bool = False, device=None):
     """(struct-or-None, keepalive).  blind = (steps, record device tensor, miss flag device tensor) for a solve
     with deferred completion."""
     options = options or {}
     forced = options.get(key)
     max_steps = int(options.get('max_num_steps', 0) or 0)
     record = int(options.get('record_dt', 0) or 0)
-    if forced is None and max_steps == 0 and record == 0 and blind is None and not grad_last_only:
+    gn = _global_norm_group(options) if device is not None else None
+    if forced is None and max_steps == 0 and record == 0 and blind is None and not grad_last_only and gn is None:
         return None, None
     o = _lib.NodeSolveOpts()
     keep = {}
+    if gn is not None:
+        # GLOBAL-NORM mode (include/node_hip.h; SURVEY.md 8e, collective 2): the library packs this rank's sums of every step decision
+        # into `buf` on the solve's stream and calls back; the all-reduce is enqueued behind them (RCCL orders its work against the
+        # current stream, which IS the solve's; gloo -- the CPU tests -- completes before it returns)
+        import torch.distributed as dist
+        buf = torch.zeros(8, dtype=torch.float32, device=device)
+        group = gn[0]
+
+        def _reduce(_ctx, _ptr, _n, _stream):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
+        cb = _lib.NORM_REDUCE_FN(_reduce)
+        keep['norm_buf'], keep['norm_cb'] = buf, cb
+        o.norm_reduce = C.cast(cb, C.c_void_p)
+        o.norm_buf = buf.data_ptr()
+        o.norm_world = dist.get_world_size(group)
     o.max_num_steps = max_steps
     o.grad_last_only = 1 if grad_last_only else 0
     if blind is not None:
@@ -297,7 +332,7 @@ def solve_forward(rec: Recognised, params: List[torch.Tensor], y0: torch.Tensor,
         out = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float32, device=y0c.device)
         tarr = (C.c_float * n_t)(*times)
         stats = _lib.NodeStats()
-        opts, keep_o = _opts_struct(options, 'forced_dts', blind)
+        opts, keep_o = _opts_struct(options, 'forced_dts', blind, device=y0c.device)
         rc = lib.node_solve_fwd(C.byref(shape), C.byref(pstruct), y0c.data_ptr(), tarr, n_t,
                                 float(rtol), float(atol), method_id,
                                 C.byref(opts) if opts is not None else None,
@@ -330,7 +365,7 @@ def solve_adjoint(rec: Recognised, params: List[torch.Tensor], y_traj: torch.Ten
         grad_t = torch.empty(n_t, dtype=torch.float32, device=dev) if want_grad_t else None
         tarr = (C.c_float * n_t)(*times)
         stats = _lib.NodeStats()
-        opts, keep_o = _opts_struct(options, 'forced_dts_bwd', blind, grad_last_only)
+        opts, keep_o = _opts_struct(options, 'forced_dts_bwd', blind, grad_last_only, device=dev)
         rc = lib.node_solve_adjoint(C.byref(shape), C.byref(pstruct), y_traj.data_ptr(), grad_out.data_ptr(),
                                     tarr, n_t, float(rtol), float(atol), method_id,
                                     C.byref(opts) if opts is not None else None,
@@ -688,7 +723,7 @@ class _HipOdeint(torch.autograd.Function):
         # deferred completion only where a predicated commit point follows: training solves (a gradient is wanted)
         # inside an armed `Deferred` scope; inference, sweeps and the drop-in API always return finished solves
         d = Deferred.active if (adjoint and wants_grad and method_id == _lib.METHOD_DOPRI5 and len(times) == 2
-                                and not options) else None
+                                and _plain(options)) else None
         if d is not None and d.device != y0.device:
             d = None
         dkey = ('fwd', _func_token(func), tuple(y0.shape), rtol, atol, tuple(times)) if d is not None else None
@@ -723,7 +758,7 @@ class _HipOdeint(torch.autograd.Function):
     def backward(ctx, grad_out):
         out, *params = ctx.saved_tensors
         if ctx.adjoint:
-            d = Deferred.active if (ctx.method_id == _lib.METHOD_DOPRI5 and len(ctx.times) == 2 and not ctx.options) else None
+            d = Deferred.active if (ctx.method_id == _lib.METHOD_DOPRI5 and len(ctx.times) == 2 and _plain(ctx.options)) else None
             if d is not None and d.device != out.device:
                 d = None
             dkey = ('bwd', _func_token(ctx.func), tuple(out.shape[1:]), ctx.rtol, ctx.atol, tuple(ctx.times)) if d is not None else None
@@ -786,10 +821,10 @@ def _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=True, last_on
                             *rec.params)
 
 
-def solve_last(func, y0, t, rtol, atol, method, adjoint):
+def solve_last(func, y0, t, rtol, atol, method, adjoint, options=None):
     """y(t[-1]) alone, [N, C, H, W]: what `ODEBlock.forward` returns with `return_last_only` (model.py:368-369),
     without materialising the gradient of the slices nobody keeps."""
-    return _odeint_impl(func, y0, t, rtol, atol, method, None, adjoint=adjoint, last_only=True)
+    return _odeint_impl(func, y0, t, rtol, atol, method, options, adjoint=adjoint, last_only=True)
 
 
 def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):

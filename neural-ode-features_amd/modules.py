@@ -79,6 +79,9 @@ class ODEBlock(nn.Module):
         self.method = method
         self.odeint = integrate.odeint_adjoint if adjoint else integrate.odeint
         self.return_last_only = True
+        # data parallel, opt-in (not in the reference, which is single-device): True or a process group = GLOBAL-NORM solves -- the ranks
+        # add the sums every step decision is taken from, so that all of them take identical steps (integrate._opts_struct)
+        self.global_norm = None
 
     def forward(self, x):
         if self.integration_time is None:      # t1 == 0: identity (model.py:363-364)
@@ -96,7 +99,12 @@ class ODEBlock(nn.Module):
         if self.return_last_only and (self.odeint is integrate.odeint or self.odeint is integrate.odeint_adjoint):
             # same solve, same `out[-1]`; the backward receives that slice's gradient alone (integrate.solve_last)
             return integrate.solve_last(self.odefunc, x, self.integration_time, self.tol, self.tol, self.method,
-                                        adjoint=self.odeint is integrate.odeint_adjoint)
+                                        adjoint=self.odeint is integrate.odeint_adjoint,
+                                        options={'global_norm': self.global_norm} if getattr(self, 'global_norm', None) else None)
+        if getattr(self, 'global_norm', None) and (self.odeint is integrate.odeint or self.odeint is integrate.odeint_adjoint):
+            out = self.odeint(self.odefunc, x, self.integration_time, method=self.method, rtol=self.tol, atol=self.tol,
+                              options={'global_norm': self.global_norm})
+            return out[-1] if self.return_last_only else out
         out = self.odeint(self.odefunc, x, self.integration_time,
                           method=self.method, rtol=self.tol, atol=self.tol)
         return out[-1] if self.return_last_only else out

@@ -151,10 +151,34 @@ def _check_inputs(func, y0, t):
     return tensor_input, func, y0, t
 
 
-def _select_initial_step(fun, t0, y0, order, rtol, atol, f0):
+def _global_means(squares, norm_reduce):
+    """NOT upstream behaviour -- the checker of this package's GLOBAL-NORM mode (include/node_hip.h, node_solve_opts::norm_reduce):
+    every rank of a data-parallel solve holds a shard; `norm_reduce = (fn, world)`, fn adding a 1-D tensor over the ranks.  Mean of
+    each tensor of `squares` over ALL ranks' elements: sum over ranks of the local sums / (local count x world)."""
+    fn, world = norm_reduce
+    sums = fn(torch.stack([q.detach().sum().to(torch.float32) for q in squares]))
+    return tuple(sums[i].to(q) / (q.numel() * world) for i, q in enumerate(squares))
+
+
+def _select_initial_step(fun, t0, y0, order, rtol, atol, f0, norm_reduce=None):
     """Hairer's starting step, order argument 4 (SURVEY.md 8c "Initial step")."""
     t0 = t0.to(y0[0])
     scale = tuple(atol + torch.abs(y0_) * rtol for y0_ in y0)
+    if norm_reduce is not None:      # (global-norm mode: the root mean squares over the unsharded batch)
+        d0 = tuple(torch.sqrt(m) for m in _global_means([(y0_ / scale_) ** 2 for y0_, scale_ in zip(y0, scale)], norm_reduce))
+        d1 = tuple(torch.sqrt(m) for m in _global_means([(f0_ / scale_) ** 2 for f0_, scale_ in zip(f0, scale)], norm_reduce))
+        if max(d0).item() < 1e-5 or max(d1).item() < 1e-5:
+            h0 = torch.tensor(1e-6).to(t0)
+        else:
+            h0 = 0.01 * max(d0_ / d1_ for d0_, d1_ in zip(d0, d1))
+        y1 = tuple(y0_ + h0 * f0_ for y0_, f0_ in zip(y0, f0))
+        f1 = fun(t0 + h0, y1)
+        d2 = tuple(torch.sqrt(m) / h0 for m in _global_means([((f1_ - f0_) / scale_) ** 2 for f1_, f0_, scale_ in zip(f1, f0, scale)], norm_reduce))
+        if max(d1).item() <= 1e-15 and max(d2).item() <= 1e-15:
+            h1 = torch.max(torch.tensor(1e-6).to(h0), h0 * 1e-3)
+        else:
+            h1 = (0.01 / max(d1 + d2)) ** (1.0 / float(order + 1))
+        return torch.min(100 * h0, h1)
     d0 = tuple(_rms(y0_ / scale_) for y0_, scale_ in zip(y0, scale))
     d1 = tuple(_rms(f0_ / scale_) for f0_, scale_ in zip(f0, scale))
     if max(d0).item() < 1e-5 or max(d1).item() < 1e-5:
@@ -171,9 +195,11 @@ def _select_initial_step(fun, t0, y0, order, rtol, atol, f0):
     return torch.min(100 * h0, h1)
 
 
-def _compute_error_ratio(error_estimate, rtol, atol, y0, y1):
+def _compute_error_ratio(error_estimate, rtol, atol, y0, y1, norm_reduce=None):
     error_tol = tuple(atol + rtol * torch.max(torch.abs(y0_), torch.abs(y1_)) for y0_, y1_ in zip(y0, y1))
     error_ratio = tuple(e / tol for e, tol in zip(error_estimate, error_tol))
+    if norm_reduce is not None:
+        return _global_means([r * r for r in error_ratio], norm_reduce)
     return tuple(torch.mean(r * r) for r in error_ratio)
 
 
@@ -246,16 +272,17 @@ def _interp_evaluate(coefficients, t0, t1, t):
 # solvers
 # --------------------------------------------------------------------------
 class _Dopri5:
-    def __init__(self, func, y0, rtol, atol, stats: SolverStats, forced_dts=None):
+    def __init__(self, func, y0, rtol, atol, stats: SolverStats, forced_dts=None, norm_reduce=None):
         self.func, self.y0, self.rtol, self.atol = func, y0, rtol, atol
         self.stats = stats
+        self.norm_reduce = norm_reduce          # (fn, world) or None: see _global_means
         # replay mode (test aid): a forced sequence of step sizes, every one accepted
         self.forced_dts = list(forced_dts) if forced_dts is not None else None
 
     def before_integrate(self, t):
         f0 = self.func(t[0].type_as(self.y0[0]), self.y0)
         if self.forced_dts is None:
-            first_step = _select_initial_step(self.func, t[0], self.y0, 4, self.rtol, self.atol, f0=f0).to(t)
+            first_step = _select_initial_step(self.func, t[0], self.y0, 4, self.rtol, self.atol, f0=f0, norm_reduce=self.norm_reduce).to(t)
         else:
             first_step = torch.tensor(self.forced_dts.pop(0)).to(t)
         self.stats.first_step = float(first_step.detach())
@@ -276,7 +303,7 @@ class _Dopri5:
         for y0_ in y0:
             assert torch.isfinite(y0_).all(), 'non-finite values in state `y`'
         y1, f1, y1_error, k = _runge_kutta_step(self.func, y0, f0, t0, dt)
-        ratio = _compute_error_ratio(y1_error, self.rtol, self.atol, y0, y1)
+        ratio = _compute_error_ratio(y1_error, self.rtol, self.atol, y0, y1, self.norm_reduce)
         if self.forced_dts is None:
             accept = bool((torch.stack([r.detach() for r in ratio]) <= 1).all())
         else:
@@ -352,7 +379,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-12, method=None, options=None, stats:
         return _f(tt, yy)
 
     if method == 'dopri5':
-        solver = _Dopri5(counted, y0, rtol, atol, stats, forced_dts=options.get('forced_dts'))
+        solver = _Dopri5(counted, y0, rtol, atol, stats, forced_dts=options.get('forced_dts'), norm_reduce=options.get('norm_reduce'))
     elif method == 'rk4':
         solver = _RK4(counted, y0, stats)
     else:

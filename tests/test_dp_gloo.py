@@ -137,6 +137,40 @@ def test_bench_train_step_through_self_launcher(tmp_path, accumulate):
         assert torch.allclose(r0['params'][k], v.detach(), rtol=5e-4, atol=5e-6), k
 
 
+def _check_global_norm_histories(tmp_path, mode):
+    import bench
+    rc = bench.spawn_ranks(2, [sys.executable, os.path.join(ROOT, 'tests', 'dp_gnorm_child.py'), str(tmp_path), mode], timeout=700)
+    assert rc == 0
+    r0 = torch.load(os.path.join(str(tmp_path), 'rank0.pt'), weights_only=False)
+    r1 = torch.load(os.path.join(str(tmp_path), 'rank1.pt'), weights_only=False)
+    g0, g1, full = r0['global'], r1['global'], r0['full']
+    # (1) every rank takes the SAME steps, forward and backward: sizes bit-identical, decisions identical
+    assert g0['fwd'] == g1['fwd'] and g0['bwd'] == g1['bwd'], (g0['fwd'], g1['fwd'], g0['bwd'], g1['bwd'])
+    # (2) with local norms the ranks do NOT agree on this batch (rank 0's samples are three times larger): the mode changes something
+    assert r0['local']['fwd'] != r1['local']['fwd'] or r0['local']['bwd'] != r1['local']['bwd']
+    # (3) the forward solve has one sharded segment: its global norm IS the norm of the unsharded batch -- the history of one process
+    # integrating the whole batch: same decisions; the step sizes agree as far as an error ESTIMATE does between two batch shapes of the
+    # same convolutions (the estimate is a difference of nearly equal terms: rounding moves it by ~1e-3, the step by its fifth root)
+    assert [a for _, a in g0['fwd']] == [a for _, a in full['fwd']]
+    for (d, _), (e, _) in zip(g0['fwd'], full['fwd']):
+        assert abs(d - e) <= 2e-3 * abs(e), (d, e)
+    per = g0['out'].shape[0]
+    assert float((g0['out'] - full['out'][:per]).abs().max()) <= 2e-4 * float(full['out'].abs().max())     # (both within tol = 1e-4 of the solution)
+    # (4) the adjoint solve: y and adj_y enter with the unsharded batch's norm, adj_params / adj_t (each rank's own partial sums) with
+    # the mean of the ranks' ratios -- identical on all ranks by construction, within a decision or two of the one-process solve
+    assert abs(len(g0['bwd']) - len(full['bwd'])) <= 2
+    print(mode, 'global-norm histories: forward', len(g0['fwd']), 'steps, backward', len(g0['bwd']), '(one process, whole batch:',
+          len(full['fwd']), '/', len(full['bwd']), '; local norms:', len(r0['local']['bwd']), '/', len(r1['local']['bwd']), ')')
+
+
+@pytest.mark.timeout(900)
+def test_global_norm_mode_definition_on_the_oracle(tmp_path):
+    """SURVEY.md 8e, collective (2): two gloo ranks, each integrating its shard with the oracle's `norm_reduce` option (the CPU
+    statement of the mode the HIP library implements behind node_solve_opts::norm_reduce): identical step histories on both ranks,
+    equal to the single-process history of the whole batch for the forward solve."""
+    _check_global_norm_histories(tmp_path, 'cpu')
+
+
 def test_bench_refuses_smaller_world():
     """`python bench.py --gpus 2` must never measure one GPU: no devices here -> non-zero exit, no JSON line;
     a launcher environment that disagrees with --gpus is refused too."""

@@ -224,3 +224,23 @@ def test_a_miss_on_one_rank_skips_the_update_on_every_rank():
             if v is not None:
                 os.environ[k] = v
     assert rc == 0
+
+
+@pytest.mark.timeout(900)
+def test_global_norm_mode_two_ranks_take_identical_steps(tmp_path):
+    """GLOBAL-NORM mode on the HIP path (include/node_hip.h, node_solve_opts::norm_reduce; `options={'global_norm': True}`): two ranks
+    sharing cuda:0 over gloo, each integrating its shard of a batch whose two halves differ threefold in size.  Both ranks take
+    bit-identical step sequences forward and backward; the forward history equals a single process integrating the whole batch; with
+    local norms the ranks disagree (tests/dp_gnorm_child.py, checks shared with tests/test_dp_gloo.py)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from tests.test_dp_gloo import _check_global_norm_histories
+    old = {k: os.environ.pop(k, None) for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    try:
+        _check_global_norm_histories(tmp_path, 'hip')
+    finally:
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
