@@ -395,6 +395,9 @@ def main():
                     help='with --gpus 1: run the N-rank code path anyway -- process group on the chosen backend (nccl = RCCL), '
                          'bucketed all-reduce of the gradients, the deferred-completion flag slot -- as a world of ONE rank; what '
                          'a 1-GPU box can prove about the multi-GPU path')
+    ap.add_argument('--global-norm', action='store_true',
+                    help='N > 1: GLOBAL-NORM solves (dp.enable_global_norm: the ranks add the sums behind every step decision -- identical '
+                         'steps on all ranks, the mixed norm of the unsharded batch; one 32-byte all-reduce per step).  Default: local norms')
     ap.add_argument('--share-gpu', action='store_true',
                     help='TESTING ONLY: ranks share the devices that exist (rank %% device_count); exercises the N-rank code '
                          'path on a 1-GPU box, the number it prints is not a measurement')
@@ -480,6 +483,8 @@ def main():
         reducer = nof.dp.GradientReducer(model, limits={model.downsample: 2 << 20}, average=False,
                                          collectives_at_world_1=args.force_dist)   # all-reduce SUM in the bucket buffers ...
         opt.grad_scale = 1.0 / world                             # ... its 1/world folded into the optimizer step
+        if args.global_norm and world > 1:
+            nof.dp.enable_global_norm(model)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -838,6 +843,7 @@ def main():
                 # instruction): forward ones are ~28 launches each, augmented ones ~60
                 'dead_steps_per_step': region['dead_steps'] / args.steps,
                 'collectives': (args.dist_backend + (' (RCCL)' if args.dist_backend == 'nccl' else '')) if dist_on else 'none (one rank)',
+                'step_norm': 'global (sums of every step decision all-reduced: identical steps on all ranks)' if (args.global_norm and world > 1) else 'local (each rank adapts its steps on its shard)',
                 'parallelism': 'dp%d' % world if not args.share_gpu else 'dp%d (ranks SHARE a GPU: smoke test, not a measurement)' % world, 'head': 'hipGraph' if args.graphs else 'eager',
                 'nfe_forward_per_step': nfe_f / args.steps, 'nfe_backward_per_step': nfe_b / args.steps,
                 'per_rank': per_rank,

@@ -132,7 +132,17 @@ def test_bench_two_ranks_through_self_launcher_on_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
     assert [r['rank'] for r in d['config']['per_rank']] == [0, 1] and all(r['ms_per_step_own'] > 0 for r in d['config']['per_rank'])
-    assert 'SHARE' in d['config']['parallelism']
+    assert 'SHARE' in d['config']['parallelism'] and d['config']['step_norm'].startswith('local')
+    # ... and with GLOBAL-NORM solves (dp.enable_global_norm): deferred completion keeps working with the hook inside the solves, and both
+    # ranks report the SAME step counts for every block (different synthetic shards: with local norms they need not)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo', '--share-gpu', '--global-norm',
+                        '--steps', '3', '--warmup', '2', '--no-cpu-baseline', '--no-roofline', '--batch', '32'],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 2 and d['config']['step_norm'].startswith('global')
+    pr = d['config']['per_rank']
+    assert pr[0]['last_steps_fwd_bwd_per_block'] == pr[1]['last_steps_fwd_bwd_per_block'], pr
 
 
 @pytest.mark.timeout(900)
