@@ -2111,7 +2111,7 @@ __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __rest
 bool w4_f16_fits(int N, int C) {
   const W4Switches sw = w4_switches();
   if (!(sw.f16 != 0 && sw.ablate == 0 && w4_uses_bf16(N, C) && N % 16 == 0 && C % 64 == 0)) return false;
-  if (C < 512) return true;
+  if (C < 512 || getenv("NODE_TUNE_W4_F16_ANYC") != nullptr) return true;      // (the second: experiments -- k_w4_gemm64h at long reductions)
   return sw.h128 != 0 && N % 32 == 0 && C % 128 == 0 && (((N / 32) * (C >> 7)) & 1) == 0;    // long reductions: the LDS-tiled kernel only
 }
 void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const Ctrl* ctrl, int N, int C, const int* v_exp, const int* u_exp,

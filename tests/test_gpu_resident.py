@@ -293,3 +293,28 @@ def test_a_captured_solve_does_not_take_the_resident_grid():
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(static_out, want) and float(flag) == 0.0
+
+
+def test_inference_graphs_around_the_resident_solve_equal_the_eager_path():
+    """`graphs.capture_inference` (the bs = 1 census, evaluate.py:97-142): stem and head as hipGraphs around the ODE block's own
+    launches give the eager path's logits bit for bit, for image after image; training-mode calls, other shapes and calls that want
+    gradients keep the ordinary path."""
+    import neural_ode_features_amd as nof
+    from neural_ode_features_amd import graphs
+    torch.manual_seed(5)
+    model = nof.ODENet(3, out=10, n_filters=64, downsample='residual', method='dopri5', tol=1e-3).cuda().eval()
+    x = torch.randn(6, 3, 32, 32, device='cuda')
+    with torch.no_grad():
+        want = [model(x[i:i + 1]).clone() for i in range(6)]
+        batch = model(x[:4]).clone()
+    graphs.capture_inference(model, x[:1])
+    with torch.no_grad():
+        for i in range(6):
+            got = model(x[i:i + 1])
+            assert torch.equal(got, want[i]), i
+        assert torch.equal(model(x[:4]), batch)                  # another shape: the eager path
+    assert model.nfe(reset=True) > 0
+    y = model(x[:1])                                             # gradients wanted: the eager path, an autograd graph behind it
+    assert y.requires_grad and torch.allclose(y.detach(), want[0], atol=1e-5)
+    model.train()
+    assert model(x[:2]).shape == (2, 10)

@@ -21,11 +21,15 @@ def main():
     ap.add_argument('--filters', type=int, default=256)
     ap.add_argument('--images', type=int, default=200)
     ap.add_argument('--tols', default='1e-3,1e-1,1e1')
+    ap.add_argument('--graphs', action='store_true', help='stem and head as inference hipGraphs (graphs.capture_inference)')
     args = ap.parse_args()
     import neural_ode_features_amd as nof
     torch.manual_seed(0)
     model = nof.ODENet(3, out=10, n_filters=args.filters, downsample='residual', method='dopri5', tol=1e-3).cuda().eval()
     x = torch.randn(args.images, 3, 32, 32, device='cuda')
+    if args.graphs:
+        from neural_ode_features_amd import graphs
+        graphs.capture_inference(model, x[:1])
     for tol in [float(v) for v in args.tols.split(',')]:
         model.odeblock.tol = tol
         with torch.no_grad():
@@ -47,7 +51,7 @@ def main():
             torch.cuda.synchronize()
             block = (time.perf_counter() - t0) / args.images
         print(json.dumps({'filters': args.filters, 'tol': tol, 'nfe_per_image': nfe, 'us_per_image': wall * 1e6, 'images_per_s': 1.0 / wall,
-                          'ode_block_us': block * 1e6, 'resident': os.environ.get('NODE_TUNE_TINY_RESIDENT', '1')}))
+                          'ode_block_us': block * 1e6, 'resident': os.environ.get('NODE_TUNE_TINY_RESIDENT', '1'), 'graphs': bool(args.graphs)}))
 
 
 if __name__ == '__main__':
