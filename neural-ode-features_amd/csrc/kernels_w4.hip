@@ -495,7 +495,7 @@ struct W4BStage { float4 a[2][2]; w4_u32x4 b[2][3]; };   // [row block][g of the
 // every wave walks its streams with the same power-of-two strides.  18.2 -> 19.8 us per launch, cfg 2 24 870 -> 24 480 images/s: the
 // waves that SHARE an operand block ask for it at the same time in the lock-step order and are served by one L2 fill; rotated,
 // they are not.  And there is no camping to cure: pulling every block 1 - 11 KB out of the power-of-two spacing changes nothing
-// (tools/w4_pad.sh, profiles/r04_w4_gemm_pad.txt).)
+// (round-4 timing experiment, profiles/r04_w4_gemm_pad.txt).)
 struct W4BPtrs { const float4* a[2]; const w4_u32x4* b[2]; };
 template <int NRB>
 __device__ __forceinline__ void w4b_load(W4BStage& s, const W4BPtrs& p, int g2) {

@@ -254,7 +254,7 @@ def test_resident_solve_with_rejected_steps_and_many_time_points(gain, tol, kink
 
 
 def test_a_captured_solve_does_not_take_the_resident_grid():
-    """A deferred-completion solve has no host synchronisation in it and can be captured into a hipGraph (tools/exp_graph_solve.py).
+    """A deferred-completion solve has no host synchronisation in it and can be captured into a hipGraph.
     A captured RESIDENT launch would replay its nonce -- the previous replay's words would pass for this one's -- so under capture the
     library keeps the launch-per-convolution path: replays on changing inputs equal the eager launch-path results bit for bit."""
     from neural_ode_features_amd import integrate
