@@ -112,7 +112,7 @@ void launch_wtime(const Dims& d, const float* w, float* wtime, hipStream_t s) {
 
 // Both layers' border maps (and, for an augmented solve, their gathered time-channel taps) in ONE launch per solve:
 // blockIdx.y = job.  Four to six launches of ~4.5 us each (their floor on this box) per training step otherwise.
-struct TimePrepArgs { const float* w[2]; float* tmap[2]; float* wtime[2]; float* zero[8]; size_t zero_n[8]; int nzero; int njobs; };
+struct TimePrepArgs { const float* w[2]; float* tmap[2]; float* wtime[2]; float* zero[12]; size_t zero_n[12]; int nzero; int njobs; };
 __global__ __launch_bounds__(256) void k_time_prep(TimePrepArgs a, int C, int H, int W) {
   const int job = blockIdx.y, layer = job & 1;
   if (job >= a.njobs) {   // the solve's zero fills (zero rows behind the conv inputs, the never-written stage derivative,
@@ -151,7 +151,7 @@ void launch_time_prep(const Dims& d, const float* w1, const float* w2, float* tm
   memset(&a, 0, sizeof(a));
   a.w[0] = w1; a.w[1] = w2; a.tmap[0] = tmap1; a.tmap[1] = tmap2; a.wtime[0] = wtime1; a.wtime[1] = wtime2;
   a.njobs = wtime1 != nullptr ? 4 : 2;
-  a.nzero = nzero > 8 ? 8 : nzero;
+  a.nzero = nzero > 12 ? 12 : nzero;
   for (int i = 0; i < a.nzero; ++i) { a.zero[i] = zero[i]; a.zero_n[i] = zero_n[i]; }
   const int total = d.HW * d.C;
   int bx = (total + 255) / 256;

@@ -431,7 +431,8 @@ __device__ void error_norm_body(const ErrSeg& seg, const Ctrl* ctrl, float rtol,
     }
   }
   const float tot = block_sum_256(acc, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+  // (agent-scope = write-through: the last-arriving workgroup of k_error_norm_ctl, on another XCD, reads it inside the same launch)
+  if (threadIdx.x == 0) __hip_atomic_store(&partial[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 void launch_error_norm(const ErrSeg* segs, float* const* partial, int nseg, const Ctrl* ctrl, float rtol, float atol, hipStream_t s) {
@@ -452,19 +453,23 @@ __device__ inline float reduce_partials_512(const float* p, float* red) {
   return block_sum_256(v, red);
 }
 
-__global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
-  __shared__ float red[4];
-  __shared__ float ratios[4];
-  if (a.ctrl->done) {   // a step enqueued past the end of the interval: nothing was computed, nothing is emitted
-    if (threadIdx.x == 0) a.ctrl->j0 = a.ctrl->j1 = a.ctrl->j;
-    return;
-  }
+// COHERENT: the partials were written by other workgroups of the SAME launch (k_error_norm_ctl): agent-scope loads
+template <bool COHERENT>
+__device__ inline void step_controller_body(const StepCtlArgs& a, float* red, float* ratios) {
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
     if (a.gbuf != nullptr) {      // global-norm mode: the sums of all ranks (k_norm_pack + the caller's all-reduce)
       if (threadIdx.x == 0) ratios[sgi] = (float)((double)a.gbuf[sgi] / (a.numel[sgi] * (double)a.gworld));
       continue;
     }
-    const float tot = reduce_partials_512(a.partial[sgi], red);
+    float tot;
+    if (COHERENT) {
+      const float* p = a.partial[sgi];
+      const float v = __hip_atomic_load(p + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                      __hip_atomic_load(p + threadIdx.x + 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot = block_sum_256(v, red);
+    } else {
+      tot = reduce_partials_512(a.partial[sgi], red);
+    }
     if (threadIdx.x == 0) ratios[sgi] = (float)((double)tot / a.numel[sgi]);
     __syncthreads();
   }
@@ -489,6 +494,51 @@ __global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
   }
   step_controller_decide(a, ratios);
 }
+__global__ __launch_bounds__(256) void k_step_controller(StepCtlArgs a) {
+  __shared__ float red[4];
+  __shared__ float ratios[4];
+  if (a.ctrl->done) {   // a step enqueued past the end of the interval: nothing was computed, nothing is emitted
+    if (threadIdx.x == 0) a.ctrl->j0 = a.ctrl->j1 = a.ctrl->j;
+    return;
+  }
+  step_controller_body<false>(a, red, ratios);
+}
+
+void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);
+}
+
+// The same two kernels as ONE launch: every workgroup of the error norm leaves its partial sum (write-through), waits for the write's
+// acknowledgement and takes a ticket; the last one to arrive is the step controller.  (The hand-off without fences of k_theta_finalize:
+// agent-scope stores / loads around an agent-scope counter -- gfx950's memory system, see there.)
+__global__ __launch_bounds__(256) void k_error_norm_ctl(ErrSegs a, StepCtlArgs ctl, unsigned* arrive) {
+  __shared__ float red[4];
+  __shared__ float ratios[4];
+  __shared__ int s_last;
+  if (ctl.ctrl->done) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ctl.ctrl->j0 = ctl.ctrl->j1 = ctl.ctrl->j;
+    return;
+  }
+  error_norm_body(a.seg[blockIdx.y], ctl.ctrl, ctl.rtol, ctl.atol, a.partial[blockIdx.y]);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial's write is acknowledged
+    s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (stream order)
+  step_controller_body<true>(ctl, red, ratios);
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_error_norm_ctl's fence-free hand-off is only valid on gfx950 (see k_theta_finalize)"
+#endif
+void launch_error_norm_ctl(const ErrSeg* segs, float* const* partial, int nseg, const StepCtlArgs& ctl, unsigned* arrive, hipStream_t s) {
+  ErrSegs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < nseg; ++i) { a.seg[i] = segs[i]; a.partial[i] = partial[i]; }
+  hipLaunchKernelGGL(k_error_norm_ctl, dim3(ERR_BLOCKS, nseg), dim3(256), 0, s, a, ctl, arrive);
+}
+
 __global__ __launch_bounds__(256) void k_w4_gscale(W4Scales* sc, int skew) {
   __shared__ float red[4];
   (void)w4_gscale_update(sc, threadIdx.x, red);
@@ -496,20 +546,20 @@ __global__ __launch_bounds__(256) void k_w4_gscale(W4Scales* sc, int skew) {
 }
 void launch_w4_gscale(W4Scales* sc, hipStream_t s, int skew) { hipLaunchKernelGGL(k_w4_gscale, dim3(1), dim3(256), 0, s, sc, skew); }
 
-void launch_step_controller(const StepCtlArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_step_controller, dim3(1), dim3(256), 0, s, a);
-}
-
 // ============================================================================
 // Hairer initial step (`_select_initial_step`, order argument 4)
 //   phase 0: sum (y0/scale)^2, sum (f0/scale)^2      scale = atol + |y0| rtol
 //   phase 1: sum ((f1-f0)/scale)^2
 // ============================================================================
 struct InitSegs { InitSeg seg[3]; float* partial[3]; };
+__device__ inline void init_norms_body(const InitSegs& a, float rtol, float atol, int phase, float* red);
 __global__ __launch_bounds__(256) void k_init_norms(InitSegs a, float rtol, float atol, int phase) {
+  __shared__ float red[4];
+  init_norms_body(a, rtol, atol, phase, red);
+}
+__device__ inline void init_norms_body(const InitSegs& a, float rtol, float atol, int phase, float* red) {
   const InitSeg& seg = a.seg[blockIdx.y];
   float* partial = a.partial[blockIdx.y];
-  __shared__ float red[4];
   float a0 = 0.f, a1 = 0.f;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < seg.n; i += stride) {
@@ -526,7 +576,10 @@ __global__ __launch_bounds__(256) void k_init_norms(InitSegs a, float rtol, floa
   }
   const float t0 = block_sum_256(a0, red);
   const float t1 = block_sum_256(a1, red);
-  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = t0; partial[blockIdx.x * 2 + 1] = t1; }
+  if (threadIdx.x == 0) {      // (agent scope = write-through: k_init_norms_ctl's last workgroup reads them inside the same launch)
+    __hip_atomic_store(&partial[blockIdx.x * 2], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partial[blockIdx.x * 2 + 1], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 void launch_init_norms(const InitSeg* segs, float* const* partial, int nseg, float rtol, float atol, int phase, hipStream_t s) {
   InitSegs a;
@@ -607,6 +660,39 @@ __global__ __launch_bounds__(256) void k_init_controller(InitCtlArgs a) {
 }
 void launch_init_controller(const InitCtlArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_controller, dim3(1), dim3(256), 0, s, a);
+}
+// norms + decision as ONE launch: the last-arriving workgroup is the controller (the hand-off of k_error_norm_ctl)
+__global__ __launch_bounds__(256) void k_init_norms_ctl(InitSegs a, InitCtlArgs ctl, unsigned* arrive) {
+  __shared__ float red[4];
+  __shared__ float sums[3][2];
+  __shared__ int s_last;
+  init_norms_body(a, ctl.rtol, ctl.atol, ctl.phase, red);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int sgi = 0; sgi < ctl.nseg; ++sgi) {
+    const float* p = ctl.partial[sgi];
+    float v0 = __hip_atomic_load(p + threadIdx.x * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+               __hip_atomic_load(p + (threadIdx.x + 256) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v1 = __hip_atomic_load(p + threadIdx.x * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+               __hip_atomic_load(p + (threadIdx.x + 256) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v0 = block_sum_256(v0, red);
+    v1 = block_sum_256(v1, red);
+    if (threadIdx.x == 0) { sums[sgi][0] = v0; sums[sgi][1] = v1; }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  init_controller_decide(ctl, sums);
+}
+void launch_init_norms_ctl(const InitSeg* segs, float* const* partial, int nseg, const InitCtlArgs& ctl, unsigned* arrive, hipStream_t s) {
+  InitSegs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < nseg; ++i) { a.seg[i] = segs[i]; a.partial[i] = partial[i]; }
+  hipLaunchKernelGGL(k_init_norms_ctl, dim3(ERR_BLOCKS, nseg), dim3(256), 0, s, a, ctl, arrive);
 }
 
 __global__ void k_set_ctrl(Ctrl* c, double t, double dt, int reset) {
@@ -887,6 +973,8 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
     float4* out = reinterpret_cast<float4*>(a.theta_out + L.wc[layer]);   // 16-B aligned: every block size is a multiple of C
     const size_t stride = (size_t)wb * 256;
     if (a.dU != nullptr) {   // F(4x4,3x3)-domain gradients, every element written once by k_w4_wgrad: dW = G^T dU G
+      // (measured, round 6: one (ci, co) pair per thread instead of four -- 2 x 256 instead of 2 x 64 workgroups with work -- 15.8 against
+      //  13.0 us: the launch is one round of 36 loads per thread either way, and 4-byte loads are four times the requests)
       const size_t cc4 = CC / 4;
       const float4* du = reinterpret_cast<const float4*>(a.dU + (size_t)layer * W4_COMPS * CC);
       for (size_t i = (size_t)bx * 256 + threadIdx.x; i < cc4; i += stride) {

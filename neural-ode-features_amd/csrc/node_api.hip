@@ -267,6 +267,7 @@ namespace {
 struct Plan {
   // common
   Ctrl* ctrl;
+  unsigned* arrive;         // arrival counter of the norm kernels whose last workgroup is the controller (zero between launches)
   float* partial[3];        // [ERR_BLOCKS][2] each
   float* wf[2];             // packed forward weights
   float* wd[2];             // packed dgrad weights (adjoint)
@@ -323,6 +324,7 @@ Plan make_plan(const Dims& d, int adjoint, int n_t, void* base) {
   memset(&p, 0, sizeof(p));
   Bump b(base);
   p.ctrl = b.take<Ctrl>(1);
+  p.arrive = b.take<unsigned>(4);
   p.targets = b.take<double>((size_t)(n_t > 0 ? n_t : 1));
   p.forced = b.take<double>(STEP_LIST_CAP);
   p.dtlog = b.take<double>(STEP_LIST_CAP);
@@ -578,6 +580,13 @@ struct Solver {
     launch_norm_pack(np, st);
     nr_fn(nr_ctx, nr_buf, 8, (void*)st);
   }
+  // NODE_TUNE_FOLD_CTL = 1: the controllers as the LAST-ARRIVING workgroup of the norm kernels (k_error_norm_ctl, k_init_norms_ctl: eight
+  // launches less per training step).  Built for the round-5 review's item 5 and measured: 27 940 against 28 110 images/s at cfg 2 -- the
+  // last workgroup's coherent re-read of the partial sums behind the arrival chain costs what the launch boundary did.  Off by default.
+  static bool fold_ctl() {
+    const char* e = getenv("NODE_TUNE_FOLD_CTL");
+    return e != nullptr && atoi(e) != 0;
+  }
   bool count_nfe = true;   // off while steps are enqueued blind: those evaluations are counted from the device's step counter
   Ctrl* hctrl = nullptr;
 
@@ -598,9 +607,10 @@ struct Solver {
     // weight zero by the error norm / dense output, never written by dopri5 steps -- the initial-step probe does
     // write it -- so it must hold finite values), the arrival counter of k_theta_finalize, and the zero rows behind
     // the conv inputs (see make_plan)
-    float* zr[8];
-    size_t zn[8];
+    float* zr[12];
+    size_t zn[12];
     int nz = 0;
+    zr[nz] = reinterpret_cast<float*>(p.arrive); zn[nz++] = 4;
     if (aug) {
       zr[nz] = p.KT[1]; zn[nz++] = d.P;
       zr[nz] = p.sred + (size_t)2 * 9 * d.C + 2 * ((9 * (size_t)d.C + 63) / 64); zn[nz++] = 1;
@@ -1055,20 +1065,27 @@ struct Solver {
   int initial_step() {
     const int nseg = aug ? 3 : 1;
     InitSeg segs[3] = {{p.Y, p.KY[0], p.KY[1], d.numel}, {p.A, p.KA[0], p.KA[1], d.numel}, {p.TH, p.KT[0], p.KT[1], d.P}};
-    launch_init_norms(segs, p.partial, nseg, rtol, atol, 0, st);
     InitCtlArgs ic;
     memset(&ic, 0, sizeof(ic));
     ic.ctrl = p.ctrl;
     for (int i = 0; i < nseg; ++i) { ic.partial[i] = p.partial[i]; ic.numel[i] = (double)segs[i].n; }
     ic.nseg = nseg; ic.has_scalar = aug ? 1 : 0; ic.phase = 0; ic.rtol = rtol; ic.atol = atol;
-    if (nr_fn != nullptr) { norm_exchange(1, nseg); ic.gbuf = nr_buf; ic.gworld = nr_world; }
-    launch_init_controller(ic, st);
+    const bool fold = nr_fn == nullptr && fold_ctl();     // norms + decision as one launch (the last workgroup decides)
+    if (fold) launch_init_norms_ctl(segs, p.partial, nseg, ic, p.arrive, st);
+    else {
+      launch_init_norms(segs, p.partial, nseg, rtol, atol, 0, st);
+      if (nr_fn != nullptr) { norm_exchange(1, nseg); ic.gbuf = nr_buf; ic.gworld = nr_world; }
+      launch_init_controller(ic, st);
+    }
     const double one[1] = {1.0};
     TRY(eval_sys(1, one, 1, SC_H0, et_probe(), false));
-    launch_init_norms(segs, p.partial, nseg, rtol, atol, 1, st);
     ic.phase = 1;
-    if (nr_fn != nullptr) norm_exchange(2, nseg);
-    launch_init_controller(ic, st);
+    if (fold) launch_init_norms_ctl(segs, p.partial, nseg, ic, p.arrive, st);
+    else {
+      launch_init_norms(segs, p.partial, nseg, rtol, atol, 1, st);
+      if (nr_fn != nullptr) norm_exchange(2, nseg);
+      launch_init_controller(ic, st);
+    }
     return check_launch("initial step");
   }
 
@@ -1106,7 +1123,6 @@ struct Solver {
       es[2].y0 = p.TH; es[2].y1 = p.TH1; es[2].n = d.P; es[2].compute_y1 = 1;
       for (int j = 0; j < 7; ++j) es[2].k[j] = p.KT[j];
     }
-    launch_error_norm(es, p.partial, nseg, p.ctrl, rtol, atol, st);
     StepCtlArgs sc;
     memset(&sc, 0, sizeof(sc));
     sc.ctrl = p.ctrl;
@@ -1118,8 +1134,13 @@ struct Solver {
     sc.dt_log = io.log_cap > 0 ? p.dtlog : nullptr; sc.dt_log_cap = io.log_cap;
     sc.interp_scalar = aug ? 1 : 0;
     sc.w4sc = (aug && w4_f16) ? p.w4sc : nullptr;
-    if (nr_fn != nullptr) { norm_exchange(0, nseg); sc.gbuf = nr_buf; sc.gworld = nr_world; }
-    launch_step_controller(sc, st);
+    if (nr_fn == nullptr && fold_ctl()) {
+      launch_error_norm_ctl(es, p.partial, nseg, sc, p.arrive, st);     // the last-arriving workgroup of the error norm is the controller
+    } else {
+      launch_error_norm(es, p.partial, nseg, p.ctrl, rtol, atol, st);
+      if (nr_fn != nullptr) { norm_exchange(0, nseg); sc.gbuf = nr_buf; sc.gworld = nr_world; }
+      launch_step_controller(sc, st);
+    }
     if (!aug) {
       EmitArgs ea;
       ea.ctrl = p.ctrl; ea.targets = p.targets; ea.y0 = p.Y; ea.y1 = p.Y1;

@@ -272,6 +272,10 @@ struct ErrSeg {
 constexpr int ERR_BLOCKS = 512;
 // all segments of the state in one launch (grid.y = segment)
 void launch_error_norm(const ErrSeg* segs, float* const* partial /*[ERR_BLOCKS] each*/, int nseg, const Ctrl* ctrl, float rtol, float atol, hipStream_t s);
+// ... with the step controller as the LAST-ARRIVING workgroup of the same launch (round 6: one launch and one kernel boundary less per
+// step): `arrive` = a device word that is zero before the launch (the last workgroup zeroes it again)
+struct StepCtlArgs;
+void launch_error_norm_ctl(const ErrSeg* segs, float* const* partial, int nseg, const StepCtlArgs& ctl, unsigned* arrive, hipStream_t s);
 
 struct StepCtlArgs {
   Ctrl* ctrl;
@@ -337,6 +341,8 @@ void launch_export_record(const Ctrl* ctrl, node_step_record* rec, float* miss_f
 // initial step (Hairer)
 struct InitSeg { const float* y0; const float* f0; const float* f1; size_t n; };
 void launch_init_norms(const InitSeg* segs, float* const* partial /*[ERR_BLOCKS][2] each*/, int nseg, float rtol, float atol, int phase, hipStream_t s);
+struct InitCtlArgs;
+void launch_init_norms_ctl(const InitSeg* segs, float* const* partial, int nseg, const InitCtlArgs& ctl, unsigned* arrive, hipStream_t s);
 struct InitCtlArgs {
   Ctrl* ctrl;
   const float* partial[3];
