@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-round evidence (round 6): the default bench line (cfg 2 with PMC traffic, CPU baseline, cfgs 3 / 5 as side runs with their
 # rooflines), rocprofv3 step profiles of cfgs 2 / 3 / 5, the fp16-pair A/B on this box, counters + in-kernel timeline of the
-# dominant kernel, stem launch times, the bs = 1 census.  Run from the repo root on the GPU box; writes gpurun_out/evidence/.
+# dominant kernel, the pure-traffic twin of its byte counts (tools/hbm_stream.hip), stem launch times, the bs = 1 census.  Run from the repo root on the GPU box; writes gpurun_out/evidence/.
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/evidence
 mkdir -p $O
@@ -16,6 +16,7 @@ STEPS=4 WARM=2 TOP=40 bash tools/profile_bench.sh $O/cfg5 --config 5 --no-pmc --
 bash tools/pmc_w4h.sh $O/pmc_w4h.txt > /dev/null 2>&1
 bash tools/pmc_w4h.sh $O/pmc_w4h128_cfg5.txt k_w4_gemm128h 64,1024,16 > /dev/null 2>&1
 python tools/w4_stamps.py > $O/w4h_stamps.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/hbm_stream.hip -o tools/hbm_stream 2>/dev/null && tools/hbm_stream > $O/hbm_stream.txt 2>&1
 python tools/f16_check.py > $O/f16_check.txt 2>&1
 python tools/f16_adjoint_ab.py > $O/f16_adjoint_ab.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
