@@ -22,6 +22,13 @@
 //     (the low-latency protocol of the collective libraries; a hand-off is one store and one load that sees it).  Nothing is
 //     zeroed between solves (stale pairs carry an older nonce); every wait is a bounded spin -- a deadline on the constant
 //     100 MHz clock -- that raises a grid-wide abort word, so the grid drains whatever happens to a neighbour.
+//     A slot is rewritten every evaluation with NO consumer acknowledgement, and no version is ever lost (advisor, round 5), because a
+//     block's KS slices together read EVERY block of the sample: reducer gp republishes act[1] (version e + 1) only behind the conv-1
+//     partial sums e + 1 of all its slices, whose workers read act[0] e + 1 of ALL blocks, which every reducer publishes only behind
+//     the conv-2 partial sums e of all ITS slices -- so every worker of the sample has read its act[1] words of version e by then.  The
+//     same chain, one convolution later, covers act[0]; a worker rewrites its part[cv] slot only behind activations whose publication
+//     needed that slot's previous version consumed.  The one exchange without such a chain -- the step decision's partial sums,
+//     which all reducers read -- is double-buffered by exchange parity (errpart).
 //   * one launch and one stream synchronisation per solve: the launch splits the model's fp32 filters itself, forms the time
 //     channel's border maps, copies y0 into the trajectory and writes the record into the caller's pinned host copy.
 // The grid must be co-resident (one workgroup per CU: N x (C/16) x (C/32) <= CUs; 128 workgroups at [1,256,8,8]); a grid that is
