@@ -40,7 +40,7 @@ component GEMMs of a Winograd F(4x4,3x3) convolution on fp16 MFMA at fp32 accura
 (both operands as scaled fp16 pairs, three products), bounded by its bytes through the
 fabric at C = 256 (`bound: hbm`, achieved = algorithmic bytes per launch / mean launch
 duration from HIP events recorded by the library on the launch stream) and by the matrix
-pipe at C = 1024 (`k_w4_gemm128h`, `bound: mfma`); `roofline.hbm` prices the HBM-bound
+pipe at C = 1024 (`k_w4_gemm256h` + `k_w4_gemm128h`, `bound: mfma`); `roofline.hbm` prices the HBM-bound
 GroupNorm / transform passes, `roofline.wgrad` the weight gradient.  `cpu_baseline` is
 the oracle (CPU restatement of the torchdiffeq path driving PyTorch-CPU conv /
 group_norm) on this box's host cores.
@@ -699,11 +699,16 @@ def main():
                 issued_bf16 = flops_bf16 / (avg_ms * 1e-3) / 1e12
                 lds_tiled = C >= 512 and Nn % 32 == 0 and C % 128 == 0 and os.environ.get('NODE_TUNE_W4_GEMM128', '1') != '0'
                 if f16:
+                    # long reductions with rows % 256 == 0 and C % 256 == 0: components 0..31 as 256 x 256 workgroup tiles (k_w4_gemm256h),
+                    # components 32..35 behind them as k_w4_gemm128h's tail launch -- one ProfScope, so `avg_launch_us` is the PAIR
+                    big = lds_tiled and Nn % 64 == 0 and C % 256 == 0 and os.environ.get('NODE_TUNE_W4_H256', '1') != '0'
                     kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on fp16 MFMA at fp32 accuracy: both operands '
                              'as scaled fp16 pairs h + l, three products%s)'
-                             % (('k_w4_gemm128h', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
+                             % (('k_w4_gemm256h + k_w4_gemm128h', '; LDS-tiled: 256x256 workgroup tiles, one wave per SIMD with sixteen accumulators, '
+                                 'for components 0..31, 128x128 tiles for 32..35; the duration is that of the pair of launches') if big
+                                else ('k_w4_gemm128h', '; LDS-tiled 128x128 workgroup tiles for long reductions') if lds_tiled
                                 else ('k_w4_gemm64h', '')))
-                    gem_pmc = 'k_w4_gemm128h' if lds_tiled else 'k_w4_gemm64h'
+                    gem_pmc = 'k_w4_gemm256h' if big else 'k_w4_gemm128h' if lds_tiled else 'k_w4_gemm64h'
                 else:
                     kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on bf16 MFMA '
                              'at fp32 accuracy: exact three-way bf16 split of both operands, six products%s)'
@@ -715,6 +720,9 @@ def main():
                 mfma_view = {'issued_bf16_tflops': issued_bf16, 'frac_of_bf16_peak': issued_bf16 / MFMA_BF16_PEAK_TFLOPS,
                              'fp32_equivalent_tflops': ach, 'vs_fp32_matrix_peak': ach / MFMA_F32_PEAK_TFLOPS,
                              'part_products_per_fp32_product': nprod,
+                             'sustained_on_this_data': 'tools/mfma_power.hip (profiles/r06_mfma_power.txt): the bare v_mfma_f32_32x32x16_f16 loop, sixteen '
+                                                       'accumulators per wave, whole chip, on RANDOM fp16 pairs holds 1.46 - 1.60 GHz = 1480 - 1670 TFLOP/s '
+                                                       '(power), not the 2500 the fractions here are priced against',
                              'note': 'issued = 16-bit MFMA FLOPs (fp16 and bf16 forms run at the same rate); fp32_equivalent = the '
                                      'component products the fp32 MFMA kernel would issue, over this launch time; against the fp32 '
                                      'matrix peak it may exceed 1 -- the products run at the 16-bit rate'}

@@ -1892,17 +1892,17 @@ __global__ __launch_bounds__(256) void k_w4_gemm_small(const float* __restrict__
 // multiplies (fp32 MFMA / bf16 triples / small batches) and how a component's tiles are dealt to waves (bit-identical).
 // The timing ablations (results wrong by design), the stamps, the padded operand spacing and the measured-and-rejected
 // kernels exist in libnode_hip_diag.so only (build.py --diag; loaded by tools/ with NODE_HIP_DIAG=1).
-struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half, f16, hdepth, hsplit, h128; };
+struct W4Switches { int g64, b16, ablate, small, uf32, sharev, lds, early, ksplit, gemm128, wgrad128, half, f16, hdepth, hsplit, h128, h256; };
 static W4Switches w4_read_switches() {
   auto rd = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   // NODE_TUNE_W4_GEMM128 / _WGRAD128 = 0 never / 1 wherever it fits / unset (-1): long reductions (C >= 512)
 #ifdef NODE_DIAG
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), rd("NODE_TUNE_W4_ABLATE", 0), rd("NODE_TUNE_W4_SMALL", 1),
           rd("NODE_TUNE_W4_UF32", 0), rd("NODE_TUNE_W4_SHAREV", 1), rd("NODE_TUNE_W4_LDS", 0), rd("NODE_TUNE_W4_EARLY", 0), rd("NODE_TUNE_W4_KSPLIT", 0),
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0), rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), rd("NODE_TUNE_W4_HALF", 0), rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1), rd("NODE_TUNE_W4_H256", 1)};
 #else
   return {rd("NODE_TUNE_W4_GEMM64", 1), rd("NODE_TUNE_W4_BF16X3", 1), 0, rd("NODE_TUNE_W4_SMALL", 1), 0, rd("NODE_TUNE_W4_SHAREV", 1), 0, 0, 0,
-          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0, rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1)};
+          rd("NODE_TUNE_W4_GEMM128", -1), rd("NODE_TUNE_W4_WGRAD128", -1), 0, rd("NODE_TUNE_W4_F16", 1), rd("NODE_TUNE_W4_HDEPTH", 4), rd("NODE_TUNE_W4_HSPLIT", 0), rd("NODE_TUNE_W4_H128", -1), rd("NODE_TUNE_W4_H256", 1)};
 #endif
 }
 // The switches are read from the environment ONCE PER C-ABI CALL (w4_refresh_tuning at the top of every entry point that
@@ -1963,14 +1963,16 @@ struct W4GLoad { w4_u32x4 a0, a1, b0, b1; };
 #define W4G_WAIT(N, L) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((L).a0), "+v"((L).a1), "+v"((L).b0), "+v"((L).b1) : : "memory")
 template <int WPC>
 __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
-                                                           const Ctrl* ctrl, W4Geom gm, const int* v_exp, const int* u_exp) {
+                                                           const Ctrl* ctrl, W4Geom gm, const int* v_exp, const int* u_exp, int tail) {
   if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
   extern __shared__ __attribute__((aligned(16))) w4_u32x4 gtile[];   // [4 stages][A 4 row blocks x 2 parts | B 4 column blocks x 2 parts][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int nCT = gm.C >> 7, nRT = gm.R >> 7, nT = nRT * nCT, G2 = gm.G8 >> 1, CB = gm.C >> 5, nRB = gm.RB;
   const int j = blockIdx.x & 7, i = blockIdx.x >> 3;            // XCD, slot: 4 nT slots per XCD
-  const int comp = 4 * j + i / nT, tile = i % nT;
+  // tail != 0 (behind k_w4_gemm256h, which multiplies components 0..31): the grid is the 4 nT tiles of components 32..35 themselves, a pair
+  // of XCDs per component, and there is no shared piece
+  const int comp = tail ? 32 + (j >> 1) : 4 * j + i / nT, tile = tail ? (j & 1) * (nT >> 1) + i : i % nT;
   const int RT = tile / nCT, CT = tile - RT * nCT;
   const float inv = ldexpf(1.f, -(*v_exp + *u_exp));
   const int a_off = ((l31 >> 2) * 8) + hi * 4 + (l31 & 3);      // lane (row = 4 s + t, k-half hi): its 16 B inside a 1 KB part of V
@@ -2068,7 +2070,7 @@ __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __rest
     }
   }
   // --- the shared piece: rows srb (32), column blocks scb, scb + 1; K range [wave sng, (wave + 1) sng) per wave
-  {
+  if (!tail) {
     float16_t sa[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -2107,6 +2109,170 @@ __global__ __launch_bounds__(256, WPC) void k_w4_gemm128h(const unsigned* __rest
 #undef W4G_FETCH
 #undef W4G_WAIT
 
+// ----------------------------------------------------------------------------
+// k_w4_gemm256h (long reductions, rows % 256 == 0, C % 256 == 0): k_w4_gemm128h with FOUR times the tile.  What holds k_w4_gemm128h at
+// 43 % matrix duty (cfg 5) is not the LDS (half its fragment reads removed: -2 %; three quarters of its writes: -5 %; profiles/
+// r06_gemm256h.txt) but operand DELIVERY: 16 KB per 192 matrix cycles and workgroup, 18 % of it cold in L2, requested 1.1 us ahead.
+// Here a workgroup owns a 256 x 256 tile of one component, ONE wave per SIMD, each wave a 128 x 128 quarter: sixteen 32 x 32 accumulators
+// (256 registers), 48 MFMAs per K = 16 step and wave against 16 fragment reads -- half the LDS and half the global bytes per MFMA, and
+// a step lasts 768 matrix cycles, so the same four steps of look-ahead are 1.5 us.  Per step a wave requests TWO row blocks and TWO
+// column blocks (both parts: eight 16-B requests per lane, inline asm, FOUR register sets in flight, counted waits), four 32 KB LDS
+// stages; the step is cut in four quadrants so that fragment halves travel under MFMAs (details at the loop).
+// Components 0..31 only (32 nT tiles: XCD j takes components 4 j .. 4 j + 3); components 32..35 follow as k_w4_gemm128h<..>(tail = 1).
+// ----------------------------------------------------------------------------
+struct W4KLoad { w4_u32x4 a00, a01, a10, a11, b00, b01, b10, b11; };      // [block 0 | 1][part h | l] of V, of U
+#define W4K_FETCH(L)                                                                                     \
+  {                                                                                                      \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a00) : "v"(pa0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a01) : "v"(pa0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a10) : "v"(pa1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a11) : "v"(pa1) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b00) : "v"(pb0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b01) : "v"(pb0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b10) : "v"(pb1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b11) : "v"(pb1) : "memory");   \
+    pa0 += 2048; pa1 += 2048; pb0 += 2048; pb1 += 2048;                                                  \
+  }
+#define W4K_WAIT(N, L)                                                                                                         \
+  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"((L).a00), "+v"((L).a01), "+v"((L).a10), "+v"((L).a11), "+v"((L).b00), "+v"((L).b01), \
+               "+v"((L).b10), "+v"((L).b11) : : "memory")
+struct W4KB { w4_u32x4 v[2][2]; };      // a fragment half: two row (or column) blocks, parts h | l
+__global__ __launch_bounds__(256, 1) void k_w4_gemm256h(const unsigned* __restrict__ Vh, const unsigned* __restrict__ Uh, float* __restrict__ M,
+                                                        const Ctrl* ctrl, W4Geom gm, const int* v_exp, const int* u_exp) {
+  if (ctrl != nullptr && ctrl->done) return;   // a step enqueued past the end of the interval (Ctrl::done)
+  extern __shared__ __attribute__((aligned(16))) w4_u32x4 ktile[];   // [4 stages][A | B][8 blocks][2 parts][64 lanes]: 128 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nCT = gm.C >> 8, nRT = gm.R >> 8, nT = nRT * nCT, G2 = gm.G8 >> 1, CB = gm.C >> 5, nRB = gm.RB;
+  const int j = blockIdx.x & 7, i = blockIdx.x >> 3;            // XCD, slot: 4 nT slots per XCD
+  const int comp = 4 * j + i / nT, tile = i % nT;
+  const int RT = tile / nCT, CT = tile - RT * nCT;
+  const float inv = ldexpf(1.f, -(*v_exp + *u_exp));
+  const int a_off = ((l31 >> 2) * 8) + hi * 4 + (l31 & 3);      // lane (row = 4 s + t, k-half hi): its 16 B inside a 1 KB part of V
+  const size_t blk_bytes = (size_t)G2 * 2048;                   // one 32-row / 32-column block over the whole reduction
+  const char* pa0 = reinterpret_cast<const char*>(reinterpret_cast<const w4_u32x4*>(Vh) + (((size_t)comp * nRB + 8 * RT + 2 * wave) * G2) * 128 + a_off);
+  const char* pa1 = pa0 + blk_bytes;
+  const char* pb0 = reinterpret_cast<const char*>(reinterpret_cast<const w4_u32x4*>(Uh) + (((size_t)comp * CB + 8 * CT + 2 * wave) * G2) * 128 + lane);
+  const char* pb1 = pb0 + blk_bytes;
+  auto blk = [&](int stage, int kind, int b, int part) { return ktile + (((stage * 2 + kind) * 8 + b) * 2 + part) * 64 + lane; };
+#define W4K_STASH(L, STAGE)                       \
+  {                                               \
+    *blk(STAGE, 0, 2 * wave, 0) = (L).a00;        \
+    *blk(STAGE, 0, 2 * wave, 1) = (L).a01;        \
+    *blk(STAGE, 0, 2 * wave + 1, 0) = (L).a10;    \
+    *blk(STAGE, 0, 2 * wave + 1, 1) = (L).a11;    \
+    *blk(STAGE, 1, 2 * wave, 0) = (L).b00;        \
+    *blk(STAGE, 1, 2 * wave, 1) = (L).b01;        \
+    *blk(STAGE, 1, 2 * wave + 1, 0) = (L).b10;    \
+    *blk(STAGE, 1, 2 * wave + 1, 1) = (L).b11;    \
+  }
+  const int wr = wave >> 1, wc = wave & 1;
+  float16_t acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[r][c][q] = 0.f;
+  // fragments travel as HALVES of the wave's quarter: two row blocks (W4K_AH: half H of its four) or two column blocks (W4K_BH), both parts
+#define W4K_AH(F, ST, H) \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int q = 0; q < 2; ++q) (F).v[b][q] = *blk(ST, 0, 4 * wr + 2 * (H) + b, q);
+#define W4K_BH(F, ST, H) \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) _Pragma("unroll") for (int q = 0; q < 2; ++q) (F).v[b][q] = *blk(ST, 1, 4 * wc + 2 * (H) + b, q);
+  // one quadrant: acc[2 RH + r][2 CH + c] += A x B; per 32 x 32 tile the products (l,h), (h,l), (h,h) in this order (k_w4_gemm64h), four
+  // independent MFMAs between two on the same accumulator
+#define W4K_MAC1(AF, BF, RH, CH, PA, PB)                                                            \
+  _Pragma("unroll") for (int r = 0; r < 2; ++r) _Pragma("unroll") for (int c = 0; c < 2; ++c)       \
+      acc[2 * (RH) + r][2 * (CH) + c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(w4_f16x8, (AF).v[r][PA]), __builtin_bit_cast(w4_f16x8, (BF).v[c][PB]), acc[2 * (RH) + r][2 * (CH) + c], 0, 0, 0);
+#define W4K_MAC(AF, BF, RH, CH) { W4K_MAC1(AF, BF, RH, CH, 1, 0) W4K_MAC1(AF, BF, RH, CH, 0, 1) W4K_MAC1(AF, BF, RH, CH, 0, 0) }
+  // FOUR register sets, never copied (step s travels in set s % 4: requested four steps before it is waited for -- with two sets the loop
+  // ran 3100 cycles per step against 1536 of matrix work: 18 % of the requests are cold in L2 and come back after ~3 us), FOUR LDS stages
+  // (step s sits in stage s % 4).  A step is four quadrants in snake order -- (A0,B0) (A0,B1) (A1,B1) (A1,B0) -- so that each transition
+  // brings ONE new fragment half under the MFMAs of the quadrant before (64 fragment registers live, not 112): step k reads B1, A1, B0
+  // again, then -- under its last quadrant -- A0 and B0 of step k + 1 (stashed in step k - 1, behind that step's barrier); between the
+  // quadrants set (k + 2) % 4 goes to stage (k + 2) % 4 and is refilled with step k + 6.  One barrier per step.
+  // (Reads past the reduction's end land in the buffers' slack: W4_SLACK.)
+  W4KLoad l0, l1, l2, l3;
+  W4KB xa, ya, xb, yb;      // xa: A0;  ya: A1;  xb / yb: B0 and B1, their roles swapping every step
+  W4K_FETCH(l0)
+  W4K_FETCH(l1)
+  W4K_FETCH(l2)
+  W4K_FETCH(l3)
+  W4K_WAIT(24, l0);
+  W4K_STASH(l0, 0)
+  W4K_FETCH(l0)
+  W4K_WAIT(24, l1);
+  W4K_STASH(l1, 1)
+  W4K_FETCH(l1)
+  __syncthreads();
+  W4K_AH(xa, 0, 0)
+  W4K_BH(xb, 0, 0)
+  // step k in stage ST, next stage STN; B0 in B0R on entry, B1 goes to B1R; on exit B0 of step k + 1 sits in B1R
+#define W4K_FENCE __builtin_amdgcn_sched_barrier(0);   /* the order below IS the schedule: left alone the compiler sinks every fragment read
+                                                          to a few MFMAs before its use, and with one wave per SIMD nothing covers the LDS latency */
+#define W4K_STEP(ST, STN, B0R, B1R, LSET, STS)                                                      \
+  {                                                                                                 \
+    W4K_BH(B1R, ST, 1)                                                                              \
+    W4K_FENCE                                                                                       \
+    W4K_MAC(xa, B0R, 0, 0)                                                                          \
+    W4K_FENCE                                                                                       \
+    W4K_AH(ya, ST, 1)                                                                               \
+    W4K_FENCE                                                                                       \
+    W4K_MAC(xa, B1R, 0, 1)                                                                          \
+    W4K_FENCE                                                                                       \
+    W4K_WAIT(24, LSET);                                                                             \
+    W4K_STASH(LSET, STS)                                                                            \
+    W4K_FETCH(LSET)                                                                                 \
+    W4K_BH(B0R, ST, 0)                                                                              \
+    W4K_FENCE                                                                                       \
+    W4K_MAC(ya, B1R, 1, 1)                                                                          \
+    W4K_FENCE                                                                                       \
+    W4K_AH(xa, STN, 0)                                                                              \
+    W4K_BH(B1R, STN, 0)                                                                             \
+    W4K_FENCE                                                                                       \
+    W4K_MAC(ya, B0R, 1, 0)                                                                          \
+    W4K_FENCE                                                                                       \
+    __syncthreads();                                                                                \
+  }
+  for (int k = 0; k < G2; k += 4) {   // (G2 = C / 16 is a multiple of 4)
+    W4K_STEP(0, 1, xb, yb, l2, 2)
+    W4K_STEP(1, 2, yb, xb, l3, 3)
+    W4K_STEP(2, 3, xb, yb, l0, 0)
+    W4K_STEP(3, 0, yb, xb, l1, 1)
+  }
+  W4K_WAIT(0, l0);                    // nothing may still be landing in registers the epilogue reuses
+  W4K_WAIT(0, l1);
+  W4K_WAIT(0, l2);
+  W4K_WAIT(0, l3);
+#undef W4K_STEP
+#undef W4K_FENCE
+#undef W4K_MAC
+#undef W4K_MAC1
+#undef W4K_AH
+#undef W4K_BH
+#undef W4K_STASH
+  {
+    // (the lane's output coordinates are formed HERE, from a lane id the compiler cannot trace back: kept alive across the loop they spill)
+    int lane2 = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane2));
+    const int l31e = lane2 & 31, hie = (lane2 >> 5) & 1;
+    const size_t sstride = (size_t)(gm.C >> 5) * 36 * 128;       // floats per sample of M
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rb = 8 * RT + 4 * wr + r;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int cb = 8 * CT + 4 * wc + c;
+        float* m0 = M + ((size_t)(rb * 8 + hie) * (gm.C >> 5) + cb) * (36 * 128) + (size_t)comp * 128 + l31e;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) st_wt(m0 + (size_t)(2 * (q >> 2)) * sstride + (q & 3) * 32, acc[r][c][q] * inv);
+      }
+    }
+  }
+}
+#undef W4K_FETCH
+#undef W4K_WAIT
+
 // NODE_TUNE_W4_F16 = 0: never the fp16-pair operands (the bf16-triple kernels everywhere: A/B measurements, tests); read per call
 bool w4_f16_fits(int N, int C) {
   const W4Switches sw = w4_switches();
@@ -2128,8 +2294,17 @@ void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const 
       static bool attr1[MAX_DEVICES] = {}, attr2[MAX_DEVICES] = {};
       allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<1>), attr1);
       allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<2>), attr2);
-      if (C >= 512) hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
-      else hipLaunchKernelGGL(k_w4_gemm128h<1>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
+      // NODE_TUNE_W4_H256 (default 1): 256 x 256 tiles for components 0..31 where the geometry has them, components 32..35 behind
+      if (sw.h256 != 0 && C >= 512 && N % 64 == 0 && C % 256 == 0) {
+        static bool attr3[MAX_DEVICES] = {};
+        allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm256h), attr3);
+        const int nT2 = (N / 64) * (C >> 8);
+        hipLaunchKernelGGL(k_w4_gemm256h, dim3(32 * nT2), dim3(256), 4 * 32 * 64 * 16, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
+        hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(4 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp, 1);
+        return;
+      }
+      if (C >= 512) hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp, 0);
+      else hipLaunchKernelGGL(k_w4_gemm128h<1>, dim3(32 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp, 0);
       return;
     }
   }

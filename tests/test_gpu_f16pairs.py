@@ -69,6 +69,30 @@ def test_pair_convolution_is_scale_invariant(shape, xs, wsc):
         assert errs['1'] <= 1.5 * errs['0'] + 1e-6, errs
 
 
+@pytest.mark.parametrize('shape', [(16, 512, 16, 16), (32, 1024, 16, 16)])
+def test_gemm256h_is_bit_identical_to_gemm128h(shape):
+    """k_w4_gemm256h (256 x 256 tiles, one wave per SIMD with sixteen accumulators; components 0..31, components 32..35 behind it as
+    k_w4_gemm128h's tail launch) forms every 32 x 32 output tile from the same products in the same order as k_w4_gemm128h; only
+    components 32..35 differ in rounding (whole reductions here, four partial ones summed through LDS there).  Against fp64 and against
+    NODE_TUNE_W4_H256 = 0."""
+    N, Cc, H, W = shape
+    for dgrad in (0, 1):
+        gen = torch.Generator().manual_seed(11 + dgrad)
+        x = torch.randn(N, Cc, H, W, generator=gen).relu().cuda()
+        w = ((torch.rand(Cc, Cc + 1, 3, 3, generator=gen) * 2 - 1) / (9 * Cc) ** 0.5).cuda()
+        wd = w[:, 1:].double()
+        ref = F.conv_transpose2d(x.double(), wd, padding=1) if dgrad else F.conv2d(x.double(), wd, padding=1)
+        with _env(NODE_TUNE_W4_H256='1'):
+            big = _conv_w4(x, w, dgrad)
+        with _env(NODE_TUNE_W4_H256='0'):
+            small = _conv_w4(x, w, dgrad)
+        err = float((big.double() - ref).abs().max() / ref.abs().max())
+        print(shape, 'dgrad' if dgrad else 'fwd', 'error vs fp64 %.2e' % err)
+        assert err < 2e-5
+        diff = float((big - small).abs().max() / ref.abs().max())
+        assert diff < 1e-5, diff
+
+
 def _adjoint(shape, tol, seed, gscale, env):
     import neural_ode_features_amd as nof
     from neural_ode_features_amd import _lib

@@ -18,8 +18,13 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'neural-ode-features_amd', 'csrc')
-KERNELS = ('k_w4_gemm128b', 'k_w4_wgrad128b', 'k_w4_gemm128h')
+KERNELS = ('k_w4_gemm128b', 'k_w4_wgrad128b', 'k_w4_gemm128h', 'k_w4_gemm256h')
 LOAD_WAW_OK = ('k_w4_gemm128h',)
+# kernels that may spill OUTSIDE their K loop (k_w4_gemm256h: 256 accumulators leave the AGPRs through a few spilled words at the loop's exit):
+# their scratch instructions are checked like every other instruction -- no register of an open request may appear in them -- but are not
+# violations by themselves.  (The compiler's own counted waits for its scratch loads stay correct beside asm requests it does not know:
+# requests return in order, so unknown OLDER ones change nothing and unknown YOUNGER ones only make its wait longer.)
+SCRATCH_OK = ('k_w4_gemm256h',)
 VMEM = re.compile(r'^\s*(global_|buffer_|flat_|scratch_)(load|store|atomic)')
 REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
 
@@ -50,7 +55,7 @@ def check(asm_path):
                 break
             if not ln or ln.endswith(':') or ln.startswith('.') or ln.startswith('s_endpgm'):
                 continue
-            if ln.startswith('scratch_'):
+            if ln.startswith('scratch_') and k not in SCRATCH_OK:
                 bad.append('%s: scratch access at line %d: %s' % (k, i + 1, ln))
             # the else side of a divergent if (`s_xor_b64 exec, exec, saved` / `s_andn2_saveexec_b64`) runs on the lanes the then side did not: what the then
             # side left in flight is on other lanes until the paths rejoin (`s_or_b64 exec, exec, saved`)
