@@ -298,7 +298,11 @@ def test_asm_load_guard_flags_a_register_touched_in_flight(tmp_path):
     nk = len(mod.KERNELS)
     assert len(bad) == nk and 'v9' in bad[0]
     assert len(stream(load + load.replace('v[8:11]', 'v[12:15]') + '\ts_waitcnt vmcnt(1)\n\tv_add_f32 v0, v8, v8\n\tv_add_f32 v0, v12, v0\n')) == nk
-    assert len(stream(load + '\tscratch_store_dword off, v1, off\n\ts_waitcnt vmcnt(0)\n')) == nk
+    # scratch traffic is a violation by itself except in the kernels listed as spilling outside their loop (SCRATCH_OK) -- and there, too,
+    # when it names a register whose request is in flight
+    assert len(stream(load + '\tscratch_store_dword off, v1, off\n\ts_waitcnt vmcnt(0)\n')) == nk - len(mod.SCRATCH_OK)
+    touched = stream(load + '\tscratch_store_dword off, v9, off\n\ts_waitcnt vmcnt(0)\n')
+    assert all(any(k in line and 'touches v9' in line for line in touched) for k in mod.KERNELS)
     other = '\ts_and_saveexec_b64 s[6:7], s[0:1]\n' + load + '\ts_andn2_saveexec_b64 s[6:7], s[6:7]\n' + load + '\ts_or_b64 exec, exec, s[6:7]\n'
     assert stream(other + '\ts_waitcnt vmcnt(0)\n') == []
     assert len(stream(other + '\tv_mov_b32 v1, v8\n')) == nk
