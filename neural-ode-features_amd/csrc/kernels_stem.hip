@@ -764,6 +764,14 @@ __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
       const float* src = j.slab + ((size_t)tap * j.Co + co) * j.Ci + c0 + cl;
       float s0 = 0.f, s1 = 0.f;
       int k = sub;
+      // (eight slabs in flight per thread instead of two; the additions keep their order, so the sums are the same bits)
+      for (; k + 28 < j.ns; k += 32) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k + 4 * q) * total];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) { s0 += v[q]; s1 += v[q + 1]; }
+      }
       for (; k + 4 < j.ns; k += 8) {
         s0 += src[(size_t)k * total];
         s1 += src[(size_t)(k + 4) * total];
@@ -774,37 +782,37 @@ __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
       if (sub == 0) j.out[((size_t)co * j.Ci + c0 + cl) * j.taps + tap] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
       __syncthreads();
     }
-  } else if (j.kind == 1) {
-    const size_t idx = (size_t)blockIdx.x * 256 + t;
-    if (idx >= 64 * 32) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= j.ns; k += 4) {
-      s0 += j.slab[(size_t)k * 2048 + idx];
-      s1 += j.slab[(size_t)(k + 1) * 2048 + idx];
-      s2 += j.slab[(size_t)(k + 2) * 2048 + idx];
-      s3 += j.slab[(size_t)(k + 3) * 2048 + idx];
-    }
-    for (; k < j.ns; ++k) s0 += j.slab[(size_t)k * 2048 + idx];
-    const float s = (s0 + s1) + (s2 + s3);
-    const int co = (int)(idx >> 5), kk = (int)(idx & 31);
-    if (kk < j.Ci) j.out[co * j.Ci + kk] = s;
-    else if (kk == j.Ci) j.out2[co] = s;
   } else {
-    const size_t idx = (size_t)blockIdx.x * 256 + t;
-    if (idx >= (size_t)2 * j.Co) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= j.ns; k += 4) {
-      s0 += j.slab[(size_t)k * 2 * j.Co + idx];
-      s1 += j.slab[(size_t)(k + 1) * 2 * j.Co + idx];
-      s2 += j.slab[(size_t)(k + 2) * 2 * j.Co + idx];
-      s3 += j.slab[(size_t)(k + 3) * 2 * j.Co + idx];
+    // kinds 1 (conv0: 64 x 32 words per slab, 450 slabs at cfg 2) and 2 (per-sample partials, 2 Co words): a workgroup sums 32 outputs, its
+    // eight 32-lane groups every eighth slab with eight loads in flight, the groups meet in LDS in a fixed order.  (One thread per output
+    // and all slabs, four in flight: 113 dependent rounds at cfg 2 -- the 48 us this launch took.)
+    const size_t nout = j.kind == 1 ? (size_t)64 * 32 : (size_t)2 * j.Co;
+    const int o = t & 31, g = t >> 5;
+    const size_t idx = (size_t)blockIdx.x * 32 + o;
+    if ((size_t)blockIdx.x * 32 >= nout) return;
+    const bool on = idx < nout;
+    const float* src = j.slab + (on ? idx : 0);
+    float acc = 0.f;
+    int k = g;
+    for (; k + 56 < j.ns; k += 64) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(k + 8 * q) * nout];
+      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
-    for (; k < j.ns; ++k) s0 += j.slab[(size_t)k * 2 * j.Co + idx];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (idx < (size_t)j.Co) j.out[idx] = s;
-    else j.out2[idx - j.Co] = s;
+    for (; k < j.ns; k += 8) acc += src[(size_t)k * nout];
+    part[g >> 1][(g & 1) * 32 + o] = acc;
+    __syncthreads();
+    if (g != 0 || !on) return;
+    const float sum = ((part[0][o] + part[0][32 + o]) + (part[1][o] + part[1][32 + o])) + ((part[2][o] + part[2][32 + o]) + (part[3][o] + part[3][32 + o]));
+    if (j.kind == 1) {
+      const int co = (int)(idx >> 5), kk = (int)(idx & 31);
+      if (kk < j.Ci) j.out[co * j.Ci + kk] = sum;
+      else if (kk == j.Ci) j.out2[co] = sum;
+    } else {
+      if (idx < (size_t)j.Co) j.out[idx] = sum;
+      else j.out2[idx - j.Co] = sum;
+    }
   }
 }
 
@@ -895,7 +903,7 @@ void launch_stem_reduce(const SReduceArgs& a, hipStream_t s) {
   int most = 8;
   for (int i = 0; i < a.njobs; ++i) {
     const SReduceJob& j = a.job[i];
-    most = max(most, j.kind == 0 ? j.Co * j.taps : (2 * j.Co + 255) / 256);
+    most = max(most, j.kind == 0 ? j.Co * j.taps : j.kind == 1 ? 64 : (2 * j.Co + 31) / 32);
   }
   hipLaunchKernelGGL(k_stem_reduce, dim3(most, a.njobs), dim3(256), 0, s, a);
 }
