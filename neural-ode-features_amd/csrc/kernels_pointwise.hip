@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(256) void k_theta_finalize(ThetaFinalizeArgs a, Dim
 
 void launch_theta_finalize(const Dims& d, const ThetaFinalizeArgs& a, hipStream_t s) {
   size_t wblocks = (9 * (size_t)d.C * d.C / 4 + 255) / 256;
+  if (a.dU != nullptr) wblocks = ((size_t)d.C * d.C / 4 + 255) / 256;      // F(4x4,3x3)-domain gradients: one float4 of (ci, co) pairs per thread
   if (wblocks > 1024) wblocks = 1024;
   const size_t nsmall = (9 * (size_t)d.C + 63) / 64;
   hipLaunchKernelGGL(k_theta_finalize, dim3((unsigned)(5 * nsmall + 2 * wblocks)), dim3(256), 0, s, a, d);
