@@ -715,8 +715,11 @@ __global__ __launch_bounds__(256) void k_stem_to_nchw(const float* __restrict__ 
 // preparation (once per forward): filters -> triples in both operand layouts, conv0's filter transposed, zero rows
 // ============================================================================
 __global__ __launch_bounds__(256) void k_stem_prep(const SPrepArgs a) {
-  const int job = blockIdx.y;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // a flat grid, every job its own run of workgroups (as [largest job] x [jobs] 18 k of the 19 k workgroups at cfg 2 came to leave at once)
+  int seg = 0;                       // 0..5: the filter jobs (those past njobs are empty), 6: conv0's filter, 7: the zero rows
+  while (seg < 7 && blockIdx.x >= a.blk0[seg + 1]) ++seg;
+  const size_t idx = (size_t)(blockIdx.x - a.blk0[seg]) * 256 + threadIdx.x;
+  const int job = seg < 6 ? seg : a.njobs + (seg - 6);
   if (job < a.njobs) {
     const SPrepJob& j = a.job[job];
     const size_t total = (size_t)j.taps * j.Cout * j.Cin;
@@ -753,10 +756,14 @@ __global__ __launch_bounds__(256) void k_stem_prep(const SPrepArgs a) {
 // ============================================================================
 __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
   __shared__ float part[4][64];
-  const SReduceJob& j = a.job[blockIdx.y];
+  // a flat grid, every job its own run of workgroups (as [largest job] x [jobs] two thirds of the 16 k workgroups at cfg 2 came to leave at once)
+  int ji = 0;
+  while (ji + 1 < a.njobs && blockIdx.x >= a.blk0[ji + 1]) ++ji;
+  const SReduceJob& j = a.job[ji];
+  const unsigned bx = blockIdx.x - a.blk0[ji];
   const int t = threadIdx.x;
   if (j.kind == 0) {
-    const int co = blockIdx.x / j.taps, tap = blockIdx.x - co * j.taps;
+    const int co = bx / j.taps, tap = bx - co * j.taps;
     if (co >= j.Co) return;
     const size_t total = (size_t)j.taps * j.Co * j.Ci;
     const int cl = t & 63, sub = t >> 6;
@@ -788,8 +795,8 @@ __global__ __launch_bounds__(256) void k_stem_reduce(const SReduceArgs a) {
     // and all slabs, four in flight: 113 dependent rounds at cfg 2 -- the 48 us this launch took.)
     const size_t nout = j.kind == 1 ? (size_t)64 * 32 : (size_t)2 * j.Co;
     const int o = t & 31, g = t >> 5;
-    const size_t idx = (size_t)blockIdx.x * 32 + o;
-    if ((size_t)blockIdx.x * 32 >= nout) return;
+    const size_t idx = (size_t)bx * 32 + o;
+    if ((size_t)bx * 32 >= nout) return;
     const bool on = idx < nout;
     const float* src = j.slab + (on ? idx : 0);
     float acc = 0.f;
@@ -884,11 +891,17 @@ void launch_stem_gn_bwd(const SGnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_gn_bwd, dim3(a.N * (a.C / a.CB)), dim3(256), ((size_t)2 * a.HW * a.CB + 1024) * sizeof(float), s, a);
 }
 
-void launch_stem_prep(const SPrepArgs& a, hipStream_t s) {
-  size_t most = 28 * 64;
-  for (int i = 0; i < a.njobs; ++i) most = max(most, (size_t)a.job[i].taps * a.job[i].Cout * a.job[i].Cin);
-  most = max(most, (size_t)a.nzero * 3 * 4096);
-  hipLaunchKernelGGL(k_stem_prep, dim3((unsigned)((most + 255) / 256), a.njobs + 2), dim3(256), 0, s, a);
+void launch_stem_prep(const SPrepArgs& a0, hipStream_t s) {
+  SPrepArgs a = a0;
+  unsigned at = 0;
+  for (int i = 0; i < 6; ++i) {
+    a.blk0[i] = at;
+    if (i < a.njobs) at += (unsigned)(((size_t)a.job[i].taps * a.job[i].Cout * a.job[i].Cin + 255) / 256);
+  }
+  a.blk0[6] = at; at += (28 * 64 + 255) / 256;                              // conv0's filter
+  a.blk0[7] = at; at += (unsigned)(((size_t)a.nzero * 3 * 4096 + 255) / 256);    // zero rows
+  a.blk0[8] = at;
+  hipLaunchKernelGGL(k_stem_prep, dim3(at), dim3(256), 0, s, a);
 }
 void launch_stem_from_nchw(const float* src, float* dst_nhwc, bf16_t* dst3, size_t plane, int N, int C, int HW, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_from_nchw, dim3(N * (C / 64) * ((HW + 63) / 64)), dim3(256), 0, s, src, dst_nhwc, dst3, plane, C, HW);
@@ -899,13 +912,17 @@ void launch_stem_split(const float* src, bf16_t* dst3, size_t plane, size_t n, h
 void launch_stem_to_nchw(const float* src_nhwc, float* dst, int N, int C, int HW, hipStream_t s) {
   hipLaunchKernelGGL(k_stem_to_nchw, dim3(N * (C / 64) * ((HW + 63) / 64)), dim3(256), 0, s, src_nhwc, dst, C, HW);
 }
-void launch_stem_reduce(const SReduceArgs& a, hipStream_t s) {
-  int most = 8;
+void launch_stem_reduce(const SReduceArgs& a0, hipStream_t s) {
+  SReduceArgs a = a0;
+  unsigned at = 0;
   for (int i = 0; i < a.njobs; ++i) {
     const SReduceJob& j = a.job[i];
-    most = max(most, j.kind == 0 ? j.Co * j.taps : j.kind == 1 ? 64 : (2 * j.Co + 31) / 32);
+    a.blk0[i] = at;
+    at += (unsigned)(j.kind == 0 ? j.Co * j.taps : j.kind == 1 ? 64 : (2 * j.Co + 31) / 32);
   }
-  hipLaunchKernelGGL(k_stem_reduce, dim3(most, a.njobs), dim3(256), 0, s, a);
+  a.blk0[a.njobs] = at;
+  if (at == 0) return;
+  hipLaunchKernelGGL(k_stem_reduce, dim3(at), dim3(256), 0, s, a);
 }
 
 }  // namespace node

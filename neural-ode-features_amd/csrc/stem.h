@@ -116,6 +116,7 @@ struct SPrepArgs {
   int njobs;
   const float* w0; float* w0t; int k0;            // conv0: [64][k0] -> [28][64], rows >= k0 zero (nullable)
   bf16_t* zero[10]; size_t zero_plane[10]; int zero_c[10]; int nzero;   // plane p of tensor i: zero[i] + p * zero_plane[i] .. + zero_c[i]
+  unsigned blk0[9];                               // (filled by launch_stem_prep) first workgroup of job 0..5, of the conv0 job, of the zero job, and the end
 };
 void launch_stem_prep(const SPrepArgs& a, hipStream_t s);
 // NCHW fp32 -> NHWC fp32 (nullable) + triples (nullable); NHWC fp32 -> NCHW fp32
@@ -126,7 +127,7 @@ void launch_stem_split(const float* src, bf16_t* dst3, size_t plane, size_t n /*
 //   kind 0: slab [ns][taps][Co][Ci] -> dW [Co][Ci][taps] (PyTorch layout); kind 1: conv0 slab [ns][64][32] -> dW0 [64][k0] + db [64];
 //   kind 2: GroupNorm partials [ns = N][2][C] -> dgamma [C], dbeta [C]
 struct SReduceJob { const float* slab; float* out; float* out2; int kind, ns, Co, Ci, taps; };
-struct SReduceArgs { SReduceJob job[12]; int njobs; };
+struct SReduceArgs { SReduceJob job[12]; int njobs; unsigned blk0[13]; };     // blk0: (filled by launch_stem_reduce) first workgroup of every job, and the end
 void launch_stem_reduce(const SReduceArgs& a, hipStream_t s);
 
 }  // namespace node
