@@ -701,7 +701,8 @@ def main():
                 if f16:
                     # long reductions with rows % 256 == 0 and C % 256 == 0: components 0..31 as 256 x 256 workgroup tiles (k_w4_gemm256h),
                     # components 32..35 behind them as k_w4_gemm128h's tail launch -- one ProfScope, so `avg_launch_us` is the PAIR
-                    big = lds_tiled and Nn % 64 == 0 and C % 256 == 0 and os.environ.get('NODE_TUNE_W4_H256', '1') != '0'
+                    big = (lds_tiled and Nn % 64 == 0 and C % 256 == 0 and os.environ.get('NODE_TUNE_W4_H256', '1') != '0' and
+                           (os.environ.get('NODE_TUNE_W4_H256', '1') == '2' or ((Nn // 64) * (C // 256)) % 8 == 0))
                     kname = ('%s (the 36 component GEMMs of Winograd F(4x4,3x3), fwd+dgrad, on fp16 MFMA at fp32 accuracy: both operands '
                              'as scaled fp16 pairs h + l, three products%s)'
                              % (('k_w4_gemm256h + k_w4_gemm128h', '; LDS-tiled: 256x256 workgroup tiles, one wave per SIMD with sixteen accumulators, '

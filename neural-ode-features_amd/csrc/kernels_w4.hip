@@ -2294,11 +2294,13 @@ void launch_w4_gemm_f16(const unsigned* Vh, const unsigned* Uh, float* M, const 
       static bool attr1[MAX_DEVICES] = {}, attr2[MAX_DEVICES] = {};
       allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<1>), attr1);
       allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm128h<2>), attr2);
-      // NODE_TUNE_W4_H256 (default 1): 256 x 256 tiles for components 0..31 where the geometry has them, components 32..35 behind
-      if (sw.h256 != 0 && C >= 512 && N % 64 == 0 && C % 256 == 0) {
+      // NODE_TUNE_W4_H256 = 1 (default): 256 x 256 tiles for components 0..31, components 32..35 behind, where the geometry has them AND
+      // they fill whole rounds of the chip (one workgroup per CU: 32 nT2 workgroups, a multiple of 256 -- a quarter-full round is slower
+      // than k_w4_gemm128h's many small tiles); 2: wherever the geometry has them (tests); 0: never
+      const int nT2 = (N / 64) * (C >> 8);
+      if (sw.h256 != 0 && C >= 512 && N % 64 == 0 && C % 256 == 0 && (sw.h256 == 2 || nT2 % 8 == 0)) {
         static bool attr3[MAX_DEVICES] = {};
         allow_full_lds(reinterpret_cast<const void*>(k_w4_gemm256h), attr3);
-        const int nT2 = (N / 64) * (C >> 8);
         hipLaunchKernelGGL(k_w4_gemm256h, dim3(32 * nT2), dim3(256), 4 * 32 * 64 * 16, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp);
         hipLaunchKernelGGL(k_w4_gemm128h<2>, dim3(4 * nT), dim3(256), lds, s, Vh, Uh, M, ctrl, gm, v_exp, u_exp, 1);
         return;

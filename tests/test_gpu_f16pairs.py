@@ -82,7 +82,7 @@ def test_gemm256h_is_bit_identical_to_gemm128h(shape):
         w = ((torch.rand(Cc, Cc + 1, 3, 3, generator=gen) * 2 - 1) / (9 * Cc) ** 0.5).cuda()
         wd = w[:, 1:].double()
         ref = F.conv_transpose2d(x.double(), wd, padding=1) if dgrad else F.conv2d(x.double(), wd, padding=1)
-        with _env(NODE_TUNE_W4_H256='1'):
+        with _env(NODE_TUNE_W4_H256='2'):      # (2: wherever the geometry has 256 x 256 tiles, not only where they fill whole rounds of the chip)
             big = _conv_w4(x, w, dgrad)
         with _env(NODE_TUNE_W4_H256='0'):
             small = _conv_w4(x, w, dgrad)
