@@ -1941,9 +1941,9 @@ __device__ __forceinline__ void w4wh_dma(const unsigned char* gsrc, unsigned lds
 // ONE component, its waves 64 x 64 quarters; per K = 16 step each wave fetches ONE quarter of the tile's operands -- its 32-row block
 // of V pairs and its 32-column block of U pairs, parts h and l: four 16-B requests per lane, already the MFMA fragments -- and
 // the 16 KB of the step go through a four-stage LDS ring (one barrier per step), so a CU takes in 16 KB per step where
-// k_w4_gemm64h's four independent 64 x 64 tiles take 32 KB.  Why: k_w4_gemm64h is bound by the texture path (64 B per clock and CU:
-// tools/w4_stamps.py -- 2.4 us to issue the first ring, then 720 cycles per K step against 384 of matrix work;
-// profiles/r06_pmc_w4h.txt) at short reductions and, like k_w4_gemm64b, by operand re-reads from the Infinity Cache at long ones.
+// k_w4_gemm64h's four independent 64 x 64 tiles take 32 KB.  Why: at long reductions k_w4_gemm64h, like k_w4_gemm64b, re-reads its
+// operands from the Infinity Cache (371 against 262 us at cfg 5).  (At SHORT reductions k_w4_gemm64h stays: its launch runs at the
+// memory system's pace for its bytes -- DESIGN.md 4.3; the texture path looked like its limit and is not, profiles/r06_gemm64v_ab.txt.)
 // Requests as inline asm with hand-placed waits, NSET register sets in flight that are never copied (k_w4_gemm128b).  (Measured and
 // removed, round 6: the same tile with the operands brought by LDS-DMA -- no staging instructions -- 14.1 - 17.9 us against
 // k_w4_gemm64h's 12.8 at cfg 2: a CU's four DMA streams deliver less than its register loads do.)
