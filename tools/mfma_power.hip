@@ -34,13 +34,23 @@ __global__ __launch_bounds__(256, 1) void k_power(float* out, unsigned long long
   __syncthreads();
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
   for (int s = 0; s < steps; ++s) {
+    if (RANDOM < 2) {
 #pragma unroll
-    for (int pr = 0; pr < 3; ++pr)      // (l,h), (h,l), (h,h)
+      for (int pr = 0; pr < 3; ++pr)      // product-major: (l,h) of all tiles, (h,l), (h,h)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[r][pr == 0 ? 1 : 0], b[c][pr == 1 ? 1 : 0], acc[r][c], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)         // RANDOM == 2: random pairs, TILE-major (the three products of a tile back to back)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[r][pr == 0 ? 1 : 0], b[c][pr == 1 ? 1 : 0], acc[r][c], 0, 0, 0);
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[r][pr == 0 ? 1 : 0], b[c][pr == 1 ? 1 : 0], acc[r][c], 0, 0, 0);
+    }
   }
   asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
   float sum = 0.f;
@@ -117,6 +127,7 @@ int main() {
   for (int steps : {64, 128, 1024}) {      // k_w4_gemm256h at C = 1024: 64 steps per tile, two tiles per CU and launch
     run<0, 32>(out, clk, steps, "32x32x16 structured");
     run<1, 32>(out, clk, steps, "32x32x16 random pairs");
+    run<2, 32>(out, clk, steps, "32x32x16 rnd, tile-major");
     run<0, 16>(out, clk, steps, "16x16x32 structured");
     run<1, 16>(out, clk, steps, "16x16x32 random pairs");
   }
