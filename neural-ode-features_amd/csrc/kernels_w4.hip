@@ -2210,28 +2210,53 @@ __global__ __launch_bounds__(256, 1) void k_w4_gemm256h(const unsigned* __restri
   // step k in stage ST, next stage STN; B0 in B0R on entry, B1 goes to B1R; on exit B0 of step k + 1 sits in B1R
 #define W4K_FENCE __builtin_amdgcn_sched_barrier(0);   /* the order below IS the schedule: left alone the compiler sinks every fragment read
                                                           to a few MFMAs before its use, and with one wave per SIMD nothing covers the LDS latency */
+// Everything that is not an MFMA goes in pieces of FOUR instructions behind groups of four MFMAs (one part product of a quadrant): the matrix
+// pipe works 128 cycles on a group while the vector / memory issue it blocks for 32 of them is free for the rest.  (As ONE block between two
+// quadrants -- wait, eight staging writes, eight requests, their pointer sums, four fragment reads -- the same instructions cost ~330 cycles
+// of a drained pipe per step: 14 of a round's 108 us, measured by leaving them out.)
+#define W4K_STASH_A(L, STAGE) { *blk(STAGE, 0, 2 * wave, 0) = (L).a00; *blk(STAGE, 0, 2 * wave, 1) = (L).a01; *blk(STAGE, 0, 2 * wave + 1, 0) = (L).a10; *blk(STAGE, 0, 2 * wave + 1, 1) = (L).a11; }
+#define W4K_STASH_B(L, STAGE) { *blk(STAGE, 1, 2 * wave, 0) = (L).b00; *blk(STAGE, 1, 2 * wave, 1) = (L).b01; *blk(STAGE, 1, 2 * wave + 1, 0) = (L).b10; *blk(STAGE, 1, 2 * wave + 1, 1) = (L).b11; }
+#define W4K_FETCH_A(L)                                                                                   \
+  {                                                                                                      \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a00) : "v"(pa0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a01) : "v"(pa0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).a10) : "v"(pa1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).a11) : "v"(pa1) : "memory");   \
+    pa0 += 2048; pa1 += 2048;                                                                            \
+  }
+#define W4K_FETCH_B(L)                                                                                   \
+  {                                                                                                      \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b00) : "v"(pb0) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b01) : "v"(pb0) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"((L).b10) : "v"(pb1) : "memory");               \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"((L).b11) : "v"(pb1) : "memory");   \
+    pb0 += 2048; pb1 += 2048;                                                                            \
+  }
 #define W4K_STEP(ST, STN, B0R, B1R, LSET, STS)                                                      \
   {                                                                                                 \
     W4K_BH(B1R, ST, 1)                                                                              \
     W4K_FENCE                                                                                       \
-    W4K_MAC(xa, B0R, 0, 0)                                                                          \
-    W4K_FENCE                                                                                       \
-    W4K_AH(ya, ST, 1)                                                                               \
-    W4K_FENCE                                                                                       \
-    W4K_MAC(xa, B1R, 0, 1)                                                                          \
-    W4K_FENCE                                                                                       \
+    W4K_MAC1(xa, B0R, 0, 0, 1, 0) W4K_FENCE                                                         \
+    W4K_AH(ya, ST, 1)             W4K_FENCE                                                         \
+    W4K_MAC1(xa, B0R, 0, 0, 0, 1) W4K_FENCE                                                         \
+    W4K_MAC1(xa, B0R, 0, 0, 0, 0) W4K_FENCE                                                         \
+    W4K_MAC1(xa, B1R, 0, 1, 1, 0) W4K_FENCE                                                         \
     W4K_WAIT(24, LSET);                                                                             \
-    W4K_STASH(LSET, STS)                                                                            \
-    W4K_FETCH(LSET)                                                                                 \
-    W4K_BH(B0R, ST, 0)                                                                              \
-    W4K_FENCE                                                                                       \
-    W4K_MAC(ya, B1R, 1, 1)                                                                          \
-    W4K_FENCE                                                                                       \
-    W4K_AH(xa, STN, 0)                                                                              \
-    W4K_BH(B1R, STN, 0)                                                                             \
-    W4K_FENCE                                                                                       \
-    W4K_MAC(ya, B0R, 1, 0)                                                                          \
-    W4K_FENCE                                                                                       \
+    W4K_STASH_A(LSET, STS)        W4K_FENCE                                                         \
+    W4K_MAC1(xa, B1R, 0, 1, 0, 1) W4K_FENCE                                                         \
+    W4K_STASH_B(LSET, STS)        W4K_FENCE                                                         \
+    W4K_MAC1(xa, B1R, 0, 1, 0, 0) W4K_FENCE                                                         \
+    W4K_FETCH_A(LSET)             W4K_FENCE                                                         \
+    W4K_MAC1(ya, B1R, 1, 1, 1, 0) W4K_FENCE                                                         \
+    W4K_FETCH_B(LSET)             W4K_FENCE                                                         \
+    W4K_MAC1(ya, B1R, 1, 1, 0, 1) W4K_FENCE                                                         \
+    W4K_BH(B0R, ST, 0)            W4K_FENCE                                                         \
+    W4K_MAC1(ya, B1R, 1, 1, 0, 0) W4K_FENCE                                                         \
+    W4K_AH(xa, STN, 0)            W4K_FENCE                                                         \
+    W4K_MAC1(ya, B0R, 1, 0, 1, 0) W4K_FENCE                                                         \
+    W4K_BH(B1R, STN, 0)           W4K_FENCE                                                         \
+    W4K_MAC1(ya, B0R, 1, 0, 0, 1) W4K_FENCE                                                         \
+    W4K_MAC1(ya, B0R, 1, 0, 0, 0) W4K_FENCE                                                         \
     __syncthreads();                                                                                \
   }
   for (int k = 0; k < G2; k += 4) {   // (G2 = C / 16 is a multiple of 4)
@@ -2245,6 +2270,10 @@ __global__ __launch_bounds__(256, 1) void k_w4_gemm256h(const unsigned* __restri
   W4K_WAIT(0, l2);
   W4K_WAIT(0, l3);
 #undef W4K_STEP
+#undef W4K_STASH_A
+#undef W4K_STASH_B
+#undef W4K_FETCH_A
+#undef W4K_FETCH_B
 #undef W4K_FENCE
 #undef W4K_MAC
 #undef W4K_MAC1
