@@ -15,6 +15,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neural_ode_features_amd as nof  # noqa: E402
+from neural_ode_features_amd import _lib  # noqa: E402
+
+if os.environ.get('NODE_HIP_LIB_AB'):      # A/B of two builds of the library
+    _lib.LIB_PATH = os.environ['NODE_HIP_LIB_AB']
 
 shape = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '64,1024,16,16').split(','))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
